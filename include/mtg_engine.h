@@ -1,0 +1,154 @@
+/*
+ * mtg_engine.h -- engine-level C-ABI underneath matchtigs.h (NEW; the reference has no such layer).
+ *
+ * It is what both the clib.rs-compatible shim (matchtigs_compute_tigs) and a Rust
+ * `impl TigAlgorithm for GreedytigAlgorithm` body (src/implementation/greedytigs/mod.rs:75-90,
+ * see INTEGRATION.md) call: an edge-centric bigraph in, (out,in,distance) pairs and tig walks out.
+ * Stages are exported separately so that they can be parity-checked tier by tier and so that
+ * bench.py / a multi-GPU driver can shard the SSSP stage across ranks:
+ *
+ *   stage                          reference lines it replaces                      where it runs
+ *   mtg_classify                   greedytigs/mod.rs:222-255 (eulertigs :64-97)     GPU (HIP)
+ *   mtg_sssp_candidates            greedytigs/mod.rs:324-335 + traitgraph-algo      GPU (HIP)
+ *                                  Dijkstra::shortest_path_lens (all sources at once)
+ *   mtg_replay_claims              greedytigs/mod.rs:301-523 (1-thread order)       host (C++)
+ *   mtg_finish_greedytigs          greedytigs/mod.rs:678-801 + implementation/      host (C++)
+ *                                  mod.rs:392-649 + bigraph Euler decomposition
+ *   mtg_compute_eulertigs          eulertigs/mod.rs:48-198                          host (C++)
+ *
+ * All pointers are plain host pointers unless the name starts with d_ (device pointer in the
+ * HBM of the GPU the mtg_device was created on). `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream). No torch types anywhere.
+ *
+ * Errors follow the reference's convention (panic => abort): message on stderr + abort().
+ * Functions that can fail recoverably return a status code instead, documented per function.
+ */
+#ifndef MTG_ENGINE_H
+#define MTG_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtg_graph mtg_graph;   /* host bigraph; grows when dummy edges are inserted */
+typedef struct mtg_device mtg_device; /* one GPU: device-resident graph + workspaces */
+typedef struct mtg_walks mtg_walks;   /* a list of edge walks (tigs or Euler cycles) */
+
+/* (out_node, in_node, distance): one matched pair, greedytigs/mod.rs:461. */
+typedef struct {
+    uint32_t out_node;
+    uint32_t in_node;
+    uint64_t distance;
+} mtg_pair;
+
+/* Counters of one SSSP stage (SURVEY.md 8d "unit of work"). */
+typedef struct {
+    uint64_t sources;          /* sources processed */
+    uint64_t settled_nodes;    /* (source,node) pairs with distance <= k-1 (full ball) */
+    uint64_t relaxed_edges;    /* sum of out-degrees of settled nodes = SSSP edges */
+    uint64_t emitted;          /* candidates written */
+    uint64_t relax_attempts;   /* edge relaxations the label-correcting kernel really performed */
+    uint64_t overflow_sources; /* sources that needed a larger kernel level */
+} mtg_sssp_stats;
+
+/* Library / device probes. */
+const char *mtg_version(void);
+int mtg_device_count(void); /* hipGetDeviceCount; 0 when no GPU (never initialises a context) */
+
+/* ---- host graph ------------------------------------------------------------------------ */
+/* Edges in id order: edge 2u = unitig u forwards, edge 2u+1 = its mirror (clib.rs:239-248).
+ * weight = k-mers of the unitig (bin.rs:357-379). Validates node pairing and the edge mirror
+ * property like clib.rs:251-252 (abort on violation). Arrays are copied. */
+mtg_graph *mtg_graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges,
+                                const uint32_t *edge_from, const uint32_t *edge_to,
+                                const uint64_t *edge_weight);
+/* The clib.rs builder as three calls (matchtigs.h wraps exactly these). */
+mtg_graph *mtg_graph_builder_new(uint64_t unitig_amount);
+void mtg_graph_builder_merge(mtg_graph *g, uint64_t unitig_a, int strand_a, uint64_t unitig_b, int strand_b);
+void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights);
+void mtg_graph_free(mtg_graph *g);
+uint64_t mtg_graph_node_count(const mtg_graph *g);
+uint64_t mtg_graph_edge_count(const mtg_graph *g); /* includes dummy edges added so far */
+/* Copy out the current graph (any pointer may be NULL). forwards: 1/0. dummy_id 0 = original. */
+void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from, uint32_t *edge_to,
+                      uint64_t *edge_weight, uint64_t *edge_dummy_id, uint64_t *edge_unitig,
+                      uint8_t *edge_forwards);
+
+/* ---- device stage ---------------------------------------------------------------------- */
+/* Builds the 32-byte node records for bound k-1 and uploads them to GPU `device_id`.
+ * Aborts if no GPU is present (there is no CPU path). Weights must be >= 1 for algorithm 5
+ * (checked here; the reference's (distance, node) pop order needs it). */
+mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id);
+void mtg_device_free(mtg_device *d);
+/* Bytes of HBM held by the device graph. */
+uint64_t mtg_device_graph_bytes(const mtg_device *d);
+
+/* Node classification on the GPU. Returns the number of sources (out-nodes, ascending). */
+uint64_t mtg_classify(mtg_device *d, void *stream);
+/* Host copies of the classification (sizes: n_sources, n_nodes, n_nodes; any may be NULL). */
+void mtg_classify_download(mtg_device *d, void *stream, uint32_t *out_nodes, int32_t *multiplicity,
+                           uint8_t *is_in_node);
+/* Device pointer to the ascending out-node list (uint32[n_sources]); valid until the next classify. */
+const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d);
+
+/* Bounded many-to-many SSSP: for every source index i in [src_begin, src_end) writes its
+ * candidate list L(s_i) = all in-nodes within k-1 of s_i (s_i excluded) as keys
+ * (distance << 32 | node), ascending, into d_pool[d_cand_start[i-src_begin] ..+ d_cand_count[..]].
+ * Returns 0 on success; 1 if pool_capacity was too small (*pool_needed tells the size to retry
+ * with; outputs are then invalid). Sources whose ball does not fit the fast kernel's LDS tables
+ * are re-run by larger kernel levels internally; a ball that fits no level aborts.
+ * Synchronises `stream` before returning. */
+int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end,
+                        uint64_t *d_pool, uint64_t pool_capacity, uint64_t *d_cand_start,
+                        uint32_t *d_cand_count, uint64_t *pool_needed);
+/* HIP-event time (ms) of the fast-level SSSP kernel in the last mtg_sssp_candidates call. */
+double mtg_last_sssp_kernel_ms(const mtg_device *d);
+/* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
+void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+/* Kernel tuning: level-0 geometry preset; returns the preset in force. */
+int mtg_set_sssp_preset(mtg_device *d, int preset);
+
+/* ---- host stages ----------------------------------------------------------------------- */
+/* Replays the reference's claim loop over the candidate lists in ascending source order.
+ * cand_start/cand_count index `pool`. multiplicity / is_in_node are the classification
+ * (copied, not modified). Returns the number of pairs; *pairs_out is malloc'd (mtg_free). */
+uint64_t mtg_replay_claims(const mtg_graph *g, uint64_t n_sources, const uint32_t *out_nodes,
+                           const int32_t *multiplicity, const uint8_t *is_in_node,
+                           const uint64_t *cand_start, const uint32_t *cand_count,
+                           const uint64_t *pool, mtg_pair **pairs_out);
+void mtg_free(void *p);
+
+/* Dummy insertion + Eulerisation + Euler decomposition + cut. Mutates g like the reference. */
+mtg_walks *mtg_finish_greedytigs(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, uint64_t k);
+mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k);
+/* Sub-stages, exported for parity tests. */
+uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs); /* returns last dummy id */
+uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k);          /* returns last dummy id */
+mtg_walks *mtg_euler_cycles(const mtg_graph *g);
+mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k);
+
+uint64_t mtg_walks_count(const mtg_walks *w);
+uint64_t mtg_walks_total_edges(const mtg_walks *w);
+/* limits[i] = exclusive end of walk i in edges[] (edge ids into the mutated graph). */
+void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges);
+void mtg_walks_free(mtg_walks *w);
+
+/* clib.rs:393-407 flattening into caller arrays sized as clib.rs:332-348. Returns #tigs. */
+uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out,
+                          uint64_t *tigs_insert_out, uint64_t *tigs_out_limits);
+
+/* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
+mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);
+
+/* Phase timings (seconds) of the last mtg_compute_tigs on this thread:
+ * [0] device build+upload, [1] classify, [2] sssp (all levels), [3] download, [4] replay,
+ * [5] dummy insertion + Euleriser, [6] Euler decomposition, [7] cut. */
+void mtg_last_phase_seconds(double out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTG_ENGINE_H */

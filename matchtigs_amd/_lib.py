@@ -1,0 +1,106 @@
+"""ctypes loader for libmatchtigs.so (the C-ABI library; include/matchtigs.h + include/mtg_engine.h).
+
+Fails loudly when the library is missing: there is no Python/CPU fallback for the device stage.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "libmatchtigs.so"
+INCLUDE_DIR = REPO_DIR / "include"
+
+_lib = None
+
+
+class MtgPair(C.Structure):
+    _fields_ = [("out_node", C.c_uint32), ("in_node", C.c_uint32), ("distance", C.c_uint64)]
+
+
+class MtgSsspStats(C.Structure):
+    _fields_ = [
+        ("sources", C.c_uint64),
+        ("settled_nodes", C.c_uint64),
+        ("relaxed_edges", C.c_uint64),
+        ("emitted", C.c_uint64),
+        ("relax_attempts", C.c_uint64),
+        ("overflow_sources", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/*.h (used by the symbol-export test)."""
+    names: list[str] = []
+    for h in sorted(INCLUDE_DIR.glob("*.h")):
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        names += re.findall(r"\b((?:mtg|matchtigs)_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C matchtigs_amd/csrc`. matchtigs_amd has no fallback without its HIP library."
+        )
+    L = C.CDLL(str(LIB_PATH))
+    vp, u32, u64, i64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_int32
+    P = C.POINTER
+    sig = {
+        "mtg_version": (C.c_char_p, []),
+        "mtg_device_count": (C.c_int, []),
+        "mtg_graph_from_edges": (vp, [u64, vp, u64, vp, vp, vp]),
+        "mtg_graph_builder_new": (vp, [u64]),
+        "mtg_graph_builder_merge": (None, [vp, u64, C.c_int, u64, C.c_int]),
+        "mtg_graph_builder_build": (None, [vp, vp]),
+        "mtg_graph_free": (None, [vp]),
+        "mtg_graph_node_count": (u64, [vp]),
+        "mtg_graph_edge_count": (u64, [vp]),
+        "mtg_graph_export": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "mtg_device_create": (vp, [vp, u64, C.c_int]),
+        "mtg_device_free": (None, [vp]),
+        "mtg_device_graph_bytes": (u64, [vp]),
+        "mtg_classify": (u64, [vp, vp]),
+        "mtg_classify_download": (None, [vp, vp, vp, vp, vp]),
+        "mtg_classify_d_out_nodes": (vp, [vp]),
+        "mtg_sssp_candidates": (C.c_int, [vp, vp, u64, u64, vp, u64, vp, vp, P(u64)]),
+        "mtg_last_sssp_kernel_ms": (C.c_double, [vp]),
+        "mtg_sssp_count": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
+        "mtg_set_sssp_preset": (C.c_int, [vp, C.c_int]),
+        "mtg_replay_claims": (u64, [vp, u64, vp, vp, vp, vp, vp, vp, P(P(MtgPair))]),
+        "mtg_free": (None, [vp]),
+        "mtg_finish_greedytigs": (vp, [vp, vp, u64, u64]),
+        "mtg_compute_eulertigs": (vp, [vp, u64]),
+        "mtg_insert_pair_edges": (u64, [vp, vp, u64]),
+        "mtg_make_eulerian": (u64, [vp, u64, u64]),
+        "mtg_euler_cycles": (vp, [vp]),
+        "mtg_cut_cycles": (vp, [vp, vp, u64]),
+        "mtg_walks_count": (u64, [vp]),
+        "mtg_walks_total_edges": (u64, [vp]),
+        "mtg_walks_export": (None, [vp, vp, vp]),
+        "mtg_walks_free": (None, [vp]),
+        "mtg_flatten_clib": (u64, [vp, vp, vp, vp, vp]),
+        "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),
+        "mtg_last_phase_seconds": (None, [P(C.c_double)]),
+        "matchtigs_initialise": (None, []),
+        "matchtigs_initialise_graph": (vp, [C.c_size_t]),
+        "matchtigs_merge_nodes": (None, [vp, C.c_size_t, C.c_bool, C.c_size_t, C.c_bool]),
+        "matchtigs_build_graph": (None, [vp, vp]),
+        "matchtigs_compute_tigs": (C.c_size_t, [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_char_p, C.c_char_p, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _ = (i64, i32, u32)
+    _lib = L
+    return L

@@ -1,0 +1,369 @@
+"""Host-side mirror of the reference's operator interface for the greedy-matchtigs / eulertigs path.
+
+Names, argument meaning and error behaviour follow the reference crate (citations into
+/root/reference/src/):
+
+* ``TigAlgorithm.compute_tigs(graph, configuration) -> walks``   implementation/mod.rs:49-59
+* ``GreedytigAlgorithm`` / ``GreedytigAlgorithmConfiguration``  implementation/greedytigs/mod.rs:33-90
+* ``EulertigAlgorithm`` / ``EulertigAlgorithmConfiguration``    implementation/eulertigs/mod.rs:18-45
+* ``HeapType`` / ``NodeWeightArrayType`` / ``PerformanceDataType`` (+ ``from_str``) implementation/mod.rs:61-126
+* ``MatchtigEdgeData`` view (``weight / is_dummy / is_original / is_forwards / is_backwards / mirror``)
+  implementation/mod.rs:287-317
+* the C-ABI of src/clib.rs through ``ClibGraph``.
+
+Everything computes through libmatchtigs.so (HIP). PyTorch is only used by callers that want to own
+device buffers (bench.py, multi-GPU); this module itself never imports torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+# ---- configuration enums (implementation/mod.rs:61-126) ---------------------------------------
+class _FromStr(enum.Enum):
+    @classmethod
+    def from_str(cls, s: str):
+        for m in cls:
+            if m.value == s:
+                return m
+        raise ValueError(f"Unknown {cls._label}: {s}")  # Err(format!("Unknown ...: {other}"))
+
+
+class NodeWeightArrayType(_FromStr):
+    EpochNodeWeightArray = "EpochNodeWeightArray"
+    HashbrownHashMap = "HashbrownHashMap"
+
+
+NodeWeightArrayType._label = "node weight array type"
+
+
+class HeapType(_FromStr):
+    StdBinaryHeap = "StdBinaryHeap"
+
+
+HeapType._label = "heap type"
+
+
+class PerformanceDataType(_FromStr):
+    None_ = "None"
+    Complete = "Complete"
+
+
+PerformanceDataType._label = "performance data type"
+
+
+@dataclass
+class GreedytigAlgorithmConfiguration:
+    """greedytigs/mod.rs:40-73. heap / node-weight-array / staged-parallelism settings select CPU data
+    structures in the reference and never change results; the MI355X engine accepts and ignores them.
+    ``threads`` likewise: results always equal the reference's 1-thread order (its only deterministic one)."""
+
+    threads: int
+    k: int
+    staged_parallelism_divisor: Optional[float] = None
+    resource_limit_factor: int = 0
+    node_weight_array_type: NodeWeightArrayType = NodeWeightArrayType.HashbrownHashMap
+    heap_type: HeapType = HeapType.StdBinaryHeap
+    performance_data_type: PerformanceDataType = PerformanceDataType.None_
+
+    @classmethod
+    def new(cls, threads: int, k: int) -> "GreedytigAlgorithmConfiguration":
+        return cls(threads, k)
+
+
+@dataclass
+class EulertigAlgorithmConfiguration:
+    """eulertigs/mod.rs:42-45."""
+
+    k: int
+
+
+# ---- edge payload view (implementation/mod.rs:287-317; clib.rs:45-85) -------------------------
+@dataclass(frozen=True)
+class MatchtigEdgeData:
+    sequence_handle: int  # unitig id; 0 (= Default) for dummy edges
+    forwards: bool
+    _weight: int
+    dummy_edge_id: int
+
+    def weight(self) -> int:
+        return self._weight
+
+    def is_dummy(self) -> bool:
+        return self.dummy_edge_id != 0
+
+    def is_original(self) -> bool:
+        return not self.is_dummy()
+
+    def is_forwards(self) -> bool:
+        return self.forwards
+
+    def is_backwards(self) -> bool:
+        return not self.forwards
+
+    def mirror(self) -> "MatchtigEdgeData":
+        return MatchtigEdgeData(self.sequence_handle, not self.forwards, self._weight, self.dummy_edge_id)
+
+    @classmethod
+    def new(cls, sequence_handle: int, forwards: bool, weight: int, dummy_id: int) -> "MatchtigEdgeData":
+        return cls(sequence_handle, forwards, weight, dummy_id)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Bigraph:
+    """Edge-centric bigraph handle (replaces ``NodeBigraphWrapper<PetGraph<(), EdgeData>>``).
+
+    compute_tigs mutates it (dummy edges are appended) exactly like the reference mutates its graph
+    (greedytigs/mod.rs:678-689, implementation/mod.rs:492-493), and the returned walks index the mutated graph.
+    """
+
+    def __init__(self, handle: int):
+        self._h = handle
+        self._L = _lib.load()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.mtg_graph_free(h)
+
+    @classmethod
+    def from_edges(cls, mirror, edge_from, edge_to, edge_weight) -> "Bigraph":
+        L = _lib.load()
+        m = np.ascontiguousarray(mirror, dtype=np.uint32)
+        f = np.ascontiguousarray(edge_from, dtype=np.uint32)
+        t = np.ascontiguousarray(edge_to, dtype=np.uint32)
+        w = np.ascontiguousarray(edge_weight, dtype=np.uint64)
+        if not (len(f) == len(t) == len(w)):
+            raise ValueError("edge arrays differ in length")
+        return cls(L.mtg_graph_from_edges(len(m), _ptr(m), len(f), _ptr(f), _ptr(t), _ptr(w)))
+
+    @classmethod
+    def from_unitig_links(cls, unitig_weights, links: Iterable[Sequence]) -> "Bigraph":
+        """The clib.rs builder: links = (unitig_a, strand_a, unitig_b, strand_b)."""
+        L = _lib.load()
+        w = np.ascontiguousarray(unitig_weights, dtype=np.uint64)
+        h = L.mtg_graph_builder_new(len(w))
+        for (ua, sa, ub, sb) in links:
+            L.mtg_graph_builder_merge(h, int(ua), 1 if sa else 0, int(ub), 1 if sb else 0)
+        L.mtg_graph_builder_build(h, _ptr(w))
+        return cls(h)
+
+    @property
+    def handle(self) -> int:
+        return self._h
+
+    def node_count(self) -> int:
+        return int(self._L.mtg_graph_node_count(self._h))
+
+    def edge_count(self) -> int:
+        return int(self._L.mtg_graph_edge_count(self._h))
+
+    def export(self) -> dict:
+        V, E = self.node_count(), self.edge_count()
+        out = {
+            "mirror": np.zeros(V, np.uint32), "edge_from": np.zeros(E, np.uint32), "edge_to": np.zeros(E, np.uint32),
+            "edge_weight": np.zeros(E, np.uint64), "edge_dummy_id": np.zeros(E, np.uint64),
+            "edge_unitig": np.zeros(E, np.uint64), "edge_forwards": np.zeros(E, np.uint8),
+        }
+        self._L.mtg_graph_export(self._h, *[_ptr(out[k]) for k in
+                                            ("mirror", "edge_from", "edge_to", "edge_weight", "edge_dummy_id",
+                                             "edge_unitig", "edge_forwards")])
+        return out
+
+    def edge_data(self, e: int, _cache={}) -> MatchtigEdgeData:
+        ex = self.export()
+        return MatchtigEdgeData(int(ex["edge_unitig"][e]), bool(ex["edge_forwards"][e]), int(ex["edge_weight"][e]),
+                                int(ex["edge_dummy_id"][e]))
+
+    # ---- host sub-stages (exported for parity tests) ----
+    def replay_claims(self, out_nodes, multiplicity, is_in_node, cand_start, cand_count, pool) -> np.ndarray:
+        on = np.ascontiguousarray(out_nodes, np.uint32)
+        mu = np.ascontiguousarray(multiplicity, np.int32)
+        li = np.ascontiguousarray(is_in_node, np.uint8)
+        cs = np.ascontiguousarray(cand_start, np.uint64)
+        cc = np.ascontiguousarray(cand_count, np.uint32)
+        po = np.ascontiguousarray(pool, np.uint64)
+        if len(mu) != self.node_count() or len(li) != self.node_count():
+            raise ValueError("classification arrays must have node_count entries")
+        pp = C.POINTER(_lib.MtgPair)()
+        n = self._L.mtg_replay_claims(self._h, len(on), _ptr(on), _ptr(mu), _ptr(li), _ptr(cs), _ptr(cc), _ptr(po), C.byref(pp))
+        dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+        arr = np.zeros(n, dt)
+        if n:
+            C.memmove(arr.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
+        self._L.mtg_free(pp)
+        return arr
+
+    def insert_pair_edges(self, pairs: np.ndarray) -> int:
+        p = np.ascontiguousarray(pairs)
+        return int(self._L.mtg_insert_pair_edges(self._h, _ptr(p), len(p)))
+
+    def make_eulerian(self, dummy_edge_id: int, k: int) -> int:
+        return int(self._L.mtg_make_eulerian(self._h, dummy_edge_id, k))
+
+    def euler_cycles(self) -> list[list[int]]:
+        return _take_walks(self._L, self._L.mtg_euler_cycles(self._h))
+
+    def finish_greedytigs(self, pairs: np.ndarray, k: int) -> list[list[int]]:
+        p = np.ascontiguousarray(pairs)
+        return _take_walks(self._L, self._L.mtg_finish_greedytigs(self._h, _ptr(p), len(p), k))
+
+    def flatten_clib(self, tigs: list[list[int]]):
+        """clib.rs:393-407 on already-computed walks (recomputed through the C-ABI for algorithm output)."""
+        ex = self.export()
+        eo, io, lim = [], [], []
+        for t in tigs:
+            for e in t:
+                eo.append(int(ex["edge_unitig"][e]) * (1 if ex["edge_forwards"][e] else -1))
+                io.append(0 if ex["edge_dummy_id"][e] == 0 else int(ex["edge_weight"][e]))
+            lim.append(len(eo))
+        return eo, io, lim
+
+
+def _take_walks(L, wp) -> list[list[int]]:
+    n, tot = int(L.mtg_walks_count(wp)), int(L.mtg_walks_total_edges(wp))
+    lim = np.zeros(max(n, 1), np.uint64)
+    ed = np.zeros(max(tot, 1), np.uint32)
+    L.mtg_walks_export(wp, _ptr(lim), _ptr(ed))
+    L.mtg_walks_free(wp)
+    out, b = [], 0
+    for i in range(n):
+        out.append(ed[b:int(lim[i])].tolist())
+        b = int(lim[i])
+    return out
+
+
+def _take_walks_np(L, wp):
+    n, tot = int(L.mtg_walks_count(wp)), int(L.mtg_walks_total_edges(wp))
+    lim = np.zeros(n, np.uint64)
+    ed = np.zeros(tot, np.uint32)
+    L.mtg_walks_export(wp, _ptr(lim) if n else None, _ptr(ed) if tot else None)
+    L.mtg_walks_free(wp)
+    return lim, ed
+
+
+class DeviceGraph:
+    """One GPU's resident copy of a Bigraph (mtg_device). Raises/aborts without a GPU: no CPU path."""
+
+    def __init__(self, graph: Bigraph, k: int, device_id: int = 0):
+        self._L = _lib.load()
+        if self._L.mtg_device_count() <= device_id:
+            raise RuntimeError(f"no HIP device {device_id}: the matchtigs_amd device stage has no CPU fallback")
+        self.graph = graph
+        self.k = k
+        self._d = self._L.mtg_device_create(graph.handle, k, device_id)
+        self.n_sources = None
+
+    def __del__(self):
+        d, self._d = getattr(self, "_d", None), None
+        if d:
+            self._L.mtg_device_free(d)
+
+    @property
+    def handle(self) -> int:
+        return self._d
+
+    def graph_bytes(self) -> int:
+        return int(self._L.mtg_device_graph_bytes(self._d))
+
+    def classify(self, stream: int = 0) -> int:
+        self.n_sources = int(self._L.mtg_classify(self._d, stream))
+        return self.n_sources
+
+    def classify_download(self, stream: int = 0):
+        V = self.graph.node_count()
+        on = np.zeros(self.n_sources, np.uint32)
+        mu = np.zeros(V, np.int32)
+        li = np.zeros(V, np.uint8)
+        self._L.mtg_classify_download(self._d, stream, _ptr(on) if len(on) else None, _ptr(mu) if V else None,
+                                      _ptr(li) if V else None)
+        return on, mu, li
+
+    def sssp_candidates(self, src_begin: int, src_end: int, d_pool: int, pool_capacity: int, d_cand_start: int,
+                        d_cand_count: int, stream: int = 0):
+        """Device pointers in, returns (status, pool_needed). status 1 = pool too small."""
+        needed = C.c_uint64()
+        rc = self._L.mtg_sssp_candidates(self._d, stream, src_begin, src_end, d_pool, pool_capacity, d_cand_start,
+                                         d_cand_count, C.byref(needed))
+        return int(rc), int(needed.value)
+
+    def last_sssp_kernel_ms(self) -> float:
+        return float(self._L.mtg_last_sssp_kernel_ms(self._d))
+
+    def sssp_count(self, src_begin: int, src_end: int, stream: int = 0) -> dict:
+        st = _lib.MtgSsspStats()
+        self._L.mtg_sssp_count(self._d, stream, src_begin, src_end, C.byref(st))
+        return st.as_dict()
+
+    def set_preset(self, preset: int) -> int:
+        return int(self._L.mtg_set_sssp_preset(self._d, preset))
+
+
+class TigAlgorithm:
+    """implementation/mod.rs:49-59."""
+
+    Configuration = None
+
+    @classmethod
+    def compute_tigs(cls, graph: Bigraph, configuration) -> list[list[int]]:
+        raise NotImplementedError
+
+
+class GreedytigAlgorithm(TigAlgorithm):
+    """greedytigs/mod.rs:75-90: walks of edge ids into the (mutated) graph."""
+
+    Configuration = GreedytigAlgorithmConfiguration
+
+    @classmethod
+    def compute_tigs(cls, graph: Bigraph, configuration: GreedytigAlgorithmConfiguration, device_id: int = 0):
+        L = _lib.load()
+        return _take_walks(L, L.mtg_compute_tigs(graph.handle, 5, configuration.k, device_id))
+
+
+class EulertigAlgorithm(TigAlgorithm):
+    """eulertigs/mod.rs:18-39."""
+
+    Configuration = EulertigAlgorithmConfiguration
+
+    @classmethod
+    def compute_tigs(cls, graph: Bigraph, configuration: EulertigAlgorithmConfiguration):
+        L = _lib.load()
+        return _take_walks(L, L.mtg_compute_eulertigs(graph.handle, configuration.k))
+
+
+def last_phase_seconds() -> dict:
+    L = _lib.load()
+    a = (C.c_double * 8)()
+    L.mtg_last_phase_seconds(a)
+    names = ["device_build", "classify", "sssp", "download", "replay", "eulerise", "euler", "cut"]
+    return {n: float(a[i]) for i, n in enumerate(names)}
+
+
+# ---- the reference's C-ABI, driven from Python exactly like a C caller would (clib.rs) ----------
+def clib_compute_tigs(unitig_weights, links, tig_algorithm: int, threads: int, k: int):
+    """matchtigs_initialise_graph -> merge_nodes* -> build_graph -> compute_tigs. Returns
+    (n_tigs, tigs_edge_out, tigs_insert_out, tigs_out_limits) trimmed to their used lengths."""
+    L = _lib.load()
+    w = np.ascontiguousarray(unitig_weights, dtype=np.uint64)
+    u = len(w)
+    data = L.matchtigs_initialise_graph(u)
+    for (ua, sa, ub, sb) in links:
+        L.matchtigs_merge_nodes(data, int(ua), bool(sa), int(ub), bool(sb))
+    L.matchtigs_build_graph(data, _ptr(w))
+    edge_count = 2 * u  # clib.rs:332-348: outputs sized by the edge count before dummies
+    eo = np.zeros(max(2 * edge_count, 1), np.int64)
+    io = np.zeros(max(2 * edge_count, 1), np.uint64)
+    lo = np.zeros(max(edge_count, 1), np.uint64)
+    n = int(L.matchtigs_compute_tigs(data, tig_algorithm, threads, k, b"", b"", _ptr(eo), _ptr(io), _ptr(lo)))
+    total = int(lo[n - 1]) if n else 0
+    return n, eo[:total].copy(), io[:total].copy(), lo[:n].copy()

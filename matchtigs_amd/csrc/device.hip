@@ -1,0 +1,821 @@
+// device.hip -- MI355X (gfx950) device stage of the greedy-matchtigs engine.
+//
+// Replaces, for ALL sources at once, what the reference does one source at a time on the CPU:
+//   * node classification                      /root/reference/src/implementation/greedytigs/mod.rs:222-255
+//   * Dijkstra::shortest_path_lens (bounded)   call site greedytigs/mod.rs:324-335 (traitgraph-algo 8.1.2)
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   NodeRec[V]   32-byte record per node: <=4 inline (neighbour, clamped weight) pairs, degree, flags,
+//                mirror node. One aligned 32-byte gather per settled node fetches everything the
+//                relaxation needs (neighbours, weights, is-target flag). Nodes with more than 4
+//                out-edges (never the case in a de Bruijn graph) spill to a CSR side array.
+//   out_nodes[S] ascending source list (u32), mult[V] (i32) from classification.
+//   pool[]       candidate keys (distance << 32 | node), per source contiguous and ascending.
+//
+// SSSP kernel (integer, HBM/latency bound, no MFMA): a workgroup takes a batch of BSRC consecutive
+// sources and runs all their bounded searches together as ONE label-correcting wavefront over a shared
+// LDS open-addressing table keyed by (local source, node) -> tentative distance (64-bit entries,
+// ds_cmpst_b64 / ds_min_u64), with LDS-staged frontier queues (double buffered, one round per hop).
+// Work is balanced over frontier items, not over sources. Distances are exact when the frontier drains
+// (non-negative weights), so the result equals Dijkstra's regardless of relaxation order. Emission
+// ranks each source's targets by (distance, node) in LDS and writes them contiguously.
+// Batches whose ball does not fit the LDS tables are flagged and re-run by larger levels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "device.hpp"
+
+namespace mtg {
+
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) MTG_DIE("HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Node records
+// ------------------------------------------------------------------------------------------------
+enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
+
+struct alignas(32) NodeRec {
+    uint32_t nbr[4];  // inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
+    uint16_t w[4];    // weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path)
+    uint8_t deg;      // inline degree 0..4 (0 if F_EXT)
+    uint8_t flags;
+    uint16_t pad;
+    uint32_t mirror;
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+
+__device__ __forceinline__ uint32_t rec_degree(const NodeRec &r) { return (r.flags & F_EXT) ? r.nbr[2] : r.deg; }
+
+// ------------------------------------------------------------------------------------------------
+// Classification kernels (greedytigs/mod.rs:229-245)
+// ------------------------------------------------------------------------------------------------
+constexpr int CLS_BLOCK = 256;
+
+__global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(NodeRec *recs, uint32_t n_nodes, int32_t *mult,
+                                                             uint32_t *block_counts) {
+    __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
+    const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
+    bool is_source = false;
+    if (n < n_nodes) {
+        const NodeRec r = recs[n];
+        const uint32_t out_d = rec_degree(r);
+        int32_t diff;
+        bool sm = (r.mirror == n);
+        if (sm) {
+            diff = (int32_t)(out_d & 1u);  // compute_eulerian_superfluous_out_biedges, self-mirror case
+        } else {
+            const NodeRec rm = recs[r.mirror];
+            diff = (int32_t)out_d - (int32_t)rec_degree(rm);  // in_degree(n) == out_degree(mirror(n))
+        }
+        uint8_t fl = r.flags & (uint8_t)~(F_TARGET | F_SOURCE | F_SELF_MIRROR);
+        if (sm) fl |= F_SELF_MIRROR;
+        if (sm && diff != 0) { fl |= F_TARGET | F_SOURCE; is_source = true; }   // :231-236
+        else if (diff > 0) fl |= F_TARGET;                                       // :237-240
+        else if (diff < 0) { fl |= F_SOURCE; is_source = true; }                 // :241-244
+        mult[n] = diff;  // 0 for balanced nodes
+        recs[n].flags = fl;  // byte store; degree/mirror bytes that other threads read are untouched
+    }
+    const unsigned long long b = __ballot(is_source);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < CLS_BLOCK / 64; i++) s += wave_cnt[i];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uint32_t n, unsigned long long *total_out) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? counts[i] : 0;
+        uint32_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int j = 0; j < wv; j++) wave_off += wave_tot[j];
+        const uint32_t c = carry;
+        if (i < n) counts[i] = c + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const NodeRec *recs, uint32_t n_nodes,
+                                                                    const uint32_t *block_offsets, uint32_t *out_nodes) {
+    __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
+    const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
+    const bool is_source = n < n_nodes && (recs[n].flags & F_SOURCE);
+    const unsigned long long b = __ballot(is_source);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (is_source) {
+        uint32_t off = block_offsets[blockIdx.x];
+        for (int j = 0; j < wv; j++) off += wave_cnt[j];
+        off += (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        out_nodes[off] = n;  // ascending: lane order within wave, wave order within block, block order
+    }
+}
+
+__global__ void export_live_kernel(const NodeRec *recs, uint32_t n_nodes, uint8_t *live) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_nodes) live[n] = (recs[n].flags & F_TARGET) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SSSP kernel
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t CAND_OVERFLOW = 0xFFFFFFFFu;
+constexpr unsigned long long TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+// table entry: [63:54] local source (10 bits) | [53:22] node (32) | [21:1] distance (21) | [0] 1 = not (yet) known to be a target
+constexpr int ENT_SRC_SHIFT = 54, ENT_NODE_SHIFT = 22;
+constexpr unsigned long long ENT_DIST_MASK = 0x1FFFFFull;
+
+enum Counter : int {
+    C_BATCH = 0,     // dynamic batch counter
+    C_POOL = 1,      // pool cursor (keys)
+    C_OVERFLOW = 2,  // number of overflowed sources
+    C_SETTLED = 3,
+    C_RELAXED = 4,
+    C_EMITTED = 5,
+    C_ATTEMPTS = 6,
+    C_OVF_LIST = 7,  // cursor of the overflow source list
+    C_COUNT = 8
+};
+
+struct SsspArgs {
+    const NodeRec *recs;
+    const uint32_t *ext_col;
+    const uint16_t *ext_w;
+    const uint32_t *sources;     // out_nodes (ascending)
+    const uint32_t *src_index;   // optional list of absolute source indices to process (re-runs); null = contiguous range
+    uint64_t n_items;            // number of sources in this launch
+    uint64_t src_begin;          // first absolute source index (outputs are indexed by abs - src_begin)
+    uint32_t K1;                 // bound k-1 (inclusive)
+    unsigned long long *pool;
+    uint64_t pool_cap;
+    unsigned long long *cand_start;
+    uint32_t *cand_count;
+    unsigned long long *counters;
+    unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
+    uint64_t ws_stride;          // 64-bit words per block
+};
+
+template <bool GLOBAL_WS>
+struct Mem {
+    // LDS: workgroup scope suffices. Global workspace: agent scope so that loads bypass the CU's L1
+    // (atomics execute in L2 and do not refresh an L1-resident line).
+    static constexpr int SCOPE = GLOBAL_WS ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
+    template <typename T> static __device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE); }
+    template <typename T> static __device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE); }
+    static __device__ __forceinline__ unsigned long long cas(unsigned long long *p, unsigned long long expect, unsigned long long v) {
+        __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, SCOPE);
+        return expect;  // previous value
+    }
+    static __device__ __forceinline__ unsigned long long fmin(unsigned long long *p, unsigned long long v) {
+        return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, SCOPE);
+    }
+    static __device__ __forceinline__ void fand(unsigned long long *p, unsigned long long v) {
+        __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, SCOPE);
+    }
+};
+
+template <int LOGH>
+__device__ __forceinline__ uint32_t tbl_hash(uint32_t src, uint32_t node) {
+    const uint32_t x = node * 0x9E3779B1u + src * 0x85EBCA77u;
+    return (x ^ (x >> 15)) * 0x2C1B3C6Du >> (32 - LOGH);
+}
+
+// returns 1 improved (slot set), 0 not improved, -1 table full
+template <int LOGH, bool GLOBAL_WS>
+__device__ __forceinline__ int tbl_relax(unsigned long long *table, uint32_t src, uint32_t node, uint32_t dist, uint32_t &slot) {
+    constexpr uint32_t H = 1u << LOGH;
+    constexpr int MAX_PROBE = H < 256 ? (int)H : 256;
+    const unsigned long long key = ((unsigned long long)src << ENT_SRC_SHIFT) | ((unsigned long long)node << ENT_NODE_SHIFT);
+    const unsigned long long val = key | ((unsigned long long)dist << 1) | 1ull;
+    uint32_t h = tbl_hash<LOGH>(src, node);
+    for (int probe = 0; probe < MAX_PROBE; probe++) {
+        unsigned long long cur = Mem<GLOBAL_WS>::ld(&table[h]);
+        if (cur == TBL_EMPTY) {
+            cur = Mem<GLOBAL_WS>::cas(&table[h], TBL_EMPTY, val);
+            if (cur == TBL_EMPTY) { slot = h; return 1; }
+        }
+        if ((cur >> ENT_NODE_SHIFT) == (key >> ENT_NODE_SHIFT)) {
+            if (((cur >> 1) & ENT_DIST_MASK) <= dist) return 0;
+            const unsigned long long old = Mem<GLOBAL_WS>::fmin(&table[h], val);
+            slot = h;
+            return (((old >> 1) & ENT_DIST_MASK) > dist) ? 1 : 0;
+        }
+        h = (h + 1) & (H - 1);
+    }
+    return -1;
+}
+
+template <int BLOCK, int LOGH, int QCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
+struct SsspLds {
+    static constexpr uint32_t H = 1u << LOGH;
+    unsigned long long table[GLOBAL_WS ? 1 : H];
+    uint32_t queue[GLOBAL_WS ? 1 : 2 * QCAP];   // two frontier buffers; reused as u64 staging at emission
+    uint16_t stage_src[GLOBAL_WS ? 1 : QCAP];
+    uint32_t qn[2];
+    uint32_t srcnode[BSRC];
+    uint32_t cnt[BSRC];
+    uint32_t off[BSRC];
+    uint32_t fill[BSRC];
+    uint32_t batch;
+    uint32_t ovf;
+    uint32_t total;
+    unsigned long long base;
+    unsigned long long st_settled, st_relaxed, st_attempts;
+};
+
+template <int BLOCK, int LOGH, int QCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
+__global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
+    static_assert(BSRC <= 512 && BSRC <= BLOCK, "BSRC limits");
+    static_assert(LOGH <= 22, "slot must fit the queue item");
+    constexpr uint32_t H = 1u << LOGH;
+    constexpr int HINT_BITS = 32 - LOGH;                 // distance hint bits in a queue item
+    constexpr uint32_t HINT_MASK = (1u << HINT_BITS) - 1u;
+    using M = Mem<GLOBAL_WS>;
+    __shared__ SsspLds<BLOCK, LOGH, QCAP, BSRC, COUNT, GLOBAL_WS> s;
+
+    unsigned long long *table;
+    uint32_t *queue;
+    uint16_t *stage_src;
+    if constexpr (GLOBAL_WS) {
+        unsigned long long *base = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
+        table = base;
+        queue = reinterpret_cast<uint32_t *>(base + H);
+        stage_src = reinterpret_cast<uint16_t *>(base + H + QCAP);
+    } else {
+        table = s.table;
+        queue = s.queue;
+        stage_src = s.stage_src;
+    }
+    unsigned long long *stage = reinterpret_cast<unsigned long long *>(queue);  // QCAP keys
+
+    const int tid = threadIdx.x;
+    const uint64_t n_batches = (a.n_items + BSRC - 1) / BSRC;
+
+    for (;;) {
+        if (tid == 0) s.batch = (uint32_t)atomicAdd(&a.counters[C_BATCH], 1ull);
+        __syncthreads();
+        const uint64_t batch = s.batch;
+        if (batch >= n_batches) break;  // uniform
+        const uint64_t item0 = batch * BSRC;
+        const int nsrc = (int)min((uint64_t)BSRC, a.n_items - item0);
+
+        // ---- init ----
+        for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
+        if (tid < BSRC) { s.cnt[tid] = 0; s.fill[tid] = 0; }
+        if (tid == 0) { s.qn[0] = (uint32_t)nsrc; s.qn[1] = 0; s.ovf = 0; s.st_settled = 0; s.st_relaxed = 0; s.st_attempts = 0; }
+        __syncthreads();
+        if (tid < nsrc) {
+            const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
+            const uint32_t node = a.sources[abs_idx];
+            s.srcnode[tid] = node;
+            uint32_t slot = 0;
+            const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
+            if (r < 0) s.ovf = 1;
+            M::st(&queue[tid], (slot << HINT_BITS) | 0u);
+        }
+        __syncthreads();
+
+        // ---- label-correcting rounds ----
+        int cur = 0;
+        for (int round = 0;; round++) {
+            const uint32_t n_items = s.qn[cur];
+            if (n_items == 0 || s.ovf) break;  // uniform (LDS, read after barrier)
+            if (round > 1 << 20) { if (tid == 0) s.ovf = 1; break; }
+            uint32_t *qin = queue + cur * QCAP;
+            uint32_t *qout = queue + (cur ^ 1) * QCAP;
+            for (uint32_t i = tid; i < n_items; i += BLOCK) {
+                const uint32_t item = M::ld(&qin[i]);
+                const uint32_t slot = item >> HINT_BITS;
+                const unsigned long long e = M::ld(&table[slot]);
+                const uint32_t d = (uint32_t)((e >> 1) & ENT_DIST_MASK);
+                if ((d & HINT_MASK) != (item & HINT_MASK)) continue;  // superseded by a shorter distance (dedup hint)
+                const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
+                const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
+                // one aligned 32-byte gather: neighbours, weights, flags
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
+                const uint4 lo = rp[0];
+                const uint4 hi = rp[1];
+                const uint32_t flags = (hi.z >> 8) & 0xFFu;
+                if (flags & F_TARGET) M::fand(&table[slot], ~1ull);  // node property: confirmed in-node
+                uint32_t deg, pushed_ovf = 0;
+                if (!(flags & F_EXT)) {
+                    deg = hi.z & 0xFFu;
+                    const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+                    const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (j < (int)deg) {
+                            const uint32_t nd = d + ww[j];
+                            if (nd <= a.K1) {
+                                uint32_t nslot = 0;
+                                const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, nb[j], nd, nslot);
+                                if (r > 0) {
+                                    const uint32_t pos = atomicAdd(&s.qn[cur ^ 1], 1u);
+                                    if (pos < (uint32_t)QCAP) M::st(&qout[pos], (nslot << HINT_BITS) | (nd & HINT_MASK));
+                                    else pushed_ovf = 1;
+                                } else if (r < 0) pushed_ovf = 1;
+                            }
+                        }
+                    }
+                } else {
+                    const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
+                    deg = lo.z;
+                    for (uint32_t j = 0; j < deg; j++) {
+                        const uint32_t nd = d + a.ext_w[eb + j];
+                        if (nd <= a.K1) {
+                            uint32_t nslot = 0;
+                            const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, a.ext_col[eb + j], nd, nslot);
+                            if (r > 0) {
+                                const uint32_t pos = atomicAdd(&s.qn[cur ^ 1], 1u);
+                                if (pos < (uint32_t)QCAP) M::st(&qout[pos], (nslot << HINT_BITS) | (nd & HINT_MASK));
+                                else pushed_ovf = 1;
+                            } else if (r < 0) pushed_ovf = 1;
+                        }
+                    }
+                }
+                if (pushed_ovf) s.ovf = 1;
+                if constexpr (COUNT) atomicAdd(&s.st_attempts, (unsigned long long)deg);
+            }
+            __syncthreads();
+            if (tid == 0) s.qn[cur] = 0;
+            cur ^= 1;
+            __syncthreads();
+        }
+        __syncthreads();
+
+        // ---- emission ----
+        const bool ovf = s.ovf != 0;
+        if (!ovf) {
+            // pass 1: per-source counts
+            for (uint32_t i = tid; i < H; i += BLOCK) {
+                const unsigned long long e = M::ld(&table[i]);
+                if (e == TBL_EMPTY) continue;
+                const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
+                const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
+                if constexpr (COUNT) {
+                    atomicAdd(&s.st_settled, 1ull);
+                    const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
+                    const uint4 lo = rp[0];
+                    const uint4 hi = rp[1];
+                    const uint32_t flags = (hi.z >> 8) & 0xFFu;
+                    atomicAdd(&s.st_relaxed, (unsigned long long)((flags & F_EXT) ? lo.z : (hi.z & 0xFFu)));
+                }
+                if (!(e & 1ull) && node != s.srcnode[src]) atomicAdd(&s.cnt[src], 1u);
+            }
+            __syncthreads();
+            // exclusive scan of cnt[0..nsrc) by the first wave
+            if (tid < 64) {
+                uint32_t running = 0;
+                for (int base = 0; base < BSRC; base += 64) {
+                    const int i = base + tid;
+                    const uint32_t v = i < nsrc ? s.cnt[i] : 0;
+                    uint32_t incl = v;
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const uint32_t t = __shfl_up(incl, dd);
+                        if (tid >= dd) incl += t;
+                    }
+                    if (i < BSRC) s.off[i] = running + incl - v;
+                    running += __shfl(incl, 63);
+                }
+                if (tid == 0) {
+                    s.total = running;
+                    if (running > (uint32_t)QCAP) s.ovf = 1;  // staging too small -> larger level
+                    else s.base = COUNT ? 0ull : atomicAdd(&a.counters[C_POOL], (unsigned long long)running);
+                }
+            }
+            __syncthreads();
+        }
+        if (!s.ovf) {
+            if constexpr (!COUNT) {
+                // pass 2: stage keys per source segment (unsorted)
+                for (uint32_t i = tid; i < H; i += BLOCK) {
+                    const unsigned long long e = M::ld(&table[i]);
+                    if (e == TBL_EMPTY || (e & 1ull)) continue;
+                    const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
+                    const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
+                    if (node == s.srcnode[src]) continue;
+                    const uint32_t pos = s.off[src] + atomicAdd(&s.fill[src], 1u);
+                    M::st(&stage[pos], (((e >> 1) & ENT_DIST_MASK) << 32) | (unsigned long long)node);
+                    M::st(&stage_src[pos], (uint16_t)src);
+                }
+                __syncthreads();
+                // pass 3: rank within the source's segment, write sorted
+                const uint32_t total = s.total;
+                const unsigned long long base = s.base;
+                for (uint32_t i = tid; i < total; i += BLOCK) {
+                    const uint32_t src = M::ld(&stage_src[i]);
+                    const unsigned long long key = M::ld(&stage[i]);
+                    const uint32_t lo_ = s.off[src], hi_ = lo_ + s.cnt[src];
+                    uint32_t rank = 0;
+                    for (uint32_t j = lo_; j < hi_; j++) rank += (M::ld(&stage[j]) < key) ? 1u : 0u;
+                    const unsigned long long dst = base + lo_ + rank;
+                    if (dst < a.pool_cap) a.pool[dst] = key;
+                }
+            }
+            if (tid < nsrc) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
+                const uint64_t o = abs_idx - a.src_begin;
+                a.cand_start[o] = s.base + s.off[tid];
+                a.cand_count[o] = s.cnt[tid];
+            }
+            if (tid == 0) {
+                if constexpr (COUNT) {
+                    atomicAdd(&a.counters[C_SETTLED], s.st_settled);
+                    atomicAdd(&a.counters[C_RELAXED], s.st_relaxed);
+                    atomicAdd(&a.counters[C_ATTEMPTS], s.st_attempts);
+                }
+                atomicAdd(&a.counters[C_EMITTED], (unsigned long long)s.total);
+            }
+        } else {
+            if (tid < nsrc) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
+                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+            }
+            if (tid == 0) atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)nsrc);
+        }
+        __syncthreads();
+    }
+}
+
+// collect absolute indices of overflowed sources (order irrelevant)
+__global__ void collect_overflow_kernel(const uint32_t *cand_count, uint64_t n, uint64_t src_begin, uint32_t *list,
+                                        unsigned long long *counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && cand_count[i] == CAND_OVERFLOW) {
+        const unsigned long long pos = atomicAdd(&counters[C_OVF_LIST], 1ull);
+        list[pos] = (uint32_t)(src_begin + i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the device stage
+// ------------------------------------------------------------------------------------------------
+struct Device {
+    int dev = 0;
+    uint64_t k = 0;
+    uint32_t K1 = 0;
+    uint64_t V = 0;
+    NodeRec *d_recs = nullptr;
+    uint32_t *d_ext_col = nullptr;
+    uint16_t *d_ext_w = nullptr;
+    uint64_t ext_n = 0;
+    int32_t *d_mult = nullptr;
+    uint32_t *d_out_nodes = nullptr;
+    uint32_t *d_block_counts = nullptr;
+    uint64_t n_cls_blocks = 0;
+    uint64_t n_sources = 0;
+    bool classified = false;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;  // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_kernel_ms = 0.0;
+    int preset = 0;
+    int n_cu = 256;
+    uint64_t graph_bytes = 0;
+};
+
+typedef void (*sssp_fn)(SsspArgs);
+
+struct LevelCfg {
+    sssp_fn fn;
+    sssp_fn fn_count;
+    int block;
+    int bsrc;
+    int logh;
+    int qcap;
+    bool global_ws;
+};
+
+template <int BLOCK, int LOGH, int QCAP, int BSRC, bool GLOBAL_WS>
+static LevelCfg make_cfg() {
+    return LevelCfg{sssp_kernel<BLOCK, LOGH, QCAP, BSRC, false, GLOBAL_WS>, sssp_kernel<BLOCK, LOGH, QCAP, BSRC, true, GLOBAL_WS>,
+                    BLOCK, BSRC, LOGH, QCAP, GLOBAL_WS};
+}
+
+static const int N_PRESETS = 4;
+static LevelCfg level0_cfg(int preset) {
+    switch (preset) {
+        case 1: return make_cfg<128, 11, 1024, 32, false>();
+        case 2: return make_cfg<64, 10, 512, 16, false>();
+        case 3: return make_cfg<512, 13, 4096, 128, false>();
+        default: return make_cfg<256, 12, 2048, 64, false>();
+    }
+}
+static LevelCfg level1_cfg() { return make_cfg<256, 14, 2048, 1, false>(); }
+static LevelCfg level2_cfg() { return make_cfg<256, 22, 1 << 21, 1, true>(); }
+
+static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool count, SsspArgs args, bool time_it) {
+    if (args.n_items == 0) return;
+    const uint64_t n_batches = (args.n_items + cfg.bsrc - 1) / cfg.bsrc;
+    sssp_fn fn = count ? cfg.fn_count : cfg.fn;
+    int occ = 1;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, cfg.block, 0));
+    if (occ < 1) occ = 1;
+    uint64_t grid = (uint64_t)d->n_cu * (uint64_t)occ;
+    unsigned long long *ws = nullptr;
+    uint64_t ws_stride = 0;
+    if (cfg.global_ws) {
+        grid = std::min<uint64_t>(grid, 64);
+        const uint64_t H = 1ull << cfg.logh;
+        ws_stride = H + (uint64_t)cfg.qcap + ((uint64_t)cfg.qcap * 2 + 7) / 8;  // table + queue(2*QCAP u32) + stage_src
+        grid = std::min<uint64_t>(grid, n_batches);
+        HIP_CHECK(hipMalloc(&ws, grid * ws_stride * 8));
+    }
+    grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, n_batches));
+    args.ws = ws;
+    args.ws_stride = ws_stride;
+    HIP_CHECK(hipMemsetAsync(&d->d_counters[C_BATCH], 0, sizeof(unsigned long long), st));
+    if (time_it) HIP_CHECK(hipEventRecord(d->ev0, st));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
+    HIP_CHECK(hipGetLastError());
+    if (time_it) HIP_CHECK(hipEventRecord(d->ev1, st));
+    if (ws) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipFree(ws));
+    }
+}
+
+static void read_counters(Device *d, hipStream_t st) {
+    HIP_CHECK(hipMemcpyAsync(d->h_counters, d->d_counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// runs level 0 over [src_begin, src_end) and larger levels over whatever overflowed
+static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin, uint64_t src_end, unsigned long long *d_pool,
+                      uint64_t pool_cap, unsigned long long *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed,
+                      mtg_sssp_stats *stats) {
+    if (!d->classified) MTG_DIE("mtg_sssp_candidates: call mtg_classify first");
+    if (src_end > d->n_sources || src_begin > src_end) MTG_DIE("mtg_sssp_candidates: source range out of bounds");
+    const uint64_t n = src_end - src_begin;
+    HIP_CHECK(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), st));
+    SsspArgs a{};
+    a.recs = d->d_recs; a.ext_col = d->d_ext_col; a.ext_w = d->d_ext_w;
+    a.sources = d->d_out_nodes; a.src_index = nullptr; a.n_items = n; a.src_begin = src_begin;
+    a.K1 = d->K1; a.pool = d_pool; a.pool_cap = pool_cap; a.cand_start = d_cand_start; a.cand_count = d_cand_count;
+    a.counters = d->d_counters;
+    launch_level(d, st, level0_cfg(d->preset), count, a, true);
+    read_counters(d, st);
+    if (n) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+        d->last_kernel_ms = ms;
+    } else d->last_kernel_ms = 0.0;
+    uint64_t total_overflow = d->h_counters[C_OVERFLOW];
+    uint32_t *d_list = nullptr;
+    for (int level = 1; level <= 2 && d->h_counters[C_OVERFLOW] > 0; level++) {
+        const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
+        if (!d_list) HIP_CHECK(hipMalloc(&d_list, n_ovf * sizeof(uint32_t)));
+        HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVF_LIST], 0, sizeof(unsigned long long), st));
+        HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVERFLOW], 0, sizeof(unsigned long long), st));
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(collect_overflow_kernel, dim3(blocks), dim3(256), 0, st, d_cand_count, n, src_begin, d_list, d->d_counters);
+        HIP_CHECK(hipGetLastError());
+        SsspArgs b = a;
+        b.src_index = d_list;
+        b.n_items = n_ovf;
+        launch_level(d, st, level == 1 ? level1_cfg() : level2_cfg(), count, b, false);
+        read_counters(d, st);
+    }
+    if (d_list) HIP_CHECK(hipFree(d_list));
+    if (d->h_counters[C_OVERFLOW] > 0)
+        MTG_DIE("bounded search from %llu source(s) exceeds every kernel level (ball larger than 2^22 table entries)",
+                (unsigned long long)d->h_counters[C_OVERFLOW]);
+    if (stats) {
+        stats->sources = n;
+        stats->settled_nodes = d->h_counters[C_SETTLED];
+        stats->relaxed_edges = d->h_counters[C_RELAXED];
+        stats->emitted = d->h_counters[C_EMITTED];
+        stats->relax_attempts = d->h_counters[C_ATTEMPTS];
+        stats->overflow_sources = total_overflow;
+    }
+    if (pool_needed) *pool_needed = d->h_counters[C_POOL];
+    if (!count && d->h_counters[C_POOL] > pool_cap) return 1;
+    return 0;
+}
+
+// ---- public (device.hpp) ----
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
+    if (k < 1) MTG_DIE("k must be >= 1");
+    if (k > 65535) MTG_DIE("k = %llu is not supported by the device stage (weights are clamped into 16 bits)", (unsigned long long)k);
+    if (device_count() <= device_id) MTG_DIE("no MI355X/HIP device %d available; libmatchtigs has no CPU path", device_id);
+    HIP_CHECK(hipSetDevice(device_id));
+    Device *d = new Device();
+    d->dev = device_id;
+    d->k = k;
+    d->K1 = (uint32_t)(k - 1);
+    d->V = g.node_count();
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    // node records are built from the ORIGINAL edges only (the search runs before any dummy edge exists, :678)
+    const uint64_t V = d->V, E = g.n_original_edges;
+    std::vector<NodeRec> recs(V);
+    std::vector<uint32_t> odeg(V, 0);
+    for (uint64_t e = 0; e < E; e++) odeg[g.e_from[e]]++;
+    uint64_t ext_total = 0;
+    for (uint64_t n = 0; n < V; n++) {
+        NodeRec &r = recs[n];
+        std::memset(&r, 0, sizeof r);
+        r.mirror = g.mirror[n];
+        if (odeg[n] > 4) {
+            r.flags = F_EXT;
+            r.nbr[0] = (uint32_t)(ext_total & 0xFFFFFFFFu);
+            r.nbr[1] = (uint32_t)(ext_total >> 32);
+            r.nbr[2] = 0;  // filled below
+            ext_total += odeg[n];
+        }
+    }
+    std::vector<uint32_t> ext_col(ext_total);
+    std::vector<uint16_t> ext_w(ext_total);
+    for (uint64_t e = 0; e < E; e++) {
+        const uint32_t f = g.e_from[e];
+        NodeRec &r = recs[f];
+        const uint64_t w = g.e_weight[e];
+        const uint16_t wc = (uint16_t)std::min<uint64_t>(w, k);
+        if (r.flags & F_EXT) {
+            const uint64_t b = ((uint64_t)r.nbr[1] << 32) | r.nbr[0];
+            ext_col[b + r.nbr[2]] = g.e_to[e];
+            ext_w[b + r.nbr[2]] = wc;
+            r.nbr[2]++;
+        } else {
+            r.nbr[r.deg] = g.e_to[e];
+            r.w[r.deg] = wc;
+            r.deg++;
+        }
+    }
+    HIP_CHECK(hipMalloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeRec)));
+    HIP_CHECK(hipMemcpy(d->d_recs, recs.data(), V * sizeof(NodeRec), hipMemcpyHostToDevice));
+    d->ext_n = ext_total;
+    HIP_CHECK(hipMalloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2));
+    if (ext_total) {
+        HIP_CHECK(hipMemcpy(d->d_ext_col, ext_col.data(), ext_total * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d->d_ext_w, ext_w.data(), ext_total * 2, hipMemcpyHostToDevice));
+    }
+    HIP_CHECK(hipMalloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4));
+    d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
+    HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_counters, C_COUNT * sizeof(unsigned long long)));
+    HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
+    HIP_CHECK(hipEventCreate(&d->ev0));
+    HIP_CHECK(hipEventCreate(&d->ev1));
+    d->graph_bytes = V * sizeof(NodeRec) + ext_total * 6 + V * 8;
+    return d;
+}
+
+void device_free(Device *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->dev);
+    void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_out_nodes, d->d_block_counts, d->d_counters};
+    for (void *b : bufs) (void)hipFree(b);
+    (void)hipHostFree(d->h_counters);
+    (void)hipEventDestroy(d->ev0);
+    (void)hipEventDestroy(d->ev1);
+    delete d;
+}
+
+uint64_t device_graph_bytes(const Device *d) { return d->graph_bytes; }
+
+uint64_t device_classify(Device *d, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(d->dev));
+    d->n_sources = 0;
+    if (d->V) {
+        hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs, (uint32_t)d->V,
+                           d->d_mult, d->d_block_counts);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
+                           &d->d_counters[C_OVF_LIST]);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs,
+                           (uint32_t)d->V, d->d_block_counts, d->d_out_nodes);
+        HIP_CHECK(hipGetLastError());
+        read_counters(d, st);
+        d->n_sources = d->h_counters[C_OVF_LIST];
+    }
+    d->classified = true;
+    return d->n_sources;
+}
+
+void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int32_t *mult, uint8_t *live) {
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(d->dev));
+    if (!d->classified) MTG_DIE("mtg_classify_download: call mtg_classify first");
+    if (out_nodes && d->n_sources)
+        HIP_CHECK(hipMemcpyAsync(out_nodes, d->d_out_nodes, d->n_sources * 4, hipMemcpyDeviceToHost, st));
+    if (mult && d->V) HIP_CHECK(hipMemcpyAsync(mult, d->d_mult, d->V * 4, hipMemcpyDeviceToHost, st));
+    if (live && d->V) {
+        uint8_t *d_live = nullptr;
+        HIP_CHECK(hipMalloc(&d_live, d->V));
+        hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((d->V + 255) / 256)), dim3(256), 0, st, d->d_recs, (uint32_t)d->V, d_live);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(live, d_live, d->V, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipFree(d_live));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
+const uint32_t *device_d_out_nodes(const Device *d) { return d->d_out_nodes; }
+uint64_t device_n_sources(const Device *d) { return d->n_sources; }
+
+int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, uint64_t *d_pool, uint64_t pool_cap,
+                uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    return run_levels(d, (hipStream_t)stream, false, src_begin, src_end, (unsigned long long *)d_pool, pool_cap,
+                      (unsigned long long *)d_cand_start, d_cand_count, pool_needed, nullptr);
+}
+
+void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t n = src_end - src_begin;
+    unsigned long long *d_start = nullptr;
+    uint32_t *d_count = nullptr;
+    HIP_CHECK(hipMalloc(&d_start, std::max<uint64_t>(n, 1) * 8));
+    HIP_CHECK(hipMalloc(&d_count, std::max<uint64_t>(n, 1) * 4));
+    const double keep_ms = d->last_kernel_ms;
+    run_levels(d, (hipStream_t)stream, true, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
+    d->last_kernel_ms = keep_ms;
+    HIP_CHECK(hipFree(d_start));
+    HIP_CHECK(hipFree(d_count));
+}
+
+double device_last_kernel_ms(const Device *d) { return d->last_kernel_ms; }
+
+int device_set_preset(Device *d, int preset) {
+    if (preset >= 0 && preset < N_PRESETS) d->preset = preset;
+    return d->preset;
+}
+
+// convenience for the one-shot path: allocates device buffers, grows the pool on demand, downloads to host vectors
+void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start, std::vector<uint32_t> &cand_count,
+                               std::vector<uint64_t> &pool) {
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t S = d->n_sources;
+    cand_start.assign(S, 0);
+    cand_count.assign(S, 0);
+    pool.clear();
+    if (!S) return;
+    unsigned long long *d_start = nullptr, *d_pool = nullptr;
+    uint32_t *d_count = nullptr;
+    HIP_CHECK(hipMalloc(&d_start, S * 8));
+    HIP_CHECK(hipMalloc(&d_count, S * 4));
+    uint64_t cap = std::max<uint64_t>(S * 4, 1024);
+    for (;;) {
+        HIP_CHECK(hipMalloc(&d_pool, cap * 8));
+        uint64_t needed = 0;
+        const int rc = run_levels(d, st, false, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr);
+        if (rc == 0) {
+            pool.resize(needed);
+            if (needed) HIP_CHECK(hipMemcpyAsync(pool.data(), d_pool, needed * 8, hipMemcpyDeviceToHost, st));
+            break;
+        }
+        HIP_CHECK(hipFree(d_pool));
+        d_pool = nullptr;
+        cap = needed + needed / 8 + 1024;
+    }
+    HIP_CHECK(hipMemcpyAsync(cand_start.data(), d_start, S * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(cand_count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(d_pool));
+    HIP_CHECK(hipFree(d_start));
+    HIP_CHECK(hipFree(d_count));
+}
+
+}  // namespace mtg

@@ -1,0 +1,30 @@
+// device.hpp -- interface of the HIP device stage (device.hip) towards the C-ABI layer.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mtg_engine.h"
+#include "host_graph.hpp"
+
+namespace mtg {
+
+struct Device;
+
+int device_count();
+Device *device_create(const HostGraph &g, uint64_t k, int device_id);
+void device_free(Device *d);
+uint64_t device_graph_bytes(const Device *d);
+uint64_t device_classify(Device *d, void *stream);
+void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int32_t *mult, uint8_t *live);
+const uint32_t *device_d_out_nodes(const Device *d);
+uint64_t device_n_sources(const Device *d);
+int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, uint64_t *d_pool, uint64_t pool_cap,
+                uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed);
+void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+double device_last_kernel_ms(const Device *d);
+int device_set_preset(Device *d, int preset);
+void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
+                               std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);
+
+}  // namespace mtg

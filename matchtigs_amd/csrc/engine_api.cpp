@@ -1,0 +1,287 @@
+// engine_api.cpp -- extern "C" surface of libmatchtigs: include/mtg_engine.h and include/matchtigs.h.
+//
+// matchtigs_* are the drop-in replacements of /root/reference/src/clib.rs:87-410; mtg_* is the
+// engine layer underneath (see the header for which reference lines each stage replaces).
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstring>
+
+#include "../../include/matchtigs.h"
+#include "../../include/mtg_engine.h"
+#include "device.hpp"
+#include "host_graph.hpp"
+
+using namespace mtg;
+
+struct mtg_graph { HostGraph g; };
+struct mtg_device { Device *d; };
+struct mtg_walks { Walks w; };
+// The clib.rs handle is the same object as the engine graph.
+struct MatchtigsData { mtg_graph graph; };
+
+static thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static bool g_log_initialised = false;
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static void log_info(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+static void log_info(const char *fmt, ...) {
+    if (!g_log_initialised) return;  // the reference logs nothing before matchtigs_initialise either
+    va_list ap;
+    va_start(ap, fmt);
+    std::fprintf(stderr, "[INFO] ");
+    std::vfprintf(stderr, fmt, ap);
+    std::fprintf(stderr, "\n");
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *mtg_version(void) { return "matchtigs-amd 0.1 (gfx950; reference algbio/matchtigs 2.1.9)"; }
+int mtg_device_count(void) { return device_count(); }
+
+// ---- host graph ----
+mtg_graph *mtg_graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *edge_from,
+                                const uint32_t *edge_to, const uint64_t *edge_weight) {
+    HostGraph *h = graph_from_edges(n_nodes, mirror, n_edges, edge_from, edge_to, edge_weight);
+    mtg_graph *g = new mtg_graph{std::move(*h)};
+    delete h;
+    return g;
+}
+mtg_graph *mtg_graph_builder_new(uint64_t unitig_amount) {
+    HostGraph *h = builder_new(unitig_amount);
+    mtg_graph *g = new mtg_graph{std::move(*h)};
+    delete h;
+    return g;
+}
+void mtg_graph_builder_merge(mtg_graph *g, uint64_t ua, int sa, uint64_t ub, int sb) {
+    if (!g) MTG_DIE("mtg_graph_builder_merge: null graph");
+    builder_merge(&g->g, ua, sa != 0, ub, sb != 0);
+}
+void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights) {
+    if (!g) MTG_DIE("mtg_graph_builder_build: null graph");
+    builder_build(&g->g, unitig_weights);
+}
+void mtg_graph_free(mtg_graph *g) { delete g; }
+uint64_t mtg_graph_node_count(const mtg_graph *g) { return g->g.node_count(); }
+uint64_t mtg_graph_edge_count(const mtg_graph *g) { return g->g.edge_count(); }
+void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from, uint32_t *edge_to, uint64_t *edge_weight,
+                      uint64_t *edge_dummy_id, uint64_t *edge_unitig, uint8_t *edge_forwards) {
+    const HostGraph &h = g->g;
+    const size_t V = h.node_count(), E = h.edge_count();
+    if (mirror && V) std::memcpy(mirror, h.mirror.data(), V * 4);
+    if (edge_from && E) std::memcpy(edge_from, h.e_from.data(), E * 4);
+    if (edge_to && E) std::memcpy(edge_to, h.e_to.data(), E * 4);
+    if (edge_weight && E) std::memcpy(edge_weight, h.e_weight.data(), E * 8);
+    if (edge_dummy_id && E) std::memcpy(edge_dummy_id, h.e_dummy.data(), E * 8);
+    if (edge_unitig && E) std::memcpy(edge_unitig, h.e_unitig.data(), E * 8);
+    if (edge_forwards && E) std::memcpy(edge_forwards, h.e_fwd.data(), E);
+}
+
+// ---- device stage ----
+mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id) {
+    if (!g || !g->g.built) MTG_DIE("mtg_device_create: graph is not built");
+    for (uint64_t e = 0; e < g->g.n_original_edges; e++)
+        if (g->g.e_weight[e] == 0)
+            MTG_DIE("unitig %llu has weight 0: the bounded search needs weights >= 1 (the reference computes "
+                    "weight = len + 1 - k >= 1, bin.rs:369-376)", (unsigned long long)(e / 2));
+    return new mtg_device{device_create(g->g, k, device_id)};
+}
+void mtg_device_free(mtg_device *d) {
+    if (!d) return;
+    device_free(d->d);
+    delete d;
+}
+uint64_t mtg_device_graph_bytes(const mtg_device *d) { return device_graph_bytes(d->d); }
+uint64_t mtg_classify(mtg_device *d, void *stream) { return device_classify(d->d, stream); }
+void mtg_classify_download(mtg_device *d, void *stream, uint32_t *out_nodes, int32_t *multiplicity, uint8_t *is_in_node) {
+    device_classify_download(d->d, stream, out_nodes, multiplicity, is_in_node);
+}
+const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d) { return device_d_out_nodes(d->d); }
+int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, uint64_t *d_pool,
+                        uint64_t pool_capacity, uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed) {
+    return device_sssp(d->d, stream, src_begin, src_end, d_pool, pool_capacity, d_cand_start, d_cand_count, pool_needed);
+}
+double mtg_last_sssp_kernel_ms(const mtg_device *d) { return device_last_kernel_ms(d->d); }
+void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
+    device_sssp_count(d->d, stream, src_begin, src_end, stats);
+}
+int mtg_set_sssp_preset(mtg_device *d, int preset) { return device_set_preset(d->d, preset); }
+
+// ---- host stages ----
+uint64_t mtg_replay_claims(const mtg_graph *g, uint64_t n_sources, const uint32_t *out_nodes, const int32_t *multiplicity,
+                           const uint8_t *is_in_node, const uint64_t *cand_start, const uint32_t *cand_count,
+                           const uint64_t *pool, mtg_pair **pairs_out) {
+    std::vector<Pair> p = replay_claims(g->g, n_sources, out_nodes, multiplicity, is_in_node, cand_start, cand_count, pool);
+    static_assert(sizeof(Pair) == sizeof(mtg_pair), "pair layout");
+    mtg_pair *out = (mtg_pair *)std::malloc(std::max<size_t>(p.size(), 1) * sizeof(mtg_pair));
+    if (!out) MTG_DIE("out of memory");
+    if (!p.empty()) std::memcpy(out, p.data(), p.size() * sizeof(mtg_pair));
+    *pairs_out = out;
+    return p.size();
+}
+void mtg_free(void *p) { std::free(p); }
+
+uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs) {
+    return insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);
+}
+uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k) { return make_eulerian(g->g, dummy_edge_id, k); }
+mtg_walks *mtg_euler_cycles(const mtg_graph *g) { return new mtg_walks{euler_cycles(g->g)}; }
+mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k) {
+    return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
+}
+
+static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
+    double t0 = now_s();
+    log_info("Making graph Eulerian by adding breaking dummy edges");
+    make_eulerian(g, dummy_edge_id, k);
+    if (!is_eulerian(g)) MTG_DIE("Failed to make the graph Eulerian. (greedytigs/mod.rs:714)");
+    double t1 = now_s();
+    g_phase[5] += t1 - t0;
+    log_info("Finding Eulerian bicycle");
+    Walks cycles = euler_cycles(g);
+    double t2 = now_s();
+    g_phase[6] = t2 - t1;
+    log_info("Found %zu Eulerian bicycles", cycles.limits.size());
+    mtg_walks *tigs = new mtg_walks{cut_cycles(g, cycles, k)};
+    g_phase[7] = now_s() - t2;
+    return tigs;
+}
+
+mtg_walks *mtg_finish_greedytigs(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, uint64_t k) {
+    double t0 = now_s();
+    const uint64_t dummy_edge_id = insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);
+    g_phase[5] = now_s() - t0;
+    mtg_walks *tigs = eulerise_and_cut(g->g, dummy_edge_id, k);
+    log_info("Found %zu greedytigs", tigs->w.limits.size());
+    return tigs;
+}
+mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k) {
+    g_phase[5] = 0;
+    mtg_walks *tigs = eulerise_and_cut(g->g, 0, k);  // eulertigs/mod.rs:101-102
+    log_info("Found %zu eulertigs", tigs->w.limits.size());
+    return tigs;
+}
+
+uint64_t mtg_walks_count(const mtg_walks *w) { return w->w.limits.size(); }
+uint64_t mtg_walks_total_edges(const mtg_walks *w) { return w->w.edges.size(); }
+void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges) {
+    if (limits && !w->w.limits.empty()) std::memcpy(limits, w->w.limits.data(), w->w.limits.size() * 8);
+    if (edges && !w->w.edges.empty()) std::memcpy(edges, w->w.edges.data(), w->w.edges.size() * 4);
+}
+void mtg_walks_free(mtg_walks *w) { delete w; }
+
+uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out, uint64_t *tigs_insert_out,
+                          uint64_t *tigs_out_limits) {
+    return flatten_clib(g->g, tigs->w, tigs_edge_out, tigs_insert_out, tigs_out_limits);
+}
+
+mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {
+    if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs: graph is not built");
+    for (double &p : g_phase) p = 0;
+    switch (tig_algorithm) {
+        case 1: {  // clib.rs:351-361: one walk per forward unitig edge
+            mtg_walks *w = new mtg_walks();
+            for (uint64_t e = 0; e < g->g.edge_count(); e += 2) {
+                w->w.edges.push_back((uint32_t)e);
+                w->w.limits.push_back(w->w.edges.size());
+            }
+            return w;
+        }
+        case 3:
+            return mtg_compute_eulertigs(g, k);
+        case 5: {
+            double t0 = now_s();
+            mtg_device *dev = mtg_device_create(g, k, device_id);
+            double t1 = now_s();
+            g_phase[0] = t1 - t0;
+            log_info("Collecting nodes with missing incoming or outgoing edges");
+            const uint64_t S = mtg_classify(dev, nullptr);
+            std::vector<uint32_t> out_nodes(S);
+            std::vector<int32_t> mult(g->g.node_count());
+            std::vector<uint8_t> live(g->g.node_count());
+            mtg_classify_download(dev, nullptr, out_nodes.data(), mult.data(), live.data());
+            double t2 = now_s();
+            g_phase[1] = t2 - t1;
+            log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
+            std::vector<uint64_t> cand_start, pool;
+            std::vector<uint32_t> cand_count;
+            device_candidates_to_host(dev->d, nullptr, cand_start, cand_count, pool);
+            double t3 = now_s();
+            g_phase[2] = t3 - t2;  // includes the download (split not observable from here)
+            mtg_device_free(dev);
+            std::vector<Pair> pairs = replay_claims(g->g, S, out_nodes.data(), mult.data(), live.data(), cand_start.data(),
+                                                    cand_count.data(), pool.data());
+            double t4 = now_s();
+            g_phase[4] = t4 - t3;
+            log_info("Found %zu shortest paths", pairs.size());
+            return mtg_finish_greedytigs(g, reinterpret_cast<const mtg_pair *>(pairs.data()), pairs.size(), k);
+        }
+        case 2:
+            MTG_DIE("tig algorithm 2 (pathtigs) is outside the scope of the MI355X engine (SURVEY.md 2, row 11)");
+        case 4:
+            MTG_DIE("tig algorithm 4 (optimal matchtigs) needs the external blossom5 matcher and is outside the scope "
+                    "of the MI355X engine (SURVEY.md 2, row 10); use 5 for greedy matchtigs");
+        default:
+            MTG_DIE("Unknown tigs algorithm identifier %llu", (unsigned long long)tig_algorithm);  // clib.rs:390
+    }
+    return nullptr;
+}
+
+void mtg_last_phase_seconds(double out[8]) {
+    for (int i = 0; i < 8; i++) out[i] = g_phase[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// matchtigs.h: the reference's C-ABI (src/clib.rs)
+// ------------------------------------------------------------------------------------------------
+void matchtigs_initialise(void) {  // clib.rs:87-92
+    g_log_initialised = true;
+    log_info("Logging initialised successfully");
+}
+
+MatchtigsData *matchtigs_initialise_graph(size_t unitig_amount) {  // clib.rs:94-102
+    HostGraph *h = builder_new(unitig_amount);
+    MatchtigsData *d = new MatchtigsData{mtg_graph{std::move(*h)}};
+    delete h;
+    return d;
+}
+
+void matchtigs_merge_nodes(MatchtigsData *data, size_t unitig_a, bool strand_a, size_t unitig_b, bool strand_b) {  // clib.rs:135-170
+    if (!data) MTG_DIE("matchtigs_merge_nodes: matchtigs_data is null");
+    builder_merge(&data->graph.g, unitig_a, strand_a, unitig_b, strand_b);
+}
+
+void matchtigs_build_graph(MatchtigsData *data, const size_t *unitig_weights) {  // clib.rs:180-259
+    if (!data) MTG_DIE("matchtigs_build_graph: matchtigs_data is null");
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "64-bit only");
+    double t0 = now_s();
+    builder_build(&data->graph.g, reinterpret_cast<const uint64_t *>(unitig_weights));
+    log_info("Took %.6fs to build the tig graph", now_s() - t0);
+}
+
+size_t matchtigs_compute_tigs(MatchtigsData *data, size_t tig_algorithm, size_t threads, size_t k,
+                              const char *matching_file_prefix, const char *matcher_path, ptrdiff_t *tigs_edge_out,
+                              size_t *tigs_insert_out, size_t *tigs_out_limits) {  // clib.rs:280-410
+    if (!data) MTG_DIE("matchtigs_compute_tigs: matchtigs_data is null");
+    log_info("Computing tigs for k = %zu and %zu threads", k, threads);
+    log_info("Graph has %llu nodes and %llu edges", (unsigned long long)data->graph.g.node_count(),
+             (unsigned long long)data->graph.g.edge_count());
+    if (!matching_file_prefix) MTG_DIE("assertion failed: !matching_file_prefix.is_null() (clib.rs:300)");
+    if (!matcher_path) MTG_DIE("assertion failed: !matcher_path.is_null() (clib.rs:316)");
+    if (!tigs_edge_out) MTG_DIE("assertion failed: !tigs_edge_out.is_null() (clib.rs:333)");
+    if (!tigs_insert_out) MTG_DIE("assertion failed: !tigs_insert_out.is_null() (clib.rs:339)");
+    if (!tigs_out_limits) MTG_DIE("assertion failed: !tigs_out_limits.is_null() (clib.rs:345)");
+    static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "64-bit only");
+    mtg_walks *tigs = mtg_compute_tigs(&data->graph, tig_algorithm, k, 0);
+    const uint64_t n = flatten_clib(data->graph.g, tigs->w, reinterpret_cast<int64_t *>(tigs_edge_out),
+                                    reinterpret_cast<uint64_t *>(tigs_insert_out),
+                                    reinterpret_cast<uint64_t *>(tigs_out_limits));
+    delete tigs;
+    delete data;  // Box::from_raw at clib.rs:291: the handle is consumed
+    return n;
+}
+
+}  // extern "C"

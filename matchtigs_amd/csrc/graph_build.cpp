@@ -1,0 +1,153 @@
+// graph_build.cpp -- building the host bigraph: from flat edge arrays, or through the reference's
+// node-centric unitig-link interface (/root/reference/src/clib.rs:94-259).
+#include "host_graph.hpp"
+
+#include <algorithm>
+
+namespace mtg {
+
+void HostGraph::init_nodes(uint64_t n) {
+    if (n >= NONE) MTG_DIE("graph has %llu nodes; node ids are 32-bit", (unsigned long long)n);
+    mirror.assign(n, NONE);
+    head_out.assign(n, NONE);
+    out_deg.assign(n, 0);
+}
+
+void HostGraph::reserve_edges(uint64_t n) {
+    e_from.reserve(n); e_to.reserve(n); e_next_out.reserve(n);
+    e_weight.reserve(n); e_dummy.reserve(n); e_unitig.reserve(n); e_fwd.reserve(n);
+}
+
+static inline void push_edge(HostGraph &g, uint32_t from, uint32_t to, uint64_t w, uint64_t dummy, uint64_t unitig,
+                             bool fwd) {
+    if (g.e_from.size() >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
+    uint32_t e = (uint32_t)g.e_from.size();
+    g.e_from.push_back(from); g.e_to.push_back(to);
+    g.e_weight.push_back(w); g.e_dummy.push_back(dummy); g.e_unitig.push_back(unitig); g.e_fwd.push_back(fwd ? 1 : 0);
+    g.e_next_out.push_back(g.head_out[from]);  // newest first, like petgraph's per-node edge list
+    g.head_out[from] = e;
+    g.out_deg[from]++;
+}
+
+uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig) {
+    uint32_t e = (uint32_t)e_from.size();
+    push_edge(*this, from, to, weight, dummy_id, unitig, true);
+    push_edge(*this, mirror[to], mirror[from], weight, dummy_id, unitig, false);
+    return e;
+}
+
+void HostGraph::validate_pairing() const {
+    // graph.verify_node_pairing(), clib.rs:251
+    const uint64_t n = mirror.size();
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t m = mirror[i];
+        if (m == NONE || m >= n || mirror[m] != i)
+            MTG_DIE("assertion failed: graph.verify_node_pairing() (node %llu)", (unsigned long long)i);
+    }
+}
+
+HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *from,
+                            const uint32_t *to, const uint64_t *weight) {
+    if ((n_nodes && !mirror) || (n_edges && (!from || !to || !weight))) MTG_DIE("mtg_graph_from_edges: null array");
+    if (n_edges % 2) MTG_DIE("mtg_graph_from_edges: edges must come in (forward, mirror) pairs");
+    HostGraph *g = new HostGraph();
+    g->init_nodes(n_nodes);
+    for (uint64_t i = 0; i < n_nodes; i++) g->mirror[i] = mirror[i];
+    g->validate_pairing();
+    g->reserve_edges(n_edges);
+    for (uint64_t e = 0; e < n_edges; e += 2) {
+        uint32_t f = from[e], t = to[e];
+        if (f >= n_nodes || t >= n_nodes) MTG_DIE("edge %llu: node id out of range", (unsigned long long)e);
+        // graph.verify_edge_mirror_property(), clib.rs:252: the partner must be mirror(to) -> mirror(from)
+        if (from[e + 1] != g->mirror[t] || to[e + 1] != g->mirror[f] || weight[e + 1] != weight[e])
+            MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (edge %llu)", (unsigned long long)e);
+        g->add_biedge(f, t, weight[e], 0, e / 2);
+    }
+    g->n_original_edges = n_edges;
+    g->built = true;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Union-find with the representative choice of disjoint-sets 0.4.2 (Cargo.lock:412-416; SURVEY
+// App. A.4): union by rank, ties attach the first argument's root under the second's.
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t uf_root(HostGraph *g, uint64_t x) {
+    auto &p = g->uf_parent;
+    uint64_t r = x;
+    while (p[r] != r) r = p[r];
+    while (p[x] != r) {  // full compression; does not change which element is the root
+        uint64_t nx = p[x];
+        p[x] = r;
+        x = nx;
+    }
+    return r;
+}
+
+HostGraph *builder_new(uint64_t unitig_amount) {
+    HostGraph *g = new HostGraph();
+    g->has_builder = true;
+    g->unitig_amount = unitig_amount;
+    g->uf_parent.resize(unitig_amount * 4);
+    for (uint64_t i = 0; i < unitig_amount * 4; i++) g->uf_parent[i] = i;
+    g->uf_rank.assign(unitig_amount * 4, 0);
+    return g;
+}
+
+void builder_merge(HostGraph *g, uint64_t ua, bool sa, uint64_t ub, bool sb) {
+    if (!g || !g->has_builder || g->built) MTG_DIE("matchtigs_merge_nodes: graph is not in the building state");
+    if (ua >= g->unitig_amount || ub >= g->unitig_amount) MTG_DIE("matchtigs_merge_nodes: unitig id out of range");
+    // slots (clib.rs:104-122): fwd-in 4u, bwd-out 4u+1, fwd-out 4u+2, bwd-in 4u+3
+    const uint64_t out_a = sa ? ua * 4 + 2 : ua * 4 + 1;
+    const uint64_t in_b = sb ? ub * 4 : ub * 4 + 3;
+    const uint64_t mirror_in_a = sa ? ua * 4 + 3 : ua * 4;
+    const uint64_t mirror_out_b = sb ? ub * 4 + 1 : ub * 4 + 2;
+    const uint64_t pairs[2][2] = {{out_a, in_b}, {mirror_in_a, mirror_out_b}};  // clib.rs:168-169
+    for (auto &pr : pairs) {
+        uint64_t a = uf_root(g, pr[0]), b = uf_root(g, pr[1]);
+        if (a == b) continue;
+        uint8_t ra = g->uf_rank[a], rb = g->uf_rank[b];
+        if (ra > rb) g->uf_parent[b] = a;
+        else if (rb > ra) g->uf_parent[a] = b;
+        else { g->uf_parent[a] = b; g->uf_rank[b]++; }
+    }
+}
+
+void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
+    if (!g || !g->has_builder || g->built) MTG_DIE("matchtigs_build_graph: graph is not in the building state");
+    if (!unitig_weights) MTG_DIE("assertion failed: !unitig_weights.is_null() (clib.rs:188)");
+    const uint64_t slots = g->unitig_amount * 4;
+    // node id = rank of the representative among the sorted distinct representatives (clib.rs:193-234):
+    // mark roots, prefix-count them.
+    std::vector<uint32_t> node_of_root(slots, 0);
+    uint64_t n_nodes = 0;
+    for (uint64_t i = 0; i < slots; i++)
+        if (g->uf_parent[i] == i) {
+            if (n_nodes >= NONE - 1) MTG_DIE("too many nodes for 32-bit ids");
+            node_of_root[i] = (uint32_t)n_nodes++;
+        }
+    g->init_nodes(n_nodes);
+    g->reserve_edges(g->unitig_amount * 2);
+    for (uint64_t u = 0; u < g->unitig_amount; u++) {
+        const uint32_t n1 = node_of_root[uf_root(g, u * 4)];
+        const uint32_t n2 = node_of_root[uf_root(g, u * 4 + 2)];
+        const uint32_t mirror_n2 = node_of_root[uf_root(g, u * 4 + 3)];
+        const uint32_t mirror_n1 = node_of_root[uf_root(g, u * 4 + 1)];
+        g->mirror[n1] = mirror_n1; g->mirror[mirror_n1] = n1;   // set_mirror_nodes, clib.rs:236
+        g->mirror[n2] = mirror_n2; g->mirror[mirror_n2] = n2;   // clib.rs:237
+        push_edge(*g, n1, n2, unitig_weights[u], 0, u, true);                // clib.rs:239-243
+        push_edge(*g, mirror_n2, mirror_n1, unitig_weights[u], 0, u, false); // clib.rs:244-248
+    }
+    g->validate_pairing();  // clib.rs:251
+    // clib.rs:252 verify_edge_mirror_property: with a valid pairing the two edges of a unitig are mirrors of
+    // each other by construction only if later set_mirror_nodes calls did not re-pair their endpoints.
+    for (uint64_t e = 0; e < g->edge_count(); e += 2)
+        if (g->e_from[e + 1] != g->mirror[g->e_to[e]] || g->e_to[e + 1] != g->mirror[g->e_from[e]])
+            MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (unitig %llu)", (unsigned long long)(e / 2));
+    g->n_original_edges = g->edge_count();
+    g->built = true;
+    std::vector<uint64_t>().swap(g->uf_parent);
+    std::vector<uint8_t>().swap(g->uf_rank);
+}
+
+}  // namespace mtg

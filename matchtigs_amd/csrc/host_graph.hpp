@@ -1,0 +1,87 @@
+// host_graph.hpp -- host-side edge-centric bigraph of the MI355X greedy-matchtigs engine.
+//
+// Replaces the container the reference gets from bigraph/traitgraph/petgraph
+// (`NodeBigraphWrapper<PetGraph<(), EdgeData>>`, /root/reference/src/clib.rs:37, src/bin.rs:349-355).
+// Layout is flat structure-of-arrays; edges are always appended as (edge, mirror edge) pairs, so the
+// mirror of edge e is e ^ 1 (the reference looks it up by data equality).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define MTG_DIE(...)                                  \
+    do {                                              \
+        std::fprintf(stderr, "libmatchtigs: ");       \
+        std::fprintf(stderr, __VA_ARGS__);            \
+        std::fprintf(stderr, "\n");                   \
+        std::abort();                                 \
+    } while (0)
+
+namespace mtg {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct Pair {
+    uint32_t out_node;
+    uint32_t in_node;
+    uint64_t distance;
+};
+
+struct Walks {
+    std::vector<uint64_t> limits;  // exclusive end of walk i
+    std::vector<uint32_t> edges;   // edge ids
+};
+
+struct HostGraph {
+    // ---- clib.rs builder state (src/clib.rs:97-170) ----
+    bool has_builder = false;
+    bool built = false;
+    uint64_t unitig_amount = 0;
+    std::vector<uint64_t> uf_parent;
+    std::vector<uint8_t> uf_rank;
+
+    // ---- graph ----
+    std::vector<uint32_t> mirror;    // [V]
+    std::vector<uint32_t> head_out;  // [V] newest outgoing edge (petgraph iteration order: newest first)
+    std::vector<uint32_t> out_deg;   // [V]; in_deg(n) == out_deg(mirror(n)) by the mirror property
+    std::vector<uint32_t> e_from, e_to, e_next_out;  // [E]
+    std::vector<uint64_t> e_weight;                  // [E]
+    std::vector<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)
+    std::vector<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
+    std::vector<uint8_t> e_fwd;                      // [E]
+    uint64_t n_original_edges = 0;
+
+    uint64_t node_count() const { return mirror.size(); }
+    uint64_t edge_count() const { return e_from.size(); }
+    bool is_dummy(uint32_t e) const { return e_dummy[e] != 0; }
+    bool self_mirror(uint32_t n) const { return mirror[n] == n; }
+    uint32_t in_deg(uint32_t n) const { return out_deg[mirror[n]]; }
+
+    void reserve_edges(uint64_t n);
+    // Appends edge `from -> to` and its mirror `mirror(to) -> mirror(from)` (ids e, e+1).
+    uint32_t add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig);
+    void init_nodes(uint64_t n);
+    void validate_pairing() const;
+};
+
+// ---- construction (graph_build.cpp) ----
+HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *from,
+                            const uint32_t *to, const uint64_t *weight);
+HostGraph *builder_new(uint64_t unitig_amount);
+void builder_merge(HostGraph *g, uint64_t ua, bool sa, uint64_t ub, bool sb);
+void builder_build(HostGraph *g, const uint64_t *unitig_weights);
+
+// ---- host stages (host_pipeline.cpp) ----
+std::vector<Pair> replay_claims(const HostGraph &g, uint64_t n_sources, const uint32_t *out_nodes,
+                                const int32_t *multiplicity, const uint8_t *is_in_node, const uint64_t *cand_start,
+                                const uint32_t *cand_count, const uint64_t *pool);
+uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs);
+uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k);
+bool is_eulerian(const HostGraph &g);
+Walks euler_cycles(const HostGraph &g);
+Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k);
+uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, uint64_t *insert_out, uint64_t *limits);
+
+}  // namespace mtg

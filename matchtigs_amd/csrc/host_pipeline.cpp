@@ -1,0 +1,336 @@
+// host_pipeline.cpp -- the sequential stages of the greedy-matchtigs path that follow the GPU SSSP stage.
+//
+//   replay_claims      greedytigs/mod.rs:301-523  (claim loop, 1-thread order) over GPU candidate lists
+//   insert_pair_edges  greedytigs/mod.rs:678-689
+//   make_eulerian      implementation/mod.rs:392-649 (+ choose_in_node_from_iterator :252-285)
+//   euler_cycles       bigraph 5.0.1 compute_minimum_bidirected_eulerian_cycle_decomposition (call :722)
+//   cut_cycles         greedytigs/mod.rs:726-789 == eulertigs/mod.rs:123-186
+//   flatten_clib       clib.rs:393-407
+//
+// All citations are into /root/reference/src/. These are O(V+E) formulations that must produce the
+// same sequences as the reference's (BTreeMap / Vec::rotate_left based) code; see DESIGN.md.
+#include "host_graph.hpp"
+
+#include <algorithm>
+
+namespace mtg {
+
+// ---------------------------------------------------------------------------------------------
+// Claim loop over precomputed candidate lists.
+//
+// The reference runs, per source o, `while demand > 0 { D = truncated Dijkstra against the live
+// bitmap; claim from D }`. Because original weights are >= 1 and the graph does not change during
+// this phase (dummy edges are added afterwards, :678), the answer of each query is "the first
+// target_amount entries of L(o) that are still live", where L(o) (all *initial* in-nodes within
+// k-1 of o, o excluded, sorted by (distance, node)) is what the GPU stage produced; live bits are
+// only ever cleared (:456, :494, :499).
+// ---------------------------------------------------------------------------------------------
+std::vector<Pair> replay_claims(const HostGraph &g, uint64_t n_sources, const uint32_t *out_nodes,
+                                const int32_t *multiplicity, const uint8_t *is_in_node, const uint64_t *cand_start,
+                                const uint32_t *cand_count, const uint64_t *pool) {
+    const uint64_t V = g.node_count();
+    std::vector<int32_t> mult(multiplicity, multiplicity + V);
+    std::vector<uint8_t> live(is_in_node, is_in_node + V);
+    std::vector<Pair> result;
+    std::vector<uint64_t> found(8);
+
+    for (uint64_t i = 0; i < n_sources; i++) {
+        const uint32_t o = out_nodes[i];
+        const uint32_t om = g.mirror[o];
+        const bool o_sm = (om == o);
+        int32_t demand = mult[om];                                    // :306-311
+        // :313-316 is a debug_assert (0..=4) only; a release build of the reference accepts any degree.
+        if (demand == 0) continue;                                    // :318-320
+        const uint64_t *list = pool + cand_start[i];
+        const uint32_t len = cand_count[i];
+        while (demand > 0) {                                          // :322
+            const int target_amount = demand + 1;                     // :323
+            if ((size_t)target_amount > found.size()) found.resize((size_t)target_amount);
+            int nf = 0;
+            for (uint32_t c = 0; c < len && nf < target_amount; c++)  // the query :324-335
+                if (live[(uint32_t)list[c]]) found[nf++] = list[c];
+            if (nf == 0) break;                                       // :338-346
+            const bool abort_after_this = nf < target_amount;         // :348
+            for (int c = 0; c < nf; c++) {                            // :350
+                const uint32_t t = (uint32_t)found[c];
+                const uint64_t dist = found[c] >> 32;
+                bool self_edge = false;
+                if (t == om) {                                        // :352-358
+                    if (demand < 2) continue;
+                    self_edge = true;
+                }
+                const uint32_t tm = g.mirror[t];
+                const bool t_sm = (tm == t);
+                demand = o_sm ? mult[o] : -mult[o];                   // :401-410
+                if (demand == 0) break;                               // :412-414
+                if (!self_edge && mult[t] == 0) {                     // :454-458
+                    live[t] = 0;
+                    continue;
+                }
+                result.push_back(Pair{o, t, dist});                   // :461
+                const int red = self_edge ? 2 : 1;                    // :399
+                if (o_sm) mult[o] -= 1;                               // :463-466
+                else { mult[o] += red; mult[om] -= red; }             // :467-473
+                demand = -mult[o];                                    // :474
+                if (!self_edge) {                                     // :476-491
+                    mult[t] -= 1;
+                    if (!t_sm) mult[tm] += 1;
+                }
+                if (demand == 0) live[om] = 0;                        // :493-495
+                if (!self_edge && mult[t] == 0) live[t] = 0;          // :497-501
+            }
+            if (abort_after_this) break;                              // :504-511
+        }
+    }
+    return result;
+}
+
+// greedytigs/mod.rs:678-689
+uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
+    uint64_t dummy_edge_id = 0;
+    g.reserve_edges(g.edge_count() + 2 * n_pairs);
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        dummy_edge_id += 1;
+        g.add_biedge(pairs[i].out_node, pairs[i].in_node, pairs[i].distance, dummy_edge_id, 0);
+    }
+    return dummy_edge_id;
+}
+
+bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicycles (call :708)
+    const uint64_t V = g.node_count();
+    for (uint64_t n = 0; n < V; n++) {
+        if (g.self_mirror((uint32_t)n)) { if (g.out_deg[n] & 1) return false; }
+        else if (g.out_deg[n] != g.in_deg((uint32_t)n)) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// make_graph_eulerian_with_breaking_edges, implementation/mod.rs:392-649.
+//
+// The reference keeps two BTreeMaps (out-nodes keyed by Reverse(node), in-nodes keyed by node) that
+// only lose entries after construction, always takes their first keys, and looks entries up by
+// node. Dense formulation: need[n] < 0 for a present out-entry, > 0 for a present in-entry, 0 for
+// "not in either map"; the first keys are two monotone cursors.
+// ---------------------------------------------------------------------------------------------
+uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
+    const uint64_t V = g.node_count();
+    std::vector<int32_t> need(V, 0);
+    std::vector<uint32_t> self_mirrors;
+    for (uint64_t n = 0; n < V; n++) {  // find_non_eulerian_binodes_with_differences, :408
+        if (g.self_mirror((uint32_t)n)) {
+            if (g.out_deg[n] & 1) self_mirrors.push_back((uint32_t)n);  // difference 0 entries, :424-427
+        } else {
+            need[n] = (int32_t)((int64_t)g.out_deg[n] - (int64_t)g.in_deg((uint32_t)n));
+        }
+    }
+    uint64_t in_cur = 0;       // smallest node with need > 0
+    int64_t out_cur = (int64_t)V - 1;  // largest node with need < 0
+    auto first_in = [&](uint64_t from) -> uint64_t {
+        while (from < V && need[from] <= 0) from++;
+        return from;
+    };
+    auto breaking = [&](uint32_t out_node, uint32_t in_node) {  // :489-493, :506-510, :572-577
+        dummy_edge_id += 1;
+        g.add_biedge(out_node, in_node, k, dummy_edge_id, 0);
+    };
+
+    for (size_t p = 0; p < self_mirrors.size(); p += 2) {  // :481-524
+        if (p + 1 < self_mirrors.size()) {
+            breaking(self_mirrors[p], self_mirrors[p + 1]);
+        } else {
+            in_cur = first_in(in_cur);
+            if (in_cur >= V)
+                MTG_DIE("Have an uneven number of self-mirrors, but no other nodes with missing in edges. "
+                        "(implementation/mod.rs:496-498)");
+            const uint32_t in_node = (uint32_t)in_cur;
+            breaking(self_mirrors[p], in_node);
+            const uint32_t m = g.mirror[in_node];
+            if (need[m] >= 0) MTG_DIE("Mirror of in_node not found (implementation/mod.rs:517)");
+            need[in_node] -= 1;  // :512
+            need[m] += 1;        // removal at 0 (:513-517) / increment (:519-521) coincide in the dense form
+        }
+    }
+
+    for (;;) {  // :526
+        while (out_cur >= 0 && need[out_cur] >= 0) out_cur--;
+        if (out_cur < 0) break;
+        const uint32_t out_node = (uint32_t)out_cur;
+        const int32_t out_diff = need[out_node];
+        // choose_in_node_from_iterator, :252-285
+        in_cur = first_in(in_cur);
+        if (in_cur >= V) MTG_DIE("in_node_iterator.next().unwrap() on an empty map (implementation/mod.rs:262)");
+        uint64_t pick = in_cur;
+        if ((pick == g.mirror[out_node] && out_diff > -2) || pick == out_node) {
+            pick = first_in(pick + 1);
+            if (pick >= V) MTG_DIE("No further in_nodes left (implementation/mod.rs:553)");
+        }
+        const uint32_t in_node = (uint32_t)pick;
+        const uint32_t mirror_out_node = g.mirror[in_node];  // :569
+        const uint32_t mirror_in_node = g.mirror[out_node];  // :570
+        breaking(out_node, in_node);
+        need[out_node] += 1;  // :582 (entry disappears at 0, :590-594)
+        need[in_node] -= 1;   // :583 (:600-602)
+        if (need[mirror_out_node] < 0) need[mirror_out_node] += 1;  // :609-627, only if still present
+        if (need[mirror_in_node] > 0) need[mirror_in_node] -= 1;    // :628-644
+    }
+    if (first_in(in_cur) < V) MTG_DIE("in_node_differences not empty after Eulerisation (implementation/mod.rs:648)");
+    return dummy_edge_id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Euler bicycle decomposition (SURVEY App. A.2 policy), O(E):
+//  * an edge and its mirror edge (e ^ 1) are consumed together;
+//  * cycles start at the lowest unused edge id; the walk always takes the first unused out-edge in
+//    adjacency order (newest first) and can only get stuck at its start node;
+//  * the reference then scans the cycle vector from index 0 for the first edge whose from-node still
+//    has an unused out-edge, rotate_left()s the vector to that index and appends the next closed
+//    sub-walk. Here the cycle is a circular singly linked list of entries and the scan is a FIFO of
+//    not-yet-exhausted entries: "rotate to x and append W" == "insert W just before x, x is the new
+//    head"; inserting before x without a prev pointer is done by moving x's edge into a fresh entry y
+//    placed after W (x's old entry receives W's first edge, which leaves the same node).
+// ---------------------------------------------------------------------------------------------
+Walks euler_cycles(const HostGraph &g) {
+    const uint64_t E = g.edge_count();
+    const uint64_t V = g.node_count();
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    std::vector<uint8_t> used(E / 2 + 1, 0);           // per biedge
+    std::vector<uint32_t> cursor(g.head_out);          // first possibly-unused out-edge per node
+    std::vector<uint32_t> ent_edge, ent_next;          // circular lists of the cycle under construction
+    std::vector<uint32_t> fifo;                        // candidate entries in cycle order
+    Walks out;
+    out.edges.reserve(E / 2);
+    (void)V;
+
+    auto next_unused = [&](uint32_t node) -> uint32_t {
+        uint32_t e = cursor[node];
+        while (e != NONE && used[e >> 1]) e = g.e_next_out[e];
+        cursor[node] = e;
+        return e;
+    };
+
+    for (uint64_t e0 = 0; e0 < E; e0++) {
+        if (used[e0 >> 1]) continue;
+        ent_edge.clear(); ent_next.clear(); fifo.clear();
+        size_t fifo_head = 0;
+        uint32_t head = NONE;  // entry index of the cycle's first edge
+        uint32_t start_edge = (uint32_t)e0;
+        uint32_t splice_at = NONE;  // entry x before which the next closed walk is inserted (NONE: first walk)
+
+        while (start_edge != NONE) {
+            // ---- one closed walk W starting with start_edge ----
+            const uint32_t start_node = g.e_from[start_edge];
+            const size_t w_begin = ent_edge.size();
+            uint32_t e = start_edge;
+            for (;;) {
+                used[e >> 1] = 1;
+                ent_edge.push_back(e);
+                ent_next.push_back((uint32_t)ent_edge.size());  // provisional: chain to the following entry
+                const uint32_t node = g.e_to[e];
+                e = next_unused(node);
+                if (e == NONE) {
+                    if (node != start_node)
+                        MTG_DIE("Euler walk stuck at node %u != start node %u: graph is not Eulerian", node, start_node);
+                    break;
+                }
+            }
+            const size_t w_end = ent_edge.size();  // entries [w_begin, w_end)
+            if (splice_at == NONE) {
+                head = (uint32_t)w_begin;
+                ent_next[w_end - 1] = head;
+                for (size_t i = w_begin; i < w_end; i++) fifo.push_back((uint32_t)i);
+            } else {
+                // insert W before x = splice_at; x becomes y (a fresh entry) and stays the head.
+                const uint32_t x = splice_at;
+                const uint32_t y = (uint32_t)ent_edge.size();
+                ent_edge.push_back(ent_edge[x]);
+                ent_next.push_back(ent_next[x]);  // if x was the only entry this is x itself: y -> x(W1)
+                ent_edge[x] = ent_edge[w_begin];  // x now carries W's first edge (same from-node)
+                if (w_end - w_begin == 1) {
+                    ent_next[x] = y;
+                } else {
+                    ent_next[x] = (uint32_t)(w_begin + 1);
+                    ent_next[w_end - 1] = y;
+                }
+                // entry w_begin itself is now unused (its edge lives in x)
+                head = y;
+                fifo[fifo_head] = y;  // x was at the front of the FIFO; y takes its place
+                fifo.push_back(x);
+                for (size_t i = w_begin + 1; i < w_end; i++) fifo.push_back((uint32_t)i);
+            }
+            // ---- find the next start edge: first entry in cycle order whose from-node has an unused out-edge ----
+            start_edge = NONE;
+            while (fifo_head < fifo.size()) {
+                const uint32_t ent = fifo[fifo_head];
+                const uint32_t cand = next_unused(g.e_from[ent_edge[ent]]);
+                if (cand != NONE) { start_edge = cand; splice_at = ent; break; }
+                fifo_head++;
+            }
+        }
+        // ---- emit the cycle starting at head ----
+        uint32_t ent = head;
+        do {
+            out.edges.push_back(ent_edge[ent]);
+            ent = ent_next[ent];
+        } while (ent != head);
+        out.limits.push_back(out.edges.size());
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotate + cut, greedytigs/mod.rs:726-789 (== eulertigs/mod.rs:123-186), without moving data.
+// ---------------------------------------------------------------------------------------------
+Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
+    Walks tigs;
+    tigs.edges.reserve(cycles.edges.size());
+    uint64_t begin = 0;
+    for (size_t c = 0; c < cycles.limits.size(); c++) {
+        const uint32_t *cyc = cycles.edges.data() + begin;
+        const uint64_t len = cycles.limits[c] - begin;
+        begin = cycles.limits[c];
+        uint64_t longest_w = 0, rot = 0;                         // :737-745
+        for (uint64_t i = 0; i < len; i++) {
+            const uint32_t e = cyc[i];
+            if (g.is_dummy(e) && g.e_weight[e] > longest_w) { longest_w = g.e_weight[e]; rot = i; }
+        }
+        if (longest_w == 0) rot = 0;                             // :746-748
+        auto at = [&](uint64_t i) -> uint32_t { uint64_t j = i + rot; return cyc[j >= len ? j - len : j]; };
+        auto emit = [&](uint64_t from, uint64_t to) {            // rotated indices [from, to)
+            for (uint64_t i = from; i < to; i++) tigs.edges.push_back(at(i));
+            tigs.limits.push_back(tigs.edges.size());
+        };
+        uint64_t offset = 0;                                     // :750
+        for (uint64_t i = 0; i < len; i++) {                     // :752
+            const uint32_t e = at(i);
+            const bool dummy = g.is_dummy(e);
+            if (dummy && (g.e_weight[e] >= k || i == 0)) {       // :767-769
+                if (offset < i) emit(offset, i);                 // :770-771
+                offset = i + 1;                                  // :775
+            }
+        }
+        if (offset < len) {                                      // :779-788
+            if (!g.is_dummy(at(len - 1))) emit(offset, len);
+            else if (offset < len - 1) emit(offset, len - 1);
+        }
+    }
+    return tigs;
+}
+
+// clib.rs:393-407
+uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, uint64_t *insert_out,
+                      uint64_t *limits) {
+    uint64_t begin = 0;
+    for (size_t i = 0; i < tigs.limits.size(); i++) {
+        for (uint64_t j = begin; j < tigs.limits[i]; j++) {
+            const uint32_t e = tigs.edges[j];
+            edge_out[j] = (int64_t)g.e_unitig[e] * (g.e_fwd[e] ? 1 : -1);
+            insert_out[j] = g.is_dummy(e) ? g.e_weight[e] : 0;
+        }
+        begin = tigs.limits[i];
+        limits[i] = begin;
+    }
+    return tigs.limits.size();
+}
+
+}  // namespace mtg
