@@ -43,6 +43,21 @@ def declared_symbols() -> list[str]:
     return sorted(set(names))
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """Process-level plumbing. PyTorch wheels bundle their own libamdhip64 and request it as
+    'libamdhip64.so', while libmatchtigs.so requests ROCm's 'libamdhip64.so.7'. If libmatchtigs is loaded
+    first, torch later maps a SECOND HIP runtime into the process and neither sees the other's device
+    pointers/streams. Loading torch's copy first makes the dynamic loader satisfy our NEEDED entry with
+    it (same SONAME), so both share one runtime. A pure C caller never goes through here."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -52,6 +67,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C matchtigs_amd/csrc`. matchtigs_amd has no fallback without its HIP library."
         )
+    _share_hip_runtime_with_torch()
     L = C.CDLL(str(LIB_PATH))
     vp, u32, u64, i64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_int32
     P = C.POINTER
