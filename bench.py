@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- greedy-matchtigs hot path on N MI355X GPUs (contract: see the task statement / DESIGN.md 'Measurement').
+
+One "step" = one full pass of the hot path over one synthetic unitig graph whose device copy is already
+resident in HBM: node classification (GPU) -> bounded many-to-many SSSP candidate generation for this
+rank's block of sources (GPU) -> [N>1: one all-gather of candidate lists over RCCL] -> greedy claim
+replay -> dummy insertion + Eulerisation -> Euler bicycle decomposition -> cut into tigs (host, rank 0)
+-> graph reset (drop the dummy edges again). Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 3 --warmup 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(stats: dict) -> int:
+    """5 B per relaxed edge + 12 B per settled node + 12 B per emitted candidate."""
+    return 5 * stats["relaxed_edges"] + 12 * stats["settled_nodes"] + 12 * stats["emitted"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2-edges", type=int, default=24, help="|E| ~ 2^x directed unitig edges per GPU-equivalent")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--preset", type=int, default=-1, help="SSSP kernel geometry preset (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the matchtigs_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from matchtigs_amd import api, synth, torch_glue
+    from matchtigs_amd import distributed as mdist
+
+    k = args.k
+    # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned
+    n_binodes = int((1 << args.log2_edges) / 1.5 / 2)
+    t_gen = time.perf_counter()
+    bg = synth.g_csr(n_binodes, seed=args.seed, k=k)
+    graph = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    dev = api.DeviceGraph(graph, k, local_rank)  # H2D: inputs resident in HBM before any timed region
+    if args.preset >= 0:
+        dev.set_preset(args.preset)
+    t_gen = time.perf_counter() - t_gen
+    stream = torch_glue.current_stream_ptr()
+
+    bufs = None
+    kernel_ms: list[float] = []
+    phases_acc: dict[str, float] = {}
+    result_info: dict = {}
+
+    def sync_barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step(record: bool):
+        nonlocal bufs
+        ph = {}
+        t0 = time.perf_counter()
+        S = dev.classify(stream)
+        ranges = mdist.partition_sources(S, world)
+        lo, hi = ranges[rank]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ph["classify"] = t1 - t0
+        if bufs is None or bufs.n != hi - lo:
+            bufs = torch_glue.CandidateBuffers(hi - lo, max(1024, 4 * (hi - lo)))
+        bufs = torch_glue.run_sssp(dev, lo, hi, bufs)
+        t2 = time.perf_counter()
+        ph["sssp"] = t2 - t1
+        if record:
+            kernel_ms.append(dev.last_sssp_kernel_ms())
+        if world > 1:
+            start_all, count_all, pool_all = mdist.allgather_candidates(bufs.start, bufs.count, bufs.pool, bufs.used, ranges)
+            torch.cuda.synchronize()
+        else:
+            start_all, count_all, pool_all = bufs.start[: bufs.n], bufs.count[: bufs.n], bufs.pool[: bufs.used]
+        t3 = time.perf_counter()
+        ph["allgather"] = t3 - t2
+        if rank == 0:
+            cs, cc, po = mdist.to_numpy_u(start_all, count_all, pool_all)
+            on, mu, li = dev.classify_download(stream)
+            t4 = time.perf_counter()
+            ph["download"] = t4 - t3
+            pairs = graph.replay_claims(on, mu, li, cs, cc, po)
+            t5 = time.perf_counter()
+            ph["replay"] = t5 - t4
+            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k)
+            t6 = time.perf_counter()
+            ph["eulerise_euler_cut"] = t6 - t5
+            hp = api.last_phase_seconds()
+            ph["host_eulerise"], ph["host_euler"], ph["host_cut"] = hp["eulerise"], hp["euler"], hp["cut"]
+            result_info.update(S=int(S), pairs=int(len(pairs)), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
+                               candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
+            graph.reset()
+            ph["reset"] = time.perf_counter() - t6
+        if record:
+            for kk, v in ph.items():
+                phases_acc[kk] = phases_acc.get(kk, 0.0) + v
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync_barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+
+    # ---- units of work (untimed counting kernel over this rank's block) ----
+    S = dev.n_sources
+    lo, hi = mdist.partition_sources(S, world)[rank]
+    stats = dev.sssp_count(lo, hi, stream)
+    local_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+    tot = torch.tensor([stats["relaxed_edges"], stats["settled_nodes"], stats["emitted"], stats["relax_attempts"],
+                        stats["overflow_sources"]], dtype=torch.int64, device="cuda")
+    kmax = torch.tensor([local_kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    tot = [int(x) for x in tot.tolist()]
+    total_stats = dict(relaxed_edges=tot[0], settled_nodes=tot[1], emitted=tot[2], relax_attempts=tot[3], overflow_sources=tot[4])
+
+    if rank == 0:
+        # roofline of the dominant kernel (sssp_kernel, level 0) on THIS rank's launch
+        alg_bytes = algorithmic_bytes(stats)
+        achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "sssp_kernel (level 0)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": args.traffic_bytes,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(local_kernel_ms, 4),
+            "kernel_sssp_edges_per_s": round(stats["relaxed_edges"] / (local_kernel_ms * 1e-3), 1) if local_kernel_ms > 0 else 0.0,
+            "work_efficiency_attempts_per_edge": round(stats["relax_attempts"] / max(stats["relaxed_edges"], 1), 4),
+        }
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_baseline = run_cpu_baseline(bg, k, args.cpu_baseline_seconds)
+        value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
+        out = {
+            "metric": "greedy-matchtigs SSSP edges/s (whole hot-path step: classify+SSSP+claim+Euler+cut)",
+            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "wall_clock_s": round(ms_per_step / 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+            "config": {"workload": f"G-csr random bidirected de Bruijn-like unitig graph (C. elegans-like), k={k}, "
+                                   f"|V|={bg.n_nodes}, |E|={bg.n_edges}, seed={args.seed}; sources block-partitioned over ranks",
+                       "V": bg.n_nodes, "E": bg.n_edges, "k": k, "sources": result_info.get("S"),
+                       "pairs": result_info.get("pairs"), "tigs": result_info.get("tigs"),
+                       "candidates": result_info.get("candidates"), "parallelism": f"sources/{world}"},
+            "units_per_step": total_stats,
+            "phases_ms": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in phases_acc.items()},
+            "setup_s": round(t_gen, 2),
+            "device_graph_bytes": dev.graph_bytes(),
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(bg, k: int, budget_s: float) -> dict:
+    """Oracle (C restatement of the reference's 1-thread CPU path) timed on a bounded prefix of the same sources."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+
+    og = oracle_lib.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    t0 = time.perf_counter()
+    _, st = og.greedy_pairs_np(k, 50000)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(len(og.classify()[0]), max(50000, 50000 * budget_s / dt)))
+    t0 = time.perf_counter()
+    _, st = og.greedy_pairs_np(k, n)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(st["relaxed_edges"] / dt, 1), "unit": "edges/s", "cores": 1, "kind": "port",
+        "sample": f"first {n} sources of the same graph, reference-style truncated Dijkstra + claim loop "
+                  f"(oracle/mtg_oracle.c og_greedy_pairs_prefix), {dt:.1f} s",
+        "sources_per_s": round(n / dt, 1), "relaxed_edges": st["relaxed_edges"], "settled_nodes": st["settled_nodes"],
+        "queries": st["queries"], "seconds": round(dt, 2),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,9 @@ mtg_graph *mtg_graph_builder_new(uint64_t unitig_amount);
 void mtg_graph_builder_merge(mtg_graph *g, uint64_t unitig_a, int strand_a, uint64_t unitig_b, int strand_b);
 void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights);
 void mtg_graph_free(mtg_graph *g);
+/* Removes every dummy edge again (undoes what compute_tigs appended), restoring the adjacency order of the
+ * original graph exactly. The reference instead clones the graph before each algorithm (bin.rs:1069). */
+void mtg_graph_reset(mtg_graph *g);
 uint64_t mtg_graph_node_count(const mtg_graph *g);
 uint64_t mtg_graph_edge_count(const mtg_graph *g); /* includes dummy edges added so far */
 /* Copy out the current graph (any pointer may be NULL). forwards: 1/0. dummy_id 0 = original. */

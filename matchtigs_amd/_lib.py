@@ -79,6 +79,7 @@ def load():
         "mtg_graph_builder_merge": (None, [vp, u64, C.c_int, u64, C.c_int]),
         "mtg_graph_builder_build": (None, [vp, vp]),
         "mtg_graph_free": (None, [vp]),
+        "mtg_graph_reset": (None, [vp]),
         "mtg_graph_node_count": (u64, [vp]),
         "mtg_graph_edge_count": (u64, [vp]),
         "mtg_graph_export": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),

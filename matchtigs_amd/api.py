@@ -162,6 +162,10 @@ class Bigraph:
     def handle(self) -> int:
         return self._h
 
+    def reset(self) -> None:
+        """Drop all dummy edges again (the reference clones its graph instead, bin.rs:1069)."""
+        self._L.mtg_graph_reset(self._h)
+
     def node_count(self) -> int:
         return int(self._L.mtg_graph_node_count(self._h))
 
@@ -339,6 +343,13 @@ class EulertigAlgorithm(TigAlgorithm):
     def compute_tigs(cls, graph: Bigraph, configuration: EulertigAlgorithmConfiguration):
         L = _lib.load()
         return _take_walks(L, L.mtg_compute_eulertigs(graph.handle, configuration.k))
+
+
+def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int):
+    """mtg_finish_greedytigs returning flat numpy walks (limits, edges) -- for large graphs."""
+    L = _lib.load()
+    p = np.ascontiguousarray(pairs)
+    return _take_walks_np(L, L.mtg_finish_greedytigs(graph.handle, _ptr(p), len(p), k))
 
 
 def last_phase_seconds() -> dict:

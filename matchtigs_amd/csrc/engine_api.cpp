@@ -65,6 +65,10 @@ void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights) {
     builder_build(&g->g, unitig_weights);
 }
 void mtg_graph_free(mtg_graph *g) { delete g; }
+void mtg_graph_reset(mtg_graph *g) {
+    if (!g || !g->g.built) MTG_DIE("mtg_graph_reset: graph is not built");
+    g->g.reset_to_original();
+}
 uint64_t mtg_graph_node_count(const mtg_graph *g) { return g->g.node_count(); }
 uint64_t mtg_graph_edge_count(const mtg_graph *g) { return g->g.edge_count(); }
 void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from, uint32_t *edge_to, uint64_t *edge_weight,

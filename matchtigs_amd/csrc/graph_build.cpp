@@ -36,6 +36,18 @@ uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint
     return e;
 }
 
+void HostGraph::reset_to_original() {
+    while (e_from.size() > n_original_edges) {
+        const uint32_t e = (uint32_t)e_from.size() - 1;
+        const uint32_t f = e_from[e];
+        if (head_out[f] != e) MTG_DIE("reset_to_original: adjacency list is not in insertion order");
+        head_out[f] = e_next_out[e];
+        out_deg[f]--;
+        e_from.pop_back(); e_to.pop_back(); e_next_out.pop_back();
+        e_weight.pop_back(); e_dummy.pop_back(); e_unitig.pop_back(); e_fwd.pop_back();
+    }
+}
+
 void HostGraph::validate_pairing() const {
     // graph.verify_node_pairing(), clib.rs:251
     const uint64_t n = mirror.size();

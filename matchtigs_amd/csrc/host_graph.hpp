@@ -64,6 +64,8 @@ struct HostGraph {
     uint32_t add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig);
     void init_nodes(uint64_t n);
     void validate_pairing() const;
+    // Pops all edges beyond the original ones (newest first), restoring head_out / out_deg.
+    void reset_to_original();
 };
 
 // ---- construction (graph_build.cpp) ----

@@ -1,0 +1,69 @@
+"""Multi-GPU plumbing for the one real exchange step of the path.
+
+The graph is replicated on every GPU; the ascending source list is block-partitioned over ranks
+(contiguous blocks, so concatenating the ranks' candidate lists in rank order *is* the replay order);
+after the per-rank SSSP stage there is ONE variable-length all-gather of candidate lists
+(``torch.distributed`` = RCCL over xGMI on GPUs, gloo in the CPU tests), then the sequential claim
+replay. No other collective exists on the path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_sources(n_sources: int, world_size: int) -> list[tuple[int, int]]:
+    """Contiguous, near-equal blocks [lo, hi) per rank (the reference hands out contiguous chunks of
+    out_nodes too, greedytigs/mod.rs:573-616, but dynamically; here the split is static)."""
+    base, rem = divmod(n_sources, world_size)
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def allgather_candidates(start: torch.Tensor, count: torch.Tensor, pool: torch.Tensor, pool_used: int,
+                         ranges: list[tuple[int, int]], group=None):
+    """All ranks contribute (start[int64 n_r], count[int32 n_r], pool[int64 >= pool_used]) for their source block.
+
+    Returns (start_all, count_all, pool_all) on the same device, indexed by absolute source index, with
+    ``start`` rebased into the concatenated pool. Message shape: per rank one padded int64 buffer
+    [n_max + n_max/2(+1) + pool_max] (starts | counts packed 2 per word | keys) -> a single all_gather.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = pool.device
+    n_local = ranges[rank][1] - ranges[rank][0]
+    sizes = torch.tensor([pool_used], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    pool_sizes = [int(t.item()) for t in all_sizes]
+    n_max = max(hi - lo for lo, hi in ranges)
+    p_max = max(pool_sizes)
+    cnt_words = (n_max + 1) // 2
+    msg = torch.zeros(n_max + cnt_words + p_max, dtype=torch.int64, device=dev)
+    msg[:n_local] = start[:n_local]
+    cnt_pad = torch.zeros(cnt_words * 2, dtype=torch.int32, device=dev)
+    cnt_pad[:n_local] = count[:n_local]
+    msg[n_max:n_max + cnt_words] = cnt_pad.view(torch.int64)
+    msg[n_max + cnt_words:n_max + cnt_words + pool_used] = pool[:pool_used]
+    gathered = [torch.empty_like(msg) for _ in range(world)]
+    dist.all_gather(gathered, msg, group=group)
+    starts, counts, pools = [], [], []
+    offset = 0
+    for r, (lo, hi) in enumerate(ranges):
+        n_r = hi - lo
+        g = gathered[r]
+        starts.append(g[:n_r] + offset)
+        counts.append(g[n_max:n_max + cnt_words].view(torch.int32)[:n_r])
+        pools.append(g[n_max + cnt_words:n_max + cnt_words + pool_sizes[r]])
+        offset += pool_sizes[r]
+    return torch.cat(starts), torch.cat(counts), torch.cat(pools)
+
+
+def to_numpy_u(start_all: torch.Tensor, count_all: torch.Tensor, pool_all: torch.Tensor):
+    return (start_all.cpu().numpy().view(np.uint64), count_all.cpu().numpy().view(np.uint32),
+            pool_all.cpu().numpy().view(np.uint64))

@@ -133,6 +133,14 @@ uint32_t og_add_edge(og_graph *g, uint32_t from, uint32_t to, uint64_t weight, u
     g->out_deg[from]++; g->in_deg[to]++;
     return e;
 }
+og_graph *og_graph_from_arrays(uint32_t n_nodes, const uint32_t *mirror, uint32_t n_edges, const uint32_t *from,
+                               const uint32_t *to, const uint64_t *weight) {
+    og_graph *g = og_graph_new(n_nodes);
+    for (uint32_t n = 0; n < n_nodes; n++) g->mirror[n] = mirror[n];
+    grow_edges(g, n_edges);
+    for (uint32_t e = 0; e < n_edges; e++) og_add_edge(g, from[e], to[e], weight[e], 0, e / 2, e % 2 == 0);
+    return g;
+}
 uint32_t og_node_count(const og_graph *g) { return g->n_nodes; }
 uint32_t og_edge_count(const og_graph *g) { return g->n_edges; }
 uint32_t og_mirror_node(const og_graph *g, uint32_t n) { return g->mirror[n]; }

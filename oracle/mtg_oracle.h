@@ -40,6 +40,9 @@ void og_set_mirror_nodes(og_graph *g, uint32_t a, uint32_t b);
 /* add_edge: edge ids are dense in insertion order (clib.rs:355 relies on it). */
 uint32_t og_add_edge(og_graph *g, uint32_t from, uint32_t to, uint64_t weight,
                      uint64_t dummy_id, uint64_t handle, int forwards);
+/* Bulk constructor for benchmarks: original edges in id order (edge 2u forwards of unitig u, 2u+1 its mirror). */
+og_graph *og_graph_from_arrays(uint32_t n_nodes, const uint32_t *mirror, uint32_t n_edges, const uint32_t *from,
+                               const uint32_t *to, const uint64_t *weight);
 uint32_t og_node_count(const og_graph *g);
 uint32_t og_edge_count(const og_graph *g);
 uint32_t og_mirror_node(const og_graph *g, uint32_t n);

@@ -61,6 +61,7 @@ def lib():
     sig = {
         "og_graph_new": (vp, [u32]),
         "og_graph_free": (None, [vp]),
+        "og_graph_from_arrays": (vp, [u32, vp, u32, vp, vp, vp]),
         "og_add_node": (u32, [vp]),
         "og_set_mirror_nodes": (None, [vp, u32, u32]),
         "og_add_edge": (u32, [vp, u32, u32, u64, u64, u64, C.c_int]),
@@ -146,12 +147,13 @@ class OracleGraph:
     def from_arrays(cls, mirror, e_from, e_to, e_weight):
         """Original-edge arrays in edge-id order; edge 2u forward of unitig u, edge 2u+1 its mirror."""
         L = lib()
-        n = len(mirror)
-        g = L.og_graph_new(n)
-        for a in range(n):
-            L.og_set_mirror_nodes(g, a, int(mirror[a]))
-        for e in range(len(e_from)):
-            L.og_add_edge(g, int(e_from[e]), int(e_to[e]), int(e_weight[e]), 0, e // 2, 1 if e % 2 == 0 else 0)
+        m = np.ascontiguousarray(mirror, dtype=np.uint32)
+        f = np.ascontiguousarray(e_from, dtype=np.uint32)
+        t = np.ascontiguousarray(e_to, dtype=np.uint32)
+        w = np.ascontiguousarray(e_weight, dtype=np.uint64)
+        vp = C.c_void_p
+        g = L.og_graph_from_arrays(len(m), m.ctypes.data_as(vp), len(f), f.ctypes.data_as(vp), t.ctypes.data_as(vp),
+                                   w.ctypes.data_as(vp))
         return cls(g)
 
     @classmethod
