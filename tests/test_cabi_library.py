@@ -1,0 +1,123 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares; host-side
+interface mirror (enums, configs, error behaviour). No compute calls that need a GPU."""
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from matchtigs_amd import _lib, api
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_loads_and_exports_every_declared_symbol(product_lib):
+    names = _lib.declared_symbols()
+    assert len(names) >= 40
+    # the reference's five clib.rs entry points are all there
+    for n in ("matchtigs_initialise", "matchtigs_initialise_graph", "matchtigs_merge_nodes", "matchtigs_build_graph",
+              "matchtigs_compute_tigs"):
+        assert n in names
+    missing = [n for n in names if not hasattr(product_lib, n)]
+    assert not missing, missing
+    assert b"matchtigs" in product_lib.mtg_version()
+
+
+def test_nm_shows_c_linkage(product_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    syms = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    for n in _lib.declared_symbols():
+        assert n in syms  # unmangled => extern "C"
+
+
+def test_headers_compile_as_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "matchtigs.h"\n#include "mtg_engine.h"\nint main(void){return sizeof(mtg_pair)==16?0:1;}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")],
+                   check=True)
+
+
+def test_enum_from_str_and_config_defaults():
+    assert api.NodeWeightArrayType.from_str("EpochNodeWeightArray") is api.NodeWeightArrayType.EpochNodeWeightArray
+    assert api.HeapType.from_str("StdBinaryHeap") is api.HeapType.StdBinaryHeap
+    assert api.PerformanceDataType.from_str("None") is api.PerformanceDataType.None_
+    with pytest.raises(ValueError, match="Unknown heap type: Foo"):          # implementation/mod.rs:98-100
+        api.HeapType.from_str("Foo")
+    with pytest.raises(ValueError, match="Unknown node weight array type"):  # :78-80
+        api.NodeWeightArrayType.from_str("x")
+    c = api.GreedytigAlgorithmConfiguration.new(4, 31)                       # greedytigs/mod.rs:62-72
+    assert (c.threads, c.k, c.staged_parallelism_divisor, c.resource_limit_factor) == (4, 31, None, 0)
+    assert c.node_weight_array_type is api.NodeWeightArrayType.HashbrownHashMap
+    assert c.heap_type is api.HeapType.StdBinaryHeap and c.performance_data_type is api.PerformanceDataType.None_
+
+
+def test_edge_data_view():
+    e = api.MatchtigEdgeData.new(7, True, 12, 0)
+    assert e.is_original() and not e.is_dummy() and e.is_forwards() and e.weight() == 12
+    m = e.mirror()
+    assert m.is_backwards() and m.sequence_handle == 7 and m.weight() == 12 and m.mirror() == e
+    assert api.MatchtigEdgeData.new(0, True, 3, 5).is_dummy()
+
+
+def _run_snippet(code: str):
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, cwd=str(ROOT))
+
+
+def test_abort_conventions_match_reference_panics(product_lib):
+    # unknown algorithm id -> panic at clib.rs:390
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api
+        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 9, 1, 5)
+    """)
+    assert r.returncode != 0 and "Unknown tigs algorithm identifier 9" in r.stderr
+    # out-of-scope algorithms say so
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api
+        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 4, 1, 5)
+    """)
+    assert r.returncode != 0 and "blossom5" in r.stderr
+    # null weights -> assert at clib.rs:188
+    r = _run_snippet("""
+        from matchtigs_amd import _lib
+        L = _lib.load(); d = L.matchtigs_initialise_graph(2); L.matchtigs_build_graph(d, None)
+    """)
+    assert r.returncode != 0 and "clib.rs:188" in r.stderr
+    # broken mirror pairing -> assert like clib.rs:251
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api
+        api.Bigraph.from_edges(np.array([1,0,2,2],np.uint32)[:3], np.zeros(0,np.uint32), np.zeros(0,np.uint32), np.zeros(0,np.uint64))
+        api.Bigraph.from_edges(np.array([1,2,0],np.uint32), np.zeros(0,np.uint32), np.zeros(0,np.uint32), np.zeros(0,np.uint64))
+    """)
+    assert r.returncode != 0 and "verify_node_pairing" in r.stderr
+
+
+def test_greedy_without_gpu_fails_loudly(product_lib):
+    """No CPU fallback: on a box without a GPU the greedy path must abort with a clear message (on a GPU box it runs)."""
+    if product_lib.mtg_device_count() > 0:
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api
+        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 5, 1, 5)
+    """)
+    assert r.returncode != 0 and "no CPU path" in r.stderr
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G = api.Bigraph.from_unitig_links(np.array([3, 3], dtype=np.uint64), [(0, True, 1, True)])
+        api.DeviceGraph(G, 5)
+
+
+def test_weight_zero_rejected_at_the_boundary(product_lib):
+    if product_lib.mtg_device_count() > 0:
+        pytest.skip("needs the no-GPU ordering of checks")
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api, _lib
+        G = api.Bigraph.from_unitig_links(np.array([0, 3], dtype=np.uint64), [(0, True, 1, True)])
+        _lib.load().mtg_device_create(G.handle, 5, 0)
+    """)
+    assert r.returncode != 0 and "weight 0" in r.stderr

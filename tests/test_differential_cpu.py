@@ -1,0 +1,132 @@
+"""Differential tests on seeded random bigraphs, CPU only:
+   oracle (C) vs independent Python restatement vs the PRODUCT's host stages (replay, Euleriser,
+   linked-list Hierholzer, cutter, clib flattening, clib builder)."""
+import numpy as np
+import pytest
+
+import helpers
+import pyref
+from matchtigs_amd import api, synth
+
+
+def _cases():
+    out = []
+    for seed in range(1, 25):
+        k = [5, 9, 31][seed % 3]
+        out.append((seed, k, dict(n_binodes=40 + seed * 9, seed=seed, k=k, mean_out_degree=1.2 + 0.1 * (seed % 8),
+                                  mean_weight=[2.0, 4.0, 8.0][seed % 3], self_mirror_frac=0.05)))
+    return out
+
+
+@pytest.mark.parametrize("seed,k,kw", _cases(), ids=[f"seed{c[0]}-k{c[1]}" for c in _cases()])
+def test_three_way_agreement(seed, k, kw, oracle, product_lib):
+    bg = synth.g_csr(**kw)
+    arrs = (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    og = helpers.oracle_graph(*arrs)
+    pairs_o, st_o = og.greedy_pairs(k)
+    pairs_p, st_p = pyref.greedy_pairs(helpers.py_graph(*arrs), k)
+    assert pairs_o == pairs_p
+    assert st_o["relaxed_edges"] == st_p["relaxed_edges"] and st_o["settled_nodes"] == st_p["settled_nodes"]
+    # product replay on oracle candidate lists == oracle's truncated-Dijkstra claim loop (T2)
+    G = helpers.product_graph(*arrs)
+    pr = helpers.product_pairs_from_oracle_lists(G, helpers.oracle_graph(*arrs), k)
+    assert [(int(a), int(b), int(c)) for a, b, c in pr] == pairs_o
+    # full tig pipelines (T3/T4)
+    og2 = helpers.oracle_graph(*arrs)
+    tigs_o, _ = og2.compute_greedytigs(k)
+    tigs_p, _, _ = pyref.compute_greedytigs(helpers.py_graph(*arrs), k)
+    assert tigs_o == tigs_p
+    assert G.finish_greedytigs(pr, k) == tigs_o
+    # the product's mutated graph equals the oracle's (same dummy edges in the same order)
+    ex = G.export()
+    oe = og2.edges()
+    assert len(oe) == len(ex["edge_from"])
+    assert [e[0] for e in oe] == ex["edge_from"].tolist() and [e[1] for e in oe] == ex["edge_to"].tolist()
+    assert [e[2] for e in oe] == ex["edge_weight"].tolist() and [e[3] for e in oe] == ex["edge_dummy_id"].tolist()
+    # invariants lifted from the reference's asserts
+    assert og2.is_eulerian() and og2.no_consecutive_dummy_edges(k)
+    for t in tigs_o:
+        assert oe[t[0]][3] == 0 and oe[t[-1]][3] == 0            # greedytigs/mod.rs:794-798
+    for e in oe:
+        if e[3] != 0:
+            assert (1 <= e[2] <= k - 1) or e[2] == k               # matched dummies <= k-1, breaking == k
+    # clib flattening
+    eo, io, lim = G.flatten_clib(tigs_o)
+    peo, pio, plim = pyref.flatten_clib(helpers.py_graph(*arrs) if False else _pg_after(arrs, k), tigs_o)
+    assert (eo, io, lim) == (peo, pio, plim)
+    # reset restores the original graph exactly
+    G.reset()
+    ex2 = G.export()
+    assert ex2["edge_from"].tolist() == bg.edge_from.tolist() and G.edge_count() == bg.n_edges
+
+
+def _pg_after(arrs, k):
+    g = helpers.py_graph(*arrs)
+    pyref.compute_greedytigs(g, k)
+    return g
+
+
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_eulertigs_three_way(seed, oracle, product_lib):
+    k = [5, 9, 31][seed % 3]
+    bg = synth.g_csr(60 + 11 * seed, seed=100 + seed, k=k, mean_out_degree=1.0 + 0.15 * (seed % 7), mean_weight=3.0,
+                     self_mirror_frac=0.08)
+    arrs = (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    et_o = helpers.oracle_graph(*arrs).compute_eulertigs(k)
+    et_p = pyref.compute_eulertigs(helpers.py_graph(*arrs), k)
+    et = api.EulertigAlgorithm.compute_tigs(helpers.product_graph(*arrs), api.EulertigAlgorithmConfiguration(k))
+    assert et_o == et_p == et
+
+
+def test_euler_cycles_linked_list_equals_literal_on_larger_graph(oracle, product_lib):
+    """The product's O(E) splice formulation vs the oracle's literal rotate_left formulation, 60k edges."""
+    k = 31
+    bg = synth.g_csr(20000, seed=77, k=k)
+    arrs = (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    og = helpers.oracle_graph(*arrs)
+    pairs, _ = og.greedy_pairs_np(k)
+    G = helpers.product_graph(*arrs)
+    og.insert_pair_edges([(int(a), int(b), int(c)) for a, b, c in pairs])
+    G.insert_pair_edges(pairs)
+    d1 = og.make_eulerian(k, len(pairs))
+    d2 = G.make_eulerian(len(pairs), k)
+    assert d1 == d2
+    assert og.euler_cycles() == G.euler_cycles()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_clib_builder_matches_oracle_and_pyref(seed, oracle, product_lib):
+    ug = synth.g_seq(1500, seed=seed, k=11, haplotypes=3, sub_rate=0.04)
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    pg = pyref.from_unitig_links([int(x) for x in ug.weights], ug.links)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    ex = G.export()
+    assert og.node_count == pg.n == G.node_count()
+    assert og.mirror().tolist() == pg.mirror == ex["mirror"].tolist()
+    oe = og.edges()
+    assert [e[0] for e in oe] == [e.frm for e in pg.edges] == ex["edge_from"].tolist()
+    assert [e[1] for e in oe] == [e.to for e in pg.edges] == ex["edge_to"].tolist()
+    assert [e[4] for e in oe] == ex["edge_unitig"].tolist()
+    assert [e[5] for e in oe] == [bool(x) for x in ex["edge_forwards"]]
+    # eulertigs and unitigs through the real C-ABI (no GPU needed for ids 3 and 1)
+    for alg in (3, 1):
+        n, eo, io, lo = api.clib_compute_tigs(ug.weights, ug.links, alg, 1, ug.k)
+        n_o, eo_o, io_o, lo_o = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links).clib_compute_tigs(alg, ug.k)
+        assert n == n_o and np.array_equal(eo, eo_o) and np.array_equal(io, io_o) and np.array_equal(lo, lo_o)
+
+
+def test_edge_cases_empty_and_balanced(oracle, product_lib):
+    # empty graph
+    G = api.Bigraph.from_edges(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64))
+    assert api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(31)) == []
+    # one isolated unitig: nodes 0,1 / mirrors 3,2 ... unitig 0->1, mirror 2... use 2 binodes
+    mirror, frm, to, w = helpers.unitigs_to_arrays([1, 0, 3, 2], [[0, 2, 7]])
+    et = api.EulertigAlgorithm.compute_tigs(helpers.product_graph(mirror, frm, to, w), api.EulertigAlgorithmConfiguration(5))
+    assert et == helpers.oracle_graph(mirror, frm, to, w).compute_eulertigs(5)
+    assert len(et) == 1 and len(et[0]) == 1
+    # a perfectly balanced cycle of three unitigs: no imbalance, no dummy edges, one circular tig (cut nowhere)
+    mirror, frm, to, w = helpers.unitigs_to_arrays([1, 0, 3, 2, 5, 4], [[0, 2, 3], [2, 4, 3], [4, 0, 3]])
+    G = helpers.product_graph(mirror, frm, to, w)
+    et = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(5))
+    assert et == helpers.oracle_graph(mirror, frm, to, w).compute_eulertigs(5)
+    assert G.edge_count() == 6 and len(et) == 1 and len(et[0]) == 3
