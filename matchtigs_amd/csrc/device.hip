@@ -153,7 +153,7 @@ constexpr int ENT_SRC_SHIFT = 54, ENT_NODE_SHIFT = 22;
 constexpr unsigned long long ENT_DIST_MASK = 0x1FFFFFull;
 
 enum Counter : int {
-    C_BATCH = 0,     // dynamic batch counter
+    C_BATCH = 0,     // (unused since kernel v2: batches are strided statically)
     C_POOL = 1,      // pool cursor (keys)
     C_OVERFLOW = 2,  // number of overflowed sources
     C_SETTLED = 3,
@@ -232,64 +232,80 @@ __device__ __forceinline__ int tbl_relax(unsigned long long *table, uint32_t src
     return -1;
 }
 
-template <int BLOCK, int LOGH, int QCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
+// ---- SSSP kernel, version 2 ------------------------------------------------------------------
+// Changes against the first correct kernel (profiles/r01_baseline_*): no global atomic per batch any more
+// (batches are strided statically over the persistent grid; pool space is taken in block-local chunks;
+// counters are flushed once per block), the frontier is ONE append-only log so that emission and the
+// table clean-up walk only the touched slots instead of scanning/clearing the whole table per batch.
+constexpr unsigned long long POOL_CHUNK = 2048;  // keys per block-local pool chunk
+
+template <int BLOCK, int LOGH, int QCAP, int SCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
 struct SsspLds {
     static constexpr uint32_t H = 1u << LOGH;
     unsigned long long table[GLOBAL_WS ? 1 : H];
-    uint32_t queue[GLOBAL_WS ? 1 : 2 * QCAP];   // two frontier buffers; reused as u64 staging at emission
-    uint16_t stage_src[GLOBAL_WS ? 1 : QCAP];
-    uint32_t qn[2];
+    unsigned long long stage[GLOBAL_WS ? 1 : SCAP];  // emission staging: keys per source segment
+    uint32_t log[GLOBAL_WS ? 1 : QCAP];              // every push of the batch, in push order (rounds are ranges)
+    uint16_t stage_src[GLOBAL_WS ? 1 : SCAP];
     uint32_t srcnode[BSRC];
     uint32_t cnt[BSRC];
     uint32_t off[BSRC];
     uint32_t fill[BSRC];
-    uint32_t batch;
+    uint32_t tail;   // next free log position (may run past QCAP -> overflow)
+    uint32_t end;    // snapshot of tail taken between two barriers
     uint32_t ovf;
-    uint32_t total;
-    unsigned long long base;
-    unsigned long long st_settled, st_relaxed, st_attempts;
+    uint32_t total;  // keys emitted by this batch
+    unsigned long long base;                    // pool position of this batch's keys
+    unsigned long long chunk_next, chunk_end;   // block-local pool chunk
+    unsigned long long bt_settled, bt_relaxed, bt_attempts;              // per batch (COUNT)
+    unsigned long long st_settled, st_relaxed, st_attempts, st_emitted;  // per block (COUNT)
 };
 
-template <int BLOCK, int LOGH, int QCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
+template <int BLOCK, int LOGH, int QCAP, int SCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
 __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
-    static_assert(BSRC <= 512 && BSRC <= BLOCK, "BSRC limits");
-    static_assert(LOGH <= 22, "slot must fit the queue item");
+    static_assert(BSRC <= 512 && BSRC <= BLOCK && BLOCK >= 64, "BSRC/BLOCK limits");
+    static_assert(LOGH <= 22, "slot must fit the log item");
     constexpr uint32_t H = 1u << LOGH;
-    constexpr int HINT_BITS = 32 - LOGH;                 // distance hint bits in a queue item
+    constexpr int HINT_BITS = 32 - LOGH;  // distance (hint) bits of a log item
     constexpr uint32_t HINT_MASK = (1u << HINT_BITS) - 1u;
+    // With >= 16 hint bits the hint IS the distance (k-1 <= 65535): the push that carries an entry's final
+    // distance is unique, so the log doubles as the list of live table slots.
+    constexpr bool LOG_EMIT = HINT_BITS >= 16;
     using M = Mem<GLOBAL_WS>;
-    __shared__ SsspLds<BLOCK, LOGH, QCAP, BSRC, COUNT, GLOBAL_WS> s;
+    __shared__ SsspLds<BLOCK, LOGH, QCAP, SCAP, BSRC, COUNT, GLOBAL_WS> s;
 
-    unsigned long long *table;
-    uint32_t *queue;
+    unsigned long long *table, *stage;
+    uint32_t *log;
     uint16_t *stage_src;
     if constexpr (GLOBAL_WS) {
         unsigned long long *base = a.ws + (uint64_t)blockIdx.x * a.ws_stride;
         table = base;
-        queue = reinterpret_cast<uint32_t *>(base + H);
-        stage_src = reinterpret_cast<uint16_t *>(base + H + QCAP);
+        stage = base + H;
+        log = reinterpret_cast<uint32_t *>(base + H + SCAP);
+        stage_src = reinterpret_cast<uint16_t *>(base + H + SCAP + (QCAP + 1) / 2);
     } else {
         table = s.table;
-        queue = s.queue;
+        stage = s.stage;
+        log = s.log;
         stage_src = s.stage_src;
     }
-    unsigned long long *stage = reinterpret_cast<unsigned long long *>(queue);  // QCAP keys
 
     const int tid = threadIdx.x;
     const uint64_t n_batches = (a.n_items + BSRC - 1) / BSRC;
 
-    for (;;) {
-        if (tid == 0) s.batch = (uint32_t)atomicAdd(&a.counters[C_BATCH], 1ull);
-        __syncthreads();
-        const uint64_t batch = s.batch;
-        if (batch >= n_batches) break;  // uniform
+    for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
+    if (tid == 0) {
+        s.chunk_next = 0; s.chunk_end = 0;
+        s.st_settled = 0; s.st_relaxed = 0; s.st_attempts = 0; s.st_emitted = 0;
+    }
+    __syncthreads();
+
+    for (uint64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
         const uint64_t item0 = batch * BSRC;
         const int nsrc = (int)min((uint64_t)BSRC, a.n_items - item0);
 
-        // ---- init ----
-        for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
+        // ---- init (the table is clean here) ----
         if (tid < BSRC) { s.cnt[tid] = 0; s.fill[tid] = 0; }
-        if (tid == 0) { s.qn[0] = (uint32_t)nsrc; s.qn[1] = 0; s.ovf = 0; s.st_settled = 0; s.st_relaxed = 0; s.st_attempts = 0; }
+        if (tid == 0) { s.tail = (uint32_t)nsrc; s.ovf = 0; s.bt_settled = 0; s.bt_relaxed = 0; s.bt_attempts = 0; }
         __syncthreads();
         if (tid < nsrc) {
             const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
@@ -298,24 +314,21 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             uint32_t slot = 0;
             const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
             if (r < 0) s.ovf = 1;
-            M::st(&queue[tid], (slot << HINT_BITS) | 0u);
+            M::st(&log[tid], (slot << HINT_BITS) | 0u);
         }
         __syncthreads();
+        if (tid == 0) s.end = s.ovf ? 0u : (uint32_t)nsrc;  // loop bounds are only ever published between two barriers
+        __syncthreads();
 
-        // ---- label-correcting rounds ----
-        int cur = 0;
-        for (int round = 0;; round++) {
-            const uint32_t n_items = s.qn[cur];
-            if (n_items == 0 || s.ovf) break;  // uniform (LDS, read after barrier)
-            if (round > 1 << 20) { if (tid == 0) s.ovf = 1; break; }
-            uint32_t *qin = queue + cur * QCAP;
-            uint32_t *qout = queue + (cur ^ 1) * QCAP;
-            for (uint32_t i = tid; i < n_items; i += BLOCK) {
-                const uint32_t item = M::ld(&qin[i]);
+        // ---- label-correcting rounds: round r processes log[begin, end), pushes append at tail ----
+        uint32_t begin = 0, end = s.end;
+        for (int round = 0; begin < end; round++) {  // uniform: `end` is a snapshot published by thread 0
+            for (uint32_t i = begin + tid; i < end; i += BLOCK) {
+                const uint32_t item = M::ld(&log[i]);
                 const uint32_t slot = item >> HINT_BITS;
                 const unsigned long long e = M::ld(&table[slot]);
                 const uint32_t d = (uint32_t)((e >> 1) & ENT_DIST_MASK);
-                if ((d & HINT_MASK) != (item & HINT_MASK)) continue;  // superseded by a shorter distance (dedup hint)
+                if ((d & HINT_MASK) != (item & HINT_MASK)) continue;  // superseded by a shorter distance
                 const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
                 const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
                 // one aligned 32-byte gather: neighbours, weights, flags
@@ -325,73 +338,78 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 const uint32_t flags = (hi.z >> 8) & 0xFFu;
                 if (flags & F_TARGET) M::fand(&table[slot], ~1ull);  // node property: confirmed in-node
                 uint32_t deg, pushed_ovf = 0;
+                auto relax = [&](uint32_t nb, uint32_t w) {
+                    const uint32_t nd = d + w;
+                    if (nd > a.K1) return;
+                    uint32_t nslot = 0;
+                    const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, nb, nd, nslot);
+                    if (r > 0) {
+                        const uint32_t pos = atomicAdd(&s.tail, 1u);
+                        if (pos < (uint32_t)QCAP) M::st(&log[pos], (nslot << HINT_BITS) | (nd & HINT_MASK));
+                        else pushed_ovf = 1;
+                    } else if (r < 0) pushed_ovf = 1;
+                };
                 if (!(flags & F_EXT)) {
                     deg = hi.z & 0xFFu;
                     const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
                     const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (j < (int)deg) {
-                            const uint32_t nd = d + ww[j];
-                            if (nd <= a.K1) {
-                                uint32_t nslot = 0;
-                                const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, nb[j], nd, nslot);
-                                if (r > 0) {
-                                    const uint32_t pos = atomicAdd(&s.qn[cur ^ 1], 1u);
-                                    if (pos < (uint32_t)QCAP) M::st(&qout[pos], (nslot << HINT_BITS) | (nd & HINT_MASK));
-                                    else pushed_ovf = 1;
-                                } else if (r < 0) pushed_ovf = 1;
-                            }
-                        }
-                    }
+                    for (int j = 0; j < 4; j++)
+                        if (j < (int)deg) relax(nb[j], ww[j]);
                 } else {
                     const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
                     deg = lo.z;
-                    for (uint32_t j = 0; j < deg; j++) {
-                        const uint32_t nd = d + a.ext_w[eb + j];
-                        if (nd <= a.K1) {
-                            uint32_t nslot = 0;
-                            const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, a.ext_col[eb + j], nd, nslot);
-                            if (r > 0) {
-                                const uint32_t pos = atomicAdd(&s.qn[cur ^ 1], 1u);
-                                if (pos < (uint32_t)QCAP) M::st(&qout[pos], (nslot << HINT_BITS) | (nd & HINT_MASK));
-                                else pushed_ovf = 1;
-                            } else if (r < 0) pushed_ovf = 1;
-                        }
-                    }
+                    for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
                 }
                 if (pushed_ovf) s.ovf = 1;
-                if constexpr (COUNT) atomicAdd(&s.st_attempts, (unsigned long long)deg);
+                if constexpr (COUNT) atomicAdd(&s.bt_attempts, (unsigned long long)deg);
             }
             __syncthreads();
-            if (tid == 0) s.qn[cur] = 0;
-            cur ^= 1;
+            if (tid == 0) {
+                if (round > (1 << 20)) s.ovf = 1;
+                s.end = s.ovf ? end : min(s.tail, (uint32_t)QCAP);  // on overflow: no progress -> the loop ends
+            }
             __syncthreads();
+            begin = end;
+            end = s.end;
         }
         __syncthreads();
+        const uint32_t n_log = min(s.tail, (uint32_t)QCAP);
+
+        // visits every live table entry exactly once: f(entry)
+        auto for_each_entry = [&](auto &&f) {
+            if constexpr (LOG_EMIT) {
+                for (uint32_t i = tid; i < n_log; i += BLOCK) {
+                    const uint32_t item = M::ld(&log[i]);
+                    const unsigned long long e = M::ld(&table[item >> HINT_BITS]);
+                    if (((uint32_t)((e >> 1) & ENT_DIST_MASK) & HINT_MASK) != (item & HINT_MASK)) continue;  // not the final push of this slot
+                    f(e);
+                }
+            } else {
+                for (uint32_t i = tid; i < H; i += BLOCK) {
+                    const unsigned long long e = M::ld(&table[i]);
+                    if (e != TBL_EMPTY) f(e);
+                }
+            }
+        };
 
         // ---- emission ----
-        const bool ovf = s.ovf != 0;
-        if (!ovf) {
-            // pass 1: per-source counts
-            for (uint32_t i = tid; i < H; i += BLOCK) {
-                const unsigned long long e = M::ld(&table[i]);
-                if (e == TBL_EMPTY) continue;
+        if (!s.ovf) {
+            for_each_entry([&](unsigned long long e) {  // pass 1: per-source counts
                 const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
                 const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
                 if constexpr (COUNT) {
-                    atomicAdd(&s.st_settled, 1ull);
+                    atomicAdd(&s.bt_settled, 1ull);
                     const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
                     const uint4 lo = rp[0];
                     const uint4 hi = rp[1];
                     const uint32_t flags = (hi.z >> 8) & 0xFFu;
-                    atomicAdd(&s.st_relaxed, (unsigned long long)((flags & F_EXT) ? lo.z : (hi.z & 0xFFu)));
+                    atomicAdd(&s.bt_relaxed, (unsigned long long)((flags & F_EXT) ? lo.z : (hi.z & 0xFFu)));
                 }
                 if (!(e & 1ull) && node != s.srcnode[src]) atomicAdd(&s.cnt[src], 1u);
-            }
+            });
             __syncthreads();
-            // exclusive scan of cnt[0..nsrc) by the first wave
-            if (tid < 64) {
+            if (tid < 64) {  // exclusive scan of cnt[0..nsrc) by the first wave, then pool space for the batch
                 uint32_t running = 0;
                 for (int base = 0; base < BSRC; base += 64) {
                     const int i = base + tid;
@@ -406,27 +424,33 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 }
                 if (tid == 0) {
                     s.total = running;
-                    if (running > (uint32_t)QCAP) s.ovf = 1;  // staging too small -> larger level
-                    else s.base = COUNT ? 0ull : atomicAdd(&a.counters[C_POOL], (unsigned long long)running);
+                    if (running > (uint32_t)SCAP) s.ovf = 1;  // staging too small -> larger level
+                    else if constexpr (!COUNT) {
+                        if (s.chunk_next + running > s.chunk_end) {
+                            const unsigned long long grab = running > POOL_CHUNK ? (unsigned long long)running : POOL_CHUNK;
+                            s.chunk_next = atomicAdd(&a.counters[C_POOL], grab);
+                            s.chunk_end = s.chunk_next + grab;
+                        }
+                        s.base = s.chunk_next;
+                        s.chunk_next += running;
+                    } else s.base = 0;
                 }
             }
             __syncthreads();
         }
         if (!s.ovf) {
             if constexpr (!COUNT) {
-                // pass 2: stage keys per source segment (unsorted)
-                for (uint32_t i = tid; i < H; i += BLOCK) {
-                    const unsigned long long e = M::ld(&table[i]);
-                    if (e == TBL_EMPTY || (e & 1ull)) continue;
+                for_each_entry([&](unsigned long long e) {  // pass 2: stage keys per source segment (unsorted)
+                    if (e & 1ull) return;
                     const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
                     const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
-                    if (node == s.srcnode[src]) continue;
+                    if (node == s.srcnode[src]) return;
                     const uint32_t pos = s.off[src] + atomicAdd(&s.fill[src], 1u);
                     M::st(&stage[pos], (((e >> 1) & ENT_DIST_MASK) << 32) | (unsigned long long)node);
                     M::st(&stage_src[pos], (uint16_t)src);
-                }
+                });
                 __syncthreads();
-                // pass 3: rank within the source's segment, write sorted
+                // pass 3: rank within the source's segment (= sort by (distance, node)), write contiguous
                 const uint32_t total = s.total;
                 const unsigned long long base = s.base;
                 for (uint32_t i = tid; i < total; i += BLOCK) {
@@ -445,13 +469,11 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 a.cand_start[o] = s.base + s.off[tid];
                 a.cand_count[o] = s.cnt[tid];
             }
-            if (tid == 0) {
-                if constexpr (COUNT) {
-                    atomicAdd(&a.counters[C_SETTLED], s.st_settled);
-                    atomicAdd(&a.counters[C_RELAXED], s.st_relaxed);
-                    atomicAdd(&a.counters[C_ATTEMPTS], s.st_attempts);
+            if constexpr (COUNT) {
+                if (tid == 0) {
+                    s.st_settled += s.bt_settled; s.st_relaxed += s.bt_relaxed; s.st_attempts += s.bt_attempts;
+                    s.st_emitted += s.total;
                 }
-                atomicAdd(&a.counters[C_EMITTED], (unsigned long long)s.total);
             }
         } else {
             if (tid < nsrc) {
@@ -461,6 +483,23 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             if (tid == 0) atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)nsrc);
         }
         __syncthreads();
+
+        // ---- clean the table for the next batch ----
+        if (LOG_EMIT && !s.ovf) {
+            for (uint32_t i = tid; i < n_log; i += BLOCK) M::st(&table[M::ld(&log[i]) >> HINT_BITS], TBL_EMPTY);
+        } else {  // overflowed batches may have table entries that never reached the log
+            for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
+        }
+        __syncthreads();
+    }
+
+    if constexpr (COUNT) {
+        if (tid == 0) {
+            atomicAdd(&a.counters[C_SETTLED], s.st_settled);
+            atomicAdd(&a.counters[C_RELAXED], s.st_relaxed);
+            atomicAdd(&a.counters[C_ATTEMPTS], s.st_attempts);
+            atomicAdd(&a.counters[C_EMITTED], s.st_emitted);
+        }
     }
 }
 
@@ -510,26 +549,28 @@ struct LevelCfg {
     int bsrc;
     int logh;
     int qcap;
+    int scap;
     bool global_ws;
 };
 
-template <int BLOCK, int LOGH, int QCAP, int BSRC, bool GLOBAL_WS>
+template <int BLOCK, int LOGH, int QCAP, int SCAP, int BSRC, bool GLOBAL_WS>
 static LevelCfg make_cfg() {
-    return LevelCfg{sssp_kernel<BLOCK, LOGH, QCAP, BSRC, false, GLOBAL_WS>, sssp_kernel<BLOCK, LOGH, QCAP, BSRC, true, GLOBAL_WS>,
-                    BLOCK, BSRC, LOGH, QCAP, GLOBAL_WS};
+    return LevelCfg{sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, false, GLOBAL_WS>,
+                    sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
 static const int N_PRESETS = 4;
 static LevelCfg level0_cfg(int preset) {
     switch (preset) {
-        case 1: return make_cfg<128, 11, 1024, 32, false>();
-        case 2: return make_cfg<64, 10, 512, 16, false>();
-        case 3: return make_cfg<512, 13, 4096, 128, false>();
-        default: return make_cfg<256, 12, 2048, 64, false>();
+        //                  BLOCK LOGH  QCAP  SCAP BSRC
+        case 1: return make_cfg<128, 11, 1024, 512, 32, false>();
+        case 2: return make_cfg<64, 10, 512, 256, 16, false>();
+        case 3: return make_cfg<512, 13, 4096, 2048, 128, false>();
+        default: return make_cfg<256, 12, 2048, 1024, 64, false>();
     }
 }
-static LevelCfg level1_cfg() { return make_cfg<256, 14, 2048, 1, false>(); }
-static LevelCfg level2_cfg() { return make_cfg<256, 22, 1 << 21, 1, true>(); }
+static LevelCfg level1_cfg() { return make_cfg<256, 14, 4096, 1024, 1, false>(); }
+static LevelCfg level2_cfg() { return make_cfg<256, 22, 1 << 22, 1 << 21, 1, true>(); }
 
 static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool count, SsspArgs args, bool time_it) {
     if (args.n_items == 0) return;
@@ -544,14 +585,14 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
     if (cfg.global_ws) {
         grid = std::min<uint64_t>(grid, 64);
         const uint64_t H = 1ull << cfg.logh;
-        ws_stride = H + (uint64_t)cfg.qcap + ((uint64_t)cfg.qcap * 2 + 7) / 8;  // table + queue(2*QCAP u32) + stage_src
+        // table[H] u64 | stage[SCAP] u64 | log[QCAP] u32 | stage_src[SCAP] u16
+        ws_stride = H + (uint64_t)cfg.scap + ((uint64_t)cfg.qcap + 1) / 2 + ((uint64_t)cfg.scap + 3) / 4;
         grid = std::min<uint64_t>(grid, n_batches);
         HIP_CHECK(hipMalloc(&ws, grid * ws_stride * 8));
     }
     grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, n_batches));
     args.ws = ws;
     args.ws_stride = ws_stride;
-    HIP_CHECK(hipMemsetAsync(&d->d_counters[C_BATCH], 0, sizeof(unsigned long long), st));
     if (time_it) HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
     HIP_CHECK(hipGetLastError());
@@ -615,9 +656,11 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         stats->relax_attempts = d->h_counters[C_ATTEMPTS];
         stats->overflow_sources = total_overflow;
     }
-    if (pool_needed) *pool_needed = d->h_counters[C_POOL];
-    if (!count && d->h_counters[C_POOL] > pool_cap) return 1;
-    return 0;
+    // C_POOL is the pool cursor: keys plus the unused tails of block-local chunks (positions are launch-dependent,
+    // (start,count) index the content). A retry may chunk differently, hence the slack.
+    const bool too_small = !count && d->h_counters[C_POOL] > pool_cap;
+    if (pool_needed) *pool_needed = d->h_counters[C_POOL] + (too_small ? (uint64_t)d->n_cu * 8 * POOL_CHUNK : 0);
+    return too_small ? 1 : 0;
 }
 
 // ---- public (device.hpp) ----

@@ -85,7 +85,7 @@ def test_t1_candidate_lists(gpu, oracle, idx, preset):
     # lists are contiguous per source but sources may land anywhere in the pool
     idx_arr = np.concatenate([np.arange(s, s + c, dtype=np.int64) for s, c in zip(start, count)]) if S else np.zeros(0, np.int64)
     assert np.array_equal(pool[idx_arr], keys), name
-    assert int(count.sum()) == len(pool)
+    assert int(count.sum()) <= len(pool)  # the pool cursor includes unused tails of block-local chunks
     # unit counters of the counting kernel == oracle's full-ball Dijkstra counters
     cnt = dev.sssp_count(0, S)
     assert cnt["settled_nodes"] == st["settled_nodes"], (name, cnt, st)
