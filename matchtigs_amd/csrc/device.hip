@@ -180,6 +180,7 @@ struct SsspArgs {
     unsigned long long *counters;
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
+    uint32_t dbg;                // timing experiments only (MTG_DBG env): 1 = gather from a 32 KB window, 2 = no emission writes
 };
 
 template <bool GLOBAL_WS>
@@ -207,7 +208,7 @@ __device__ __forceinline__ uint32_t tbl_hash(uint32_t src, uint32_t node) {
     return (x ^ (x >> 15)) * 0x2C1B3C6Du >> (32 - LOGH);
 }
 
-// returns 1 improved (slot set), 0 not improved, -1 table full
+// returns > 0 improved (2 = new entry, 1 = existing entry; slot set), 0 not improved, -1 table full
 template <int LOGH, bool GLOBAL_WS>
 __device__ __forceinline__ int tbl_relax(unsigned long long *table, uint32_t src, uint32_t node, uint32_t dist, uint32_t &slot) {
     constexpr uint32_t H = 1u << LOGH;
@@ -219,7 +220,7 @@ __device__ __forceinline__ int tbl_relax(unsigned long long *table, uint32_t src
         unsigned long long cur = Mem<GLOBAL_WS>::ld(&table[h]);
         if (cur == TBL_EMPTY) {
             cur = Mem<GLOBAL_WS>::cas(&table[h], TBL_EMPTY, val);
-            if (cur == TBL_EMPTY) { slot = h; return 1; }
+            if (cur == TBL_EMPTY) { slot = h; return 2; }
         }
         if ((cur >> ENT_NODE_SHIFT) == (key >> ENT_NODE_SHIFT)) {
             if (((cur >> 1) & ENT_DIST_MASK) <= dist) return 0;
@@ -503,6 +504,194 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-per-source kernel (level 0 for small balls)
+//
+// Measured on the cooperative kernel above (profiles/r01_v2_pmc.md): 79 % of wave cycles waiting, ~15 of
+// 64 lanes active per VMEM instruction, 12 waves per CU -- latency bound, because a (k-1)-ball in a unitig
+// graph is typically a handful of nodes. Here every LANE runs its own exact Dijkstra (select the unsettled
+// minimum by scanning its <= C-entry private table) and refills itself with the next source the moment it
+// finishes, so all 64 lanes keep one 32-byte record gather in flight each, with no barrier anywhere.
+// Per-lane tables live in LDS as node[C][64] (u32) + dist[C][64] (u16): index-major / lane-minor, so any
+// per-lane index is bank-conflict free. A source whose ball exceeds C entries is flagged and re-run by the
+// cooperative kernel. Each settled node is expanded exactly once (work-efficient).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long LANE_SRC_CHUNK = 512;  // sources a wave takes per global atomic
+
+template <int WPB, int C, bool COUNT>
+__global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
+    static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
+    __shared__ uint32_t s_node[WPB][C][64];
+    __shared__ uint16_t s_dist[WPB][C][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t(*node)[64] = s_node[wv];
+    uint16_t(*dist)[64] = s_dist[wv];
+
+    // wave-uniform state
+    unsigned long long chunk_lo = 0, chunk_hi = 0;  // source items [lo, hi) this wave still owns
+    unsigned long long pool_next = 0, pool_end = 0; // wave-local pool chunk
+    bool exhausted = false;
+    // lane state
+    bool active = false;
+    uint32_t n = 0, settled = 0, targets = 0, cur_relaxed = 0;
+    unsigned long long item = 0;
+    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0;
+    uint32_t n_overflow = 0;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        const unsigned long long need = __ballot(!active);
+        if (need && !exhausted) {
+            if (chunk_lo >= chunk_hi) {
+                unsigned long long c0 = 0;
+                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
+                c0 = __shfl(c0, 0);
+                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
+                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
+                if (chunk_lo >= chunk_hi) exhausted = true;
+            }
+            const unsigned want = (unsigned)__popcll(need);
+            if (!active) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const unsigned long long it = chunk_lo + rank;
+                if (it < chunk_hi) {
+                    item = it;
+                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
+                    node[0][lane] = a.sources[abs_idx];
+                    dist[0][lane] = 0;
+                    n = 1; settled = 0; targets = 0; cur_relaxed = 0;
+                    active = true;
+                }
+            }
+            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- one Dijkstra step per active lane ----
+        bool fin = false, ovf = false;
+        if (active) {
+            uint32_t best = 0, bestd = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t di = dist[i][lane];
+                if (!((settled >> i) & 1u) && di < bestd) { bestd = di; best = i; }
+            }
+            settled |= 1u << best;
+            const uint32_t u = node[best][lane];
+            const uint32_t d = bestd;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((a.dbg & 1u) ? (u & 1023u) : u));  // one aligned 32-byte gather
+            const uint4 lo = rp[0];
+            const uint4 hi = rp[1];
+            const uint32_t flags = (hi.z >> 8) & 0xFFu;
+            if ((flags & F_TARGET) && best != 0) targets |= 1u << best;  // entry 0 is the source itself (forbid_source_target)
+            auto relax = [&](uint32_t nb, uint32_t w) {
+                const uint32_t nd = d + w;
+                if (nd > a.K1) return;
+                int f = -1;
+                for (uint32_t i = 0; i < n; i++)
+                    if (node[i][lane] == nb) f = (int)i;
+                if (f >= 0) {
+                    if (nd < dist[f][lane]) dist[f][lane] = (uint16_t)nd;  // a settled entry already has dist <= d < nd
+                } else if (n < (uint32_t)C) {
+                    node[n][lane] = nb;
+                    dist[n][lane] = (uint16_t)nd;
+                    n++;
+                } else ovf = true;
+            };
+            uint32_t deg;
+            if (!(flags & F_EXT)) {
+                deg = hi.z & 0xFFu;
+                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < (int)deg) relax(nb[j], ww[j]);
+            } else {
+                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
+                deg = lo.z;
+                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
+            }
+            cur_relaxed += deg;
+            const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+            fin = !ovf && settled == all;
+        }
+
+        // ---- lanes whose search is complete emit (wave-collective pool allocation) ----
+        const unsigned long long finmask = __ballot(fin);
+        if (finmask) {
+            const uint32_t c = fin ? (uint32_t)__popc(targets) : 0u;
+            uint32_t incl = c;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t t = __shfl_up(incl, dd);
+                if (lane >= dd) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            if constexpr (!COUNT) {
+                if (total && pool_next + total > pool_end) {
+                    const unsigned long long grab = total > POOL_CHUNK ? (unsigned long long)total : POOL_CHUNK;
+                    unsigned long long p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
+                    pool_next = __shfl(p0, 0);
+                    pool_end = pool_next + grab;
+                }
+            }
+            if (fin) {
+                const unsigned long long pos0 = pool_next + (incl - c);
+                if constexpr (!COUNT) {
+                    uint32_t rem = targets;
+                    for (uint32_t r = 0; r < c; r++) {  // selection sort by (distance, node)
+                        unsigned long long bk = ~0ull;
+                        uint32_t bi = 0;
+                        for (uint32_t i = 1; i < n; i++) {
+                            const unsigned long long key = ((unsigned long long)dist[i][lane] << 32) | node[i][lane];
+                            if (((rem >> i) & 1u) && key < bk) { bk = key; bi = i; }
+                        }
+                        rem &= ~(1u << bi);
+                        if (pos0 + r < a.pool_cap && !(a.dbg & 2u)) a.pool[pos0 + r] = bk;
+                    }
+                }
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                if (!(a.dbg & 2u)) {
+                    a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
+                    a.cand_count[abs_idx - a.src_begin] = c;
+                }
+                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
+                active = false;
+            }
+            pool_next += total;
+        }
+        if (ovf) {  // ball larger than the per-lane table: hand the source to the cooperative level
+            const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+            a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+            n_overflow++;
+            active = false;
+        }
+    }
+    {   // one atomic per wave instead of one per overflowed source
+        unsigned long long o = n_overflow;
+        for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_down(o, dd);
+        if (lane == 0 && o) atomicAdd(&a.counters[C_OVERFLOW], o);
+    }
+
+    if constexpr (COUNT) {
+        // wave reduction, one atomic per wave and counter
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            st_settled += __shfl_down(st_settled, dd);
+            st_relaxed += __shfl_down(st_relaxed, dd);
+            st_emitted += __shfl_down(st_emitted, dd);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[C_SETTLED], st_settled);
+            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
+            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed);
+            atomicAdd(&a.counters[C_EMITTED], st_emitted);
+        }
+    }
+}
+
 // collect absolute indices of overflowed sources (order irrelevant)
 __global__ void collect_overflow_kernel(const uint32_t *cand_count, uint64_t n, uint64_t src_begin, uint32_t *list,
                                         unsigned long long *counters) {
@@ -534,8 +723,9 @@ struct Device {
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_kernel_ms = 0.0;
-    int preset = 0;
+    double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
+    uint64_t last_level0_overflow = 0;
+    int preset = 3;  // lane kernel with 12-entry per-lane tables, then the cooperative cascade
     int n_cu = 256;
     uint64_t graph_bytes = 0;
 };
@@ -559,20 +749,63 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-static const int N_PRESETS = 4;
-static LevelCfg level0_cfg(int preset) {
+static const int N_PRESETS = 5;
+// Level plan: lane-per-source kernel (per-lane table of C entries) -> cooperative kernel, 64 sources per
+// workgroup -> cooperative kernel, 1 source per workgroup with a 128 KB LDS table -> cooperative kernel with
+// a 32 MB global-memory table. `preset` picks the lane kernel's table size (4 = skip the lane level).
+struct LaneCfg {
+    sssp_fn fn;
+    sssp_fn fn_count;
+    int block;
+};
+template <int WPB, int C>
+static LaneCfg make_lane_cfg() {
+    return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64};
+}
+static LaneCfg lane_cfg(int preset) {
     switch (preset) {
-        //                  BLOCK LOGH  QCAP  SCAP BSRC
-        case 1: return make_cfg<128, 11, 1024, 512, 32, false>();
-        case 2: return make_cfg<64, 10, 512, 256, 16, false>();
-        case 3: return make_cfg<512, 13, 4096, 2048, 128, false>();
-        default: return make_cfg<256, 12, 2048, 1024, 64, false>();
+        case 1: return make_lane_cfg<4, 32>();
+        case 2: return make_lane_cfg<4, 24>();
+        case 3: return make_lane_cfg<4, 12>();
+        default: return make_lane_cfg<4, 16>();
     }
 }
-static LevelCfg level1_cfg() { return make_cfg<256, 14, 4096, 1024, 1, false>(); }
-static LevelCfg level2_cfg() { return make_cfg<256, 22, 1 << 22, 1 << 21, 1, true>(); }
+//                                              BLOCK LOGH  QCAP  SCAP BSRC
+// Cascade of cooperative levels: 64 sources per workgroup, then 8, then 1 (128 KB LDS table), then a 32 MB
+// global-memory table. A level re-runs the sources whose batch overflowed the previous level's tables.
+static const int N_COOP_LEVELS = 4;
+static LevelCfg coop_level(int i) {
+    switch (i) {  //                    BLOCK LOGH  QCAP  SCAP BSRC
+        case 0: return make_cfg<256, 12, 2048, 1024, 64, false>();
+        case 1: return make_cfg<256, 12, 4096, 1024, 8, false>();
+        case 2: return make_cfg<256, 14, 4096, 1024, 1, false>();
+        default: return make_cfg<256, 22, 1 << 22, 1 << 21, 1, true>();
+    }
+}
 
-static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool count, SsspArgs args, bool time_it) {
+static float elapsed_ms(Device *d) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    return ms;
+}
+
+static void launch_lane(Device *d, hipStream_t st, const LaneCfg &cfg, bool count, SsspArgs args) {
+    if (args.n_items == 0) return;
+    sssp_fn fn = count ? cfg.fn_count : cfg.fn;
+    int occ = 1;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, cfg.block, 0));
+    if (occ < 1) occ = 1;
+    const uint64_t waves_needed = (args.n_items + 63) / 64;
+    const uint64_t wpb = (uint64_t)cfg.block / 64;
+    uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + wpb - 1) / wpb);
+    grid = std::max<uint64_t>(grid, 1);
+    HIP_CHECK(hipEventRecord(d->ev0, st));
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(d->ev1, st));
+}
+
+static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool count, SsspArgs args) {
     if (args.n_items == 0) return;
     const uint64_t n_batches = (args.n_items + cfg.bsrc - 1) / cfg.bsrc;
     sssp_fn fn = count ? cfg.fn_count : cfg.fn;
@@ -593,10 +826,10 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
     grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, n_batches));
     args.ws = ws;
     args.ws_stride = ws_stride;
-    if (time_it) HIP_CHECK(hipEventRecord(d->ev0, st));
+    HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    if (time_it) HIP_CHECK(hipEventRecord(d->ev1, st));
+    HIP_CHECK(hipEventRecord(d->ev1, st));
     if (ws) {
         HIP_CHECK(hipStreamSynchronize(st));
         HIP_CHECK(hipFree(ws));
@@ -621,16 +854,22 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     a.sources = d->d_out_nodes; a.src_index = nullptr; a.n_items = n; a.src_begin = src_begin;
     a.K1 = d->K1; a.pool = d_pool; a.pool_cap = pool_cap; a.cand_start = d_cand_start; a.cand_count = d_cand_count;
     a.counters = d->d_counters;
-    launch_level(d, st, level0_cfg(d->preset), count, a, true);
+    { const char *e = std::getenv("MTG_DBG"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
+    double total_ms = 0.0;
+    const bool use_lane = d->preset < 4;
+    if (use_lane) launch_lane(d, st, lane_cfg(d->preset), count, a);
+    else launch_level(d, st, coop_level(0), count, a);
     read_counters(d, st);
-    if (n) {
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
-        d->last_kernel_ms = ms;
-    } else d->last_kernel_ms = 0.0;
+    if (n) total_ms += elapsed_ms(d);
+    static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
+    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed\n", use_lane ? "lane" : "coop level 0",
+                                 (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
     uint64_t total_overflow = d->h_counters[C_OVERFLOW];
+    d->last_level0_overflow = total_overflow;
     uint32_t *d_list = nullptr;
-    for (int level = 1; level <= 2 && d->h_counters[C_OVERFLOW] > 0; level++) {
+    // remaining levels over whatever overflowed the previous one
+    for (int li = use_lane ? 0 : 1; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
+        const LevelCfg next = coop_level(li);
         const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
         if (!d_list) HIP_CHECK(hipMalloc(&d_list, n_ovf * sizeof(uint32_t)));
         HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVF_LIST], 0, sizeof(unsigned long long), st));
@@ -641,9 +880,13 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         SsspArgs b = a;
         b.src_index = d_list;
         b.n_items = n_ovf;
-        launch_level(d, st, level == 1 ? level1_cfg() : level2_cfg(), count, b, false);
+        launch_level(d, st, next, count, b);
         read_counters(d, st);
+        total_ms += elapsed_ms(d);
+        if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed\n", li + 1,
+                                next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
     }
+    d->last_kernel_ms = total_ms;
     if (d_list) HIP_CHECK(hipFree(d_list));
     if (d->h_counters[C_OVERFLOW] > 0)
         MTG_DIE("bounded search from %llu source(s) exceeds every kernel level (ball larger than 2^22 table entries)",
