@@ -79,6 +79,7 @@ def main():
 
     bufs = None
     kernel_ms: list[float] = []
+    level_ms: list[list[dict]] = []
     phases_acc: dict[str, float] = {}
     result_info: dict = {}
 
@@ -104,6 +105,7 @@ def main():
         ph["sssp"] = t2 - t1
         if record:
             kernel_ms.append(dev.last_sssp_kernel_ms())
+            level_ms.append(dev.last_sssp_levels())
         if world > 1:
             start_all, count_all, pool_all = mdist.allgather_candidates(bufs.start, bufs.count, bufs.pool, bufs.used, ranges)
             torch.cuda.synchronize()
@@ -164,10 +166,24 @@ def main():
         # roofline of the dominant kernel (sssp_kernel, level 0) on THIS rank's launch
         alg_bytes = algorithmic_bytes(stats)
         achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
+        level_names = ["sssp_lane_kernel<4,12>", "sssp_kernel<256,12,2048,1024,64>", "sssp_kernel<256,12,4096,1024,8>",
+                       "sssp_kernel<256,14,4096,1024,1>", "sssp_kernel<256,22,...,global>"]
+        if args.preset == 4:
+            level_names = level_names[1:]
+        kernels = []
+        if level_ms:
+            for li in range(max(len(x) for x in level_ms)):
+                vals = [x[li] for x in level_ms if li < len(x)]
+                kernels.append({"kernel": level_names[li] if li < len(level_names) else f"level{li}",
+                                "avg_launch_ms": round(float(np.mean([v["ms"] for v in vals])), 4),
+                                "sources": int(vals[0]["sources"])})
         roofline = {
-            "bound": "hbm", "kernel": "sssp_kernel (level 0)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "SSSP stage = sum of its level kernels (see 'kernels')", "kernels": kernels,
+            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": args.traffic_bytes,
+            "gather_ceiling_note": "dependent random 32-B gathers saturate at ~54 G/s on MI355X (tools/gather_bench.hip): "
+                                   "floor for this stage = settled_nodes / 54e9",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(local_kernel_ms, 4),
             "kernel_sssp_edges_per_s": round(stats["relaxed_edges"] / (local_kernel_ms * 1e-3), 1) if local_kernel_ms > 0 else 0.0,
             "work_efficiency_attempts_per_edge": round(stats["relax_attempts"] / max(stats["relaxed_edges"], 1), 4),

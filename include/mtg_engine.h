@@ -107,11 +107,16 @@ const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d);
 int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end,
                         uint64_t *d_pool, uint64_t pool_capacity, uint64_t *d_cand_start,
                         uint32_t *d_cand_count, uint64_t *pool_needed);
-/* HIP-event time (ms) of the fast-level SSSP kernel in the last mtg_sssp_candidates call. */
+/* Sum of the HIP-event durations (ms) of the SSSP level kernels of the last mtg_sssp_candidates call. */
 double mtg_last_sssp_kernel_ms(const mtg_device *d);
+/* Per level of that call: kernel duration (ms) and number of sources handed to the level. Level 0 is the
+ * lane-per-source kernel (or the first cooperative level with preset 4); later levels re-run overflowed sources.
+ * Returns the number of levels written (<= capacity). */
+int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
-/* Kernel tuning: level-0 geometry preset; returns the preset in force. */
+/* Kernel tuning: 0-3 = per-lane table size 16/32/24/12 of the lane kernel (default 3), 4 = cooperative kernels
+ * only; returns the preset in force. */
 int mtg_set_sssp_preset(mtg_device *d, int preset);
 
 /* ---- host stages ----------------------------------------------------------------------- */

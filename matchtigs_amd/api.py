@@ -304,6 +304,12 @@ class DeviceGraph:
     def last_sssp_kernel_ms(self) -> float:
         return float(self._L.mtg_last_sssp_kernel_ms(self._d))
 
+    def last_sssp_levels(self) -> list[dict]:
+        ms = (C.c_double * 8)()
+        src = (C.c_uint64 * 8)()
+        n = self._L.mtg_last_sssp_levels(self._d, ms, src, 8)
+        return [{"level": i, "ms": float(ms[i]), "sources": int(src[i])} for i in range(n)]
+
     def sssp_count(self, src_begin: int, src_end: int, stream: int = 0) -> dict:
         st = _lib.MtgSsspStats()
         self._L.mtg_sssp_count(self._d, stream, src_begin, src_end, C.byref(st))

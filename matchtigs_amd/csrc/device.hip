@@ -517,6 +517,7 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 // cooperative kernel. Each settled node is expanded exactly once (work-efficient).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long LANE_SRC_CHUNK = 512;  // sources a wave takes per global atomic
+constexpr unsigned long long LANE_POOL_CHUNK = 256; // keys per wave-local pool chunk
 
 template <int WPB, int C, bool COUNT>
 __global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
             const uint32_t total = __shfl(incl, 63);
             if constexpr (!COUNT) {
                 if (total && pool_next + total > pool_end) {
-                    const unsigned long long grab = total > POOL_CHUNK ? (unsigned long long)total : POOL_CHUNK;
+                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
                     unsigned long long p0 = 0;
                     if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
                     pool_next = __shfl(p0, 0);
@@ -725,6 +726,9 @@ struct Device {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint64_t last_level0_overflow = 0;
+    int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
+    double last_level_ms[8] = {0};
+    uint64_t last_level_sources[8] = {0};
     int preset = 3;  // lane kernel with 12-entry per-lane tables, then the cooperative cascade
     int n_cu = 256;
     uint64_t graph_bytes = 0;
@@ -861,6 +865,8 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     else launch_level(d, st, coop_level(0), count, a);
     read_counters(d, st);
     if (n) total_ms += elapsed_ms(d);
+    d->last_n_levels = 0;
+    if (n) { d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1; }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed\n", use_lane ? "lane" : "coop level 0",
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
@@ -883,6 +889,11 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         launch_level(d, st, next, count, b);
         read_counters(d, st);
         total_ms += elapsed_ms(d);
+        if (d->last_n_levels < 8) {
+            d->last_level_ms[d->last_n_levels] = elapsed_ms(d);
+            d->last_level_sources[d->last_n_levels] = n_ovf;
+            d->last_n_levels++;
+        }
         if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed\n", li + 1,
                                 next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
     }
@@ -1062,6 +1073,11 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
 }
 
 double device_last_kernel_ms(const Device *d) { return d->last_kernel_ms; }
+int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) {
+    const int n = d->last_n_levels < cap ? d->last_n_levels : cap;
+    for (int i = 0; i < n; i++) { ms[i] = d->last_level_ms[i]; sources[i] = d->last_level_sources[i]; }
+    return n;
+}
 
 int device_set_preset(Device *d, int preset) {
     if (preset >= 0 && preset < N_PRESETS) d->preset = preset;

@@ -23,6 +23,7 @@ int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, u
                 uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed);
 void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
 double device_last_kernel_ms(const Device *d);
+int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_preset(Device *d, int preset);
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
                                std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);

@@ -109,6 +109,9 @@ int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_
     return device_sssp(d->d, stream, src_begin, src_end, d_pool, pool_capacity, d_cand_start, d_cand_count, pool_needed);
 }
 double mtg_last_sssp_kernel_ms(const mtg_device *d) { return device_last_kernel_ms(d->d); }
+int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity) {
+    return device_last_levels(d->d, ms_out, sources_out, capacity);
+}
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
     device_sssp_count(d->d, stream, src_begin, src_end, stats);
 }

@@ -37,6 +37,9 @@ uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint
 }
 
 void HostGraph::reset_to_original() {
+    first_breaking_edge = UINT64_MAX;
+    breaking_weight = 0;
+    dummies_canonical = true;
     while (e_from.size() > n_original_edges) {
         const uint32_t e = (uint32_t)e_from.size() - 1;
         const uint32_t f = e_from[e];

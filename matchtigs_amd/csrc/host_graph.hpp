@@ -52,6 +52,10 @@ struct HostGraph {
     std::vector<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
     std::vector<uint8_t> e_fwd;                      // [E]
     uint64_t n_original_edges = 0;
+    // bookkeeping for the streaming cutter: ids >= first_breaking_edge are breaking dummies of weight breaking_weight
+    uint64_t first_breaking_edge = UINT64_MAX;
+    uint64_t breaking_weight = 0;
+    bool dummies_canonical = true;
 
     uint64_t node_count() const { return mirror.size(); }
     uint64_t edge_count() const { return e_from.size(); }

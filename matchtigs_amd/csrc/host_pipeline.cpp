@@ -11,7 +11,11 @@
 // same sequences as the reference's (BTreeMap / Vec::rotate_left based) code; see DESIGN.md.
 #include "host_graph.hpp"
 
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <chrono>
+#include <cstring>
 
 namespace mtg {
 
@@ -90,6 +94,7 @@ uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
     uint64_t dummy_edge_id = 0;
     g.reserve_edges(g.edge_count() + 2 * n_pairs);
     for (uint64_t i = 0; i < n_pairs; i++) {
+        if (g.first_breaking_edge != UINT64_MAX) g.dummies_canonical = false;  // matched edges after breaking edges
         dummy_edge_id += 1;
         g.add_biedge(pairs[i].out_node, pairs[i].in_node, pairs[i].distance, dummy_edge_id, 0);
     }
@@ -130,6 +135,12 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         while (from < V && need[from] <= 0) from++;
         return from;
     };
+    if (g.first_breaking_edge == UINT64_MAX) {
+        g.first_breaking_edge = g.edge_count();
+        g.breaking_weight = k;
+        for (uint64_t e = g.n_original_edges; e < g.edge_count(); e++)
+            if (g.e_weight[e] >= k) g.dummies_canonical = false;  // a matched dummy as long as a breaking edge
+    } else g.dummies_canonical = false;  // Eulerised twice
     auto breaking = [&](uint32_t out_node, uint32_t in_node) {  // :489-493, :506-510, :572-577
         dummy_edge_id += 1;
         g.add_biedge(out_node, in_node, k, dummy_edge_id, 0);
@@ -190,7 +201,179 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
 //    head"; inserting before x without a prev pointer is done by moving x's edge into a fresh entry y
 //    placed after W (x's old entry receives W's first edge, which leaves the same node).
 // ---------------------------------------------------------------------------------------------
+// Cache-conscious formulation (same sequences as the literal algorithm, see the block comment above).
+// The walk is a chain of dependent random accesses; the first version paid ~7 cache misses per biedge
+// (used[], e_to, cursor, used[], e_next_out, and e_from + cursor again in the FIFO scan). Here:
+//  * per node ONE 32-byte record holds the cursor and the first 3 adjacency entries (edge id + head node) in
+//    iteration order (newest first), the rest spills to a CSR side array: the chain is ~1 miss per step;
+//  * "used" is a bitmap per biedge (E/16 bytes: cache resident);
+//  * cycle entries carry their from-node, and the FIFO scan prefetches the node records it will look at.
+namespace {
+// Big randomly-accessed arrays go on transparent huge pages (THP is in `madvise` mode on the target hosts): with 4 KB
+// pages every step of the walk is also a TLB miss.
+template <typename T>
+struct HugeBuf {
+    T *p = nullptr;
+    size_t n = 0, bytes = 0;
+    explicit HugeBuf(size_t count) : n(count) {
+        bytes = ((count * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
+        if (bytes == 0) bytes = 2u << 20;
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) MTG_DIE("out of memory (%zu bytes)", bytes);
+        madvise(m, bytes, MADV_HUGEPAGE);
+        p = static_cast<T *>(m);
+    }
+    ~HugeBuf() { if (p) munmap(p, bytes); }
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+struct alignas(32) EulerNode {
+    uint32_t eid[3];
+    uint32_t to[3];
+    uint32_t ext_begin;  // first spill entry (adjacency positions 3..deg-1)
+    uint16_t deg;
+    uint16_t pos;        // adjacency positions < pos are known to be used
+};
+static_assert(sizeof(EulerNode) == 32, "EulerNode must be 32 bytes");
+}  // namespace
+
+static Walks euler_cycles_generic(const HostGraph &g);
+
 Walks euler_cycles(const HostGraph &g) {
+    const uint64_t E = g.edge_count();
+    const uint64_t V = g.node_count();
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    for (uint64_t n = 0; n < V; n++)
+        if (g.out_deg[n] > 65535) return euler_cycles_generic(g);  // not a de Bruijn graph; keep the simple formulation
+
+    // ---- node records with adjacency in iteration order (newest edge first) ----
+    HugeBuf<EulerNode> nodes(V);
+    uint64_t ext_total = 0;
+    for (uint64_t n = 0; n < V; n++) {
+        EulerNode &r = nodes[n];
+        r.deg = (uint16_t)g.out_deg[n];
+        r.pos = 0;
+        r.ext_begin = (uint32_t)ext_total;
+        if (r.deg > 3) ext_total += r.deg - 3;
+        r.eid[0] = r.eid[1] = r.eid[2] = NONE;
+        r.to[0] = r.to[1] = r.to[2] = NONE;
+    }
+    if (ext_total >= NONE) MTG_DIE("adjacency spill too large");
+    std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
+    {
+        std::vector<uint16_t> fill(V, 0);
+        for (uint64_t e = E; e-- > 0;) {  // descending edge id == newest first
+            const uint32_t f = g.e_from[e];
+            EulerNode &r = nodes[f];
+            const uint16_t i = fill[f]++;
+            if (i < 3) { r.eid[i] = (uint32_t)e; r.to[i] = g.e_to[e]; }
+            else { ext_eid[r.ext_begin + i - 3] = (uint32_t)e; ext_to[r.ext_begin + i - 3] = g.e_to[e]; }
+        }
+    }
+    static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
+    const auto t_build = std::chrono::steady_clock::now();
+    std::vector<uint64_t> used((E / 2 + 63) / 64 + 1, 0);
+    auto is_used = [&](uint32_t e) -> bool { return (used[(e >> 1) >> 6] >> ((e >> 1) & 63)) & 1ull; };
+    auto set_used = [&](uint32_t e) { used[(e >> 1) >> 6] |= 1ull << ((e >> 1) & 63); };
+    // first unused out-edge of `node` in iteration order: (edge, head) or NONE
+    auto next_unused = [&](uint32_t node, uint32_t &to_out) -> uint32_t {
+        EulerNode &r = nodes[node];
+        while (r.pos < r.deg) {
+            const uint32_t e = r.pos < 3 ? r.eid[r.pos] : ext_eid[r.ext_begin + r.pos - 3];
+            if (!is_used(e)) {
+                to_out = r.pos < 3 ? r.to[r.pos] : ext_to[r.ext_begin + r.pos - 3];
+                return e;
+            }
+            r.pos++;
+        }
+        return NONE;
+    };
+
+    // entries: one per biedge plus one per splice (<= E/2 each); the FIFO sees every entry once plus one re-push per splice
+    HugeBuf<uint32_t> ent_edge(E + 1), ent_next(E + 1), ent_node(E + 1), fifo(E + E / 2 + 2);
+    size_t n_ent = 0, fifo_tail = 0;
+    Walks out;
+    out.edges.reserve(E / 2);
+    constexpr size_t PF = 12;  // FIFO prefetch distance
+    uint64_t n_splices = 0;
+    double t_walk = 0, t_fifo = 0;
+
+    for (uint64_t e0 = 0; e0 < E; e0++) {
+        if (is_used((uint32_t)e0)) continue;
+        n_ent = 0; fifo_tail = 0;
+        size_t fifo_head = 0;
+        uint32_t head = NONE;
+        uint32_t start_edge = (uint32_t)e0, start_to = g.e_to[e0];
+        uint32_t start_node = g.e_from[e0];
+        uint32_t splice_at = NONE;
+
+        while (start_edge != NONE) {
+            n_splices++;
+            const auto tw0 = dbg_t ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            const size_t w_begin = n_ent;
+            uint32_t e = start_edge, from = start_node, to = start_to;
+            for (;;) {
+                set_used(e);
+                ent_edge[n_ent] = e;
+                ent_node[n_ent] = from;
+                ent_next[n_ent] = (uint32_t)(n_ent + 1);
+                n_ent++;
+                from = to;
+                e = next_unused(from, to);
+                if (e == NONE) {
+                    if (from != start_node)
+                        MTG_DIE("Euler walk stuck at node %u != start node %u: graph is not Eulerian", from, start_node);
+                    break;
+                }
+            }
+            const size_t w_end = n_ent;
+            if (splice_at == NONE) {
+                head = (uint32_t)w_begin;
+                ent_next[w_end - 1] = head;
+                for (size_t i = w_begin; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
+            } else {
+                const uint32_t x = splice_at;
+                const uint32_t y = (uint32_t)n_ent++;
+                ent_edge[y] = ent_edge[x];
+                ent_node[y] = ent_node[x];
+                ent_next[y] = ent_next[x];  // if x was the only entry this is x itself: y -> x(W1)
+                ent_edge[x] = ent_edge[w_begin];  // x now carries W's first edge (it leaves the same node)
+                if (w_end - w_begin == 1) ent_next[x] = y;
+                else { ent_next[x] = (uint32_t)(w_begin + 1); ent_next[w_end - 1] = y; }
+                head = y;
+                fifo[fifo_head] = y;
+                fifo[fifo_tail++] = x;
+                for (size_t i = w_begin + 1; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
+            }
+            const auto tw1 = dbg_t ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            start_edge = NONE;
+            while (fifo_head < fifo_tail) {
+                if (fifo_head + PF < fifo_tail) __builtin_prefetch(&nodes[ent_node[fifo[fifo_head + PF]]]);
+                const uint32_t ent = fifo[fifo_head];
+                const uint32_t node = ent_node[ent];
+                uint32_t to = NONE;
+                const uint32_t cand = next_unused(node, to);
+                if (cand != NONE) { start_edge = cand; start_to = to; start_node = node; splice_at = ent; break; }
+                fifo_head++;
+            }
+            if (dbg_t) { const auto tw2 = std::chrono::steady_clock::now(); t_walk += std::chrono::duration<double>(tw1 - tw0).count(); t_fifo += std::chrono::duration<double>(tw2 - tw1).count(); }
+        }
+        uint32_t ent = head;
+        do {
+            out.edges.push_back(ent_edge[ent]);
+            ent = ent_next[ent];
+        } while (ent != head);
+        out.limits.push_back(out.edges.size());
+    }
+    if (dbg_t)
+        std::fprintf(stderr, "[mtg] euler_cycles: walk+splice %.3f s (walk %.3f, fifo %.3f, %llu closed sub-walks, %zu entries)\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(), t_walk, t_fifo, (unsigned long long)n_splices, out.edges.size());
+    return out;
+}
+
+static Walks euler_cycles_generic(const HostGraph &g) {
     const uint64_t E = g.edge_count();
     const uint64_t V = g.node_count();
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
@@ -281,9 +464,11 @@ Walks euler_cycles(const HostGraph &g) {
 // ---------------------------------------------------------------------------------------------
 // rotate + cut, greedytigs/mod.rs:726-789 (== eulertigs/mod.rs:123-186), without moving data.
 // ---------------------------------------------------------------------------------------------
-Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
+// Generic form: follows the reference line by line (weights looked up per dummy edge).
+static Walks cut_cycles_generic(const HostGraph &g, const Walks &cycles, uint64_t k) {
     Walks tigs;
     tigs.edges.reserve(cycles.edges.size());
+    const uint64_t n_orig = g.n_original_edges;  // dummy edges are exactly the edges appended after the original ones
     uint64_t begin = 0;
     for (size_t c = 0; c < cycles.limits.size(); c++) {
         const uint32_t *cyc = cycles.edges.data() + begin;
@@ -292,7 +477,7 @@ Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
         uint64_t longest_w = 0, rot = 0;                         // :737-745
         for (uint64_t i = 0; i < len; i++) {
             const uint32_t e = cyc[i];
-            if (g.is_dummy(e) && g.e_weight[e] > longest_w) { longest_w = g.e_weight[e]; rot = i; }
+            if (e >= n_orig && g.e_weight[e] > longest_w) { longest_w = g.e_weight[e]; rot = i; }
         }
         if (longest_w == 0) rot = 0;                             // :746-748
         auto at = [&](uint64_t i) -> uint32_t { uint64_t j = i + rot; return cyc[j >= len ? j - len : j]; };
@@ -303,17 +488,67 @@ Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
         uint64_t offset = 0;                                     // :750
         for (uint64_t i = 0; i < len; i++) {                     // :752
             const uint32_t e = at(i);
-            const bool dummy = g.is_dummy(e);
+            const bool dummy = e >= n_orig;
             if (dummy && (g.e_weight[e] >= k || i == 0)) {       // :767-769
                 if (offset < i) emit(offset, i);                 // :770-771
                 offset = i + 1;                                  // :775
             }
         }
         if (offset < len) {                                      // :779-788
-            if (!g.is_dummy(at(len - 1))) emit(offset, len);
+            if (at(len - 1) < n_orig) emit(offset, len);
             else if (offset < len - 1) emit(offset, len - 1);
         }
     }
+    return tigs;
+}
+
+// Streaming form for graphs produced by insert_pair_edges + make_eulerian (the only producers on the path): matched
+// dummies (weight <= k-1) occupy edge ids [n_original, first_breaking), breaking dummies (weight == k) the ids from
+// first_breaking on, so "dummy" and "weight >= k" are id comparisons and no per-edge lookup is needed. A cycle's
+// rotation point (first strictly-longest dummy, :737-748) is its first breaking edge if it has one.
+Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
+    if (!g.dummies_canonical || g.first_breaking_edge == UINT64_MAX || g.breaking_weight != k)
+        return cut_cycles_generic(g, cycles, k);
+    Walks tigs;
+    tigs.edges.resize(cycles.edges.size());
+    uint32_t *out = tigs.edges.data();
+    uint64_t n_out = 0;
+    const uint64_t n_orig = g.n_original_edges, first_brk = g.first_breaking_edge;
+    uint64_t begin = 0;
+    for (size_t c = 0; c < cycles.limits.size(); c++) {
+        const uint32_t *cyc = cycles.edges.data() + begin;
+        const uint64_t len = cycles.limits[c] - begin;
+        begin = cycles.limits[c];
+        uint64_t rot = len;
+        for (uint64_t i = 0; i < len; i++)
+            if (cyc[i] >= first_brk) { rot = i; break; }
+        if (rot == len) {  // no breaking edge: rotate to the first strictly-longest matched dummy, if any
+            uint64_t longest_w = 0;
+            rot = 0;
+            for (uint64_t i = 0; i < len; i++)
+                if (cyc[i] >= n_orig && g.e_weight[cyc[i]] > longest_w) { longest_w = g.e_weight[cyc[i]]; rot = i; }
+        }
+        uint64_t tig_begin = n_out;  // start of the tig being assembled
+        auto close_tig = [&]() {
+            if (n_out > tig_begin) tigs.limits.push_back(n_out);
+            tig_begin = n_out;
+        };
+        bool first = true;  // rotated index 0: a dummy there is a cut point whatever its weight (:768)
+        auto segment = [&](const uint32_t *p, uint64_t n) {
+            for (uint64_t i = 0; i < n; i++) {
+                const uint32_t e = p[i];
+                if (e >= first_brk || (first && e >= n_orig)) close_tig();  // cut: drop the edge
+                else out[n_out++] = e;
+                first = false;
+            }
+        };
+        segment(cyc + rot, len - rot);
+        segment(cyc, rot);
+        // tail (:779-788): a trailing (matched) dummy is dropped
+        if (n_out > tig_begin && out[n_out - 1] >= n_orig) n_out--;
+        close_tig();
+    }
+    tigs.edges.resize(n_out);
     return tigs;
 }
 
