@@ -148,6 +148,13 @@ void mtg_walks_free(mtg_walks *w);
 uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out,
                           uint64_t *tigs_insert_out, uint64_t *tigs_out_limits);
 
+/* Tig spelling (replaces write_walks_fasta, bin.rs:466-606): walks (edge ids into the mutated graph,
+ * limits[i] = exclusive end of walk i) -> FASTA text. unitig_seqs = concatenated ASCII sequences, unitig u occupies
+ * [seq_offsets[u], seq_offsets[u+1]). Header ">{i+1}"; overlaps k-1 after a unitig edge, k-1-weight after a dummy
+ * edge; backwards edges are reverse-complemented. Returns the byte count; *fasta_out is malloc'd (mtg_free). */
+uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
+                               uint64_t k, const char *unitig_seqs, const uint64_t *seq_offsets, char **fasta_out);
+
 /* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);
 

@@ -107,6 +107,7 @@ def load():
         "mtg_walks_export": (None, [vp, vp, vp]),
         "mtg_walks_free": (None, [vp]),
         "mtg_flatten_clib": (u64, [vp, vp, vp, vp, vp]),
+        "mtg_write_walks_fasta": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, P(vp)]),
         "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),
         "mtg_last_phase_seconds": (None, [P(C.c_double)]),
         "matchtigs_initialise": (None, []),

@@ -358,6 +358,25 @@ def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int):
     return _take_walks_np(L, L.mtg_finish_greedytigs(graph.handle, _ptr(p), len(p), k))
 
 
+def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int) -> bytes:
+    """bin.rs:466-606 through the C-ABI: tigs = list of edge-id lists (or (limits, edges) numpy pair) -> FASTA bytes."""
+    L = _lib.load()
+    if isinstance(tigs, tuple):
+        lim, ed = np.ascontiguousarray(tigs[0], np.uint64), np.ascontiguousarray(tigs[1], np.uint32)
+    else:
+        ed = np.fromiter((e for t in tigs for e in t), dtype=np.uint32)
+        lim = np.cumsum([len(t) for t in tigs], dtype=np.uint64) if len(tigs) else np.zeros(0, np.uint64)
+    cat = "".join(unitigs).encode()
+    off = np.zeros(len(unitigs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(u) for u in unitigs])
+    out = C.c_void_p()
+    n = L.mtg_write_walks_fasta(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None, k,
+                                cat, _ptr(off), C.byref(out))
+    data = C.string_at(out, n)
+    L.mtg_free(out)
+    return data
+
+
 def last_phase_seconds() -> dict:
     L = _lib.load()
     a = (C.c_double * 8)()

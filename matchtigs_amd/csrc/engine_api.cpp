@@ -185,6 +185,13 @@ uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *ti
     return flatten_clib(g->g, tigs->w, tigs_edge_out, tigs_insert_out, tigs_out_limits);
 }
 
+uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                               const char *unitig_seqs, const uint64_t *seq_offsets, char **fasta_out) {
+    if (!g || !fasta_out || (n_walks && (!limits || !edges)) || !unitig_seqs || !seq_offsets)
+        MTG_DIE("mtg_write_walks_fasta: null argument");
+    return write_walks_fasta(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, fasta_out);
+}
+
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {
     if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs: graph is not built");
     for (double &p : g_phase) p = 0;

@@ -88,6 +88,9 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k);
 bool is_eulerian(const HostGraph &g);
 Walks euler_cycles(const HostGraph &g);
 Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k);
+// spell.cpp: bin.rs:466-606
+uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                           const char *seqs, const uint64_t *seq_off, char **out_buf);
 uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, uint64_t *insert_out, uint64_t *limits);
 
 }  // namespace mtg

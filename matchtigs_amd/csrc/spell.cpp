@@ -1,0 +1,113 @@
+// spell.cpp -- tig spelling: walks -> FASTA text, /root/reference/src/bin.rs:466-606.
+//
+// Per walk i: header ">{i+1}\n" (:492); the first edge's full sequence, reverse-complemented for a backwards edge
+// (:497-501, :269-285); every following ORIGINAL edge contributes its sequence minus the overlap with what is already
+// written: offset = k-1 after an original edge, k-1-weight after a dummy edge (:533-537); a forwards edge appends
+// seq[offset..] (:539-566), a backwards edge appends revcomp(seq[0..len-offset]) (:567-596); dummy edges emit
+// nothing (:519-531); "\n" closes the record (:601).
+//
+// Two passes so the output buffer is allocated once and records can be written independently (the second pass is
+// embarrassingly parallel over walks; it is a plain loop here and the shape a GPU kernel would take).
+#include <cstring>
+
+#include "host_graph.hpp"
+
+namespace mtg {
+
+static inline char complement(char c) {
+    switch (c) {
+        case 'A': return 'T';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        case 'T': return 'A';
+        case 'a': return 't';
+        case 'c': return 'g';
+        case 'g': return 'c';
+        case 't': return 'a';
+        default: return 'N';
+    }
+}
+
+static inline unsigned decimal_digits(uint64_t v) {
+    unsigned d = 1;
+    while (v >= 10) { v /= 10; d++; }
+    return d;
+}
+
+// Returns the number of bytes; *out_buf is malloc'd (caller frees with mtg_free).
+uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                           const char *seqs, const uint64_t *seq_off, char **out_buf) {
+    if (k < 1) MTG_DIE("k must be >= 1");
+    const uint64_t n_orig = g.n_original_edges;
+    auto seq_len = [&](uint32_t e) -> uint64_t { return seq_off[g.e_unitig[e] + 1] - seq_off[g.e_unitig[e]]; };
+    // pass 1: record offsets
+    std::vector<uint64_t> rec_off(n_walks + 1, 0);
+    uint64_t begin = 0;
+    for (uint64_t i = 0; i < n_walks; i++) {
+        const uint64_t end = limits[i];
+        if (end <= begin) MTG_DIE("empty walk %llu", (unsigned long long)i);
+        uint64_t len = 1 + decimal_digits(i + 1) + 1;  // ">", number, "\n"
+        uint32_t prev = edges[begin];
+        if (prev >= n_orig) MTG_DIE("walk %llu starts with a dummy edge (bin.rs:489)", (unsigned long long)i);
+        len += seq_len(prev);
+        for (uint64_t j = begin + 1; j < end; j++) {
+            const uint32_t cur = edges[j];
+            if (cur >= n_orig) { prev = cur; continue; }
+            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.e_weight[prev];
+            const uint64_t sl = seq_len(cur);
+            if (offset > sl) MTG_DIE("overlap %llu longer than unitig %llu", (unsigned long long)offset, (unsigned long long)g.e_unitig[cur]);
+            len += sl - offset;
+            prev = cur;
+        }
+        len += 1;  // "\n"
+        rec_off[i + 1] = rec_off[i] + len;
+        begin = end;
+    }
+    const uint64_t total = rec_off[n_walks];
+    char *out = static_cast<char *>(std::malloc(total + 1));
+    if (!out) MTG_DIE("out of memory (%llu bytes)", (unsigned long long)total);
+    // pass 2: spell
+    auto put_edge = [&](char *dst, uint32_t e, uint64_t offset) -> char * {
+        const char *s = seqs + seq_off[g.e_unitig[e]];
+        const uint64_t sl = seq_len(e);
+        const uint64_t n = sl - offset;
+        if (g.e_fwd[e]) {
+            std::memcpy(dst, s + offset, n);
+        } else {
+            for (uint64_t i = 0; i < n; i++) dst[i] = complement(s[n - 1 - i]);
+        }
+        return dst + n;
+    };
+    begin = 0;
+    for (uint64_t i = 0; i < n_walks; i++) {
+        const uint64_t end = limits[i];
+        char *p = out + rec_off[i];
+        *p++ = '>';
+        {
+            char num[24];
+            unsigned d = decimal_digits(i + 1);
+            uint64_t v = i + 1;
+            for (unsigned q = d; q-- > 0;) { num[q] = (char)('0' + v % 10); v /= 10; }
+            std::memcpy(p, num, d);
+            p += d;
+        }
+        *p++ = '\n';
+        uint32_t prev = edges[begin];
+        p = put_edge(p, prev, 0);
+        for (uint64_t j = begin + 1; j < end; j++) {
+            const uint32_t cur = edges[j];
+            if (cur >= n_orig) { prev = cur; continue; }
+            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.e_weight[prev];
+            p = put_edge(p, cur, offset);
+            prev = cur;
+        }
+        *p++ = '\n';
+        if ((uint64_t)(p - out) != rec_off[i + 1]) MTG_DIE("internal error: record length mismatch");
+        begin = end;
+    }
+    out[total] = '\0';
+    *out_buf = out;
+    return total;
+}
+
+}  // namespace mtg

@@ -185,3 +185,56 @@ def test_smoke_entry(gpu):
     import __graft_entry__ as ge
 
     ge.smoke()
+
+
+def test_full_bench_size_properties(gpu, oracle):
+    """At the bench workload's full size (|E| = 2^24 nominal) the oracle's Euler stage is too slow to run in a test, so the
+    GPU path is checked through size-independent properties, plus exact pair parity (the oracle's claim loop takes ~30 s)."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    k = 31
+    bg = synth.g_csr(int((1 << 24) / 1.5 / 2), seed=1, k=k)
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify(torch_glue.current_stream_ptr())
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    start, count, pool = torch_glue.candidates_to_numpy(bufs)
+    on, mu, li = dev.classify_download()
+    # candidate lists: strictly ascending keys (sortedness by (distance, node), no duplicates), targets only, bound respected
+    tot = int(count.sum())
+    cnt64 = count.astype(np.int64)
+    seg_begin = np.cumsum(cnt64) - cnt64
+    idx = np.repeat(start.astype(np.int64), cnt64) + (np.arange(tot, dtype=np.int64) - np.repeat(seg_begin, cnt64))
+    keys = pool[idx]
+    seg_first = np.zeros(tot, bool)
+    seg_first[seg_begin[cnt64 > 0]] = True
+    assert (np.diff(keys.astype(np.int64))[~seg_first[1:]] > 0).all()
+    nodes, dist = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64), (keys >> np.uint64(32)).astype(np.int64)
+    assert li[nodes].all() and dist.min() >= 1 and dist.max() <= k - 1
+    assert (nodes != np.repeat(on.astype(np.int64), cnt64)).all()      # forbid_source_target
+    cnt = dev.sssp_count(0, S)
+    assert cnt["emitted"] == tot
+    # T2 at full size: exact pair list vs the oracle's reference-style claim loop
+    pairs = G.replay_claims(on, mu, li, start, count, pool)
+    og = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    want, st = og.greedy_pairs_np(k)
+    assert len(pairs) == len(want) and all(np.array_equal(pairs[f], want[f]) for f in ("out", "in", "dist"))
+    # tigs: every unitig appears exactly once (in one orientation), tigs start/end with unitigs, dummy weights in range
+    lim, edges = api.finish_greedytigs_np(G, pairs, k)
+    ex = G.export()
+    n_orig = bg.n_edges
+    orig = edges[edges < n_orig]
+    assert len(orig) == n_orig // 2 and len(np.unique(orig >> 1)) == n_orig // 2
+    starts = np.r_[0, lim[:-1]].astype(np.int64)
+    assert (edges[starts] < n_orig).all() and (edges[lim.astype(np.int64) - 1] < n_orig).all()
+    dummies_in_tigs = edges[edges >= n_orig]
+    w = ex["edge_weight"][dummies_in_tigs]
+    assert (w >= 1).all() and (w <= k - 1).all()                         # only matched dummies survive inside tigs
+    # Eulerian after Eulerisation: out-degree == in-degree per non-self-mirror node, even degree for self-mirrors
+    outd = np.bincount(ex["edge_from"], minlength=bg.n_nodes)
+    ind = np.bincount(ex["edge_to"], minlength=bg.n_nodes)
+    sm = ex["mirror"] == np.arange(bg.n_nodes)
+    assert (outd[~sm] == ind[~sm]).all() and (outd[sm] % 2 == 0).all()
+    # cumulative length identity (SURVEY 8a): sum of unitig k-mers + kept dummy weights + (k-1) * #tigs
+    cum = int(ex["edge_weight"][edges].sum()) + (k - 1) * len(lim)
+    assert cum == int(bg.edge_weight[0::2].sum()) + int(w.sum()) + (k - 1) * len(lim)

@@ -1,0 +1,67 @@
+"""Tig spelling (bin.rs:466-606): the product's mtg_write_walks_fasta against the oracle's C restatement and
+the independent Python restatement, byte for byte; plus the k-mer-set semantic check. The eulertig path and the
+spelling itself need no GPU; the greedy end-to-end FASTA check is marked gpu."""
+import numpy as np
+import pytest
+
+import pyref
+from matchtigs_amd import api, synth
+
+
+def _fasta_seqs(fa: str):
+    return [l for l in fa.split("\n") if l and not l.startswith(">")]
+
+
+@pytest.mark.parametrize("seed,k,length", [(1, 11, 1500), (2, 15, 3000), (5, 31, 5000)])
+def test_eulertig_fasta_product_equals_oracle_and_pyref(seed, k, length, oracle, product_lib):
+    ug = synth.g_seq(length, seed=seed, k=k, haplotypes=3, sub_rate=0.03)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    tigs = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(k))
+    fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    otigs = og.compute_eulertigs(k)
+    assert otigs == tigs
+    assert og.fasta(otigs, ug.unitigs, k) == fa
+    pg = pyref.from_unitig_links([int(x) for x in ug.weights], ug.links)
+    assert pyref.fasta(pg, pyref.compute_eulertigs(pg, k), ug.unitigs, k) == fa
+    assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
+    # numpy (limits, edges) form gives the same bytes
+    lim = np.cumsum([len(t) for t in tigs]).astype(np.uint64)
+    ed = np.array([e for t in tigs for e in t], dtype=np.uint32)
+    assert api.write_walks_fasta(G, (lim, ed), ug.unitigs, k).decode() == fa
+
+
+def test_greedy_fasta_from_oracle_walks_spelled_by_product(oracle, product_lib):
+    """Greedy tigs contain matched dummy edges (shortened overlaps k-1-weight): spell the ORACLE's walks with the PRODUCT's
+    speller on the product's identically mutated graph (host stages only, no GPU)."""
+    import helpers
+
+    k = 15
+    ug = synth.g_seq(4000, seed=3, k=k, haplotypes=4, sub_rate=0.03)
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    pr = helpers.product_pairs_from_oracle_lists(G, oracle.OracleGraph.from_unitig_links(ug.weights, ug.links), k)
+    tigs = G.finish_greedytigs(pr, k)
+    otigs, _ = og.compute_greedytigs(k)
+    assert tigs == otigs
+    assert any(e >= 2 * len(ug.unitigs) for t in tigs for e in t), "expected at least one kept dummy edge"
+    fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
+    assert fa == og.fasta(otigs, ug.unitigs, k)
+    assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
+    assert fa.count(">") == len(tigs) and fa.startswith(">1\n")
+
+
+@pytest.mark.gpu
+def test_greedy_fasta_end_to_end_on_gpu(oracle, product_lib):
+    """Unitig links in -> GPU greedy matchtigs -> FASTA out, bit-identical to the oracle's FASTA (T4 + spelling)."""
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU")
+    k = 21
+    ug = synth.g_seq(6000, seed=9, k=k, haplotypes=4, sub_rate=0.02)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    tigs = api.GreedytigAlgorithm.compute_tigs(G, api.GreedytigAlgorithmConfiguration.new(1, k))
+    fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    otigs, _ = og.compute_greedytigs(k)
+    assert fa == og.fasta(otigs, ug.unitigs, k)
+    assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
