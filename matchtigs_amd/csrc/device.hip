@@ -693,6 +693,200 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-per-source kernel, hash-indexed (level 0)
+//
+// Same idea as sssp_lane_kernel above (every lane runs its own search and refills itself, so all 64 lanes keep a
+// 32-byte gather in flight and nothing ever waits at a barrier), but the per-lane table is indexed by a per-lane
+// open-addressing byte table (HS = 2C slots holding entry numbers) and the search is label-correcting with a
+// `pending` bitmask, so a step costs O(degree) LDS probes instead of O(n) scans: the table can be 32..64 entries
+// without slowing the small searches that share the wave, and far fewer sources overflow to the cooperative levels.
+// LDS per lane: node[C] u32 + dist[C] u16 + hidx[2C] u8 = 8C bytes (C = 32: 16 KB per wave).
+// ------------------------------------------------------------------------------------------------
+template <int WPB, int C, bool COUNT>
+__global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
+    static_assert(C >= 8 && C <= 64 && (C & (C - 1)) == 0, "C must be a power of two <= 64 (64-bit masks)");
+    constexpr int HS = 2 * C;  // hash slots per lane
+    __shared__ uint32_t s_node[WPB][C][64];
+    __shared__ uint16_t s_dist[WPB][C][64];
+    __shared__ uint8_t s_hidx[WPB][HS][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t(*node)[64] = s_node[wv];
+    uint16_t(*dist)[64] = s_dist[wv];
+    uint8_t(*hidx)[64] = s_hidx[wv];
+
+    unsigned long long chunk_lo = 0, chunk_hi = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    bool exhausted = false;
+    bool active = false;  // lane state
+    uint32_t n = 0, cur_relaxed = 0, n_overflow = 0;
+    unsigned long long pending = 0, targets = 0, expanded = 0, item = 0;
+    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0, st_attempts = 0;
+
+    auto hslot = [](uint32_t nb) -> uint32_t { return ((nb * 0x9E3779B1u) >> 16) & (uint32_t)(HS - 1); };
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        const unsigned long long need = __ballot(!active);
+        if (need && !exhausted) {
+            if (chunk_lo >= chunk_hi) {
+                unsigned long long c0 = 0;
+                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
+                c0 = __shfl(c0, 0);
+                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
+                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
+                if (chunk_lo >= chunk_hi) exhausted = true;
+            }
+            const unsigned want = (unsigned)__popcll(need);
+            if (!active) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const unsigned long long it = chunk_lo + rank;
+                if (it < chunk_hi) {
+                    item = it;
+                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
+                    const uint32_t sn = a.sources[abs_idx];
+#pragma unroll 4
+                    for (int h = 0; h < HS; h++) hidx[h][lane] = 0xFF;
+                    node[0][lane] = sn;
+                    dist[0][lane] = 0;
+                    hidx[hslot(sn)][lane] = 0;
+                    n = 1; pending = 1ull; targets = 0; expanded = 0; cur_relaxed = 0;
+                    active = true;
+                }
+            }
+            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- one expansion per active lane ----
+        bool fin = false, ovf = false;
+        if (active) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(pending);  // lowest pending entry (discovery order)
+            pending &= pending - 1ull;
+            const uint32_t u = node[i][lane];
+            const uint32_t d = dist[i][lane];
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);  // one aligned 32-byte gather
+            const uint4 lo = rp[0];
+            const uint4 hi = rp[1];
+            const uint32_t flags = (hi.z >> 8) & 0xFFu;
+            if ((flags & F_TARGET) && i != 0) targets |= 1ull << i;  // entry 0 is the source itself (forbid_source_target)
+            auto relax = [&](uint32_t nb, uint32_t w) {
+                const uint32_t nd = d + w;
+                if (nd > a.K1) return;
+                uint32_t h = hslot(nb);
+                for (int probe = 0; probe < HS; probe++) {
+                    const uint32_t idx = hidx[h][lane];
+                    if (idx == 0xFFu) {  // new node
+                        if (n < (uint32_t)C) {
+                            hidx[h][lane] = (uint8_t)n;
+                            node[n][lane] = nb;
+                            dist[n][lane] = (uint16_t)nd;
+                            pending |= 1ull << n;
+                            n++;
+                        } else ovf = true;
+                        return;
+                    }
+                    if (node[idx][lane] == nb) {
+                        if (nd < dist[idx][lane]) { dist[idx][lane] = (uint16_t)nd; pending |= 1ull << idx; }
+                        return;
+                    }
+                    h = (h + 1) & (uint32_t)(HS - 1);
+                }
+                ovf = true;
+            };
+            uint32_t deg;
+            if (!(flags & F_EXT)) {
+                deg = hi.z & 0xFFu;
+                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < (int)deg) relax(nb[j], ww[j]);
+            } else {
+                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
+                deg = lo.z;
+                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
+            }
+            if (!((expanded >> i) & 1ull)) { cur_relaxed += deg; expanded |= 1ull << i; }  // algorithmic edges: once per node
+            if constexpr (COUNT) st_attempts += deg;
+            fin = !ovf && pending == 0ull;
+        }
+
+        // ---- finished lanes emit (wave-collective pool allocation) ----
+        const unsigned long long finmask = __ballot(fin);
+        if (finmask) {
+            const uint32_t c = fin ? (uint32_t)__popcll(targets) : 0u;
+            uint32_t incl = c;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t t = __shfl_up(incl, dd);
+                if (lane >= dd) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            if constexpr (!COUNT) {
+                if (total && pool_next + total > pool_end) {
+                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
+                    unsigned long long p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
+                    pool_next = __shfl(p0, 0);
+                    pool_end = pool_next + grab;
+                }
+            }
+            if (fin) {
+                const unsigned long long pos0 = pool_next + (incl - c);
+                if constexpr (!COUNT) {
+                    unsigned long long rem = targets;
+                    for (uint32_t r = 0; r < c; r++) {  // selection sort of the (few) targets by (distance, node)
+                        unsigned long long bk = ~0ull, scan = rem;
+                        uint32_t bi = 0;
+                        while (scan) {
+                            const uint32_t i = (uint32_t)__builtin_ctzll(scan);
+                            scan &= scan - 1ull;
+                            const unsigned long long key = ((unsigned long long)dist[i][lane] << 32) | node[i][lane];
+                            if (key < bk) { bk = key; bi = i; }
+                        }
+                        rem &= ~(1ull << bi);
+                        if (pos0 + r < a.pool_cap && !(a.dbg & 2u)) a.pool[pos0 + r] = bk;
+                    }
+                }
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
+                a.cand_count[abs_idx - a.src_begin] = c;
+                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
+                active = false;
+            }
+            pool_next += total;
+        }
+        if (ovf) {  // ball larger than the per-lane table: hand the source to the cooperative level
+            const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+            a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+            n_overflow++;
+            active = false;
+        }
+    }
+    {   // one atomic per wave
+        unsigned long long o = n_overflow;
+        for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_down(o, dd);
+        if (lane == 0 && o) atomicAdd(&a.counters[C_OVERFLOW], o);
+    }
+    if constexpr (COUNT) {
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            st_settled += __shfl_down(st_settled, dd);
+            st_relaxed += __shfl_down(st_relaxed, dd);
+            st_emitted += __shfl_down(st_emitted, dd);
+            st_attempts += __shfl_down(st_attempts, dd);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[C_SETTLED], st_settled);
+            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
+            atomicAdd(&a.counters[C_ATTEMPTS], st_attempts);
+            atomicAdd(&a.counters[C_EMITTED], st_emitted);
+        }
+    }
+}
+
 // collect absolute indices of overflowed sources (order irrelevant)
 __global__ void collect_overflow_kernel(const uint32_t *cand_count, uint64_t n, uint64_t src_begin, uint32_t *list,
                                         unsigned long long *counters) {
@@ -766,12 +960,16 @@ template <int WPB, int C>
 static LaneCfg make_lane_cfg() {
     return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64};
 }
+template <int WPB, int C>
+static LaneCfg make_lane_hash_cfg() {
+    return LaneCfg{sssp_lane_hash_kernel<WPB, C, false>, sssp_lane_hash_kernel<WPB, C, true>, WPB * 64};
+}
 static LaneCfg lane_cfg(int preset) {
     switch (preset) {
-        case 1: return make_lane_cfg<4, 32>();
-        case 2: return make_lane_cfg<4, 24>();
-        case 3: return make_lane_cfg<4, 12>();
-        default: return make_lane_cfg<4, 16>();
+        case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane table, 32 entries
+        case 1: return make_lane_hash_cfg<2, 64>();  // 64 entries (32 KB per wave)
+        case 2: return make_lane_hash_cfg<4, 16>();
+        default: return make_lane_cfg<4, 12>();      // preset 3: scan-based per-lane table, 12 entries
     }
 }
 //                                              BLOCK LOGH  QCAP  SCAP BSRC
@@ -779,6 +977,12 @@ static LaneCfg lane_cfg(int preset) {
 // global-memory table. A level re-runs the sources whose batch overflowed the previous level's tables.
 static const int N_COOP_LEVELS = 4;
 static LevelCfg coop_level(int i) {
+    static const int exp_l1 = std::getenv("MTG_L1") ? std::atoi(std::getenv("MTG_L1")) : 0;  // tuning experiments
+    if (i == 0 && exp_l1 == 1) return make_cfg<64, 10, 2048, 512, 8, false>();
+    if (i == 0 && exp_l1 == 2) return make_cfg<64, 10, 1024, 512, 8, false>();
+    if (i == 0 && exp_l1 == 3) return make_cfg<128, 11, 2048, 512, 16, false>();
+    if (i == 0 && exp_l1 == 4) return make_cfg<64, 9, 1024, 256, 4, false>();
+    if (i == 0 && exp_l1 == 5) return make_cfg<128, 11, 2048, 512, 32, false>();
     switch (i) {  //                    BLOCK LOGH  QCAP  SCAP BSRC
         case 0: return make_cfg<256, 12, 2048, 1024, 64, false>();
         case 1: return make_cfg<256, 12, 4096, 1024, 8, false>();

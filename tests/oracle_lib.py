@@ -259,6 +259,32 @@ class OracleGraph:
         self.L.og_free(keys)
         return out_nodes, offsets, ks, st.as_dict()
 
+    def whole_path_timed(self, k):
+        """The reference's whole greedy path, stage by stage with wall-clock timers (bench.py cpu_baseline leg).
+        Mutates the graph. Returns (seconds per stage, counters)."""
+        import time
+
+        t = {}
+        t0 = time.perf_counter()
+        pairs, st = self.greedy_pairs_np(k)                     # greedytigs/mod.rs:222-526 (classification + Dijkstra + claim)
+        t["dijkstra_claim"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        arr = np.ascontiguousarray(pairs)
+        did = self.L.og_insert_pair_edges(self.h, arr.ctypes.data_as(C.POINTER(Pair)), len(arr))   # :678-689
+        d = C.c_uint64(did)
+        self.L.og_make_eulerian_with_breaking_edges(self.h, C.byref(d), k)                          # :705
+        t["eulerise"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cyc = self.L.og_euler_cycles(self.h)                    # :722
+        t["euler"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tigs = self.L.og_cut_cycles(self.h, cyc, k, None)       # :726-789
+        t["cut"] = time.perf_counter() - t0
+        n_tigs = int(tigs.contents.n_walks)
+        self.L.og_walks_free(cyc)
+        self.L.og_walks_free(tigs)
+        return t, dict(st, pairs=len(arr), tigs=n_tigs)
+
     def insert_pair_edges(self, pairs):
         arr = (Pair * max(len(pairs), 1))()
         for i, (o, t, d) in enumerate(pairs):
