@@ -11,8 +11,6 @@
 // same sequences as the reference's (BTreeMap / Vec::rotate_left based) code; see DESIGN.md.
 #include "host_graph.hpp"
 
-#include <sys/mman.h>
-
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -201,179 +199,9 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
 //    head"; inserting before x without a prev pointer is done by moving x's edge into a fresh entry y
 //    placed after W (x's old entry receives W's first edge, which leaves the same node).
 // ---------------------------------------------------------------------------------------------
-// Cache-conscious formulation (same sequences as the literal algorithm, see the block comment above).
-// The walk is a chain of dependent random accesses; the first version paid ~7 cache misses per biedge
-// (used[], e_to, cursor, used[], e_next_out, and e_from + cursor again in the FIFO scan). Here:
-//  * per node ONE 32-byte record holds the cursor and the first 3 adjacency entries (edge id + head node) in
-//    iteration order (newest first), the rest spills to a CSR side array: the chain is ~1 miss per step;
-//  * "used" is a bitmap per biedge (E/16 bytes: cache resident);
-//  * cycle entries carry their from-node, and the FIFO scan prefetches the node records it will look at.
-namespace {
-// Big randomly-accessed arrays go on transparent huge pages (THP is in `madvise` mode on the target hosts): with 4 KB
-// pages every step of the walk is also a TLB miss.
-template <typename T>
-struct HugeBuf {
-    T *p = nullptr;
-    size_t n = 0, bytes = 0;
-    explicit HugeBuf(size_t count) : n(count) {
-        bytes = ((count * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
-        if (bytes == 0) bytes = 2u << 20;
-        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (m == MAP_FAILED) MTG_DIE("out of memory (%zu bytes)", bytes);
-        madvise(m, bytes, MADV_HUGEPAGE);
-        p = static_cast<T *>(m);
-    }
-    ~HugeBuf() { if (p) munmap(p, bytes); }
-    HugeBuf(const HugeBuf &) = delete;
-    HugeBuf &operator=(const HugeBuf &) = delete;
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
-};
-struct alignas(32) EulerNode {
-    uint32_t eid[3];
-    uint32_t to[3];
-    uint32_t ext_begin;  // first spill entry (adjacency positions 3..deg-1)
-    uint16_t deg;
-    uint16_t pos;        // adjacency positions < pos are known to be used
-};
-static_assert(sizeof(EulerNode) == 32, "EulerNode must be 32 bytes");
-}  // namespace
-
-static Walks euler_cycles_generic(const HostGraph &g);
-
-Walks euler_cycles(const HostGraph &g) {
-    const uint64_t E = g.edge_count();
-    const uint64_t V = g.node_count();
-    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
-    for (uint64_t n = 0; n < V; n++)
-        if (g.out_deg[n] > 65535) return euler_cycles_generic(g);  // not a de Bruijn graph; keep the simple formulation
-
-    // ---- node records with adjacency in iteration order (newest edge first) ----
-    HugeBuf<EulerNode> nodes(V);
-    uint64_t ext_total = 0;
-    for (uint64_t n = 0; n < V; n++) {
-        EulerNode &r = nodes[n];
-        r.deg = (uint16_t)g.out_deg[n];
-        r.pos = 0;
-        r.ext_begin = (uint32_t)ext_total;
-        if (r.deg > 3) ext_total += r.deg - 3;
-        r.eid[0] = r.eid[1] = r.eid[2] = NONE;
-        r.to[0] = r.to[1] = r.to[2] = NONE;
-    }
-    if (ext_total >= NONE) MTG_DIE("adjacency spill too large");
-    std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
-    {
-        std::vector<uint16_t> fill(V, 0);
-        for (uint64_t e = E; e-- > 0;) {  // descending edge id == newest first
-            const uint32_t f = g.e_from[e];
-            EulerNode &r = nodes[f];
-            const uint16_t i = fill[f]++;
-            if (i < 3) { r.eid[i] = (uint32_t)e; r.to[i] = g.e_to[e]; }
-            else { ext_eid[r.ext_begin + i - 3] = (uint32_t)e; ext_to[r.ext_begin + i - 3] = g.e_to[e]; }
-        }
-    }
-    static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
-    const auto t_build = std::chrono::steady_clock::now();
-    std::vector<uint64_t> used((E / 2 + 63) / 64 + 1, 0);
-    auto is_used = [&](uint32_t e) -> bool { return (used[(e >> 1) >> 6] >> ((e >> 1) & 63)) & 1ull; };
-    auto set_used = [&](uint32_t e) { used[(e >> 1) >> 6] |= 1ull << ((e >> 1) & 63); };
-    // first unused out-edge of `node` in iteration order: (edge, head) or NONE
-    auto next_unused = [&](uint32_t node, uint32_t &to_out) -> uint32_t {
-        EulerNode &r = nodes[node];
-        while (r.pos < r.deg) {
-            const uint32_t e = r.pos < 3 ? r.eid[r.pos] : ext_eid[r.ext_begin + r.pos - 3];
-            if (!is_used(e)) {
-                to_out = r.pos < 3 ? r.to[r.pos] : ext_to[r.ext_begin + r.pos - 3];
-                return e;
-            }
-            r.pos++;
-        }
-        return NONE;
-    };
-
-    // entries: one per biedge plus one per splice (<= E/2 each); the FIFO sees every entry once plus one re-push per splice
-    HugeBuf<uint32_t> ent_edge(E + 1), ent_next(E + 1), ent_node(E + 1), fifo(E + E / 2 + 2);
-    size_t n_ent = 0, fifo_tail = 0;
-    Walks out;
-    out.edges.reserve(E / 2);
-    constexpr size_t PF = 12;  // FIFO prefetch distance
-    uint64_t n_splices = 0;
-    double t_walk = 0, t_fifo = 0;
-
-    for (uint64_t e0 = 0; e0 < E; e0++) {
-        if (is_used((uint32_t)e0)) continue;
-        n_ent = 0; fifo_tail = 0;
-        size_t fifo_head = 0;
-        uint32_t head = NONE;
-        uint32_t start_edge = (uint32_t)e0, start_to = g.e_to[e0];
-        uint32_t start_node = g.e_from[e0];
-        uint32_t splice_at = NONE;
-
-        while (start_edge != NONE) {
-            n_splices++;
-            const auto tw0 = dbg_t ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            const size_t w_begin = n_ent;
-            uint32_t e = start_edge, from = start_node, to = start_to;
-            for (;;) {
-                set_used(e);
-                ent_edge[n_ent] = e;
-                ent_node[n_ent] = from;
-                ent_next[n_ent] = (uint32_t)(n_ent + 1);
-                n_ent++;
-                from = to;
-                e = next_unused(from, to);
-                if (e == NONE) {
-                    if (from != start_node)
-                        MTG_DIE("Euler walk stuck at node %u != start node %u: graph is not Eulerian", from, start_node);
-                    break;
-                }
-            }
-            const size_t w_end = n_ent;
-            if (splice_at == NONE) {
-                head = (uint32_t)w_begin;
-                ent_next[w_end - 1] = head;
-                for (size_t i = w_begin; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
-            } else {
-                const uint32_t x = splice_at;
-                const uint32_t y = (uint32_t)n_ent++;
-                ent_edge[y] = ent_edge[x];
-                ent_node[y] = ent_node[x];
-                ent_next[y] = ent_next[x];  // if x was the only entry this is x itself: y -> x(W1)
-                ent_edge[x] = ent_edge[w_begin];  // x now carries W's first edge (it leaves the same node)
-                if (w_end - w_begin == 1) ent_next[x] = y;
-                else { ent_next[x] = (uint32_t)(w_begin + 1); ent_next[w_end - 1] = y; }
-                head = y;
-                fifo[fifo_head] = y;
-                fifo[fifo_tail++] = x;
-                for (size_t i = w_begin + 1; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
-            }
-            const auto tw1 = dbg_t ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            start_edge = NONE;
-            while (fifo_head < fifo_tail) {
-                if (fifo_head + PF < fifo_tail) __builtin_prefetch(&nodes[ent_node[fifo[fifo_head + PF]]]);
-                const uint32_t ent = fifo[fifo_head];
-                const uint32_t node = ent_node[ent];
-                uint32_t to = NONE;
-                const uint32_t cand = next_unused(node, to);
-                if (cand != NONE) { start_edge = cand; start_to = to; start_node = node; splice_at = ent; break; }
-                fifo_head++;
-            }
-            if (dbg_t) { const auto tw2 = std::chrono::steady_clock::now(); t_walk += std::chrono::duration<double>(tw1 - tw0).count(); t_fifo += std::chrono::duration<double>(tw2 - tw1).count(); }
-        }
-        uint32_t ent = head;
-        do {
-            out.edges.push_back(ent_edge[ent]);
-            ent = ent_next[ent];
-        } while (ent != head);
-        out.limits.push_back(out.edges.size());
-    }
-    if (dbg_t)
-        std::fprintf(stderr, "[mtg] euler_cycles: walk+splice %.3f s (walk %.3f, fifo %.3f, %llu closed sub-walks, %zu entries)\n",
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(), t_walk, t_fifo, (unsigned long long)n_splices, out.edges.size());
-    return out;
-}
-
-static Walks euler_cycles_generic(const HostGraph &g) {
+// The latency-optimised formulation lives in euler_fast.cpp (euler_cycles); this is the simple O(E) one it falls
+// back to for graphs whose node degrees do not fit its records.
+Walks euler_cycles_generic(const HostGraph &g) {
     const uint64_t E = g.edge_count();
     const uint64_t V = g.node_count();
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
