@@ -180,6 +180,7 @@ struct SsspArgs {
     unsigned long long *counters;
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
+    uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
     uint32_t dbg;                // timing experiments only (MTG_DBG env): 1 = gather from a 32 KB window, 2 = no emission writes
 };
 
@@ -477,11 +478,13 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 }
             }
         } else {
+            if (tid == 0) s.base = atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)nsrc);  // slot in the overflow list
+            __syncthreads();
             if (tid < nsrc) {
                 const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
                 a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+                a.ovf_list[s.base + tid] = (uint32_t)abs_idx;
             }
-            if (tid == 0) atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)nsrc);
         }
         __syncthreads();
 
@@ -517,6 +520,35 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 // cooperative kernel. Each settled node is expanded exactly once (work-efficient).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long LANE_SRC_CHUNK = 512;  // sources a wave takes per global atomic
+
+// Overflowed sources of a wave are buffered in LDS and appended to the global overflow list 64 at a time, so the
+// list cursor sees one atomic per 64 sources instead of one per overflow event.
+struct WaveOvfBuf {
+    uint32_t buf[128];
+};
+__device__ __forceinline__ void wave_ovf_push(WaveOvfBuf &w, uint32_t &nbuf, bool ovf, uint32_t abs_idx, const SsspArgs &a, int lane) {
+    const unsigned long long m = __ballot(ovf);
+    if (!m) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (ovf) w.buf[nbuf + rank] = abs_idx;
+    nbuf += (uint32_t)__popcll(m);
+    if (nbuf >= 64) {
+        unsigned long long p0 = 0;
+        if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], 64ull);
+        p0 = __shfl(p0, 0);
+        a.ovf_list[p0 + lane] = w.buf[lane];
+        const uint32_t rest = w.buf[64 + lane];
+        w.buf[lane] = rest;
+        nbuf -= 64;
+    }
+}
+__device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, const SsspArgs &a, int lane) {
+    if (!nbuf) return;
+    unsigned long long p0 = 0;
+    if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)nbuf);
+    p0 = __shfl(p0, 0);
+    if ((uint32_t)lane < nbuf) a.ovf_list[p0 + lane] = w.buf[lane];
+}
 constexpr unsigned long long LANE_POOL_CHUNK = 256; // keys per wave-local pool chunk
 
 template <int WPB, int C, bool COUNT>
@@ -524,6 +556,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
     static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
     __shared__ uint32_t s_node[WPB][C][64];
     __shared__ uint16_t s_dist[WPB][C][64];
+    __shared__ WaveOvfBuf s_ovf[WPB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     uint32_t(*node)[64] = s_node[wv];
@@ -664,18 +697,18 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
             }
             pool_next += total;
         }
-        if (ovf) {  // ball larger than the per-lane table: hand the source to the cooperative level
-            const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-            a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-            n_overflow++;
-            active = false;
+        {   // ball larger than the per-lane table: hand the source to the cooperative level
+            uint32_t ovf_idx = 0;
+            if (ovf) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+                ovf_idx = (uint32_t)abs_idx;
+                active = false;
+            }
+            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
         }
     }
-    {   // one atomic per wave instead of one per overflowed source
-        unsigned long long o = n_overflow;
-        for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_down(o, dd);
-        if (lane == 0 && o) atomicAdd(&a.counters[C_OVERFLOW], o);
-    }
+    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
 
     if constexpr (COUNT) {
         // wave reduction, one atomic per wave and counter
@@ -710,6 +743,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
     __shared__ uint32_t s_node[WPB][C][64];
     __shared__ uint16_t s_dist[WPB][C][64];
     __shared__ uint8_t s_hidx[WPB][HS][64];
+    __shared__ WaveOvfBuf s_ovf[WPB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     uint32_t(*node)[64] = s_node[wv];
@@ -859,18 +893,18 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
             }
             pool_next += total;
         }
-        if (ovf) {  // ball larger than the per-lane table: hand the source to the cooperative level
-            const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-            a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-            n_overflow++;
-            active = false;
+        {   // ball larger than the per-lane table: hand the source to the cooperative level
+            uint32_t ovf_idx = 0;
+            if (ovf) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+                ovf_idx = (uint32_t)abs_idx;
+                active = false;
+            }
+            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
         }
     }
-    {   // one atomic per wave
-        unsigned long long o = n_overflow;
-        for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_down(o, dd);
-        if (lane == 0 && o) atomicAdd(&a.counters[C_OVERFLOW], o);
-    }
+    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
     if constexpr (COUNT) {
         for (int dd = 32; dd >= 1; dd >>= 1) {
             st_settled += __shfl_down(st_settled, dd);
@@ -884,16 +918,6 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
             atomicAdd(&a.counters[C_ATTEMPTS], st_attempts);
             atomicAdd(&a.counters[C_EMITTED], st_emitted);
         }
-    }
-}
-
-// collect absolute indices of overflowed sources (order irrelevant)
-__global__ void collect_overflow_kernel(const uint32_t *cand_count, uint64_t n, uint64_t src_begin, uint32_t *list,
-                                        unsigned long long *counters) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && cand_count[i] == CAND_OVERFLOW) {
-        const unsigned long long pos = atomicAdd(&counters[C_OVF_LIST], 1ull);
-        list[pos] = (uint32_t)(src_begin + i);
     }
 }
 
@@ -920,6 +944,8 @@ struct Device {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint64_t last_level0_overflow = 0;
+    uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
+    uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
@@ -1062,6 +1088,14 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     a.sources = d->d_out_nodes; a.src_index = nullptr; a.n_items = n; a.src_begin = src_begin;
     a.K1 = d->K1; a.pool = d_pool; a.pool_cap = pool_cap; a.cand_start = d_cand_start; a.cand_count = d_cand_count;
     a.counters = d->d_counters;
+    if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each
+        for (int i = 0; i < 2; i++) {
+            if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
+            HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        }
+        d->ovf_cap = n;
+    }
+    a.ovf_list = d->d_ovf[0];
     { const char *e = std::getenv("MTG_DBG"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
     double total_ms = 0.0;
     const bool use_lane = d->preset < 4;
@@ -1076,19 +1110,17 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
     uint64_t total_overflow = d->h_counters[C_OVERFLOW];
     d->last_level0_overflow = total_overflow;
-    uint32_t *d_list = nullptr;
-    // remaining levels over whatever overflowed the previous one
+    // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
+    // to the other of two ping-pong lists
+    int cur_list = 0;
     for (int li = use_lane ? 0 : 1; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
         const LevelCfg next = coop_level(li);
         const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
-        if (!d_list) HIP_CHECK(hipMalloc(&d_list, n_ovf * sizeof(uint32_t)));
-        HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVF_LIST], 0, sizeof(unsigned long long), st));
         HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVERFLOW], 0, sizeof(unsigned long long), st));
-        const unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(collect_overflow_kernel, dim3(blocks), dim3(256), 0, st, d_cand_count, n, src_begin, d_list, d->d_counters);
-        HIP_CHECK(hipGetLastError());
         SsspArgs b = a;
-        b.src_index = d_list;
+        b.src_index = d->d_ovf[cur_list];
+        b.ovf_list = d->d_ovf[cur_list ^ 1];
+        cur_list ^= 1;
         b.n_items = n_ovf;
         launch_level(d, st, next, count, b);
         read_counters(d, st);
@@ -1102,7 +1134,6 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
                                 next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
     }
     d->last_kernel_ms = total_ms;
-    if (d_list) HIP_CHECK(hipFree(d_list));
     if (d->h_counters[C_OVERFLOW] > 0)
         MTG_DIE("bounded search from %llu source(s) exceeds every kernel level (ball larger than 2^22 table entries)",
                 (unsigned long long)d->h_counters[C_OVERFLOW]);
@@ -1204,6 +1235,7 @@ void device_free(Device *d) {
     (void)hipSetDevice(d->dev);
     void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_out_nodes, d->d_block_counts, d->d_counters};
     for (void *b : bufs) (void)hipFree(b);
+    for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
