@@ -35,6 +35,18 @@ def algorithmic_bytes(stats: dict) -> int:
     return 5 * stats["relaxed_edges"] + 12 * stats["settled_nodes"] + 12 * stats["emitted"]
 
 
+def traffic_bytes(args, world: int):
+    """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement for exactly this workload, else null."""
+    if args.traffic_bytes is not None:
+        return args.traffic_bytes
+    preset = 3 if args.preset < 0 else args.preset
+    key = f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:preset={preset}:gpus={world}"
+    try:
+        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key, {}).get("traffic_bytes")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +198,7 @@ def main():
             "bound": "hbm", "kernel": "SSSP stage = sum of its level kernels (see 'kernels')", "kernels": kernels,
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": args.traffic_bytes,
+            "traffic": traffic_bytes(args, world),
             "gather_ceiling_note": "dependent random 32-B gathers saturate at ~54 G/s on MI355X (tools/gather_bench.hip): "
                                    "floor for this stage = settled_nodes / 54e9",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(local_kernel_ms, 4),
