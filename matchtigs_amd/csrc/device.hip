@@ -922,6 +922,197 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lane-per-source kernel, tables in registers (level 0, default)
+//
+// PMC on sssp_lane_kernel (LDS tables): ~640 wave-instructions and ~12 us per wave iteration, most of it waiting on
+// the dependent ds_read -> compare chains of the table scans. With C <= 16 the whole per-lane table fits in VGPRs:
+// node[C] / dist[C] are register arrays that are only ever indexed with compile-time constants (fully unrolled
+// compare / v_cndmask chains for "read entry best", "find nb", "write entry n"), so a step has NO LDS traffic and
+// no dependent memory latency besides its one 32-byte record gather, and occupancy is bounded by VGPRs alone.
+// Exact Dijkstra per lane (select the unsettled minimum), dynamic lane refill, wave-collective pool allocation:
+// as in sssp_lane_kernel. Only the overflow buffer of a wave lives in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int WPB, int C, bool COUNT>
+__global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
+    static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
+    __shared__ WaveOvfBuf s_ovf[WPB];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+
+    unsigned long long chunk_lo = 0, chunk_hi = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    bool exhausted = false;
+    bool active = false;  // lane state
+    uint32_t node[C], dist[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) { node[i] = 0; dist[i] = 0; }
+    uint32_t n = 0, settled = 0, targets = 0, cur_relaxed = 0, n_overflow = 0;
+    unsigned long long item = 0;
+    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        const unsigned long long need = __ballot(!active);
+        if (need && !exhausted) {
+            if (chunk_lo >= chunk_hi) {
+                unsigned long long c0 = 0;
+                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
+                c0 = __shfl(c0, 0);
+                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
+                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
+                if (chunk_lo >= chunk_hi) exhausted = true;
+            }
+            const unsigned want = (unsigned)__popcll(need);
+            if (!active) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const unsigned long long it = chunk_lo + rank;
+                if (it < chunk_hi) {
+                    item = it;
+                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
+                    node[0] = a.sources[abs_idx];
+                    dist[0] = 0;
+                    n = 1; settled = 0; targets = 0; cur_relaxed = 0;
+                    active = true;
+                }
+            }
+            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- one Dijkstra step per active lane (registers only, one 32-byte gather) ----
+        bool fin = false, ovf = false;
+        if (active) {
+            uint32_t best = 0, bestd = 0xFFFFFFFFu, u = 0;
+#pragma unroll
+            for (int i = 0; i < C; i++) {
+                const bool cand = (uint32_t)i < n && !((settled >> i) & 1u) && dist[i] < bestd;
+                bestd = cand ? dist[i] : bestd;
+                best = cand ? (uint32_t)i : best;
+                u = cand ? node[i] : u;
+            }
+            settled |= 1u << best;
+            const uint32_t d = bestd;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);
+            const uint4 lo = rp[0];
+            const uint4 hi = rp[1];
+            const uint32_t flags = (hi.z >> 8) & 0xFFu;
+            if ((flags & F_TARGET) && best != 0) targets |= 1u << best;  // entry 0 is the source itself
+            auto relax = [&](uint32_t nb, uint32_t w) {
+                const uint32_t nd = d + w;
+                if (nd > a.K1) return;
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < C; i++) {
+                    const bool hit = (uint32_t)i < n && node[i] == nb;
+                    found |= hit;
+                    dist[i] = (hit && nd < dist[i]) ? nd : dist[i];  // a settled entry already has dist <= d < nd
+                }
+                if (!found) {
+                    if (n < (uint32_t)C) {
+#pragma unroll
+                        for (int i = 0; i < C; i++) {
+                            const bool here = (uint32_t)i == n;
+                            node[i] = here ? nb : node[i];
+                            dist[i] = here ? nd : dist[i];
+                        }
+                        n++;
+                    } else ovf = true;
+                }
+            };
+            uint32_t deg;
+            if (!(flags & F_EXT)) {
+                deg = hi.z & 0xFFu;
+                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < (int)deg) relax(nb[j], ww[j]);
+            } else {
+                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
+                deg = lo.z;
+                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
+            }
+            cur_relaxed += deg;
+            const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+            fin = !ovf && settled == all;
+        }
+
+        // ---- finished lanes emit (wave-collective pool allocation) ----
+        const unsigned long long finmask = __ballot(fin);
+        if (finmask) {
+            const uint32_t c = fin ? (uint32_t)__popc(targets) : 0u;
+            uint32_t incl = c;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t t = __shfl_up(incl, dd);
+                if (lane >= dd) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            if constexpr (!COUNT) {
+                if (total && pool_next + total > pool_end) {
+                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
+                    unsigned long long p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
+                    pool_next = __shfl(p0, 0);
+                    pool_end = pool_next + grab;
+                }
+            }
+            if (fin) {
+                const unsigned long long pos0 = pool_next + (incl - c);
+                if constexpr (!COUNT) {
+                    uint32_t rem = targets;
+                    for (uint32_t r = 0; r < c; r++) {  // selection sort of the (few) targets by (distance, node)
+                        unsigned long long bk = ~0ull;
+                        uint32_t bi = 0;
+#pragma unroll
+                        for (int i = 1; i < C; i++) {
+                            const unsigned long long key = ((unsigned long long)dist[i] << 32) | node[i];
+                            const bool better = ((rem >> i) & 1u) && key < bk;
+                            bk = better ? key : bk;
+                            bi = better ? (uint32_t)i : bi;
+                        }
+                        rem &= ~(1u << bi);
+                        if (pos0 + r < a.pool_cap) a.pool[pos0 + r] = bk;
+                    }
+                }
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
+                a.cand_count[abs_idx - a.src_begin] = c;
+                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
+                active = false;
+            }
+            pool_next += total;
+        }
+        {   // ball larger than the per-lane table: hand the source to the cooperative level
+            uint32_t ovf_idx = 0;
+            if (ovf) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+                ovf_idx = (uint32_t)abs_idx;
+                active = false;
+            }
+            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
+        }
+    }
+    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
+
+    if constexpr (COUNT) {
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            st_settled += __shfl_down(st_settled, dd);
+            st_relaxed += __shfl_down(st_relaxed, dd);
+            st_emitted += __shfl_down(st_emitted, dd);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.counters[C_SETTLED], st_settled);
+            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
+            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed);
+            atomicAdd(&a.counters[C_EMITTED], st_emitted);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host side of the device stage
 // ------------------------------------------------------------------------------------------------
 struct Device {
@@ -949,7 +1140,7 @@ struct Device {
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
-    int preset = 3;  // lane kernel with 12-entry per-lane tables, then the cooperative cascade
+    int preset = 5;  // lane kernel with 8-entry per-lane register tables, then the cooperative cascade
     int n_cu = 256;
     uint64_t graph_bytes = 0;
 };
@@ -973,7 +1164,7 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-static const int N_PRESETS = 5;
+static const int N_PRESETS = 9;
 // Level plan: lane-per-source kernel (per-lane table of C entries) -> cooperative kernel, 64 sources per
 // workgroup -> cooperative kernel, 1 source per workgroup with a 128 KB LDS table -> cooperative kernel with
 // a 32 MB global-memory table. `preset` picks the lane kernel's table size (4 = skip the lane level).
@@ -987,15 +1178,23 @@ static LaneCfg make_lane_cfg() {
     return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64};
 }
 template <int WPB, int C>
+static LaneCfg make_lane_reg_cfg() {
+    return LaneCfg{sssp_lane_reg_kernel<WPB, C, false>, sssp_lane_reg_kernel<WPB, C, true>, WPB * 64};
+}
+template <int WPB, int C>
 static LaneCfg make_lane_hash_cfg() {
     return LaneCfg{sssp_lane_hash_kernel<WPB, C, false>, sssp_lane_hash_kernel<WPB, C, true>, WPB * 64};
 }
 static LaneCfg lane_cfg(int preset) {
     switch (preset) {
-        case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane table, 32 entries
-        case 1: return make_lane_hash_cfg<2, 64>();  // 64 entries (32 KB per wave)
-        case 2: return make_lane_hash_cfg<4, 16>();
-        default: return make_lane_cfg<4, 12>();      // preset 3: scan-based per-lane table, 12 entries
+        case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane LDS table, 32 entries
+        case 1: return make_lane_reg_cfg<4, 16>();   // register tables, 16 entries
+        case 2: return make_lane_reg_cfg<4, 12>();   // register tables, 12 entries
+        case 5: return make_lane_reg_cfg<4, 8>();    // default: register tables, 8 entries
+        case 6: return make_lane_reg_cfg<4, 24>();
+        case 7: return make_lane_reg_cfg<4, 6>();
+        case 8: return make_lane_reg_cfg<4, 10>();
+        default: return make_lane_cfg<4, 12>();      // preset 3: scan-based per-lane LDS table, 12 entries
     }
 }
 //                                              BLOCK LOGH  QCAP  SCAP BSRC
@@ -1031,6 +1230,7 @@ static void launch_lane(Device *d, hipStream_t st, const LaneCfg &cfg, bool coun
     if (occ < 1) occ = 1;
     const uint64_t waves_needed = (args.n_items + 63) / 64;
     const uint64_t wpb = (uint64_t)cfg.block / 64;
+    if (const char *e = std::getenv("MTG_LANE_OCC")) occ = std::max(1, std::min(occ, std::atoi(e)));  // tuning experiments
     uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + wpb - 1) / wpb);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
@@ -1098,7 +1298,7 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     a.ovf_list = d->d_ovf[0];
     { const char *e = std::getenv("MTG_DBG"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
     double total_ms = 0.0;
-    const bool use_lane = d->preset < 4;
+    const bool use_lane = d->preset != 4;
     if (use_lane) launch_lane(d, st, lane_cfg(d->preset), count, a);
     else launch_level(d, st, coop_level(0), count, a);
     read_counters(d, st);
@@ -1106,8 +1306,8 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     d->last_n_levels = 0;
     if (n) { d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1; }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
-    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed\n", use_lane ? "lane" : "coop level 0",
-                                 (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
+    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_lane ? "lane" : "coop level 0",
+                                 (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
     uint64_t total_overflow = d->h_counters[C_OVERFLOW];
     d->last_level0_overflow = total_overflow;
     // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
@@ -1130,8 +1330,8 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
             d->last_level_sources[d->last_n_levels] = n_ovf;
             d->last_n_levels++;
         }
-        if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed\n", li + 1,
-                                next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW]);
+        if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li + 1,
+                                next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
     }
     d->last_kernel_ms = total_ms;
     if (d->h_counters[C_OVERFLOW] > 0)

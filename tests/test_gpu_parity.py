@@ -74,7 +74,7 @@ def test_classification_matches_oracle(gpu, oracle, idx):
     assert np.array_equal(li, o_live), name
 
 
-@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4])  # lane-kernel table sizes 16/32/24/12, 4 = cooperative kernel only
+@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4, 5, 6])  # lane kernels: 0 hash/LDS, 1/2/5/6 register tables, 3 LDS scan; 4 = cooperative only
 @pytest.mark.parametrize("idx", range(5))
 def test_t1_candidate_lists(gpu, oracle, idx, preset):
     name, bg = graphs()[idx]
