@@ -155,6 +155,21 @@ uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *ti
 uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
                                uint64_t k, const char *unitig_seqs, const uint64_t *seq_offsets, char **fasta_out);
 
+/* BCALM2 / GGCAT unitig FASTA input (the `--bcalm-in X -k K` route, bin.rs:902-912): every
+ * `L:<strand>:<id>:<strand>` annotation becomes one merge of unitig ends exactly as matchtigs_merge_nodes does
+ * (clib.rs:135-170), weights are len + 1 - k (bin.rs:369). `.gz` files are inflated. Returns the built graph and the
+ * sequence store (free with mtg_unitigs_free). Aborts on malformed input, non-ACGT characters, sequences shorter than k. */
+typedef struct mtg_unitigs mtg_unitigs;
+mtg_graph *mtg_read_bcalm2(const char *path, uint64_t k, mtg_unitigs **unitigs_out);
+uint64_t mtg_unitigs_count(const mtg_unitigs *u);
+const char *mtg_unitigs_data(const mtg_unitigs *u);        /* concatenated ASCII sequences */
+const uint64_t *mtg_unitigs_offsets(const mtg_unitigs *u); /* count + 1 offsets into data */
+void mtg_unitigs_free(mtg_unitigs *u);
+/* Spells `tigs` (mtg_write_walks_fasta) into a file; a ".gz" suffix selects gzip at compression_level 0-9
+ * (bin.rs:203, :442-446; pass 6 for the reference's default). Returns the uncompressed byte count. */
+uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
+                                   const char *path, int compression_level);
+
 /* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);
 

@@ -108,6 +108,12 @@ def load():
         "mtg_walks_free": (None, [vp]),
         "mtg_flatten_clib": (u64, [vp, vp, vp, vp, vp]),
         "mtg_write_walks_fasta": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, P(vp)]),
+        "mtg_read_bcalm2": (vp, [C.c_char_p, u64, P(vp)]),
+        "mtg_unitigs_count": (u64, [vp]),
+        "mtg_unitigs_data": (vp, [vp]),
+        "mtg_unitigs_offsets": (vp, [vp]),
+        "mtg_unitigs_free": (None, [vp]),
+        "mtg_write_tigs_fasta_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_int]),
         "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),
         "mtg_last_phase_seconds": (None, [P(C.c_double)]),
         "matchtigs_initialise": (None, []),

@@ -358,6 +358,56 @@ def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int):
     return _take_walks_np(L, L.mtg_finish_greedytigs(graph.handle, _ptr(p), len(p), k))
 
 
+class UnitigStore:
+    """Sequence store filled by read_bcalm2 (replaces DefaultSequenceStore<DnaAlphabet>, bin.rs:871)."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+        self._L = _lib.load()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.mtg_unitigs_free(h)
+
+    @property
+    def handle(self) -> int:
+        return self._h
+
+    def __len__(self) -> int:
+        return int(self._L.mtg_unitigs_count(self._h))
+
+    def sequences(self) -> list[str]:
+        n = len(self)
+        off = np.ctypeslib.as_array(C.cast(self._L.mtg_unitigs_offsets(self._h), C.POINTER(C.c_uint64)), shape=(n + 1,))
+        data = C.string_at(self._L.mtg_unitigs_data(self._h), int(off[n])).decode()
+        return [data[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+def read_bcalm2(path: str, k: int):
+    """`--bcalm-in path -k k` (bin.rs:902-912): BCALM2/GGCAT unitig FASTA (optionally .gz) -> (Bigraph, UnitigStore)."""
+    L = _lib.load()
+    st = C.c_void_p()
+    g = L.mtg_read_bcalm2(str(path).encode(), k, C.byref(st))
+    return Bigraph(g), UnitigStore(st.value)
+
+
+def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: int, k: int, path: str,
+                               compression_level: int = 6, device_id: int = 0) -> dict:
+    """compute (3 = eulertigs, 5 = greedy matchtigs) + spell + write, all inside the library. Returns counts/timings."""
+    import time
+
+    L = _lib.load()
+    t0 = time.perf_counter()
+    w = L.mtg_compute_tigs(graph.handle, algorithm, k, device_id)
+    t1 = time.perf_counter()
+    n_tigs = int(L.mtg_walks_count(w))
+    nbytes = int(L.mtg_write_tigs_fasta_file(graph.handle, w, k, store.handle, str(path).encode(), compression_level))
+    t2 = time.perf_counter()
+    L.mtg_walks_free(w)
+    return {"tigs": n_tigs, "fasta_bytes": nbytes, "compute_s": t1 - t0, "write_s": t2 - t1}
+
+
 def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int) -> bytes:
     """bin.rs:466-606 through the C-ABI: tigs = list of edge-id lists (or (limits, edges) numpy pair) -> FASTA bytes."""
     L = _lib.load()

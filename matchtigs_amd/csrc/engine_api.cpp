@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstring>
+#include <string>
 
 #include "../../include/matchtigs.h"
 #include "../../include/mtg_engine.h"
@@ -190,6 +191,37 @@ uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint6
     if (!g || !fasta_out || (n_walks && (!limits || !edges)) || !unitig_seqs || !seq_offsets)
         MTG_DIE("mtg_write_walks_fasta: null argument");
     return write_walks_fasta(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, fasta_out);
+}
+
+// ---- f-2: BCALM2 input route + FASTA file output ----
+struct mtg_unitigs { UnitigStore *s; };
+
+mtg_graph *mtg_read_bcalm2(const char *path, uint64_t k, mtg_unitigs **unitigs_out) {
+    if (!unitigs_out) MTG_DIE("mtg_read_bcalm2: null argument");
+    UnitigStore *st = nullptr;
+    HostGraph *h = read_bcalm2(path, k, &st);
+    mtg_graph *g = new mtg_graph{std::move(*h)};
+    delete h;
+    *unitigs_out = new mtg_unitigs{st};
+    return g;
+}
+uint64_t mtg_unitigs_count(const mtg_unitigs *u) { return u->s->off.size() - 1; }
+const char *mtg_unitigs_data(const mtg_unitigs *u) { return u->s->data.data(); }
+const uint64_t *mtg_unitigs_offsets(const mtg_unitigs *u) { return u->s->off.data(); }
+void mtg_unitigs_free(mtg_unitigs *u) {
+    if (!u) return;
+    delete u->s;
+    delete u;
+}
+uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
+                                   const char *path, int compression_level) {
+    if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_fasta_file: null argument");
+    char *buf = nullptr;
+    const uint64_t n = write_walks_fasta(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                                         unitigs->s->data.data(), unitigs->s->off.data(), &buf);
+    write_file(path, buf, n, compression_level);
+    std::free(buf);
+    return n;
 }
 
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define MTG_DIE(...)                                  \
@@ -88,6 +89,13 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k);
 bool is_eulerian(const HostGraph &g);
 Walks euler_cycles(const HostGraph &g);
 Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k);
+// bcalm2.cpp: bin.rs:902-912 input route, FASTA file output
+struct UnitigStore {
+    std::string data;           // concatenated ASCII sequences
+    std::vector<uint64_t> off;  // count + 1 offsets
+};
+HostGraph *read_bcalm2(const char *path, uint64_t k, UnitigStore **store_out);
+void write_file(const char *path, const char *data, uint64_t len, int compression_level);
 // spell.cpp: bin.rs:466-606
 uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
                            const char *seqs, const uint64_t *seq_off, char **out_buf);
