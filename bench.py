@@ -39,7 +39,7 @@ def traffic_bytes(args, world: int):
     """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement for exactly this workload, else null."""
     if args.traffic_bytes is not None:
         return args.traffic_bytes
-    preset = 3 if args.preset < 0 else args.preset
+    preset = 5 if args.preset < 0 else args.preset
     key = f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:preset={preset}:gpus={world}"
     try:
         return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key, {}).get("traffic_bytes")
@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
+    ap.add_argument("--host-replay", action="store_true", help="run the claim loop on the host instead of the GPU (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional checks)")
     ap.add_argument("--single-device", action="store_true",
                     help="functional check of the N>1 code path on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo)")
@@ -131,11 +132,18 @@ def main():
         t3 = time.perf_counter()
         ph["allgather"] = t3 - t2
         if rank == 0:
-            cs, cc, po = mdist.to_numpy_u(start_all, count_all, pool_all)
-            on, mu, li = dev.classify_download(stream)
-            t4 = time.perf_counter()
-            ph["download"] = t4 - t3
-            pairs = graph.replay_claims(on, mu, li, cs, cc, po)
+            if args.host_replay:
+                cs, cc, po = mdist.to_numpy_u(start_all, count_all, pool_all)
+                on, mu, li = dev.classify_download(stream)
+                t4 = time.perf_counter()
+                ph["download"] = t4 - t3
+                pairs = graph.replay_claims(on, mu, li, cs, cc, po)
+            else:  # claim loop on the GPU (deterministic reservations); only the matched pairs are downloaded
+                t4 = time.perf_counter()
+                ph["download"] = 0.0
+                pairs = dev.replay_claims_device(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
+                po = pool_all
+                result_info["replay_rounds"] = dev.last_replay_rounds()
             t5 = time.perf_counter()
             ph["replay"] = t5 - t4
             tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k)
@@ -183,10 +191,13 @@ def main():
         # roofline of the dominant kernel (sssp_kernel, level 0) on THIS rank's launch
         alg_bytes = algorithmic_bytes(stats)
         achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
-        level_names = ["sssp_lane_kernel<4,12>", "sssp_kernel<256,12,2048,1024,64>", "sssp_kernel<256,12,4096,1024,8>",
-                       "sssp_kernel<256,14,4096,1024,1>", "sssp_kernel<256,22,...,global>"]
-        if args.preset == 4:
-            level_names = level_names[1:]
+        lane_names = {0: "sssp_lane_hash_kernel<4,32>", 1: "sssp_lane_reg_kernel<4,16>", 2: "sssp_lane_reg_kernel<4,12>",
+                      3: "sssp_lane_kernel<4,12>", 5: "sssp_lane_reg_kernel<4,8>", 6: "sssp_lane_reg_kernel<4,24>",
+                      7: "sssp_lane_reg_kernel<4,6>", 8: "sssp_lane_reg_kernel<4,10>"}
+        preset = 5 if args.preset < 0 else args.preset  # library default: device.hip Device::preset
+        level_names = ([lane_names[preset]] if preset in lane_names else []) + [
+            "sssp_kernel<256,12,2048,1024,64>", "sssp_kernel<256,12,4096,1024,8>", "sssp_kernel<256,14,4096,1024,1>",
+            "sssp_kernel<256,22,...,global>"]
         kernels = []
         if level_ms:
             for li in range(max(len(x) for x in level_ms)):

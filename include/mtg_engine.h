@@ -119,6 +119,15 @@ void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t sr
  * only; returns the preset in force. */
 int mtg_set_sssp_preset(mtg_device *d, int preset);
 
+/* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified
+ * sources (device arrays indexed by absolute source index, e.g. straight from mtg_sssp_candidates or an all-gather):
+ * deterministic reservations by source index reproduce the sequential result exactly. Returns the number of pairs;
+ * *pairs_out (HOST memory, malloc'd, free with mtg_free) holds them in the reference's push order. */
+uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
+                                  const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out);
+/* Reservation rounds the last mtg_replay_claims_device needed. */
+int mtg_last_replay_rounds(const mtg_device *d);
+
 /* ---- host stages ----------------------------------------------------------------------- */
 /* Replays the reference's claim loop over the candidate lists in ascending source order.
  * cand_start/cand_count index `pool`. multiplicity / is_in_node are the classification

@@ -94,6 +94,8 @@ def load():
         "mtg_last_sssp_levels": (C.c_int, [vp, P(C.c_double), P(u64), C.c_int]),
         "mtg_sssp_count": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
         "mtg_set_sssp_preset": (C.c_int, [vp, C.c_int]),
+        "mtg_replay_claims_device": (u64, [vp, vp, u64, vp, vp, vp, P(P(MtgPair))]),
+        "mtg_last_replay_rounds": (C.c_int, [vp]),
         "mtg_replay_claims": (u64, [vp, u64, vp, vp, vp, vp, vp, vp, P(P(MtgPair))]),
         "mtg_free": (None, [vp]),
         "mtg_finish_greedytigs": (vp, [vp, vp, u64, u64]),

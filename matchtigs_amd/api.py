@@ -304,6 +304,20 @@ class DeviceGraph:
     def last_sssp_kernel_ms(self) -> float:
         return float(self._L.mtg_last_sssp_kernel_ms(self._d))
 
+    def replay_claims_device(self, d_cand_start: int, d_cand_count: int, d_pool: int, stream: int = 0) -> np.ndarray:
+        """The claim loop on the GPU over device-resident candidate arrays of ALL sources -> pairs (host numpy)."""
+        pp = C.POINTER(_lib.MtgPair)()
+        n = self._L.mtg_replay_claims_device(self._d, stream, self.n_sources, d_cand_start, d_cand_count, d_pool, C.byref(pp))
+        dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+        arr = np.zeros(n, dt)
+        if n:
+            C.memmove(arr.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
+        self._L.mtg_free(pp)
+        return arr
+
+    def last_replay_rounds(self) -> int:
+        return int(self._L.mtg_last_replay_rounds(self._d))
+
     def last_sssp_levels(self) -> list[dict]:
         ms = (C.c_double * 8)()
         src = (C.c_uint64 * 8)()

@@ -1112,6 +1112,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
     }
 }
 
+#include "replay_kernels.inc"
+
 // ------------------------------------------------------------------------------------------------
 // Host side of the device stage
 // ------------------------------------------------------------------------------------------------
@@ -1135,6 +1137,7 @@ struct Device {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint64_t last_level0_overflow = 0;
+    uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
     uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
@@ -1419,6 +1422,8 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         HIP_CHECK(hipMemcpy(d->d_ext_w, ext_w.data(), ext_total * 2, hipMemcpyHostToDevice));
     }
     HIP_CHECK(hipMalloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4));
+    if (V) HIP_CHECK(hipMemcpy(d->d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4));
     d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
     HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 4));
@@ -1433,7 +1438,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
 void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
-    void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_out_nodes, d->d_block_counts, d->d_counters};
+    void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipHostFree(d->h_counters);
@@ -1515,12 +1520,176 @@ int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) 
     return n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// GPU claim replay (replay_kernels.inc): host driver
+// ------------------------------------------------------------------------------------------------
+struct ReplayWork {
+    uint64_t cap_v = 0, cap_s = 0, cap_slots = 0, cap_blocks = 0;
+    int32_t *mult = nullptr;
+    uint8_t *live = nullptr;
+    uint32_t *resv = nullptr;
+    uint32_t *demand0 = nullptr, *pair_count = nullptr, *pending[2] = {nullptr, nullptr};
+    unsigned long long *pair_off = nullptr, *final_off = nullptr, *block_sums = nullptr;
+    mtg_pair *slots = nullptr;
+};
+
+static void scan_u32(Device *d, hipStream_t st, ReplayWork &w, const uint32_t *in, uint64_t n, unsigned long long *out,
+                     unsigned long long *d_total) {
+    const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nb > w.cap_blocks) {
+        if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
+        HIP_CHECK(hipMalloc(&w.block_sums, nb * 8));
+        w.cap_blocks = nb;
+    }
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, w.block_sums, nb, d_total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums, out);
+    HIP_CHECK(hipGetLastError());
+    (void)d;
+}
+
+// Claims for ALL n_sources classified sources (candidate arrays indexed by absolute source index, device pointers).
+// Returns the number of pairs; *pairs_out (host, malloc'd) holds them in the reference's push order.
+uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
+                       const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out) {
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(d->dev));
+    if (!d->classified || n_sources != d->n_sources) MTG_DIE("mtg_replay_claims_device: classify first; n_sources must be all sources");
+    static ReplayWork w;  // one engine per process in practice; buffers are re-used across calls
+    const uint64_t V = d->V, S = n_sources;
+    if (S == 0) {
+        *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        if (rounds_out) *rounds_out = 0;
+        return 0;
+    }
+    if (V > w.cap_v) {
+        if (w.mult) { HIP_CHECK(hipFree(w.mult)); HIP_CHECK(hipFree(w.live)); HIP_CHECK(hipFree(w.resv)); }
+        HIP_CHECK(hipMalloc(&w.mult, V * 4));
+        HIP_CHECK(hipMalloc(&w.live, V));
+        HIP_CHECK(hipMalloc(&w.resv, V * 4));
+        w.cap_v = V;
+    }
+    if (S > w.cap_s) {
+        if (w.demand0) {
+            HIP_CHECK(hipFree(w.demand0)); HIP_CHECK(hipFree(w.pair_count)); HIP_CHECK(hipFree(w.pending[0]));
+            HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.pair_off)); HIP_CHECK(hipFree(w.final_off));
+        }
+        HIP_CHECK(hipMalloc(&w.demand0, S * 4));
+        HIP_CHECK(hipMalloc(&w.pair_count, S * 4));
+        HIP_CHECK(hipMalloc(&w.pending[0], S * 4));
+        HIP_CHECK(hipMalloc(&w.pending[1], S * 4));
+        HIP_CHECK(hipMalloc(&w.pair_off, S * 8));
+        HIP_CHECK(hipMalloc(&w.final_off, S * 8));
+        w.cap_s = S;
+    }
+    // working copies of the classification state
+    HIP_CHECK(hipMemcpyAsync(w.mult, d->d_mult, V * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_recs, (uint32_t)V, w.live);
+    HIP_CHECK(hipMemsetAsync(w.resv, 0xFF, V * 4, st));
+    unsigned long long *cnt = &d->d_counters[C_OVF_LIST];  // scratch counters: [C_OVF_LIST] and [C_BATCH]
+    unsigned long long *cnt2 = &d->d_counters[C_BATCH];
+    HIP_CHECK(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), st));
+
+    ReplayArgs a{};
+    a.out_nodes = d->d_out_nodes; a.mirror = d->d_mirror; a.mult = w.mult; a.live = w.live;
+    a.cand_start = (const unsigned long long *)d_cand_start; a.cand_count = d_cand_count; a.pool = (const unsigned long long *)d_pool;
+    a.resv = w.resv; a.pair_off = w.pair_off; a.pair_count = w.pair_count; a.n_sources = S;
+    const unsigned sb = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(replay_init_kernel, dim3(sb), dim3(256), 0, st, a, w.demand0, w.pending[0], cnt);
+    HIP_CHECK(hipGetLastError());
+    scan_u32(d, st, w, w.demand0, S, w.pair_off, cnt2);
+    read_counters(d, st);
+    uint64_t n_pending = d->h_counters[C_OVF_LIST];
+    const uint64_t n_slots = d->h_counters[C_BATCH];
+    if (n_slots > w.cap_slots) {
+        if (w.slots) HIP_CHECK(hipFree(w.slots));
+        HIP_CHECK(hipMalloc(&w.slots, std::max<uint64_t>(n_slots, 1) * sizeof(mtg_pair)));
+        w.cap_slots = n_slots;
+    }
+    a.slots = w.slots;
+
+    int cur = 0, rounds = 0;
+    constexpr int MAX_ROUNDS = 256;
+    while (n_pending > 0 && rounds < MAX_ROUNDS) {
+        const unsigned pb = (unsigned)((n_pending + 255) / 256);
+        HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(replay_reserve_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending);
+        hipLaunchKernelGGL(replay_commit_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending, w.pending[cur ^ 1], cnt);
+        hipLaunchKernelGGL(replay_release_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending);
+        HIP_CHECK(hipGetLastError());
+        read_counters(d, st);
+        n_pending = d->h_counters[C_OVF_LIST];
+        cur ^= 1;
+        rounds++;
+    }
+    if (n_pending > 0) {  // very long priority chain: finish the rest in order on one GPU thread
+        std::vector<uint32_t> rest(n_pending);
+        HIP_CHECK(hipMemcpyAsync(rest.data(), w.pending[cur], n_pending * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::sort(rest.begin(), rest.end());
+        HIP_CHECK(hipMemcpyAsync(w.pending[cur], rest.data(), n_pending * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(replay_tail_kernel, dim3(1), dim3(64), 0, st, a, w.pending[cur], n_pending);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (rounds_out) *rounds_out = rounds;
+
+    // compaction in source order
+    scan_u32(d, st, w, w.pair_count, S, w.final_off, cnt);
+    read_counters(d, st);
+    const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
+    mtg_pair *host = (mtg_pair *)std::malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
+    if (!host) MTG_DIE("out of memory");
+    if (n_pairs) {
+        mtg_pair *d_out = nullptr;
+        HIP_CHECK(hipMalloc(&d_out, n_pairs * sizeof(mtg_pair)));
+        hipLaunchKernelGGL(replay_compact_kernel, dim3(sb), dim3(256), 0, st, w.slots, w.pair_off, w.pair_count, w.final_off, S, d_out);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(host, d_out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipFree(d_out));
+    }
+    *pairs_out = host;
+    return n_pairs;
+}
+
 int device_set_preset(Device *d, int preset) {
     if (preset >= 0 && preset < N_PRESETS) d->preset = preset;
     return d->preset;
 }
 
-// convenience for the one-shot path: allocates device buffers, grows the pool on demand, downloads to host vectors
+// one-shot path: SSSP candidates for all sources into engine-owned device buffers (pool grown on demand), then the
+// claim replay on the GPU; only the matched pairs travel to the host.
+uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out) {
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t S = d->n_sources;
+    if (!S) {
+        *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        if (rounds_out) *rounds_out = 0;
+        return 0;
+    }
+    unsigned long long *d_start = nullptr, *d_pool = nullptr;
+    uint32_t *d_count = nullptr;
+    HIP_CHECK(hipMalloc(&d_start, S * 8));
+    HIP_CHECK(hipMalloc(&d_count, S * 4));
+    uint64_t cap = std::max<uint64_t>(S * 2 + (uint64_t)d->n_cu * 32 * LANE_POOL_CHUNK, 1024);
+    for (;;) {
+        HIP_CHECK(hipMalloc(&d_pool, cap * 8));
+        uint64_t needed = 0;
+        if (run_levels(d, st, false, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr) == 0) break;
+        HIP_CHECK(hipFree(d_pool));
+        d_pool = nullptr;
+        cap = needed + needed / 8 + 1024;
+    }
+    const uint64_t n = device_replay(d, stream, S, (const uint64_t *)d_start, d_count, (const uint64_t *)d_pool, pairs_out, rounds_out);
+    HIP_CHECK(hipFree(d_pool));
+    HIP_CHECK(hipFree(d_start));
+    HIP_CHECK(hipFree(d_count));
+    return n;
+}
+
+// convenience for tests: allocates device buffers, grows the pool on demand, downloads to host vectors
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start, std::vector<uint32_t> &cand_count,
                                std::vector<uint64_t> &pool) {
     hipStream_t st = (hipStream_t)stream;

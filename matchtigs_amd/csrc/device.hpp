@@ -25,6 +25,9 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
 double device_last_kernel_ms(const Device *d);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_preset(Device *d, int preset);
+uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
+                       const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out);
+uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out);
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
                                std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);
 

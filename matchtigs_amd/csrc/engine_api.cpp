@@ -23,6 +23,7 @@ struct MatchtigsData { mtg_graph graph; };
 
 static thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static bool g_log_initialised = false;
+static thread_local int g_last_replay_rounds = 0;
 
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -117,6 +118,12 @@ void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t sr
     device_sssp_count(d->d, stream, src_begin, src_end, stats);
 }
 int mtg_set_sssp_preset(mtg_device *d, int preset) { return device_set_preset(d->d, preset); }
+uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
+                                  const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out) {
+    if (!d || !pairs_out) MTG_DIE("mtg_replay_claims_device: null argument");
+    return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, &g_last_replay_rounds);
+}
+int mtg_last_replay_rounds(const mtg_device *) { return g_last_replay_rounds; }
 
 // ---- host stages ----
 uint64_t mtg_replay_claims(const mtg_graph *g, uint64_t n_sources, const uint32_t *out_nodes, const int32_t *multiplicity,
@@ -245,25 +252,19 @@ mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, in
             g_phase[0] = t1 - t0;
             log_info("Collecting nodes with missing incoming or outgoing edges");
             const uint64_t S = mtg_classify(dev, nullptr);
-            std::vector<uint32_t> out_nodes(S);
-            std::vector<int32_t> mult(g->g.node_count());
-            std::vector<uint8_t> live(g->g.node_count());
-            mtg_classify_download(dev, nullptr, out_nodes.data(), mult.data(), live.data());
             double t2 = now_s();
             g_phase[1] = t2 - t1;
             log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
-            std::vector<uint64_t> cand_start, pool;
-            std::vector<uint32_t> cand_count;
-            device_candidates_to_host(dev->d, nullptr, cand_start, cand_count, pool);
+            // SSSP candidates and the claim loop both run on the GPU; only the matched pairs come back
+            mtg_pair *pairs = nullptr;
+            const uint64_t n_pairs = device_pairs(dev->d, nullptr, &pairs, &g_last_replay_rounds);
             double t3 = now_s();
-            g_phase[2] = t3 - t2;  // includes the download (split not observable from here)
+            g_phase[2] = t3 - t2;  // SSSP + replay + pair download
             mtg_device_free(dev);
-            std::vector<Pair> pairs = replay_claims(g->g, S, out_nodes.data(), mult.data(), live.data(), cand_start.data(),
-                                                    cand_count.data(), pool.data());
-            double t4 = now_s();
-            g_phase[4] = t4 - t3;
-            log_info("Found %zu shortest paths", pairs.size());
-            return mtg_finish_greedytigs(g, reinterpret_cast<const mtg_pair *>(pairs.data()), pairs.size(), k);
+            log_info("Found %llu shortest paths", (unsigned long long)n_pairs);
+            mtg_walks *tigs = mtg_finish_greedytigs(g, pairs, n_pairs, k);
+            std::free(pairs);
+            return tigs;
         }
         case 2:
             MTG_DIE("tig algorithm 2 (pathtigs) is outside the scope of the MI355X engine (SURVEY.md 2, row 11)");
