@@ -19,6 +19,7 @@
 
 #include "host_graph.hpp"
 #include "hugebuf.hpp"
+#include "parallel.hpp"
 
 namespace mtg {
 
@@ -37,21 +38,6 @@ struct alignas(128) EulerNode2 {
     uint8_t pad[21];
 };
 static_assert(sizeof(EulerNode2) == 128, "EulerNode2 must be 128 bytes");
-
-template <typename F>
-void parallel_ranges(uint64_t n, F &&f) {
-    unsigned t = std::thread::hardware_concurrency();
-    t = std::max(1u, std::min(t, 32u));
-    if (n < (1u << 16)) t = 1;
-    if (t == 1) { f(0, n); return; }
-    std::vector<std::thread> th;
-    const uint64_t chunk = (n + t - 1) / t;
-    for (unsigned i = 0; i < t; i++) {
-        const uint64_t lo = std::min<uint64_t>(n, i * chunk), hi = std::min<uint64_t>(n, lo + chunk);
-        if (lo < hi) th.emplace_back([&f, lo, hi]() { f(lo, hi); });
-    }
-    for (auto &x : th) x.join();
-}
 }  // namespace
 
 Walks euler_cycles(const HostGraph &g) {

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 
+#include "parallel.hpp"
+
 namespace mtg {
 
 void HostGraph::init_nodes(uint64_t n) {
@@ -36,19 +38,57 @@ uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint
     return e;
 }
 
+// Appends n dummy biedges (out[i] -> in[i] with weight[i] and dummy id first_dummy_id + 1 + i, each followed by its
+// mirror) exactly as n add_biedge calls would: the edge arrays are filled sequentially, the per-node adjacency lists
+// are then linked by node range in parallel (every node's new edges are prepended in ascending edge id by one thread,
+// so the newest-first iteration order is the same as with one-by-one insertion).
+void HostGraph::add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id,
+                                 uint64_t n) {
+    if (!n) return;
+    const uint64_t base = e_from.size();
+    if (base + 2 * n >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
+    const uint64_t total = base + 2 * n;
+    e_from.resize(total); e_to.resize(total); e_next_out.resize(total);
+    e_weight.resize(total); e_dummy.resize(total); e_unitig.resize(total); e_fwd.resize(total);
+    parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint64_t e = base + 2 * i;
+            e_from[e] = out[i]; e_to[e] = in[i];
+            e_from[e + 1] = mirror[in[i]]; e_to[e + 1] = mirror[out[i]];
+            e_weight[e] = e_weight[e + 1] = weight[i];
+            e_dummy[e] = e_dummy[e + 1] = first_dummy_id + 1 + i;
+            e_unitig[e] = e_unitig[e + 1] = 0;
+            e_fwd[e] = 1; e_fwd[e + 1] = 0;
+        }
+    });
+    parallel_ranges(node_count(), [&](uint64_t nlo, uint64_t nhi) {
+        for (uint64_t e = base; e < total; e++) {
+            const uint32_t f = e_from[e];
+            if (f < nlo || f >= nhi) continue;
+            e_next_out[e] = head_out[f];  // newest first, like petgraph's per-node edge list
+            head_out[f] = (uint32_t)e;
+            out_deg[f]++;
+        }
+    });
+}
+
 void HostGraph::reset_to_original() {
     first_breaking_edge = UINT64_MAX;
     breaking_weight = 0;
     dummies_canonical = true;
-    while (e_from.size() > n_original_edges) {
-        const uint32_t e = (uint32_t)e_from.size() - 1;
-        const uint32_t f = e_from[e];
-        if (head_out[f] != e) MTG_DIE("reset_to_original: adjacency list is not in insertion order");
-        head_out[f] = e_next_out[e];
-        out_deg[f]--;
-        e_from.pop_back(); e_to.pop_back(); e_next_out.pop_back();
-        e_weight.pop_back(); e_dummy.pop_back(); e_unitig.pop_back(); e_fwd.pop_back();
-    }
+    const uint64_t total = e_from.size(), keep = n_original_edges;
+    if (total == keep) return;
+    parallel_ranges(node_count(), [&](uint64_t nlo, uint64_t nhi) {  // pop per node, newest edge first
+        for (uint64_t e = total; e-- > keep;) {
+            const uint32_t f = e_from[e];
+            if (f < nlo || f >= nhi) continue;
+            if (head_out[f] != e) MTG_DIE("reset_to_original: adjacency list is not in insertion order");
+            head_out[f] = e_next_out[e];
+            out_deg[f]--;
+        }
+    });
+    e_from.resize(keep); e_to.resize(keep); e_next_out.resize(keep);
+    e_weight.resize(keep); e_dummy.resize(keep); e_unitig.resize(keep); e_fwd.resize(keep);
 }
 
 void HostGraph::validate_pairing() const {

@@ -67,6 +67,8 @@ struct HostGraph {
     void reserve_edges(uint64_t n);
     // Appends edge `from -> to` and its mirror `mirror(to) -> mirror(from)` (ids e, e+1).
     uint32_t add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig);
+    // n dummy biedges at once (same result as n add_biedge calls; adjacency linked in parallel by node range)
+    void add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id, uint64_t n);
     void init_nodes(uint64_t n);
     void validate_pairing() const;
     // Pops all edges beyond the original ones (newest first), restoring head_out / out_deg.

@@ -89,14 +89,12 @@ std::vector<Pair> replay_claims(const HostGraph &g, uint64_t n_sources, const ui
 
 // greedytigs/mod.rs:678-689
 uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
-    uint64_t dummy_edge_id = 0;
-    g.reserve_edges(g.edge_count() + 2 * n_pairs);
-    for (uint64_t i = 0; i < n_pairs; i++) {
-        if (g.first_breaking_edge != UINT64_MAX) g.dummies_canonical = false;  // matched edges after breaking edges
-        dummy_edge_id += 1;
-        g.add_biedge(pairs[i].out_node, pairs[i].in_node, pairs[i].distance, dummy_edge_id, 0);
-    }
-    return dummy_edge_id;
+    if (n_pairs && g.first_breaking_edge != UINT64_MAX) g.dummies_canonical = false;  // matched edges after breaking edges
+    std::vector<uint32_t> out(n_pairs), in(n_pairs);
+    std::vector<uint64_t> w(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; i++) { out[i] = pairs[i].out_node; in[i] = pairs[i].in_node; w[i] = pairs[i].distance; }
+    g.add_biedges_bulk(out.data(), in.data(), w.data(), 0, n_pairs);  // dummy ids 1..n_pairs, :681
+    return n_pairs;
 }
 
 bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicycles (call :708)
@@ -139,9 +137,11 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         for (uint64_t e = g.n_original_edges; e < g.edge_count(); e++)
             if (g.e_weight[e] >= k) g.dummies_canonical = false;  // a matched dummy as long as a breaking edge
     } else g.dummies_canonical = false;  // Eulerised twice
+    // the pairing below only needs `need[]`; the breaking biedges are collected and appended in one bulk call
+    std::vector<uint32_t> brk_out, brk_in;
     auto breaking = [&](uint32_t out_node, uint32_t in_node) {  // :489-493, :506-510, :572-577
-        dummy_edge_id += 1;
-        g.add_biedge(out_node, in_node, k, dummy_edge_id, 0);
+        brk_out.push_back(out_node);
+        brk_in.push_back(in_node);
     };
 
     for (size_t p = 0; p < self_mirrors.size(); p += 2) {  // :481-524
@@ -184,7 +184,9 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         if (need[mirror_in_node] > 0) need[mirror_in_node] -= 1;    // :628-644
     }
     if (first_in(in_cur) < V) MTG_DIE("in_node_differences not empty after Eulerisation (implementation/mod.rs:648)");
-    return dummy_edge_id;
+    const std::vector<uint64_t> brk_w(brk_out.size(), k);
+    g.add_biedges_bulk(brk_out.data(), brk_in.data(), brk_w.data(), dummy_edge_id, brk_out.size());  // ids continue, :573
+    return dummy_edge_id + brk_out.size();
 }
 
 // ---------------------------------------------------------------------------------------------

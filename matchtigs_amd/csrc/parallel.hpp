@@ -1,0 +1,31 @@
+// parallel.hpp -- tiny fork/join helper for the embarrassingly parallel parts of the host stages (record building,
+// adjacency linking). Threads inherit the caller's CPU affinity, so work started under a NumaPin stays on that node.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+namespace mtg {
+
+// Calls f(lo, hi) on disjoint sub-ranges of [0, n) from up to 32 threads (1 thread for small n).
+template <typename F>
+void parallel_ranges(uint64_t n, F &&f) {
+    unsigned t = std::thread::hardware_concurrency();
+    t = std::max(1u, std::min(t, 32u));
+    if (n < (1u << 16)) t = 1;
+    if (t == 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const uint64_t chunk = (n + t - 1) / t;
+    for (unsigned i = 0; i < t; i++) {
+        const uint64_t lo = std::min<uint64_t>(n, i * chunk), hi = std::min<uint64_t>(n, lo + chunk);
+        if (lo < hi) th.emplace_back([&f, lo, hi]() { f(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+}  // namespace mtg
