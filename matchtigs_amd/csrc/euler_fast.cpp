@@ -154,7 +154,16 @@ Walks euler_cycles(const HostGraph &g) {
                     e = next_unused(from, to, j);
                     if (e != NONE && j < 3) {
                         const EulerNode2 &r = nodes[from];
-                        if (r.sub_deg[j] != 0xFF) { h_eid = r.sub_eid[j]; h_to = r.sub_to[j]; h_deg = r.sub_deg[j]; }
+                        if (r.sub_deg[j] != 0xFF) {
+                            h_eid = r.sub_eid[j]; h_to = r.sub_to[j]; h_deg = r.sub_deg[j];
+                            // the node after next is one of h_to[*]: start those (<= 3) record fetches and the used-bitmap
+                            // words now, one whole step before the chain needs them
+                            for (uint32_t q = 0; q < h_deg; q++) {
+                                __builtin_prefetch(&nodes[h_to[q]]);
+                                __builtin_prefetch(reinterpret_cast<const char *>(&nodes[h_to[q]]) + 64);
+                                __builtin_prefetch(&used[(h_eid[q] >> 1) >> 6]);
+                            }
+                        }
                     }
                 }
                 if (e == NONE) {
