@@ -1527,7 +1527,7 @@ struct ReplayWork {
     uint64_t cap_v = 0, cap_s = 0, cap_slots = 0, cap_blocks = 0;
     int32_t *mult = nullptr;
     uint8_t *live = nullptr;
-    uint32_t *resv = nullptr;
+    unsigned long long *resv = nullptr;
     uint32_t *demand0 = nullptr, *pair_count = nullptr, *pending[2] = {nullptr, nullptr};
     unsigned long long *pair_off = nullptr, *final_off = nullptr, *block_sums = nullptr;
     mtg_pair *slots = nullptr;
@@ -1566,7 +1566,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         if (w.mult) { HIP_CHECK(hipFree(w.mult)); HIP_CHECK(hipFree(w.live)); HIP_CHECK(hipFree(w.resv)); }
         HIP_CHECK(hipMalloc(&w.mult, V * 4));
         HIP_CHECK(hipMalloc(&w.live, V));
-        HIP_CHECK(hipMalloc(&w.resv, V * 4));
+        HIP_CHECK(hipMalloc(&w.resv, V * 8));
         w.cap_v = V;
     }
     if (S > w.cap_s) {
@@ -1585,7 +1585,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // working copies of the classification state
     HIP_CHECK(hipMemcpyAsync(w.mult, d->d_mult, V * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_recs, (uint32_t)V, w.live);
-    HIP_CHECK(hipMemsetAsync(w.resv, 0xFF, V * 4, st));
+    HIP_CHECK(hipMemsetAsync(w.resv, 0xFF, V * 8, st));
     unsigned long long *cnt = &d->d_counters[C_OVF_LIST];  // scratch counters: [C_OVF_LIST] and [C_BATCH]
     unsigned long long *cnt2 = &d->d_counters[C_BATCH];
     HIP_CHECK(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), st));
@@ -1613,9 +1613,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     while (n_pending > 0 && rounds < MAX_ROUNDS) {
         const unsigned pb = (unsigned)((n_pending + 255) / 256);
         HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+        a.round_tag = (unsigned long long)(0xFFFFFFFFu - (uint32_t)rounds) << 32;
         hipLaunchKernelGGL(replay_reserve_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending);
         hipLaunchKernelGGL(replay_commit_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending, w.pending[cur ^ 1], cnt);
-        hipLaunchKernelGGL(replay_release_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending);
         HIP_CHECK(hipGetLastError());
         read_counters(d, st);
         n_pending = d->h_counters[C_OVF_LIST];
