@@ -12,14 +12,20 @@
 //   out_nodes[S] ascending source list (u32), mult[V] (i32) from classification.
 //   pool[]       candidate keys (distance << 32 | node), per source contiguous and ascending.
 //
-// SSSP kernel (integer, HBM/latency bound, no MFMA): a workgroup takes a batch of BSRC consecutive
-// sources and runs all their bounded searches together as ONE label-correcting wavefront over a shared
-// LDS open-addressing table keyed by (local source, node) -> tentative distance (64-bit entries,
-// ds_cmpst_b64 / ds_min_u64), with LDS-staged frontier queues (double buffered, one round per hop).
-// Work is balanced over frontier items, not over sources. Distances are exact when the frontier drains
-// (non-negative weights), so the result equals Dijkstra's regardless of relaxation order. Emission
-// ranks each source's targets by (distance, node) in LDS and writes them contiguously.
-// Batches whose ball does not fit the LDS tables are flagged and re-run by larger levels.
+// SSSP stage (integer, gather/latency bound, no MFMA) = a cascade of levels; a source a
+// level cannot finish is appended to a device list by that kernel and re-run from scratch by the next:
+//   level 0   sssp_lane_reg_kernel: one LANE per source, exact Dijkstra over a <=C-entry table held in
+//             VGPRs (compile-time indexed), one 32-byte gather per step, self-refilling lanes, no barrier.
+//             (sssp_lane_kernel / sssp_lane_hash_kernel: the same with LDS tables, kept as presets.)
+//   level 1+  sssp_kernel: a workgroup takes a batch of BSRC sources and runs all their bounded searches
+//             together as ONE label-correcting wavefront over a shared LDS open-addressing table keyed by
+//             (local source, node) -> tentative distance (64-bit entries, ds_cmpst_b64 / ds_min_u64) with
+//             one append-only frontier log. Work is balanced over frontier items, not over sources.
+//             Distances are exact when the log drains (non-negative weights), so the result equals
+//             Dijkstra's regardless of relaxation order. Emission ranks each source's targets by
+//             (distance, node) in LDS and writes them contiguously. The last level keeps table and log
+//             in a global workspace.
+// Claim loop (greedytigs/mod.rs:301-523) on the device: replay_kernels.inc.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
