@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
     ap.add_argument("--host-replay", action="store_true", help="run the claim loop on the host instead of the GPU (A/B)")
+    ap.add_argument("--euler", choices=["host", "device"], default="host",
+                    help="host = Euler walk in the reference's order (default, bit-exact tigs); device = parallel Euler "
+                         "bicycles on the GPU (SURVEY 8 f-3: valid walks, same #tigs/cumulative length, different order)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional checks)")
     ap.add_argument("--single-device", action="store_true",
                     help="functional check of the N>1 code path on a 1-GPU box: every rank uses GPU 0 (needs --backend gloo)")
@@ -92,6 +95,8 @@ def main():
     dev = api.DeviceGraph(graph, k, local_rank)  # H2D: inputs resident in HBM before any timed region
     if args.preset >= 0:
         dev.set_preset(args.preset)
+    if args.euler == "device":
+        api.set_euler_mode(1, local_rank)
     t_gen = time.perf_counter() - t_gen
     stream = torch_glue.current_stream_ptr()
 
@@ -151,6 +156,8 @@ def main():
             ph["eulerise_euler_cut"] = t6 - t5
             hp = api.last_phase_seconds()
             ph["host_eulerise"], ph["host_euler"], ph["host_cut"] = hp["eulerise"], hp["euler"], hp["cut"]
+            if args.euler == "device":
+                ph["euler_device_kernels"] = api.last_euler_kernel_ms() * 1e-3
             result_info.update(S=int(S), pairs=int(len(pairs)), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
                                candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
             graph.reset()
@@ -232,6 +239,7 @@ def main():
                        "candidates": result_info.get("candidates"), "parallelism": f"sources/{world}"},
             "units_per_step": total_stats,
             "phases_ms": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in phases_acc.items()},
+            "euler_mode": args.euler,
             "setup_s": round(t_gen, 2),
             "device_graph_bytes": dev.graph_bytes(),
             "roofline": roofline,

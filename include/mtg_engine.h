@@ -146,6 +146,15 @@ uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_p
 uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k);          /* returns last dummy id */
 mtg_walks *mtg_euler_cycles(const mtg_graph *g);
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k);
+/* the Euler bicycles computed on the GPU by a parallel algorithm (trail pairing, union-find merge,
+ * list ranking). Same guarantees as the reference's decomposition (greedytigs/mod.rs:722: one closed biwalk per
+ * connected component, every biedge exactly once in one orientation) but NOT the reference's walk order, so tig
+ * boundaries differ while #tigs and cumulative length stay the same (SURVEY 8a invariance note). Opt-in:
+ * mode 0 (default) = host walk in the reference's order, mode 1 = this. Aborts without a GPU. */
+mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id);
+void mtg_set_euler_mode(int mode, int device_id); /* used by mtg_finish_greedytigs / mtg_compute_eulertigs / mtg_compute_tigs */
+int mtg_get_euler_mode(void);
+double mtg_last_euler_kernel_ms(void);
 
 uint64_t mtg_walks_count(const mtg_walks *w);
 uint64_t mtg_walks_total_edges(const mtg_walks *w);

@@ -104,6 +104,10 @@ def load():
         "mtg_make_eulerian": (u64, [vp, u64, u64]),
         "mtg_euler_cycles": (vp, [vp]),
         "mtg_cut_cycles": (vp, [vp, vp, u64]),
+        "mtg_euler_cycles_device": (vp, [vp, C.c_int]),
+        "mtg_set_euler_mode": (None, [C.c_int, C.c_int]),
+        "mtg_get_euler_mode": (C.c_int, []),
+        "mtg_last_euler_kernel_ms": (C.c_double, []),
         "mtg_walks_count": (u64, [vp]),
         "mtg_walks_total_edges": (u64, [vp]),
         "mtg_walks_export": (None, [vp, vp, vp]),

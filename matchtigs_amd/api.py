@@ -218,6 +218,14 @@ class Bigraph:
     def euler_cycles(self) -> list[list[int]]:
         return _take_walks(self._L, self._L.mtg_euler_cycles(self._h))
 
+    def euler_cycles_device(self, device_id: int = 0) -> list[list[int]]:
+        """Euler bicycles on the GPU (valid walks, not the reference's order)."""
+        return _take_walks(self._L, self._L.mtg_euler_cycles_device(self._h, device_id))
+
+    def euler_cycles_device_np(self, device_id: int = 0):
+        """(limits, edges) arrays of the GPU Euler bicycles."""
+        return _take_walks_np(self._L, self._L.mtg_euler_cycles_device(self._h, device_id))
+
     def finish_greedytigs(self, pairs: np.ndarray, k: int) -> list[list[int]]:
         p = np.ascontiguousarray(pairs)
         return _take_walks(self._L, self._L.mtg_finish_greedytigs(self._h, _ptr(p), len(p), k))
@@ -439,6 +447,19 @@ def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int) -> b
     data = C.string_at(out, n)
     L.mtg_free(out)
     return data
+
+
+def set_euler_mode(mode: int, device_id: int = 0) -> None:
+    """0 = host Euler walk in the reference's order (default), 1 = parallel Euler bicycles on the GPU (f-3)."""
+    _lib.load().mtg_set_euler_mode(mode, device_id)
+
+
+def get_euler_mode() -> int:
+    return int(_lib.load().mtg_get_euler_mode())
+
+
+def last_euler_kernel_ms() -> float:
+    return float(_lib.load().mtg_last_euler_kernel_ms())
 
 
 def last_phase_seconds() -> dict:

@@ -28,6 +28,8 @@ int device_set_preset(Device *d, int preset);
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
                        const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out);
 uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out);
+// euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
+Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out);
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
                                std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);
 

@@ -24,6 +24,14 @@ struct MatchtigsData { mtg_graph graph; };
 static thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static bool g_log_initialised = false;
 static thread_local int g_last_replay_rounds = 0;
+static int g_euler_mode = 0;    // 0 = host walk in the reference's order, 1 = GPU (euler_device.hip)
+static int g_euler_device = 0;
+static thread_local double g_last_euler_kernel_ms = 0;
+
+static Walks euler_cycles_by_mode(const HostGraph &g) {
+    if (g_euler_mode == 1) return device_euler_cycles(g, g_euler_device, &g_last_euler_kernel_ms);
+    return euler_cycles(g);
+}
 
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -144,6 +152,16 @@ uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_p
 }
 uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k) { return make_eulerian(g->g, dummy_edge_id, k); }
 mtg_walks *mtg_euler_cycles(const mtg_graph *g) { return new mtg_walks{euler_cycles(g->g)}; }
+mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id) {
+    return new mtg_walks{device_euler_cycles(g->g, device_id, &g_last_euler_kernel_ms)};
+}
+void mtg_set_euler_mode(int mode, int device_id) {
+    if (mode != 0 && mode != 1) MTG_DIE("mtg_set_euler_mode: unknown mode %d", mode);
+    g_euler_mode = mode;
+    g_euler_device = device_id;
+}
+int mtg_get_euler_mode(void) { return g_euler_mode; }
+double mtg_last_euler_kernel_ms(void) { return g_last_euler_kernel_ms; }
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k) {
     return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
 }
@@ -156,7 +174,7 @@ static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, uint64_
     double t1 = now_s();
     g_phase[5] += t1 - t0;
     log_info("Finding Eulerian bicycle");
-    Walks cycles = euler_cycles(g);
+    Walks cycles = euler_cycles_by_mode(g);
     double t2 = now_s();
     g_phase[6] = t2 - t1;
     log_info("Found %zu Eulerian bicycles", cycles.limits.size());

@@ -1,0 +1,140 @@
+"""Euler bicycles on the GPU (euler_device.hip).
+
+A parallel Euler decomposition cannot reproduce the sequential tie-breaks of the reference's Hierholzer walk, so this
+mode is judged on the guarantees the reference's callers rely on (greedytigs/mod.rs:708-789), not on bytes:
+closed walks, consecutive edges adjacent, every biedge exactly once in one orientation, one walk per connected
+component (= the number the reference-order walk finds), and -- after the unchanged cutter -- the same number of tigs
+and the same cumulative length as the reference-order path (SURVEY 8a invariance note).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(product_lib):
+    import torch
+
+    if product_lib.mtg_device_count() < 1 or not torch.cuda.is_available():
+        pytest.fail("these tests need a GPU: the device Euler mode has no CPU fallback")
+    return torch
+
+
+def _cases():
+    from matchtigs_amd import synth
+
+    return [
+        ("k5-selfmirror", synth.g_csr(300, seed=3, k=5, mean_weight=2.0, self_mirror_frac=0.05)),
+        ("k9", synth.g_csr(5000, seed=11, k=9, mean_weight=3.0, mean_out_degree=1.8, self_mirror_frac=0.01)),
+        ("k31", synth.g_csr(30000, seed=1, k=31, self_mirror_frac=0.0)),
+        ("k31-dense", synth.g_csr(20000, seed=2, k=31, mean_out_degree=2.2, mean_weight=4.0, self_mirror_frac=0.0)),
+        ("k31-sparse-many-components", synth.g_csr(20000, seed=4, k=31, mean_out_degree=0.6, self_mirror_frac=0.0)),
+        ("k63", synth.g_csr(8000, seed=5, k=63, mean_weight=10.0)),
+    ]
+
+
+def check_bicycles(ex, limits, edges):
+    """Every biedge once, walks closed, consecutive edges adjacent."""
+    E = len(ex["edge_from"])
+    assert len(edges) == E // 2
+    assert np.array_equal(np.sort(edges >> 1), np.arange(E // 2, dtype=edges.dtype))
+    frm, to = ex["edge_from"][edges], ex["edge_to"][edges]
+    begin = np.concatenate([[0], limits[:-1]]).astype(np.int64)
+    end = limits.astype(np.int64)
+    assert (end > begin).all()
+    nxt = np.arange(1, len(edges) + 1, dtype=np.int64)
+    nxt[end - 1] = begin                       # the successor of a walk's last edge is its first
+    assert np.array_equal(to, frm[nxt])
+    # walks start at the smallest edge id of their component, ascending
+    first = edges[begin]
+    assert (np.diff(first.astype(np.int64)) > 0).all()
+    assert (first % 2 == 0).all()
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_device_bicycles_on_eulerised_graph(gpu, idx):
+    name, bg = _cases()[idx]
+    from matchtigs_amd import api
+
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    G.make_eulerian(0, bg.k)
+    ex = G.export()
+    limits, edges = G.euler_cycles_device_np()
+    check_bicycles(ex, limits, edges)
+    host = G.euler_cycles()
+    assert len(limits) == len(host), name      # one closed walk per connected component
+    assert sorted(min(e & ~1 for e in c) for c in host) == edges[np.concatenate([[0], limits[:-1]]).astype(np.int64)].tolist()
+    assert sorted(len(c) for c in host) == sorted(np.diff(np.concatenate([[0], limits]).astype(np.int64)).tolist())
+
+
+def _tig_invariants(ex, tigs, k):
+    dummy = ex["edge_dummy_id"] != 0
+    seen = np.zeros(len(dummy) // 2, np.int64)
+    for t in tigs:
+        a = np.asarray(t, dtype=np.int64)
+        assert not dummy[a[0]] and not dummy[a[-1]]                     # greedytigs/mod.rs:794-798
+        assert np.array_equal(ex["edge_to"][a[:-1]], ex["edge_from"][a[1:]])
+        assert not (dummy[a[:-1]] & dummy[a[1:]]).any()                 # implementation/mod.rs:319-390
+        assert (ex["edge_weight"][a[dummy[a]]] < k).all()               # no breaking edge survives the cut
+        np.add.at(seen, a[~dummy[a]] >> 1, 1)
+    n_orig = int((~dummy).sum()) // 2
+    assert (seen[:n_orig] == 1).all()                                   # every unitig exactly once
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_greedytigs_with_device_euler_mode(gpu, idx):
+    name, bg = _cases()[idx]
+    from matchtigs_amd import api
+
+    k = bg.k
+    cfg = api.GreedytigAlgorithmConfiguration.new(1, k)
+    G0 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    ref_tigs = api.GreedytigAlgorithm.compute_tigs(G0, cfg)            # host walk, reference order
+    w0 = G0.export()["edge_weight"]
+    api.set_euler_mode(1)
+    try:
+        assert api.get_euler_mode() == 1
+        G1 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        tigs = api.GreedytigAlgorithm.compute_tigs(G1, cfg)
+        G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        etigs = api.EulertigAlgorithm.compute_tigs(G2, api.EulertigAlgorithmConfiguration(k))
+    finally:
+        api.set_euler_mode(0)
+    ex = G1.export()
+    _tig_invariants(ex, tigs, k)
+    _tig_invariants(G2.export(), etigs, k)
+    cum = lambda ts, w: sum(int(w[np.asarray(t)].sum()) + k - 1 for t in ts)
+    has_self_mirror = bool((bg.mirror == np.arange(len(bg.mirror))).any())
+    if not has_self_mirror:
+        # T3 is invariant under the Euler order when no two breaking edges can become consecutive (SURVEY 8a note)
+        assert len(tigs) == len(ref_tigs), name
+        assert cum(tigs, ex["edge_weight"]) == cum(ref_tigs, w0), name
+    else:
+        assert abs(len(tigs) - len(ref_tigs)) <= max(2, len(ref_tigs) // 50), name
+
+
+def test_device_euler_real_dbg_kmer_set(gpu):
+    """Spelled tigs of a real (tiny) de Bruijn graph still contain exactly the input k-mer set."""
+    from matchtigs_amd import api, synth
+
+    ug = synth.g_seq(3000, seed=7, k=15)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    api.set_euler_mode(1)
+    try:
+        tigs = api.GreedytigAlgorithm.compute_tigs(G, api.GreedytigAlgorithmConfiguration.new(1, ug.k))
+    finally:
+        api.set_euler_mode(0)
+    fasta = api.write_walks_fasta(G, tigs, ug.unitigs, ug.k).decode()
+    seqs = [l for l in fasta.splitlines() if l and not l.startswith(">")]
+    assert synth.kmer_set_of_tigs(seqs, ug.k) == ug.kmers
+
+
+def test_device_euler_full_bench_size(gpu):
+    from matchtigs_amd import api, synth
+
+    bg = synth.g_csr(5_592_405, seed=1, k=31)
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    G.make_eulerian(0, bg.k)
+    limits, edges = G.euler_cycles_device_np()
+    check_bicycles(G.export(), limits, edges)
