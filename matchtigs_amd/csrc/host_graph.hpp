@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,21 @@ namespace mtg {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
+// std::vector whose resize() leaves new elements uninitialised: the bulk edge insertion fills them from host threads,
+// and a sequential zero-fill of hundreds of MB first would cost as much as the fill itself.
+template <typename T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <typename U>
+    struct rebind { using other = DefaultInitAlloc<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U>
+    void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A>
+    void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T>
+using PodVec = std::vector<T, DefaultInitAlloc<T>>;
+
 struct Pair {
     uint32_t out_node;
     uint32_t in_node;
@@ -31,8 +47,8 @@ struct Pair {
 };
 
 struct Walks {
-    std::vector<uint64_t> limits;  // exclusive end of walk i
-    std::vector<uint32_t> edges;   // edge ids
+    PodVec<uint64_t> limits;  // exclusive end of walk i
+    PodVec<uint32_t> edges;   // edge ids
 };
 
 struct HostGraph {
@@ -47,11 +63,11 @@ struct HostGraph {
     std::vector<uint32_t> mirror;    // [V]
     std::vector<uint32_t> head_out;  // [V] newest outgoing edge (petgraph iteration order: newest first)
     std::vector<uint32_t> out_deg;   // [V]; in_deg(n) == out_deg(mirror(n)) by the mirror property
-    std::vector<uint32_t> e_from, e_to, e_next_out;  // [E]
-    std::vector<uint64_t> e_weight;                  // [E]
-    std::vector<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)
-    std::vector<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
-    std::vector<uint8_t> e_fwd;                      // [E]
+    PodVec<uint32_t> e_from, e_to, e_next_out;  // [E]
+    PodVec<uint64_t> e_weight;                  // [E]
+    PodVec<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)
+    PodVec<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
+    PodVec<uint8_t> e_fwd;                      // [E]
     uint64_t n_original_edges = 0;
     // bookkeeping for the streaming cutter: ids >= first_breaking_edge are breaking dummies of weight breaking_weight
     uint64_t first_breaking_edge = UINT64_MAX;

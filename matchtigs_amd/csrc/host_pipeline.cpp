@@ -12,10 +12,27 @@
 #include "host_graph.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
+
+#include "parallel.hpp"
 
 namespace mtg {
+
+namespace {
+struct StageTimer {  // MTG_DEBUG=1: per-stage host timings on stderr
+    const bool on = std::getenv("MTG_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mtg] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // Claim loop over precomputed candidate lists.
@@ -89,21 +106,27 @@ std::vector<Pair> replay_claims(const HostGraph &g, uint64_t n_sources, const ui
 
 // greedytigs/mod.rs:678-689
 uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
+    StageTimer tm;
     if (n_pairs && g.first_breaking_edge != UINT64_MAX) g.dummies_canonical = false;  // matched edges after breaking edges
     std::vector<uint32_t> out(n_pairs), in(n_pairs);
     std::vector<uint64_t> w(n_pairs);
     for (uint64_t i = 0; i < n_pairs; i++) { out[i] = pairs[i].out_node; in[i] = pairs[i].in_node; w[i] = pairs[i].distance; }
+    tm.lap("insert_pairs: unpack");
     g.add_biedges_bulk(out.data(), in.data(), w.data(), 0, n_pairs);  // dummy ids 1..n_pairs, :681
+    tm.lap("insert_pairs: bulk add");
     return n_pairs;
 }
 
 bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicycles (call :708)
-    const uint64_t V = g.node_count();
-    for (uint64_t n = 0; n < V; n++) {
-        if (g.self_mirror((uint32_t)n)) { if (g.out_deg[n] & 1) return false; }
-        else if (g.out_deg[n] != g.in_deg((uint32_t)n)) return false;
-    }
-    return true;
+    std::atomic<bool> ok{true};
+    parallel_ranges(g.node_count(), [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++) {
+            if (g.self_mirror((uint32_t)n)) {
+                if (g.out_deg[n] & 1) ok = false;
+            } else if (g.out_deg[n] != g.in_deg((uint32_t)n)) ok = false;
+        }
+    });
+    return ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -112,23 +135,57 @@ bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicy
 // The reference keeps two BTreeMaps (out-nodes keyed by Reverse(node), in-nodes keyed by node) that
 // only lose entries after construction, always takes their first keys, and looks entries up by
 // node. Dense formulation: need[n] < 0 for a present out-entry, > 0 for a present in-entry, 0 for
-// "not in either map"; the first keys are two monotone cursors.
+// "not in either map"; the maps' key sets are two static sorted node lists (built by host threads) and
+// their first keys two monotone cursors into those lists that skip entries whose need has reached 0.
 // ---------------------------------------------------------------------------------------------
 uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
+    StageTimer tm;
     const uint64_t V = g.node_count();
-    std::vector<int32_t> need(V, 0);
-    std::vector<uint32_t> self_mirrors;
-    for (uint64_t n = 0; n < V; n++) {  // find_non_eulerian_binodes_with_differences, :408
-        if (g.self_mirror((uint32_t)n)) {
-            if (g.out_deg[n] & 1) self_mirrors.push_back((uint32_t)n);  // difference 0 entries, :424-427
-        } else {
-            need[n] = (int32_t)((int64_t)g.out_deg[n] - (int64_t)g.in_deg((uint32_t)n));
+    PodVec<int32_t> need(V);
+    // find_non_eulerian_binodes_with_differences, :408: per node range, then concatenated in node order
+    constexpr unsigned MAX_PARTS = 64;
+    std::vector<uint32_t> part_sm[MAX_PARTS], part_in[MAX_PARTS], part_out[MAX_PARTS];
+    std::atomic<unsigned> n_parts{0};
+    std::vector<std::pair<uint64_t, unsigned>> part_of;  // (range begin, part id)
+    std::mutex part_mutex;
+    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
+        const unsigned id = n_parts++;
+        if (id >= MAX_PARTS) MTG_DIE("make_eulerian: too many host threads");
+        {
+            std::lock_guard<std::mutex> l(part_mutex);
+            part_of.emplace_back(lo, id);
         }
+        std::vector<uint32_t> sm, in, out;  // thread-local while growing (the shared headers would false-share)
+        for (uint64_t n = lo; n < hi; n++) {
+            int32_t d = 0;
+            if (g.self_mirror((uint32_t)n)) {
+                if (g.out_deg[n] & 1) sm.push_back((uint32_t)n);  // difference 0 entries, :424-427
+            } else {
+                d = (int32_t)((int64_t)g.out_deg[n] - (int64_t)g.in_deg((uint32_t)n));
+                if (d > 0) in.push_back((uint32_t)n);
+                else if (d < 0) out.push_back((uint32_t)n);
+            }
+            need[n] = d;
+        }
+        part_sm[id] = std::move(sm);
+        part_in[id] = std::move(in);
+        part_out[id] = std::move(out);
+    });
+    std::sort(part_of.begin(), part_of.end());
+    std::vector<uint32_t> self_mirrors, in_list, out_list;  // ascending node order
+    uint64_t total_in = 0;
+    for (auto &po : part_of) {
+        self_mirrors.insert(self_mirrors.end(), part_sm[po.second].begin(), part_sm[po.second].end());
+        in_list.insert(in_list.end(), part_in[po.second].begin(), part_in[po.second].end());
+        out_list.insert(out_list.end(), part_out[po.second].begin(), part_out[po.second].end());
     }
-    uint64_t in_cur = 0;       // smallest node with need > 0
-    int64_t out_cur = (int64_t)V - 1;  // largest node with need < 0
+    for (uint32_t n : in_list) total_in += (uint64_t)need[n];
+    tm.lap("make_eulerian: need[]");
+    const uint64_t NI = in_list.size();
+    uint64_t in_cur = 0;                         // index into in_list: smallest node with need > 0
+    int64_t out_cur = (int64_t)out_list.size() - 1;  // index into out_list: largest node with need < 0
     auto first_in = [&](uint64_t from) -> uint64_t {
-        while (from < V && need[from] <= 0) from++;
+        while (from < NI && need[in_list[from]] <= 0) from++;
         return from;
     };
     if (g.first_breaking_edge == UINT64_MAX) {
@@ -139,6 +196,8 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
     } else g.dummies_canonical = false;  // Eulerised twice
     // the pairing below only needs `need[]`; the breaking biedges are collected and appended in one bulk call
     std::vector<uint32_t> brk_out, brk_in;
+    brk_out.reserve(total_in + self_mirrors.size());
+    brk_in.reserve(total_in + self_mirrors.size());
     auto breaking = [&](uint32_t out_node, uint32_t in_node) {  // :489-493, :506-510, :572-577
         brk_out.push_back(out_node);
         brk_in.push_back(in_node);
@@ -149,10 +208,10 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
             breaking(self_mirrors[p], self_mirrors[p + 1]);
         } else {
             in_cur = first_in(in_cur);
-            if (in_cur >= V)
+            if (in_cur >= NI)
                 MTG_DIE("Have an uneven number of self-mirrors, but no other nodes with missing in edges. "
                         "(implementation/mod.rs:496-498)");
-            const uint32_t in_node = (uint32_t)in_cur;
+            const uint32_t in_node = in_list[in_cur];
             breaking(self_mirrors[p], in_node);
             const uint32_t m = g.mirror[in_node];
             if (need[m] >= 0) MTG_DIE("Mirror of in_node not found (implementation/mod.rs:517)");
@@ -162,19 +221,19 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
     }
 
     for (;;) {  // :526
-        while (out_cur >= 0 && need[out_cur] >= 0) out_cur--;
+        while (out_cur >= 0 && need[out_list[out_cur]] >= 0) out_cur--;
         if (out_cur < 0) break;
-        const uint32_t out_node = (uint32_t)out_cur;
+        const uint32_t out_node = out_list[out_cur];
         const int32_t out_diff = need[out_node];
         // choose_in_node_from_iterator, :252-285
         in_cur = first_in(in_cur);
-        if (in_cur >= V) MTG_DIE("in_node_iterator.next().unwrap() on an empty map (implementation/mod.rs:262)");
+        if (in_cur >= NI) MTG_DIE("in_node_iterator.next().unwrap() on an empty map (implementation/mod.rs:262)");
         uint64_t pick = in_cur;
-        if ((pick == g.mirror[out_node] && out_diff > -2) || pick == out_node) {
+        if ((in_list[pick] == g.mirror[out_node] && out_diff > -2) || in_list[pick] == out_node) {
             pick = first_in(pick + 1);
-            if (pick >= V) MTG_DIE("No further in_nodes left (implementation/mod.rs:553)");
+            if (pick >= NI) MTG_DIE("No further in_nodes left (implementation/mod.rs:553)");
         }
-        const uint32_t in_node = (uint32_t)pick;
+        const uint32_t in_node = in_list[pick];
         const uint32_t mirror_out_node = g.mirror[in_node];  // :569
         const uint32_t mirror_in_node = g.mirror[out_node];  // :570
         breaking(out_node, in_node);
@@ -183,9 +242,11 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         if (need[mirror_out_node] < 0) need[mirror_out_node] += 1;  // :609-627, only if still present
         if (need[mirror_in_node] > 0) need[mirror_in_node] -= 1;    // :628-644
     }
-    if (first_in(in_cur) < V) MTG_DIE("in_node_differences not empty after Eulerisation (implementation/mod.rs:648)");
+    if (first_in(in_cur) < NI) MTG_DIE("in_node_differences not empty after Eulerisation (implementation/mod.rs:648)");
+    tm.lap("make_eulerian: pairing");
     const std::vector<uint64_t> brk_w(brk_out.size(), k);
     g.add_biedges_bulk(brk_out.data(), brk_in.data(), brk_w.data(), dummy_edge_id, brk_out.size());  // ids continue, :573
+    tm.lap("make_eulerian: bulk add");
     return dummy_edge_id + brk_out.size();
 }
 
@@ -357,6 +418,67 @@ Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
             rot = 0;
             for (uint64_t i = 0; i < len; i++)
                 if (cyc[i] >= n_orig && g.e_weight[cyc[i]] > longest_w) { longest_w = g.e_weight[cyc[i]]; rot = i; }
+        }
+        if (len >= (1u << 20)) {
+            // long cycle: the same cut, by host threads over chunks of the rotated index j (edge = cyc[(rot + j) % len]):
+            // cut(j) = breaking edge, or any dummy at j == 0 (:768); a tig ends at a kept j whose successor is cut or absent.
+            auto edge_at = [&](uint64_t j) { return cyc[j + rot < len ? j + rot : j + rot - len]; };
+            auto is_cut = [&](uint64_t j, uint32_t e) { return e >= first_brk || (j == 0 && e >= n_orig); };
+            constexpr unsigned MAXP = 64;
+            uint64_t part_lo[MAXP], part_kept[MAXP], part_ends[MAXP];
+            std::atomic<unsigned> n_parts{0};
+            parallel_ranges(len, [&](uint64_t lo, uint64_t hi) {
+                const unsigned id = n_parts++;
+                uint64_t kept = 0, ends = 0;
+                uint32_t e = edge_at(lo);
+                for (uint64_t j = lo; j < hi; j++) {
+                    const uint32_t nx = j + 1 < len ? edge_at(j + 1) : 0;
+                    if (!is_cut(j, e)) {
+                        kept++;
+                        if (j + 1 == len || is_cut(j + 1, nx)) ends++;
+                    }
+                    e = nx;
+                }
+                part_lo[id] = lo; part_kept[id] = kept; part_ends[id] = ends;
+            });
+            const unsigned P = n_parts;
+            unsigned order[MAXP];
+            for (unsigned i = 0; i < P; i++) order[i] = i;
+            std::sort(order, order + P, [&](unsigned a, unsigned b) { return part_lo[a] < part_lo[b]; });
+            uint64_t kept_off[MAXP], ends_off[MAXP], kept_total = 0, ends_total = 0;
+            for (unsigned i = 0; i < P; i++) {
+                kept_off[order[i]] = kept_total; ends_off[order[i]] = ends_total;
+                kept_total += part_kept[order[i]]; ends_total += part_ends[order[i]];
+            }
+            const uint64_t lim_base = tigs.limits.size();
+            tigs.limits.resize(lim_base + ends_total);
+            uint64_t *lim = tigs.limits.data() + lim_base;
+            const uint64_t out_base = n_out;
+            std::atomic<unsigned> n_parts2{0};
+            parallel_ranges(len, [&](uint64_t lo, uint64_t hi) {
+                n_parts2++;
+                unsigned id = 0;
+                while (part_lo[id] != lo) id++;
+                uint64_t w = out_base + kept_off[id], l = ends_off[id];
+                uint32_t e = edge_at(lo);
+                for (uint64_t j = lo; j < hi; j++) {
+                    const uint32_t nx = j + 1 < len ? edge_at(j + 1) : 0;
+                    if (!is_cut(j, e)) {
+                        out[w++] = e;
+                        if (j + 1 == len || is_cut(j + 1, nx)) lim[l++] = w;
+                    }
+                    e = nx;
+                }
+            });
+            n_out = out_base + kept_total;
+            // tail (:779-788): a trailing (matched) dummy is dropped
+            if (kept_total && !is_cut(len - 1, edge_at(len - 1)) && out[n_out - 1] >= n_orig) {
+                n_out--;
+                const uint64_t prev = tigs.limits.size() >= 2 && ends_total >= 2 ? tigs.limits[tigs.limits.size() - 2] : out_base;
+                if (n_out > prev) tigs.limits.back() = n_out;
+                else tigs.limits.pop_back();
+            }
+            continue;
         }
         uint64_t tig_begin = n_out;  // start of the tig being assembled
         auto close_tig = [&]() {

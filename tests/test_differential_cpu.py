@@ -130,3 +130,17 @@ def test_edge_cases_empty_and_balanced(oracle, product_lib):
     et = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(5))
     assert et == helpers.oracle_graph(mirror, frm, to, w).compute_eulertigs(5)
     assert G.edge_count() == 6 and len(et) == 1 and len(et[0]) == 3
+
+
+def test_long_cycle_parallel_cutter_equals_oracle(oracle, product_lib):
+    """A closed walk above 2^20 biedges takes the threaded cutter (host_pipeline.cpp); same tigs as the oracle's."""
+    from matchtigs_amd import api, synth
+
+    bg = synth.g_csr(750000, seed=3, k=31)
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    L = api._lib.load()
+    lim, ed = api._take_walks_np(L, L.mtg_compute_eulertigs(G.handle, 31))
+    og = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    want = og.compute_eulertigs(31)
+    assert np.array_equal(np.cumsum([len(t) for t in want]), lim)
+    assert np.array_equal(np.array([e for t in want for e in t], dtype=np.uint32), ed)
