@@ -187,8 +187,16 @@ struct SsspArgs {
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
+    uint32_t *seed_out;          // out (lane level, optional): search state of every overflowed source, SEED_WORDS per ovf_list entry
+    const uint32_t *seed_in;     // in (cooperative level, optional): seeds parallel to src_index -- continue instead of restart
     uint32_t dbg;                // timing experiments only (MTG_DBG env): 1 = gather from a 32 KB window, 2 = no emission writes
 };
+
+// Seed = the state of a lane-level Dijkstra at the moment its table overflowed, so that the cooperative level
+// continues the search instead of repeating it: word 0..7 node, 8..11 distances (u16 pairs), 12 = n | settled << 8 |
+// targets << 16 (the node whose relaxation was interrupted is stored as unsettled), 13..15 unused (64-byte records).
+constexpr int SEED_WORDS = 16;
+constexpr int SEED_C = 8;
 
 template <bool GLOBAL_WS>
 struct Mem {
@@ -313,23 +321,54 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 
         // ---- init (the table is clean here) ----
         if (tid < BSRC) { s.cnt[tid] = 0; s.fill[tid] = 0; }
-        if (tid == 0) { s.tail = (uint32_t)nsrc; s.ovf = 0; s.bt_settled = 0; s.bt_relaxed = 0; s.bt_attempts = 0; }
+        if (tid == 0) { s.tail = a.seed_in ? 0u : (uint32_t)nsrc; s.ovf = 0; s.bt_settled = 0; s.bt_relaxed = 0; s.bt_attempts = 0; }
         __syncthreads();
-        if (tid < nsrc) {
-            const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
-            const uint32_t node = a.sources[abs_idx];
-            s.srcnode[tid] = node;
-            uint32_t slot = 0;
-            const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
-            if (r < 0) s.ovf = 1;
-            M::st(&log[tid], (slot << HINT_BITS) | 0u);
+        uint32_t begin = 0;
+        if (!a.seed_in) {
+            if (tid < nsrc) {
+                const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
+                const uint32_t node = a.sources[abs_idx];
+                s.srcnode[tid] = node;
+                uint32_t slot = 0;
+                const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
+                if (r < 0) s.ovf = 1;
+                M::st(&log[tid], (slot << HINT_BITS) | 0u);
+            }
+            __syncthreads();
+            if (tid == 0) s.end = s.ovf ? 0u : (uint32_t)nsrc;  // loop bounds are only ever published between two barriers
+            __syncthreads();
+        } else {
+            // continue the lane level's searches: its settled entries go to the log first (never expanded again, but
+            // walked by emission and clean-up), its open entries form the first frontier
+            if (tid < nsrc) s.srcnode[tid] = a.sources[a.src_index[item0 + tid]];
+            for (int pass = 0; pass < 2; pass++) {
+                for (uint32_t w = tid; w < (uint32_t)nsrc * SEED_C; w += BLOCK) {
+                    const uint32_t t = w / SEED_C, j = w % SEED_C;
+                    const uint32_t *sd = a.seed_in + (item0 + t) * SEED_WORDS;
+                    const uint32_t meta = sd[12];
+                    if (j >= (meta & 0xFFu)) continue;
+                    const bool is_settled = (meta >> (8 + j)) & 1u;
+                    if (is_settled != (pass == 0)) continue;
+                    const uint32_t node = sd[j];
+                    const uint32_t dist = (sd[8 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+                    uint32_t slot = 0;
+                    const int r = tbl_relax<LOGH, GLOBAL_WS>(table, t, node, dist, slot);
+                    if (r <= 0) { s.ovf = 1; continue; }  // table full (a seed never holds a node twice)
+                    if (is_settled && ((meta >> (16 + j)) & 1u)) M::fand(&table[slot], ~1ull);  // confirmed in-node
+                    const uint32_t pos = atomicAdd(&s.tail, 1u);
+                    if (pos < (uint32_t)QCAP) M::st(&log[pos], (slot << HINT_BITS) | (dist & HINT_MASK));
+                    else s.ovf = 1;
+                }
+                __syncthreads();
+                if (tid == 0) s.end = s.ovf ? 0u : min(s.tail, (uint32_t)QCAP);
+                __syncthreads();
+                if (pass == 0) begin = s.end;
+            }
+            if (s.ovf) begin = 0;  // uniform (s.ovf is stable after the barrier): no rounds
         }
-        __syncthreads();
-        if (tid == 0) s.end = s.ovf ? 0u : (uint32_t)nsrc;  // loop bounds are only ever published between two barriers
-        __syncthreads();
 
         // ---- label-correcting rounds: round r processes log[begin, end), pushes append at tail ----
-        uint32_t begin = 0, end = s.end;
+        uint32_t end = s.end;
         for (int round = 0; begin < end; round++) {  // uniform: `end` is a snapshot published by thread 0
             for (uint32_t i = begin + tid; i < end; i += BLOCK) {
                 const uint32_t item = M::ld(&log[i]);
@@ -941,9 +980,12 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
 template <int WPB, int C, bool COUNT>
 __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
     static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
+    constexpr bool SEEDED = (C == SEED_C);  // the 8-entry instantiation can hand its state to the cooperative level
     __shared__ WaveOvfBuf s_ovf[WPB];
+    __shared__ uint32_t s_seed[SEEDED ? WPB : 1][SEEDED ? 128 * SEED_WORDS : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
+    const bool seeding = SEEDED && a.seed_out != nullptr;
 
     unsigned long long chunk_lo = 0, chunk_hi = 0, pool_next = 0, pool_end = 0;  // wave-uniform
     bool exhausted = false;
@@ -953,7 +995,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
     for (int i = 0; i < C; i++) { node[i] = 0; dist[i] = 0; }
     uint32_t n = 0, settled = 0, targets = 0, cur_relaxed = 0, n_overflow = 0;
     unsigned long long item = 0;
-    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0;
+    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0, st_attempts = 0;
 
     for (;;) {
         // ---- refill idle lanes ----
@@ -989,6 +1031,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
 
         // ---- one Dijkstra step per active lane (registers only, one 32-byte gather) ----
         bool fin = false, ovf = false;
+        uint32_t popped = 0;
         if (active) {
             uint32_t best = 0, bestd = 0xFFFFFFFFu, u = 0;
 #pragma unroll
@@ -999,6 +1042,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
                 u = cand ? node[i] : u;
             }
             settled |= 1u << best;
+            popped = best;
             const uint32_t d = bestd;
             const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);
             const uint4 lo = rp[0];
@@ -1090,29 +1134,78 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
             }
             pool_next += total;
         }
-        {   // ball larger than the per-lane table: hand the source to the cooperative level
-            uint32_t ovf_idx = 0;
-            if (ovf) {
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-                ovf_idx = (uint32_t)abs_idx;
-                active = false;
+        {   // ball larger than the per-lane table: hand the source (and, if asked, the search state) to the cooperative level
+            const unsigned long long om = __ballot(ovf);
+            if (om) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+                if (ovf) {
+                    const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                    a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
+                    const uint32_t slot = n_overflow + rank;
+                    s_ovf[wv].buf[slot] = (uint32_t)abs_idx;
+                    if constexpr (SEEDED) {
+                        if (seeding) {
+                            uint32_t *sd = &s_seed[wv][slot * SEED_WORDS];
+#pragma unroll
+                            for (int i = 0; i < C; i++) sd[i] = node[i];
+#pragma unroll
+                            for (int i = 0; i < C; i += 2) sd[8 + i / 2] = (dist[i] & 0xFFFFu) | (dist[i + 1] << 16);
+                            // the node popped in this step was not fully relaxed: it stays open
+                            sd[12] = n | ((settled & ~(1u << popped)) << 8) | (targets << 16);
+                        }
+                    }
+                    if constexpr (COUNT) st_attempts += cur_relaxed;
+                    active = false;
+                }
+                n_overflow += (uint32_t)__popcll(om);
+                if (n_overflow >= 64) {
+                    unsigned long long p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], 64ull);
+                    p0 = __shfl(p0, 0);
+                    a.ovf_list[p0 + lane] = s_ovf[wv].buf[lane];
+                    const uint32_t rest = s_ovf[wv].buf[64 + lane];
+                    s_ovf[wv].buf[lane] = rest;
+                    if constexpr (SEEDED) {
+                        if (seeding) {
+                            uint32_t *out = a.seed_out + p0 * SEED_WORDS;
+#pragma unroll
+                            for (int w = 0; w < SEED_WORDS; w++) out[w * 64 + lane] = s_seed[wv][w * 64 + lane];
+#pragma unroll
+                            for (int w = 0; w < SEED_WORDS; w++) {
+                                const uint32_t v = s_seed[wv][64 * SEED_WORDS + w * 64 + lane];
+                                s_seed[wv][w * 64 + lane] = v;
+                            }
+                        }
+                    }
+                    n_overflow -= 64;
+                }
             }
-            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
         }
     }
-    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
+    if (n_overflow) {
+        unsigned long long p0 = 0;
+        if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)n_overflow);
+        p0 = __shfl(p0, 0);
+        if ((uint32_t)lane < n_overflow) a.ovf_list[p0 + lane] = s_ovf[wv].buf[lane];
+        if constexpr (SEEDED) {
+            if (seeding) {
+                uint32_t *out = a.seed_out + p0 * SEED_WORDS;
+                for (uint32_t w = lane; w < n_overflow * SEED_WORDS; w += 64) out[w] = s_seed[wv][w];
+            }
+        }
+    }
 
     if constexpr (COUNT) {
         for (int dd = 32; dd >= 1; dd >>= 1) {
             st_settled += __shfl_down(st_settled, dd);
             st_relaxed += __shfl_down(st_relaxed, dd);
             st_emitted += __shfl_down(st_emitted, dd);
+            st_attempts += __shfl_down(st_attempts, dd);
         }
         if (lane == 0) {
             atomicAdd(&a.counters[C_SETTLED], st_settled);
             atomicAdd(&a.counters[C_RELAXED], st_relaxed);
-            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed);
+            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed + st_attempts);
             atomicAdd(&a.counters[C_EMITTED], st_emitted);
         }
     }
@@ -1146,6 +1239,8 @@ struct Device {
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
     uint64_t ovf_cap = 0;
+    uint32_t *d_seed = nullptr;               // lane-level search states of the overflowed sources (SEED_WORDS each)
+    bool use_seeds = true;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
@@ -1181,6 +1276,7 @@ struct LaneCfg {
     sssp_fn fn;
     sssp_fn fn_count;
     int block;
+    int max_occ = 0;  // workgroups per CU to launch at most (0 = what fits)
 };
 template <int WPB, int C>
 static LaneCfg make_lane_cfg() {
@@ -1199,7 +1295,11 @@ static LaneCfg lane_cfg(int preset) {
         case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane LDS table, 32 entries
         case 1: return make_lane_reg_cfg<4, 16>();   // register tables, 16 entries
         case 2: return make_lane_reg_cfg<4, 12>();   // register tables, 12 entries
-        case 5: return make_lane_reg_cfg<4, 8>();    // default: register tables, 8 entries
+        case 5: {  // default: register tables, 8 entries; measured best at 12 waves per CU (0.52 ms vs 0.56 at 16)
+            LaneCfg c = make_lane_reg_cfg<4, 8>();
+            c.max_occ = 3;
+            return c;
+        }
         case 6: return make_lane_reg_cfg<4, 24>();
         case 7: return make_lane_reg_cfg<4, 6>();
         case 8: return make_lane_reg_cfg<4, 10>();
@@ -1239,7 +1339,8 @@ static void launch_lane(Device *d, hipStream_t st, const LaneCfg &cfg, bool coun
     if (occ < 1) occ = 1;
     const uint64_t waves_needed = (args.n_items + 63) / 64;
     const uint64_t wpb = (uint64_t)cfg.block / 64;
-    if (const char *e = std::getenv("MTG_LANE_OCC")) occ = std::max(1, std::min(occ, std::atoi(e)));  // tuning experiments
+    if (cfg.max_occ > 0) occ = std::min(occ, cfg.max_occ);
+    if (const char *e = std::getenv("MTG_LANE_OCC")) occ = std::max(1, std::atoi(e));  // tuning experiments
     uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + wpb - 1) / wpb);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
@@ -1302,9 +1403,15 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
             if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
+        if (d->d_seed) HIP_CHECK(hipFree(d->d_seed));
+        HIP_CHECK(hipMalloc(&d->d_seed, std::max<uint64_t>(n, 1) * SEED_WORDS * sizeof(uint32_t)));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
+    static const bool seeds_off = std::getenv("MTG_NO_SEEDS") != nullptr;  // A/B: restart overflowed sources from scratch
+    const bool seeded = d->use_seeds && !seeds_off && d->preset == 5;  // only the 8-entry register kernel writes seeds
+    a.seed_out = seeded ? d->d_seed : nullptr;
+    a.seed_in = nullptr;
     { const char *e = std::getenv("MTG_DBG"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
     double total_ms = 0.0;
     const bool use_lane = d->preset != 4;
@@ -1329,6 +1436,8 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         SsspArgs b = a;
         b.src_index = d->d_ovf[cur_list];
         b.ovf_list = d->d_ovf[cur_list ^ 1];
+        b.seed_out = nullptr;
+        b.seed_in = (seeded && use_lane && li == 0) ? d->d_seed : nullptr;  // seeds are parallel to the lane level's list
         cur_list ^= 1;
         b.n_items = n_ovf;
         launch_level(d, st, next, count, b);
@@ -1447,6 +1556,7 @@ void device_free(Device *d) {
     void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
+    (void)hipFree(d->d_seed);
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
