@@ -167,7 +167,12 @@ enum Counter : int {
     C_EMITTED = 5,
     C_ATTEMPTS = 6,
     C_OVF_LIST = 7,  // cursor of the overflow source list
-    C_COUNT = 8
+    C_T_INIT = 8,    // MTG_DBG=3: wall-clock ticks (100 MHz) thread 0 of every block spent per phase, and rounds
+    C_T_ROUNDS = 9,
+    C_T_EMIT = 10,
+    C_T_CLEAN = 11,
+    C_N_ROUNDS = 12,
+    C_COUNT = 13
 };
 
 struct SsspArgs {
@@ -318,6 +323,8 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
     for (uint64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
         const uint64_t item0 = batch * BSRC;
         const int nsrc = (int)min((uint64_t)BSRC, a.n_items - item0);
+        const bool prof = a.dbg == 3 && tid == 0;
+        unsigned long long tp0 = prof ? wall_clock64() : 0ull, tp1 = 0, tp2 = 0, tp3 = 0;
 
         // ---- init (the table is clean here) ----
         if (tid < BSRC) { s.cnt[tid] = 0; s.fill[tid] = 0; }
@@ -369,7 +376,9 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 
         // ---- label-correcting rounds: round r processes log[begin, end), pushes append at tail ----
         uint32_t end = s.end;
-        for (int round = 0; begin < end; round++) {  // uniform: `end` is a snapshot published by thread 0
+        if (prof) tp1 = wall_clock64();
+        int n_rounds = 0;
+        for (int round = 0; begin < end; round++, n_rounds++) {  // uniform: `end` is a snapshot published by thread 0
             for (uint32_t i = begin + tid; i < end; i += BLOCK) {
                 const uint32_t item = M::ld(&log[i]);
                 const uint32_t slot = item >> HINT_BITS;
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
         }
         __syncthreads();
         const uint32_t n_log = min(s.tail, (uint32_t)QCAP);
+        if (prof) tp2 = wall_clock64();
 
         // visits every live table entry exactly once: f(entry)
         auto for_each_entry = [&](auto &&f) {
@@ -532,6 +542,7 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             }
         }
         __syncthreads();
+        if (prof) tp3 = wall_clock64();
 
         // ---- clean the table for the next batch ----
         if (LOG_EMIT && !s.ovf) {
@@ -540,6 +551,14 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
         }
         __syncthreads();
+        if (prof) {
+            const unsigned long long tp4 = wall_clock64();
+            atomicAdd(&a.counters[C_T_INIT], tp1 - tp0);
+            atomicAdd(&a.counters[C_T_ROUNDS], tp2 - tp1);
+            atomicAdd(&a.counters[C_T_EMIT], tp3 - tp2);
+            atomicAdd(&a.counters[C_T_CLEAN], tp4 - tp3);
+            atomicAdd(&a.counters[C_N_ROUNDS], (unsigned long long)n_rounds);
+        }
     }
 
     if constexpr (COUNT) {
@@ -1309,18 +1328,23 @@ static LaneCfg lane_cfg(int preset) {
 //                                              BLOCK LOGH  QCAP  SCAP BSRC
 // Cascade of cooperative levels: 64 sources per workgroup, then 8, then 1 (128 KB LDS table), then a 32 MB
 // global-memory table. A level re-runs the sources whose batch overflowed the previous level's tables.
-static const int N_COOP_LEVELS = 4;
+static const int N_COOP_LEVELS = 5;
 static LevelCfg coop_level(int i) {
-    static const int exp_l1 = std::getenv("MTG_L1") ? std::atoi(std::getenv("MTG_L1")) : 0;  // tuning experiments
-    if (i == 0 && exp_l1 == 1) return make_cfg<64, 10, 2048, 512, 8, false>();
-    if (i == 0 && exp_l1 == 2) return make_cfg<64, 10, 1024, 512, 8, false>();
-    if (i == 0 && exp_l1 == 3) return make_cfg<128, 11, 2048, 512, 16, false>();
-    if (i == 0 && exp_l1 == 4) return make_cfg<64, 9, 1024, 256, 4, false>();
-    if (i == 0 && exp_l1 == 5) return make_cfg<128, 11, 2048, 512, 32, false>();
+    // tuning experiments for the first cooperative level: MTG_L1=<n>
+    static const int exp_l1 = std::getenv("MTG_L1") ? std::atoi(std::getenv("MTG_L1")) : 0;
+    if (i == 0 && exp_l1 == 1) return make_cfg<256, 12, 2048, 1024, 64, false>();  // the round-1 geometry before seeds
+    if (i == 0 && exp_l1 == 2) return make_cfg<256, 11, 2048, 512, 32, false>();
+    if (i == 0 && exp_l1 == 3) return make_cfg<256, 11, 1024, 512, 24, false>();
+    if (i == 0 && exp_l1 == 4) return make_cfg<512, 12, 2048, 512, 64, false>();
     switch (i) {  //                    BLOCK LOGH  QCAP  SCAP BSRC
-        case 0: return make_cfg<256, 12, 2048, 1024, 64, false>();
-        case 1: return make_cfg<256, 12, 4096, 1024, 8, false>();
-        case 2: return make_cfg<256, 14, 4096, 1024, 1, false>();
+        // 25 KB of LDS per workgroup -> 6 workgroups per CU: the level is bound by rounds x gather latency per batch
+        // (4 us per round, ~10 rounds), so concurrency per CU is what counts; its heavy batches overflow the 1024-item
+        // log early and are re-run by the next level (measured: 0.93 + 0.10 ms against 1.17 + 0.04 ms for 64 sources
+        // per workgroup with a 4096-entry table)
+        case 0: return make_cfg<256, 11, 1024, 512, 32, false>();
+        case 1: return make_cfg<256, 12, 4096, 1024, 16, false>();
+        case 2: return make_cfg<256, 13, 8192, 2048, 8, false>();
+        case 3: return make_cfg<256, 14, 4096, 1024, 1, false>();
         default: return make_cfg<256, 22, 1 << 22, 1 << 21, 1, true>();
     }
 }
@@ -1450,6 +1474,11 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         }
         if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li + 1,
                                 next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
+        if (debug && a.dbg == 3)
+            std::fprintf(stderr, "[mtg]   cumulative block-time (10 ns ticks): init %llu rounds %llu emit %llu clean %llu; rounds %llu\n",
+                         (unsigned long long)d->h_counters[C_T_INIT], (unsigned long long)d->h_counters[C_T_ROUNDS],
+                         (unsigned long long)d->h_counters[C_T_EMIT], (unsigned long long)d->h_counters[C_T_CLEAN],
+                         (unsigned long long)d->h_counters[C_N_ROUNDS]);
     }
     d->last_kernel_ms = total_ms;
     if (d->h_counters[C_OVERFLOW] > 0)

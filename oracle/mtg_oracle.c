@@ -517,6 +517,11 @@ uint64_t og_greedy_pairs(const og_graph *g, uint64_t k, og_pair **pairs, og_sssp
 /* Full candidate lists: one untruncated query per out-node against the *initial* bitmap. */
 uint32_t og_candidate_lists(const og_graph *g, uint64_t k, uint32_t **out_nodes_p, uint64_t **offsets_p,
                             uint64_t **keys_p, og_sssp_stats *stats) {
+    return og_candidate_lists_range(g, k, 0, UINT32_MAX, out_nodes_p, offsets_p, keys_p, stats);
+}
+
+uint32_t og_candidate_lists_range(const og_graph *g, uint64_t k, uint32_t src_lo, uint32_t src_hi, uint32_t **out_nodes_p,
+                                  uint64_t **offsets_p, uint64_t **keys_p, og_sssp_stats *stats) {
     uint32_t nn = g->n_nodes;
     uint32_t *out_nodes = xmalloc((size_t)nn * 4);
     uint8_t *live = xmalloc(nn);
@@ -529,6 +534,7 @@ uint32_t og_candidate_lists(const og_graph *g, uint64_t k, uint32_t **out_nodes_
     uint64_t *keys = NULL; uint64_t nk = 0, capk = 0;
     for (uint32_t i = 0; i < n_out; i++) {
         offsets[i] = nk;
+        if (i < src_lo || i >= src_hi) continue;  /* sources outside the range keep empty lists */
         shortest_path_lens(g, dj, out_nodes[i], live, UINT64_MAX, k - 1, 1, &distances, stats);
         for (size_t c = 0; c < distances.n; c++) {
             if (nk == capk) { capk = capk ? capk * 2 : 256; keys = xrealloc(keys, capk * 8); }

@@ -97,6 +97,10 @@ uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sour
 uint32_t og_candidate_lists(const og_graph *g, uint64_t k, uint32_t **out_nodes,
                             uint64_t **offsets, uint64_t **keys, og_sssp_stats *stats);
 
+/* Same, but only sources with index in [src_lo, src_hi) are searched (the others get empty lists). */
+uint32_t og_candidate_lists_range(const og_graph *g, uint64_t k, uint32_t src_lo, uint32_t src_hi, uint32_t **out_nodes,
+                                  uint64_t **offsets, uint64_t **keys, og_sssp_stats *stats);
+
 void og_free(void *p);
 
 /* ---- later stages ---- */

@@ -82,6 +82,7 @@ def lib():
         "og_greedy_pairs": (u64, [vp, u64, P(P(Pair)), P(Stats)]),
         "og_greedy_pairs_prefix": (u64, [vp, u64, u64, P(P(Pair)), P(Stats)]),
         "og_candidate_lists": (u32, [vp, u64, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
+        "og_candidate_lists_range": (u32, [vp, u64, u32, u32, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
         "og_free": (None, [vp]),
         "og_insert_pair_edges": (u64, [vp, P(Pair), u64]),
         "og_make_eulerian_with_breaking_edges": (None, [vp, P(u64), u64]),
@@ -246,10 +247,10 @@ class OracleGraph:
         self.L.og_free(pp)
         return arr, st.as_dict()
 
-    def candidate_lists(self, k):
+    def candidate_lists(self, k, lo=0, hi=0xFFFFFFFF):
         on, off, keys = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
         st = Stats()
-        n = self.L.og_candidate_lists(self.h, k, C.byref(on), C.byref(off), C.byref(keys), C.byref(st))
+        n = self.L.og_candidate_lists_range(self.h, k, lo, hi, C.byref(on), C.byref(off), C.byref(keys), C.byref(st))
         out_nodes = np.ctypeslib.as_array(on, shape=(max(n, 1),))[:n].copy()
         offsets = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
         nk = int(offsets[-1])

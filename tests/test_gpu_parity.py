@@ -139,12 +139,14 @@ def test_t2_t3_t4_pairs_and_tigs(gpu, oracle, idx):
     assert (ex["edge_weight"][matched] >= 1).all()
 
 
-def test_overflow_levels_big_balls(gpu, oracle):
-    """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 LDS table: levels 1/2 must agree."""
+@pytest.mark.parametrize("preset", [0, 5])
+def test_overflow_levels_big_balls(gpu, oracle, preset):
+    """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 tables: the larger levels must agree
+    (preset 5 = the default plan, where the lane level hands its search state to the first cooperative level)."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01)
-    G, dev, S, start, count, pool = _gpu_candidates(bg, 0)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, preset)
     cnt = dev.sssp_count(0, S)
     assert cnt["overflow_sources"] > 0, "test graph should overflow level 0"
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
@@ -154,14 +156,33 @@ def test_overflow_levels_big_balls(gpu, oracle):
     assert cnt["settled_nodes"] == st["settled_nodes"] and cnt["relaxed_edges"] == st["relaxed_edges"]
 
 
-def test_high_degree_nodes_use_spill_adjacency(gpu, oracle):
+@pytest.mark.parametrize("preset", [0, 5])
+def test_deepest_levels_huge_balls(gpu, oracle, preset):
+    """Balls above 16384 nodes only fit the last level (table in a global workspace): a unit-weight graph whose
+    (k-1)-balls cover most of its 36000 nodes, on a slice of the sources (the oracle would need minutes for all)."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(18000, seed=21, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.0)
+    lo, hi = 100, 148
+    G, dev, S, start, count, pool = _gpu_candidates(bg, preset, lo, hi)
+    levels = dev.last_sssp_levels()
+    assert len(levels) == 6, levels          # lane + every cooperative level down to the global-workspace one
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k, lo, hi)
+    assert st["settled_nodes"] > 16384 * 8   # the balls really are that large
+    assert np.array_equal(count.astype(np.uint64), np.diff(off)[lo:hi])
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])
+    assert np.array_equal(got, keys)
+
+
+@pytest.mark.parametrize("preset", [0, 5])
+def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, preset):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(2000, seed=4, k=15, mean_out_degree=5.0, mean_weight=4.0, max_degree=9)
     deg = np.bincount(bg.edge_from, minlength=bg.n_nodes)
     assert deg.max() > 4
-    G, dev, S, start, count, pool = _gpu_candidates(bg, 0)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, preset)
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
     assert np.array_equal(count.astype(np.uint64), np.diff(off))
     got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])
