@@ -379,7 +379,10 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
         if (prof) tp1 = wall_clock64();
         int n_rounds = 0;
         for (int round = 0; begin < end; round++, n_rounds++) {  // uniform: `end` is a snapshot published by thread 0
-            for (uint32_t i = begin + tid; i < end; i += BLOCK) {
+            // one lane per (frontier item, inline edge j): the four lanes of an item read the same 32-byte record
+            // (one memory request) and each relaxes one edge, instead of one lane running four divergent table updates
+            for (uint32_t w = begin * 4 + tid; w < end * 4; w += BLOCK) {
+                const uint32_t i = w >> 2, j = w & 3u;
                 const uint32_t item = M::ld(&log[i]);
                 const uint32_t slot = item >> HINT_BITS;
                 const unsigned long long e = M::ld(&table[slot]);
@@ -387,15 +390,15 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 if ((d & HINT_MASK) != (item & HINT_MASK)) continue;  // superseded by a shorter distance
                 const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
                 const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
-                // one aligned 32-byte gather: neighbours, weights, flags
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
-                const uint4 lo = rp[0];
-                const uint4 hi = rp[1];
-                const uint32_t flags = (hi.z >> 8) & 0xFFu;
-                if (flags & F_TARGET) M::fand(&table[slot], ~1ull);  // node property: confirmed in-node
-                uint32_t deg, pushed_ovf = 0;
-                auto relax = [&](uint32_t nb, uint32_t w) {
-                    const uint32_t nd = d + w;
+                const uint32_t *rw = reinterpret_cast<const uint32_t *>(a.recs + node);
+                const uint32_t meta = rw[6];  // deg | flags << 8
+                const uint32_t nb_j = rw[j];  // issued together with meta: one memory latency per round, not two
+                const uint32_t w_pair = rw[4 + (j >> 1)];
+                const uint32_t flags = (meta >> 8) & 0xFFu;
+                if (j == 0 && (flags & F_TARGET)) M::fand(&table[slot], ~1ull);  // node property: confirmed in-node
+                uint32_t pushed_ovf = 0;
+                auto relax = [&](uint32_t nb, uint32_t wt) {
+                    const uint32_t nd = d + wt;
                     if (nd > a.K1) return;
                     uint32_t nslot = 0;
                     const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, nb, nd, nslot);
@@ -406,19 +409,16 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                     } else if (r < 0) pushed_ovf = 1;
                 };
                 if (!(flags & F_EXT)) {
-                    deg = hi.z & 0xFFu;
-                    const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
-                    const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (j < (int)deg) relax(nb[j], ww[j]);
-                } else {
-                    const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
-                    deg = lo.z;
-                    for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
+                    const uint32_t deg = meta & 0xFFu;
+                    if (j < deg) relax(nb_j, (w_pair >> ((j & 1u) * 16)) & 0xFFFFu);
+                    if constexpr (COUNT) { if (j == 0) atomicAdd(&s.bt_attempts, (unsigned long long)deg); }
+                } else if (j == 0) {  // spilled adjacency (more than 4 out-edges): one lane walks the list
+                    const uint64_t eb = ((uint64_t)rw[1] << 32) | nb_j;  // j == 0: nb_j is word 0
+                    const uint32_t deg = rw[2];
+                    for (uint32_t q = 0; q < deg; q++) relax(a.ext_col[eb + q], a.ext_w[eb + q]);
+                    if constexpr (COUNT) atomicAdd(&s.bt_attempts, (unsigned long long)deg);
                 }
                 if (pushed_ovf) s.ovf = 1;
-                if constexpr (COUNT) atomicAdd(&s.bt_attempts, (unsigned long long)deg);
             }
             __syncthreads();
             if (tid == 0) {
