@@ -12,6 +12,7 @@
  */
 #include "mtg_oracle.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -512,6 +513,117 @@ uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sour
 }
 uint64_t og_greedy_pairs(const og_graph *g, uint64_t k, og_pair **pairs, og_sssp_stats *stats) {
     return og_greedy_pairs_prefix(g, k, UINT64_MAX, pairs, stats);
+}
+
+/* ===================================================================================== */
+/* The same claim loop run by `threads` workers, greedytigs/mod.rs:528-644 (no staging:    */
+/* resource limits stay usize::MAX): workers take chunks of 1024 sources from a shared     */
+/* cursor (:573-616 without the 5-second re-sizing), each with its own Dijkstra state; the  */
+/* live bytes are relaxed atomics (implementation/mod.rs:128-186), every multiplicity cell  */
+/* has its own lock and a claim takes {out, out', in, in'} in ascending order (:366-397).   */
+/* Like the reference with threads > 1 the result depends on thread timing: this entry      */
+/* exists for the bench's multi-core CPU timing and is checked by invariants only.          */
+/* ===================================================================================== */
+typedef struct {
+    const og_graph *g; uint64_t k; uint32_t n_out; const uint32_t *out_nodes;
+    uint8_t *live; int64_t *mult; uint8_t *locks; uint64_t *cursor;
+    pair_vec res; og_sssp_stats st;
+} mt_worker;
+
+static void mt_lock(uint8_t *l) { while (__atomic_test_and_set(l, __ATOMIC_ACQUIRE)) { while (__atomic_load_n(l, __ATOMIC_RELAXED)) {} } }
+static void mt_unlock(uint8_t *l) { __atomic_clear(l, __ATOMIC_RELEASE); }
+
+static void *mt_worker_main(void *arg) {
+    mt_worker *w = arg;
+    const og_graph *g = w->g;
+    dijkstra *dj = dijkstra_new(g->n_nodes);
+    dist_vec distances = {0};
+    for (;;) {
+        uint64_t lo = __atomic_fetch_add(w->cursor, 1024, __ATOMIC_RELAXED);
+        if (lo >= w->n_out) break;
+        uint64_t hi = lo + 1024 < w->n_out ? lo + 1024 : w->n_out;
+        for (uint64_t i = lo; i < hi; i++) {
+            uint32_t out_node = w->out_nodes[i];
+            int out_sm = is_self_mirror(g, out_node);
+            uint32_t out_mirror = g->mirror[out_node];
+            mt_lock(&w->locks[out_mirror]);
+            int64_t out_mult = w->mult[out_mirror];                  /* :306-311 */
+            mt_unlock(&w->locks[out_mirror]);
+            while (out_mult > 0) {
+                uint64_t target_amount = (uint64_t)(out_mult + 1);
+                shortest_path_lens(g, dj, out_node, w->live, target_amount, w->k - 1, 1, &distances, &w->st);
+                if (distances.n == 0) break;
+                int abort_after_this = distances.n < target_amount;
+                for (size_t c = 0; c < distances.n; c++) {
+                    uint32_t in_node = distances.v[c].node;
+                    uint64_t dist = distances.v[c].dist;
+                    int self_edge = 0;
+                    if (in_node == out_mirror) { if (out_mult < 2) continue; self_edge = 1; }
+                    uint32_t in_mirror = g->mirror[in_node];
+                    int in_sm = is_self_mirror(g, in_node);
+                    uint32_t ls[4] = {out_node, out_mirror, in_node, in_mirror}; int nl = 4;   /* :366-397 */
+                    for (int a = 1; a < nl; a++) for (int b = a; b > 0 && ls[b] < ls[b - 1]; b--) { uint32_t t = ls[b]; ls[b] = ls[b - 1]; ls[b - 1] = t; }
+                    int u = 1; for (int a = 1; a < nl; a++) if (ls[a] != ls[u - 1]) ls[u++] = ls[a];
+                    nl = u;
+                    for (int a = 0; a < nl; a++) mt_lock(&w->locks[ls[a]]);
+                    int64_t red = self_edge ? 2 : 1;
+                    out_mult = out_sm ? w->mult[out_node] : -w->mult[out_node];
+                    int claimed = 0, stop = 0;
+                    if (out_mult == 0) stop = 1;                      /* :412-414 */
+                    else if (!self_edge && w->mult[in_node] == 0) __atomic_store_n(&w->live[in_node], 0, __ATOMIC_RELAXED);  /* :454-458 */
+                    else {
+                        claimed = 1;
+                        if (out_sm) w->mult[out_node] -= 1; else { w->mult[out_node] += red; w->mult[out_mirror] -= red; }
+                        out_mult = -w->mult[out_node];
+                        if (!self_edge) { w->mult[in_node] -= 1; if (!in_sm) w->mult[in_mirror] += 1; }
+                        if (out_mult == 0) __atomic_store_n(&w->live[out_mirror], 0, __ATOMIC_RELAXED);
+                        if (!self_edge && w->mult[in_node] == 0) __atomic_store_n(&w->live[in_node], 0, __ATOMIC_RELAXED);
+                    }
+                    for (int a = nl; a-- > 0;) mt_unlock(&w->locks[ls[a]]);
+                    if (claimed) pv_push(&w->res, out_node, in_node, dist);
+                    if (stop) break;
+                }
+                if (abort_after_this) break;
+            }
+        }
+    }
+    dijkstra_free(dj); free(distances.v);
+    return NULL;
+}
+
+uint64_t og_greedy_pairs_mt(const og_graph *g, uint64_t k, uint32_t threads, og_pair **pairs, og_sssp_stats *stats) {
+    uint32_t nn = g->n_nodes;
+    if (threads < 1) threads = 1;
+    uint32_t *out_nodes = xmalloc((size_t)nn * 4);
+    uint8_t *live = xmalloc(nn);
+    int64_t *mult = xmalloc((size_t)nn * 8);
+    uint8_t *locks = xmalloc(nn ? nn : 1);
+    memset(locks, 0, nn);
+    uint32_t n_out = og_classify(g, out_nodes, live, mult, NULL, NULL);
+    uint64_t cursor = 0;
+    mt_worker *ws = xmalloc(sizeof(mt_worker) * threads);
+    pthread_t *th = xmalloc(sizeof(pthread_t) * threads);
+    for (uint32_t t = 0; t < threads; t++) {
+        memset(&ws[t], 0, sizeof ws[t]);
+        ws[t].g = g; ws[t].k = k; ws[t].n_out = n_out; ws[t].out_nodes = out_nodes;
+        ws[t].live = live; ws[t].mult = mult; ws[t].locks = locks; ws[t].cursor = &cursor;
+        if (pthread_create(&th[t], NULL, mt_worker_main, &ws[t])) DIE("pthread_create failed");
+    }
+    pair_vec res = {0};
+    if (stats) memset(stats, 0, sizeof *stats);
+    for (uint32_t t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        for (uint64_t i = 0; i < ws[t].res.n; i++) pv_push(&res, ws[t].res.v[i].out_node, ws[t].res.v[i].in_node, ws[t].res.v[i].distance);
+        free(ws[t].res.v);
+        if (stats) {
+            stats->iterations += ws[t].st.iterations; stats->unnecessary += ws[t].st.unnecessary;
+            stats->settled_nodes += ws[t].st.settled_nodes; stats->relaxed_edges += ws[t].st.relaxed_edges;
+            stats->queries += ws[t].st.queries;
+        }
+    }
+    free(ws); free(th); free(out_nodes); free(live); free(mult); free(locks);
+    *pairs = res.v;
+    return res.n;
 }
 
 /* Full candidate lists: one untruncated query per out-node against the *initial* bitmap. */

