@@ -187,6 +187,12 @@ void mtg_unitigs_free(mtg_unitigs *u);
  * (bin.rs:203, :442-446; pass 6 for the reference's default). Returns the uncompressed byte count. */
 uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
                                    const char *path, int compression_level);
+/* The same tigs as GFA1 text (bin.rs:667-818): header line (`header`, e.g. the one read from a GFA input, or NULL for
+ * "H\tKL:Z:{k}"), then one "S\t{i+1}\t{sequence}" record per tig. */
+uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                             const char *unitig_seqs, const uint64_t *seq_offsets, const char *header, char **gfa_out);
+uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
+                                 const char *header, const char *path, int compression_level);
 
 /* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);

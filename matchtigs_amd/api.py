@@ -414,9 +414,10 @@ def read_bcalm2(path: str, k: int):
     return Bigraph(g), UnitigStore(st.value)
 
 
-def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: int, k: int, path: str,
-                               compression_level: int = 6, device_id: int = 0) -> dict:
-    """compute (3 = eulertigs, 5 = greedy matchtigs) + spell + write, all inside the library. Returns counts/timings."""
+def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: int, k: int, path: Optional[str],
+                               compression_level: int = 6, device_id: int = 0, gfa_path: Optional[str] = None,
+                               gfa_header: Optional[str] = None) -> dict:
+    """compute (3 = eulertigs, 5 = greedy matchtigs) + spell + write FASTA and/or GFA, all inside the library."""
     import time
 
     L = _lib.load()
@@ -424,13 +425,24 @@ def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: in
     w = L.mtg_compute_tigs(graph.handle, algorithm, k, device_id)
     t1 = time.perf_counter()
     n_tigs = int(L.mtg_walks_count(w))
-    nbytes = int(L.mtg_write_tigs_fasta_file(graph.handle, w, k, store.handle, str(path).encode(), compression_level))
+    nbytes = gbytes = 0
+    if path:
+        nbytes = int(L.mtg_write_tigs_fasta_file(graph.handle, w, k, store.handle, str(path).encode(), compression_level))
+    if gfa_path:
+        gbytes = int(L.mtg_write_tigs_gfa_file(graph.handle, w, k, store.handle, gfa_header.encode() if gfa_header else None,
+                                               str(gfa_path).encode(), compression_level))
     t2 = time.perf_counter()
     L.mtg_walks_free(w)
-    return {"tigs": n_tigs, "fasta_bytes": nbytes, "compute_s": t1 - t0, "write_s": t2 - t1}
+    return {"tigs": n_tigs, "fasta_bytes": nbytes, "gfa_bytes": gbytes, "compute_s": t1 - t0, "write_s": t2 - t1}
 
 
-def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int) -> bytes:
+def write_walks_gfa(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, header: Optional[str] = None) -> bytes:
+    """bin.rs:667-818 through the C-ABI: GFA1 text (header line, then one S record per tig)."""
+    return write_walks_fasta(graph, tigs, unitigs, k, _gfa=True, _header=header)
+
+
+def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, _gfa: bool = False,
+                      _header: Optional[str] = None) -> bytes:
     """bin.rs:466-606 through the C-ABI: tigs = list of edge-id lists (or (limits, edges) numpy pair) -> FASTA bytes."""
     L = _lib.load()
     if isinstance(tigs, tuple):
@@ -442,8 +454,12 @@ def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int) -> b
     off = np.zeros(len(unitigs) + 1, np.uint64)
     off[1:] = np.cumsum([len(u) for u in unitigs])
     out = C.c_void_p()
-    n = L.mtg_write_walks_fasta(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None, k,
-                                cat, _ptr(off), C.byref(out))
+    if _gfa:
+        n = L.mtg_write_walks_gfa(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None, k,
+                                  cat, _ptr(off), _header.encode() if _header else None, C.byref(out))
+    else:
+        n = L.mtg_write_walks_fasta(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None, k,
+                                    cat, _ptr(off), C.byref(out))
     data = C.string_at(out, n)
     L.mtg_free(out)
     return data

@@ -218,6 +218,13 @@ uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint6
     return write_walks_fasta(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, fasta_out);
 }
 
+uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                             const char *unitig_seqs, const uint64_t *seq_offsets, const char *header, char **gfa_out) {
+    if (!g || !gfa_out || (n_walks && (!limits || !edges)) || !unitig_seqs || !seq_offsets)
+        MTG_DIE("mtg_write_walks_gfa: null argument");
+    return write_walks_text(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, true, header, gfa_out);
+}
+
 // ---- f-2: BCALM2 input route + FASTA file output ----
 struct mtg_unitigs { UnitigStore *s; };
 
@@ -244,6 +251,17 @@ uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, ui
     char *buf = nullptr;
     const uint64_t n = write_walks_fasta(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
                                          unitigs->s->data.data(), unitigs->s->off.data(), &buf);
+    write_file(path, buf, n, compression_level);
+    std::free(buf);
+    return n;
+}
+
+uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
+                                 const char *header, const char *path, int compression_level) {
+    if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_gfa_file: null argument");
+    char *buf = nullptr;
+    const uint64_t n = write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                                        unitigs->s->data.data(), unitigs->s->off.data(), true, header, &buf);
     write_file(path, buf, n, compression_level);
     std::free(buf);
     return n;

@@ -1,4 +1,6 @@
-// spell.cpp -- tig spelling: walks -> FASTA text, /root/reference/src/bin.rs:466-606.
+// spell.cpp -- tig spelling: walks -> FASTA text, /root/reference/src/bin.rs:466-606, and GFA text,
+// bin.rs:667-818 (same spelling; a header line "H\tKL:Z:{k}" -- or the input file's header -- and records
+// "S\t{i+1}\t{sequence}\n" instead of ">{i+1}\n{sequence}\n").
 //
 // Per walk i: header ">{i+1}\n" (:492); the first edge's full sequence, reverse-complemented for a backwards edge
 // (:497-501, :269-285); every following ORIGINAL edge contributes its sequence minus the overlap with what is already
@@ -9,6 +11,7 @@
 // Two passes so the output buffer is allocated once and records can be written independently (the second pass is
 // embarrassingly parallel over walks; it is a plain loop here and the shape a GPU kernel would take).
 #include <cstring>
+#include <string>
 
 #include "host_graph.hpp"
 
@@ -35,18 +38,22 @@ static inline unsigned decimal_digits(uint64_t v) {
 }
 
 // Returns the number of bytes; *out_buf is malloc'd (caller frees with mtg_free).
-uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
-                           const char *seqs, const uint64_t *seq_off, char **out_buf) {
+uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                          const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, char **out_buf) {
     if (k < 1) MTG_DIE("k must be >= 1");
+    std::string head;  // bin.rs:688-693
+    if (gfa) head = (gfa_header ? std::string(gfa_header) : "H\tKL:Z:" + std::to_string(k)) + "\n";
+    const uint64_t prefix_len = gfa ? 2 : 1, after_number = 1;  // "S\t" / ">", then the number, then "\t" / "\n"
     const uint64_t n_orig = g.n_original_edges;
     auto seq_len = [&](uint32_t e) -> uint64_t { return seq_off[g.e_unitig[e] + 1] - seq_off[g.e_unitig[e]]; };
     // pass 1: record offsets
     std::vector<uint64_t> rec_off(n_walks + 1, 0);
+    rec_off[0] = head.size();
     uint64_t begin = 0;
     for (uint64_t i = 0; i < n_walks; i++) {
         const uint64_t end = limits[i];
         if (end <= begin) MTG_DIE("empty walk %llu", (unsigned long long)i);
-        uint64_t len = 1 + decimal_digits(i + 1) + 1;  // ">", number, "\n"
+        uint64_t len = prefix_len + decimal_digits(i + 1) + after_number;
         uint32_t prev = edges[begin];
         if (prev >= n_orig) MTG_DIE("walk %llu starts with a dummy edge (bin.rs:489)", (unsigned long long)i);
         len += seq_len(prev);
@@ -66,6 +73,7 @@ uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t 
     const uint64_t total = rec_off[n_walks];
     char *out = static_cast<char *>(std::malloc(total + 1));
     if (!out) MTG_DIE("out of memory (%llu bytes)", (unsigned long long)total);
+    std::memcpy(out, head.data(), head.size());
     // pass 2: spell
     auto put_edge = [&](char *dst, uint32_t e, uint64_t offset) -> char * {
         const char *s = seqs + seq_off[g.e_unitig[e]];
@@ -82,7 +90,8 @@ uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t 
     for (uint64_t i = 0; i < n_walks; i++) {
         const uint64_t end = limits[i];
         char *p = out + rec_off[i];
-        *p++ = '>';
+        if (gfa) { *p++ = 'S'; *p++ = '\t'; }  // bin.rs:704
+        else *p++ = '>';                       // bin.rs:492
         {
             char num[24];
             unsigned d = decimal_digits(i + 1);
@@ -91,7 +100,7 @@ uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t 
             std::memcpy(p, num, d);
             p += d;
         }
-        *p++ = '\n';
+        *p++ = gfa ? '\t' : '\n';
         uint32_t prev = edges[begin];
         p = put_edge(p, prev, 0);
         for (uint64_t j = begin + 1; j < end; j++) {
@@ -108,6 +117,11 @@ uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t 
     out[total] = '\0';
     *out_buf = out;
     return total;
+}
+
+uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                           const char *seqs, const uint64_t *seq_off, char **out_buf) {
+    return write_walks_text(g, n_walks, limits, edges, k, seqs, seq_off, false, nullptr, out_buf);
 }
 
 }  // namespace mtg

@@ -66,6 +66,23 @@ def test_cli_eulertigs_fasta(tmp_path, oracle, product_lib):
     assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
 
 
+def test_cli_eulertigs_gfa_out(tmp_path, oracle, product_lib):
+    """--eulertigs-gfa-out (bin.rs:97-99, 667-818): same tigs as the fasta output, as GFA S records, optionally gzipped."""
+    k = 15
+    ug = synth.g_seq(2500, seed=12, k=k, haplotypes=3, sub_rate=0.03)
+    inp = tmp_path / "unitigs.fa"
+    write_bcalm2(inp, ug, gz=False)
+    r = subprocess.run([sys.executable, "-m", "matchtigs_amd", "--bcalm-in", str(inp), "-k", str(k),
+                        "--eulertigs-gfa-out", str(tmp_path / "e.gfa.gz"), "--eulertigs-fa-out", str(tmp_path / "e.fa")],
+                       capture_output=True, text=True, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr
+    seqs = _fasta_seqs((tmp_path / "e.fa").read_text())
+    gfa = gzip.open(tmp_path / "e.gfa.gz", "rt").read()
+    assert gfa == f"H\tKL:Z:{k}\n" + "".join(f"S\t{i + 1}\t{s}\n" for i, s in enumerate(seqs))
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    assert (tmp_path / "e.fa").read_text() == og.fasta(og.compute_eulertigs(k), ug.unitigs, k)
+
+
 def test_cli_flag_rules(tmp_path, product_lib):
     def run(*a):
         return subprocess.run([sys.executable, "-m", "matchtigs_amd", *a], capture_output=True, text=True, cwd=str(ROOT))

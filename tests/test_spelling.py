@@ -65,3 +65,17 @@ def test_greedy_fasta_end_to_end_on_gpu(oracle, product_lib):
     otigs, _ = og.compute_greedytigs(k)
     assert fa == og.fasta(otigs, ug.unitigs, k)
     assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
+
+
+def test_gfa_records_are_the_fasta_records(product_lib):
+    """bin.rs:667-818: GFA output = header line + one S record per tig with the same spelling as the FASTA writer."""
+    k = 15
+    ug = synth.g_seq(3000, seed=4, k=k, haplotypes=3, sub_rate=0.03)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    tigs = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(k))
+    fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
+    seqs = _fasta_seqs(fa)
+    want = "H\tKL:Z:15\n" + "".join(f"S\t{i + 1}\t{s}\n" for i, s in enumerate(seqs))
+    assert api.write_walks_gfa(G, tigs, ug.unitigs, k).decode() == want
+    custom = api.write_walks_gfa(G, tigs, ug.unitigs, k, header="H\tVN:Z:1.0\tKL:Z:15").decode()
+    assert custom == "H\tVN:Z:1.0\tKL:Z:15\n" + want.split("\n", 1)[1]
