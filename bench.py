@@ -198,18 +198,11 @@ def main():
         # roofline of the dominant kernel (sssp_kernel, level 0) on THIS rank's launch
         alg_bytes = algorithmic_bytes(stats)
         achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
-        lane_names = {0: "sssp_lane_hash_kernel<4,32>", 1: "sssp_lane_reg_kernel<4,16>", 2: "sssp_lane_reg_kernel<4,12>",
-                      3: "sssp_lane_kernel<4,12>", 5: "sssp_lane_reg_kernel<4,8>", 6: "sssp_lane_reg_kernel<4,24>",
-                      7: "sssp_lane_reg_kernel<4,6>", 8: "sssp_lane_reg_kernel<4,10>"}
-        preset = 5 if args.preset < 0 else args.preset  # library default: device.hip Device::preset
-        level_names = ([lane_names[preset]] if preset in lane_names else []) + [
-            "sssp_kernel<256,12,2048,1024,64>", "sssp_kernel<256,12,4096,1024,8>", "sssp_kernel<256,14,4096,1024,1>",
-            "sssp_kernel<256,22,...,global>"]
         kernels = []
         if level_ms:
             for li in range(max(len(x) for x in level_ms)):
                 vals = [x[li] for x in level_ms if li < len(x)]
-                kernels.append({"kernel": level_names[li] if li < len(level_names) else f"level{li}",
+                kernels.append({"kernel": vals[0].get("kernel", f"level{li}"),
                                 "avg_launch_ms": round(float(np.mean([v["ms"] for v in vals])), 4),
                                 "sources": int(vals[0]["sources"])})
         roofline = {

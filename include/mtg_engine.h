@@ -113,10 +113,13 @@ double mtg_last_sssp_kernel_ms(const mtg_device *d);
  * lane-per-source kernel (or the first cooperative level with preset 4); later levels re-run overflowed sources.
  * Returns the number of levels written (<= capacity). */
 int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity);
+/* Kernel instantiation that ran as level `level` of the last call ("" beyond the last level); valid until the next call. */
+const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
-/* Kernel tuning: 0-3 = per-lane table size 16/32/24/12 of the lane kernel (default 3), 4 = cooperative kernels
- * only; returns the preset in force. */
+/* Kernel tuning: which lane-per-source kernel runs as level 0 (5 = default: 8-entry register tables with seed hand-off;
+ * 0 = hash-indexed LDS tables of 32, 1/2/6/7/8 = register tables of 16/12/24/6/10, 3 = scanned LDS tables of 12),
+ * 4 = cooperative kernels only; returns the preset in force. */
 int mtg_set_sssp_preset(mtg_device *d, int preset);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified

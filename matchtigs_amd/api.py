@@ -330,7 +330,8 @@ class DeviceGraph:
         ms = (C.c_double * 8)()
         src = (C.c_uint64 * 8)()
         n = self._L.mtg_last_sssp_levels(self._d, ms, src, 8)
-        return [{"level": i, "ms": float(ms[i]), "sources": int(src[i])} for i in range(n)]
+        return [{"level": i, "ms": float(ms[i]), "sources": int(src[i]),
+                 "kernel": self._L.mtg_last_sssp_level_name(self._d, i).decode()} for i in range(n)]
 
     def sssp_count(self, src_begin: int, src_end: int, stream: int = 0) -> dict:
         st = _lib.MtgSsspStats()

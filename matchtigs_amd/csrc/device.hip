@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "device.hpp"
@@ -1063,7 +1064,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
             settled |= 1u << best;
             popped = best;
             const uint32_t d = bestd;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);
+            // MTG_DBG bit 3 (timing experiments only, wrong results): gather from a 32 KB window = no DRAM latency
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((a.dbg & 8u) ? (u & 1023u) : u));
             const uint4 lo = rp[0];
             const uint4 hi = rp[1];
             const uint32_t flags = (hi.z >> 8) & 0xFFu;
@@ -1263,6 +1265,7 @@ struct Device {
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
+    std::string last_level_name[8];
     int preset = 5;  // lane kernel with 8-entry per-lane register tables, then the cooperative cascade
     int n_cu = 256;
     uint64_t graph_bytes = 0;
@@ -1279,6 +1282,11 @@ struct LevelCfg {
     int qcap;
     int scap;
     bool global_ws;
+    std::string name() const {
+        char b[96];
+        std::snprintf(b, sizeof b, "sssp_kernel<%d,%d,%d,%d,%d%s>", block, logh, qcap, scap, bsrc, global_ws ? ",global" : "");
+        return b;
+    }
 };
 
 template <int BLOCK, int LOGH, int QCAP, int SCAP, int BSRC, bool GLOBAL_WS>
@@ -1296,18 +1304,25 @@ struct LaneCfg {
     sssp_fn fn_count;
     int block;
     int max_occ = 0;  // workgroups per CU to launch at most (0 = what fits)
+    const char *kind = "";
+    int c = 0;
+    std::string name() const {
+        char b[96];
+        std::snprintf(b, sizeof b, "%s<%d,%d>", kind, block / 64, c);
+        return b;
+    }
 };
 template <int WPB, int C>
 static LaneCfg make_lane_cfg() {
-    return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64};
+    return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_kernel", C};
 }
 template <int WPB, int C>
 static LaneCfg make_lane_reg_cfg() {
-    return LaneCfg{sssp_lane_reg_kernel<WPB, C, false>, sssp_lane_reg_kernel<WPB, C, true>, WPB * 64};
+    return LaneCfg{sssp_lane_reg_kernel<WPB, C, false>, sssp_lane_reg_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_reg_kernel", C};
 }
 template <int WPB, int C>
 static LaneCfg make_lane_hash_cfg() {
-    return LaneCfg{sssp_lane_hash_kernel<WPB, C, false>, sssp_lane_hash_kernel<WPB, C, true>, WPB * 64};
+    return LaneCfg{sssp_lane_hash_kernel<WPB, C, false>, sssp_lane_hash_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_hash_kernel", C};
 }
 static LaneCfg lane_cfg(int preset) {
     switch (preset) {
@@ -1444,7 +1459,10 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     read_counters(d, st);
     if (n) total_ms += elapsed_ms(d);
     d->last_n_levels = 0;
-    if (n) { d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1; }
+    if (n) {
+        d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1;
+        d->last_level_name[0] = use_lane ? lane_cfg(d->preset).name() : coop_level(0).name();
+    }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_lane ? "lane" : "coop level 0",
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
@@ -1470,6 +1488,7 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         if (d->last_n_levels < 8) {
             d->last_level_ms[d->last_n_levels] = elapsed_ms(d);
             d->last_level_sources[d->last_n_levels] = n_ovf;
+            d->last_level_name[d->last_n_levels] = next.name();
             d->last_n_levels++;
         }
         if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li + 1,
@@ -1659,6 +1678,9 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
 }
 
 double device_last_kernel_ms(const Device *d) { return d->last_kernel_ms; }
+const char *device_last_level_name(const Device *d, int level) {
+    return level >= 0 && level < d->last_n_levels ? d->last_level_name[level].c_str() : "";
+}
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) {
     const int n = d->last_n_levels < cap ? d->last_n_levels : cap;
     for (int i = 0; i < n; i++) { ms[i] = d->last_level_ms[i]; sources[i] = d->last_level_sources[i]; }

@@ -23,6 +23,7 @@ int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, u
                 uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed);
 void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
 double device_last_kernel_ms(const Device *d);
+const char *device_last_level_name(const Device *d, int level);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_preset(Device *d, int preset);
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,

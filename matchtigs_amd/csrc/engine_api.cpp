@@ -122,6 +122,7 @@ double mtg_last_sssp_kernel_ms(const mtg_device *d) { return device_last_kernel_
 int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity) {
     return device_last_levels(d->d, ms_out, sources_out, capacity);
 }
+const char *mtg_last_sssp_level_name(const mtg_device *d, int level) { return device_last_level_name(d->d, level); }
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
     device_sssp_count(d->d, stream, src_begin, src_end, stats);
 }

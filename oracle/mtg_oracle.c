@@ -327,6 +327,9 @@ typedef struct { uint64_t w; uint32_t n; } hitem;
 typedef struct {
     hitem *heap; size_t hn, hcap;
     uint64_t *dist; uint32_t *epoch; uint32_t cur_epoch; uint32_t n_nodes;
+    /* hash-map node weights (the CLI default NodeWeightArrayType, bin.rs:156: hashbrown) for the worker-thread variant,
+     * where a V-sized array per thread would be page-fault bound: open addressing, cleared through the touched list */
+    int hashed; uint32_t *mkey; uint64_t *mval; uint32_t mcap, mn; uint32_t *mtouched;
 } dijkstra;
 
 static inline int hless(hitem a, hitem b) { return a.w < b.w || (a.w == b.w && a.n < b.n); }
@@ -363,9 +366,47 @@ static dijkstra *dijkstra_new(uint32_t n_nodes) {
     d->n_nodes = n_nodes;
     return d;
 }
-static void dijkstra_free(dijkstra *d) { free(d->heap); free(d->dist); free(d->epoch); free(d); }
-static inline uint64_t dget(dijkstra *d, uint32_t n) { return d->epoch[n] == d->cur_epoch ? d->dist[n] : UINT64_MAX; }
-static inline void dset(dijkstra *d, uint32_t n, uint64_t w) { d->epoch[n] = d->cur_epoch; d->dist[n] = w; }
+static dijkstra *dijkstra_new_hashed(uint32_t n_nodes) {
+    dijkstra *d = xcalloc(1, sizeof *d);
+    d->hashed = 1; d->n_nodes = n_nodes; d->cur_epoch = 1;
+    d->mcap = 1024; d->mkey = xmalloc((size_t)d->mcap * 4); d->mval = xmalloc((size_t)d->mcap * 8);
+    d->mtouched = xmalloc((size_t)d->mcap * 4);
+    memset(d->mkey, 0xFF, (size_t)d->mcap * 4);
+    return d;
+}
+static void dijkstra_free(dijkstra *d) { free(d->heap); free(d->dist); free(d->epoch); free(d->mkey); free(d->mval); free(d->mtouched); free(d); }
+static inline uint32_t mslot(const dijkstra *d, uint32_t n) {
+    uint32_t h = (n * 0x9E3779B1u) & (d->mcap - 1);
+    while (d->mkey[h] != OG_NONE && d->mkey[h] != n) h = (h + 1) & (d->mcap - 1);
+    return h;
+}
+static void mgrow(dijkstra *d) {
+    uint32_t ocap = d->mcap, on = d->mn; uint32_t *ok = d->mkey, *ot = d->mtouched; uint64_t *ov = d->mval;
+    d->mcap = ocap * 2; d->mn = 0;
+    d->mkey = xmalloc((size_t)d->mcap * 4); d->mval = xmalloc((size_t)d->mcap * 8); d->mtouched = xmalloc((size_t)d->mcap * 4);
+    memset(d->mkey, 0xFF, (size_t)d->mcap * 4);
+    for (uint32_t i = 0; i < on; i++) {
+        uint32_t os = ot[i], h = mslot(d, ok[os]);
+        d->mkey[h] = ok[os]; d->mval[h] = ov[os]; d->mtouched[d->mn++] = h;
+    }
+    free(ok); free(ov); free(ot);
+}
+static inline uint64_t dget(dijkstra *d, uint32_t n) {
+    if (d->hashed) { uint32_t h = mslot(d, n); return d->mkey[h] == n ? d->mval[h] : UINT64_MAX; }
+    return d->epoch[n] == d->cur_epoch ? d->dist[n] : UINT64_MAX;
+}
+static inline void dset(dijkstra *d, uint32_t n, uint64_t w) {
+    if (d->hashed) {
+        uint32_t h = mslot(d, n);
+        if (d->mkey[h] != n) {
+            if ((d->mn + 1) * 2 > d->mcap) { mgrow(d); h = mslot(d, n); }
+            d->mkey[h] = n; d->mtouched[d->mn++] = h;
+        }
+        d->mval[h] = w;
+        return;
+    }
+    d->epoch[n] = d->cur_epoch; d->dist[n] = w;
+}
 
 typedef struct { uint32_t node; uint64_t dist; } dist_entry;
 typedef struct { dist_entry *v; size_t n, cap; } dist_vec;
@@ -404,6 +445,11 @@ static void shortest_path_lens(const og_graph *g, dijkstra *d, uint32_t source, 
         }
     }
     d->hn = 0;       /* heap.clear() */
+    if (d->hashed) {  /* node_weights.clear() */
+        for (uint32_t i = 0; i < d->mn; i++) d->mkey[d->mtouched[i]] = OG_NONE;
+        d->mn = 0;
+        return;
+    }
     d->cur_epoch++;  /* node_weights.clear() */
     if (d->cur_epoch == 0) { memset(d->epoch, 0, (size_t)d->n_nodes * 4); d->cur_epoch = 1; }
 }
@@ -536,7 +582,7 @@ static void mt_unlock(uint8_t *l) { __atomic_clear(l, __ATOMIC_RELEASE); }
 static void *mt_worker_main(void *arg) {
     mt_worker *w = arg;
     const og_graph *g = w->g;
-    dijkstra *dj = dijkstra_new(g->n_nodes);
+    dijkstra *dj = dijkstra_new_hashed(g->n_nodes);
     dist_vec distances = {0};
     for (;;) {
         uint64_t lo = __atomic_fetch_add(w->cursor, 1024, __ATOMIC_RELAXED);
