@@ -10,21 +10,25 @@
 //
 // Method (Atallah/Vishkin-style, adapted to mirror pairs; all arrays indexed by directed edge = "dart"; the mirror
 // of dart e is e ^ 1):
-//   1. bucket the darts by from-node (degree count, scan, slot fill): adj[row[v] + i] = i-th out-dart of v.
+//   1. bucket the darts by from-node (degree count, scan, slot fill, per-node sort): adj[row[v] + i] = i-th out-dart
+//      of v in ascending dart id.
 //   2. pair every in-dart of a node with an out-dart, mirror-symmetrically: for dart e = (u -> v), j = slot of
 //      e^1 among the out-darts of mirror(v); succ[e] = out(v)[j] (self-mirror v: out(v)[j ^ 1]). By construction
 //      succ[succ[e] ^ 1] = e ^ 1, so the closed trails succ defines come in disjoint mirror pairs.
 //   3. label the trails (lock-free union-find over darts, root = smallest dart id); a biedge component is a
 //      trail together with its mirror trail.
-//   4. spanning forest over (biedge components x binodes): per binode, union the component of every passage with
-//      the component of passage 0 in a second union-find; each union that performed a link selects that passage.
-//      The node then rotates the successors of the selected passages (and, mirrored, at the mirror node), which
-//      merges all their trails into one. A forest means every link joins two trails that are still distinct, so
+//   4. spanning forest over (biedge components x binodes): rounds of deterministic hooking -- every binode proposes,
+//      for each passage whose component differs from its passage 0's, to hang the larger component root below the
+//      smaller; a root accepts its smallest proposal (64-bit atomicMin) -- until every binode sees one component.
+//      Each accepted proposal selects its passage; a node then rotates the successors of passage 0 and its selected
+//      passages (and, mirrored, at the mirror node), which merges all their trails into one. Roots only hang below
+//      smaller ids, so the accepted proposals form a forest: every one joins two trails that are still distinct, and
 //      the result is exactly one trail pair per connected component.
 //   5. rank the final trails: random splitters (1/64 of the darts + the smallest dart of every component) walk to
 //      the next splitter, the reduced list is ranked by pointer jumping, and a second walk writes the darts at
 //      their final positions. Only the trail that contains the component's smallest dart is emitted.
-// Everything is integer gather/scatter work; no MFMA.
+// No step depends on thread timing (atomics are only used for counts, minima and idempotent flags), so the same graph
+// always gives the same walks. Everything is integer gather/scatter work; no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -157,6 +161,24 @@ __global__ __launch_bounds__(EB) void fill_kernel(const uint32_t *from, uint32_t
     pos[e] = p;
 }
 
+// buckets are filled in atomic order; sorting each node's few out-darts by id makes slots (and with them the whole
+// decomposition) independent of thread timing
+__global__ __launch_bounds__(EB) void sort_buckets_kernel(uint32_t n_nodes, const uint32_t *row, uint32_t *adj, uint32_t *pos) {
+    const uint32_t v = blockIdx.x * EB + threadIdx.x;
+    if (v >= n_nodes) return;
+    const uint32_t lo = row[v], hi = row[v + 1];
+    for (uint32_t i = lo + 1; i < hi; i++) {  // insertion sort (degrees are tiny in a de Bruijn graph)
+        const uint32_t x = adj[i];
+        uint32_t j = i;
+        while (j > lo && adj[j - 1] > x) {
+            adj[j] = adj[j - 1];
+            j--;
+        }
+        adj[j] = x;
+    }
+    for (uint32_t i = lo; i < hi; i++) pos[adj[i]] = i - lo;
+}
+
 // ---- step 2: mirror-symmetric pairing --------------------------------------------------------------------------
 __global__ __launch_bounds__(EB) void succ_kernel(const uint32_t *from, const uint32_t *mirror, uint32_t n_darts, const uint32_t *row,
                                                  const uint32_t *adj, const uint32_t *pos, uint32_t *succ, uint32_t *parent,
@@ -199,32 +221,71 @@ __global__ __launch_bounds__(EB) void comp_kernel(const uint32_t *label, uint32_
     parent2[e] = e;
 }
 
-// ---- step 4: spanning forest + successor rotation, one thread per binode -------------------------------------
-__global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint32_t n_nodes, const uint32_t *row, const uint32_t *adj,
-                                                   const uint32_t *comp, uint32_t *parent2, uint32_t *succ) {
-    const uint32_t v = blockIdx.x * EB + threadIdx.x;
-    if (v >= n_nodes) return;
+// ---- step 4: spanning forest (deterministic hooking rounds) + successor rotation ------------------------------
+// Round: every binode proposes, for each passage i >= 1 whose component root differs from passage 0's, to hang the
+// LARGER root below the smaller one; a root keeps the smallest proposal (smaller target root, then smaller passage
+// dart) by a 64-bit atomicMin, so the outcome does not depend on thread timing. Roots only ever hang below smaller ids,
+// so the accepted proposals of all rounds form a forest over the components.
+template <typename F>
+__device__ __forceinline__ void for_each_passage(const uint32_t *mirror, const uint32_t *row, const uint32_t *adj, uint32_t v, F &&f) {
     const uint32_t vm = mirror[v];
     if (vm < v) return;  // the lower node of a pair works for both
     const uint32_t d = row[v + 1] - row[v];
     const bool self = vm == v;
     const uint32_t n_pass = self ? d / 2 : d;
-    if (n_pass < 2) return;
     // passage i: in-dart a_i -> out-dart b_i at v (and, mirrored, b_i^1 -> a_i^1 at mirror v)
-    auto in_dart = [&](uint32_t i) { return (self ? adj[row[v] + 2 * i] : adj[row[vm] + i]) ^ 1u; };
-    auto out_dart = [&](uint32_t i) { return self ? adj[row[v] + 2 * i + 1] : adj[row[v] + i]; };
-    const uint32_t b0 = out_dart(0);
-    const uint32_t c0 = comp[b0];
-    uint32_t a_prev = in_dart(0);
-    bool any = false;
-    for (uint32_t i = 1; i < n_pass; i++) {
-        const uint32_t bi = out_dart(i);
-        if (!uf_union(parent2, comp[bi], c0)) continue;
-        succ[a_prev] = bi;
-        succ[bi ^ 1] = a_prev ^ 1;
-        a_prev = in_dart(i);
-        any = true;
+    for (uint32_t i = 0; i < n_pass; i++) {
+        const uint32_t a = (self ? adj[row[v] + 2 * i] : adj[row[vm] + i]) ^ 1u;
+        const uint32_t b = self ? adj[row[v] + 2 * i + 1] : adj[row[v] + i];
+        f(i, a, b);
     }
+}
+__global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uint32_t n_nodes, const uint32_t *row, const uint32_t *adj,
+                                                    const uint32_t *comp, uint32_t *parent2, unsigned long long *best) {
+    const uint32_t v = blockIdx.x * EB + threadIdx.x;
+    if (v >= n_nodes) return;
+    uint32_t r0 = 0;
+    for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t, uint32_t b) {
+        const uint32_t r = uf_find(parent2, comp[b]);
+        if (i == 0) {
+            r0 = r;
+            return;
+        }
+        if (r == r0) return;
+        const uint32_t hi = r > r0 ? r : r0, lo = r > r0 ? r0 : r;
+        const unsigned long long key = ((unsigned long long)lo << 32) | b;
+        // a long trail receives one proposal per shared binode: filter the losers before they queue up on its word
+        if (key < __hip_atomic_load(&best[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[hi], key);
+    });
+}
+__global__ __launch_bounds__(EB) void hook_kernel(uint32_t n_darts, uint32_t *parent2, const unsigned long long *best, uint32_t *selected,
+                                                 uint32_t *changed) {
+    const uint32_t r = blockIdx.x * EB + threadIdx.x;
+    if (r >= n_darts) return;
+    const unsigned long long p = best[r];
+    if (p == ~0ull) return;
+    parent2[r] = (uint32_t)(p >> 32);  // r was a root when it was proposed for, and only this thread writes it
+    selected[(uint32_t)p] = 1u;        // the passage whose out-dart this is joins its node's rotation
+    *changed = 1u;
+}
+__global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint32_t n_nodes, const uint32_t *row, const uint32_t *adj,
+                                                   const uint32_t *selected, uint32_t *succ) {
+    const uint32_t v = blockIdx.x * EB + threadIdx.x;
+    if (v >= n_nodes) return;
+    uint32_t a_prev = 0, b0 = 0;
+    bool any = false;
+    for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t a, uint32_t b) {
+        if (i == 0) {
+            a_prev = a;
+            b0 = b;
+            return;
+        }
+        if (!selected[b]) return;
+        succ[a_prev] = b;
+        succ[b ^ 1] = a_prev ^ 1;
+        a_prev = a;
+        any = true;
+    });
     if (any) {
         succ[a_prev] = b0;
         succ[b0 ^ 1] = a_prev ^ 1;
@@ -312,14 +373,17 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
     }
 }
 
+// Stream-ordered allocations from the device's default memory pool, which is told to keep freed memory: the ~25
+// work arrays of a call cost milliseconds to map afresh, and a driver that Eulerises graph after graph reuses them.
+thread_local hipStream_t g_alloc_stream = nullptr;
 struct Buf {
     void *p = nullptr;
     ~Buf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFreeAsync(p, g_alloc_stream);
     }
     template <typename T>
     T *alloc(uint64_t n) {
-        HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+        HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), g_alloc_stream));
         return (T *)p;
     }
 };
@@ -348,13 +412,22 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device_id)
         MTG_DIE("device_euler_cycles: no MI355X device %d visible (there is no CPU fallback for this mode)", device_id);
     HIP_CHECK(hipSetDevice(device_id));
-    hipStream_t st;
-    HIP_CHECK(hipStreamCreate(&st));
+    static hipStream_t streams[64] = {nullptr};
+    if (device_id >= 64) MTG_DIE("device_euler_cycles: device id %d out of range", device_id);
+    if (!streams[device_id]) {
+        HIP_CHECK(hipStreamCreate(&streams[device_id]));
+        hipMemPool_t pool;
+        HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
+        uint64_t keep = UINT64_MAX;
+        HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    }
+    hipStream_t st = streams[device_id];
+    g_alloc_stream = st;
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));
     HIP_CHECK(hipEventCreate(&ev1));
 
-    Buf b_from, b_mirror, b_row, b_cursor, b_adj, b_pos, b_succ, b_parent, b_label, b_comp, b_parent2, b_flag, b_sidx, b_isroot,
+    Buf b_best, b_from, b_mirror, b_row, b_cursor, b_adj, b_pos, b_succ, b_parent, b_label, b_comp, b_parent2, b_flag, b_sidx, b_isroot,
         b_bsum, b_small;
     uint32_t *d_from = b_from.alloc<uint32_t>(E);
     uint32_t *d_mirror = b_mirror.alloc<uint32_t>(V);
@@ -370,6 +443,7 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     uint32_t *d_flag = b_flag.alloc<uint32_t>(E);
     uint32_t *d_sidx = b_sidx.alloc<uint32_t>(E);
     uint8_t *d_isroot = b_isroot.alloc<uint8_t>(E);
+    unsigned long long *d_best = b_best.alloc<unsigned long long>(E);
     const uint64_t max_scan = std::max<uint64_t>(E, (uint64_t)V + 1);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(max_scan / SCAN_CHUNK + 2);
     uint32_t *d_small = b_small.alloc<uint32_t>(8);  // [0] error, [1..] scan totals
@@ -386,6 +460,7 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     degree_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row);
     scan_u32(st, d_row, (uint64_t)V + 1, d_row, d_bsum, d_total);
     fill_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_cursor, d_adj, d_pos);
+    sort_buckets_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_pos);
     // 2. pairing, 3. trail labels
     succ_kernel<<<grid_for(E), EB, 0, st>>>(d_from, d_mirror, E, d_row, d_adj, d_pos, d_succ, d_parent, d_error);
     uint32_t h_small[8];
@@ -396,7 +471,20 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent, E, d_label);
     comp_kernel<<<grid_for(E), EB, 0, st>>>(d_label, E, d_comp, d_parent2);
     // 4. merge the trails of every connected component
-    rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_succ);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, (uint64_t)E * 4, st));  // `selected`, reused as the splitter flags afterwards
+    int hook_rounds = 0;
+    for (;; hook_rounds++) {
+        if (hook_rounds > 64) MTG_DIE("device_euler_cycles: internal error (component hooking does not converge)");
+        HIP_CHECK(hipMemsetAsync(d_best, 0xFF, (uint64_t)E * 8, st));
+        HIP_CHECK(hipMemsetAsync(d_small + 4, 0, 4, st));
+        propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best);
+        hook_kernel<<<grid_for(E), EB, 0, st>>>(E, d_parent2, d_best, d_flag, d_small + 4);
+        flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent2, E, d_parent2);
+        HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (!h_small[4]) break;
+    }
+    rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_flag, d_succ);
     // 5. ranking
     splitter_flag_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, d_parent2, E, d_flag, d_isroot);
     scan_u32(st, d_flag, E, d_sidx, d_bsum, d_total);
@@ -458,7 +546,6 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     }
     HIP_CHECK(hipEventDestroy(ev0));
     HIP_CHECK(hipEventDestroy(ev1));
-    HIP_CHECK(hipStreamDestroy(st));
     return result;
 }
 

@@ -138,3 +138,17 @@ def test_device_euler_full_bench_size(gpu):
     G.make_eulerian(0, bg.k)
     limits, edges = G.euler_cycles_device_np()
     check_bicycles(G.export(), limits, edges)
+
+
+def test_device_euler_is_reproducible(gpu):
+    """No step of the device decomposition depends on thread timing: two runs give identical walks."""
+    from matchtigs_amd import api, synth
+
+    bg = synth.g_csr(200000, seed=13, k=31, mean_out_degree=1.2)   # many components of very different sizes
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    G.make_eulerian(0, bg.k)
+    a = G.euler_cycles_device_np()
+    for _ in range(3):
+        b = G.euler_cycles_device_np()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    check_bicycles(G.export(), a[0], a[1])
