@@ -168,7 +168,7 @@ enum Counter : int {
     C_EMITTED = 5,
     C_ATTEMPTS = 6,
     C_OVF_LIST = 7,  // cursor of the overflow source list
-    C_T_INIT = 8,    // MTG_DBG=3: wall-clock ticks (100 MHz) thread 0 of every block spent per phase, and rounds
+    C_T_INIT = 8,    // MTG_UNSAFE_TIMING_EXPERIMENT=3: wall-clock ticks (100 MHz) thread 0 of every block spent per phase, and rounds
     C_T_ROUNDS = 9,
     C_T_EMIT = 10,
     C_T_CLEAN = 11,
@@ -195,7 +195,8 @@ struct SsspArgs {
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
     uint32_t *seed_out;          // out (lane level, optional): search state of every overflowed source, SEED_WORDS per ovf_list entry
     const uint32_t *seed_in;     // in (cooperative level, optional): seeds parallel to src_index -- continue instead of restart
-    uint32_t dbg;                // timing experiments only (MTG_DBG env): 1 = gather from a 32 KB window, 2 = no emission writes
+    uint32_t dbg;                // MTG_UNSAFE_TIMING_EXPERIMENT env, never set in production: bits 1/2/8 give WRONG RESULTS (gather from a
+                                 // 32 KB window / skip emission writes: what-if timings), 3 = per-phase clocks of the cooperative kernel
 };
 
 // Seed = the state of a lane-level Dijkstra at the moment its table overflowed, so that the cooperative level
@@ -1064,7 +1065,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
             settled |= 1u << best;
             popped = best;
             const uint32_t d = bestd;
-            // MTG_DBG bit 3 (timing experiments only, wrong results): gather from a 32 KB window = no DRAM latency
+            // MTG_UNSAFE_TIMING_EXPERIMENT bit 3 (timing experiments only, wrong results): gather from a 32 KB window = no DRAM latency
             const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((a.dbg & 8u) ? (u & 1023u) : u));
             const uint4 lo = rp[0];
             const uint4 hi = rp[1];
@@ -1451,7 +1452,7 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     const bool seeded = d->use_seeds && !seeds_off && d->preset == 5;  // only the 8-entry register kernel writes seeds
     a.seed_out = seeded ? d->d_seed : nullptr;
     a.seed_in = nullptr;
-    { const char *e = std::getenv("MTG_DBG"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
+    { const char *e = std::getenv("MTG_UNSAFE_TIMING_EXPERIMENT"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
     double total_ms = 0.0;
     const bool use_lane = d->preset != 4;
     if (use_lane) launch_lane(d, st, lane_cfg(d->preset), count, a);
@@ -1777,6 +1778,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 
     int cur = 0, rounds = 0;
     constexpr int MAX_ROUNDS = 256;
+    static const bool replay_debug = std::getenv("MTG_DEBUG_REPLAY") != nullptr;
     while (n_pending > 0 && rounds < MAX_ROUNDS) {
         const unsigned pb = (unsigned)((n_pending + 255) / 256);
         HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
@@ -1788,6 +1790,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         n_pending = d->h_counters[C_OVF_LIST];
         cur ^= 1;
         rounds++;
+        if (replay_debug) std::fprintf(stderr, "[mtg] replay round %d: %llu pending\n", rounds, (unsigned long long)n_pending);
     }
     if (n_pending > 0) {  // very long priority chain: finish the rest in order on one GPU thread
         std::vector<uint32_t> rest(n_pending);
