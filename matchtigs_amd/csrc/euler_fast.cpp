@@ -7,11 +7,16 @@
 // number of DRAM misses on that chain:
 //   v0  used[] / e_to / cursor / e_next_out / e_from ...  ~7 misses per biedge   4.2 s  (profiles/r01_*)
 //   v1  one 32-byte record per node (cursor + 3 inline adjacency entries), used-bitmap      ~1 miss per biedge, 1.5 s
-//   v2  (this file) 128-byte records that also carry, for each of the 3 inline out-edges, the inline adjacency of the
-//       edge's HEAD node: after one miss the walk knows where it can go from the next node too  ->  ~1 miss per 2 biedges.
+//   v2  128-byte records that also carry, for each of the 3 inline out-edges, the inline adjacency of the edge's HEAD
+//       node: after one miss the walk knows where it can go from the next node too  ->  ~1 miss per 2 biedges, 1.4 s
+//   v3  (this file) 256-byte records with TWO levels of copied adjacency (3 positions of every head node, 2 positions of
+//       every head's head): one record access serves up to three steps, and -- what matters more -- the record the walk
+//       will need three steps from now is known (up to used-bit changes in between) when the current one arrives, so its
+//       fetch overlaps two whole steps instead of a fraction of one.
 // Record build and sub-adjacency fill are embarrassingly parallel gathers and run on host threads; the walk itself is
 // inherently sequential (each step depends on every edge used so far).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -26,18 +31,28 @@ namespace mtg {
 Walks euler_cycles_generic(const HostGraph &g);
 
 namespace {
-struct alignas(128) EulerNode2 {
-    uint32_t eid[3];         // adjacency positions 0..2 in iteration order (newest edge first)
+// Copied adjacency is in the owner's iteration order (newest edge first). A copy holds the first `cnt` positions of its
+// node and a `more` bit (the node has further positions): if none of the copied edges is unused and `more` is clear the
+// node is exhausted, with `more` set the walk falls back to the node's own record.
+struct alignas(256) EulerNode3 {
+    uint32_t eid[3];             // own adjacency positions 0..2
     uint32_t to[3];
-    uint32_t ext_begin;      // spill entries for positions 3..deg-1
     uint16_t deg;
-    uint16_t pos;            // positions < pos are known to be used
-    uint32_t sub_eid[3][3];  // inline adjacency of to[j] (valid if sub_deg[j] != 0xFF)
+    uint16_t pos;                // positions < pos are known to be used
+    uint16_t sub_info;           // 3 bits per inline edge j: cnt (0..3) | more << 2
+    uint16_t pad;
+    uint32_t sub2_info;          // 3 bits per (j, q): cnt (0..2) | more << 2
+    uint32_t ext_begin;          // spill entries for own positions 3..deg-1
+    uint32_t sub_eid[3][3];      // adjacency of to[j]
     uint32_t sub_to[3][3];
-    uint8_t sub_deg[3];
-    uint8_t pad[21];
+    uint32_t sub2_eid[3][3][2];  // adjacency of sub_to[j][q]
+    uint32_t sub2_to[3][3][2];
+    uint32_t sub_cnt(uint32_t j) const { return (sub_info >> (3 * j)) & 3u; }
+    bool sub_more(uint32_t j) const { return (sub_info >> (3 * j + 2)) & 1u; }
+    uint32_t sub2_cnt(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q))) & 3u; }
+    bool sub2_more(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q) + 2)) & 1u; }
 };
-static_assert(sizeof(EulerNode2) == 128, "EulerNode2 must be 128 bytes");
+static_assert(sizeof(EulerNode3) == 256, "EulerNode3 must be 256 bytes");
 }  // namespace
 
 Walks euler_cycles(const HostGraph &g) {
@@ -52,7 +67,7 @@ Walks euler_cycles(const HostGraph &g) {
     NumaPin pin;  // the walk is one latency-bound thread: keep it next to the memory it chases through
 
     // ---- records ----
-    HugeBuf<EulerNode2> nodes(V);
+    HugeBuf<EulerNode3> nodes(V);
     std::vector<uint32_t> ext_begin(V + 1, 0);
     {
         uint64_t ext_total = 0;
@@ -66,13 +81,15 @@ Walks euler_cycles(const HostGraph &g) {
     std::vector<uint32_t> ext_eid(ext_begin[V]), ext_to(ext_begin[V]);
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase A: own adjacency, newest first (the petgraph order)
         for (uint64_t n = lo; n < hi; n++) {
-            EulerNode2 &r = nodes[n];
+            EulerNode3 &r = nodes[n];
             r.deg = (uint16_t)g.out_deg[n];
             r.pos = 0;
+            r.pad = 0;
+            r.sub_info = 0;
+            r.sub2_info = 0;
             r.ext_begin = ext_begin[n];
             r.eid[0] = r.eid[1] = r.eid[2] = NONE;
             r.to[0] = r.to[1] = r.to[2] = NONE;
-            r.sub_deg[0] = r.sub_deg[1] = r.sub_deg[2] = 0xFF;
             uint32_t i = 0;
             for (uint32_t e = g.head_out[n]; e != NONE; e = g.e_next_out[e], i++) {
                 if (i < 3) { r.eid[i] = e; r.to[i] = g.e_to[e]; }
@@ -80,27 +97,68 @@ Walks euler_cycles(const HostGraph &g) {
             }
         }
     });
-    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: inline adjacency of each inline edge's head node
+    const auto t_a = std::chrono::steady_clock::now();
+    constexpr unsigned BUILD_THREADS = 128;  // phases B and C are random gathers: latency bound, so more threads than cores pay
+    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: first 3 positions of each inline edge's head node
         for (uint64_t n = lo; n < hi; n++) {
-            EulerNode2 &r = nodes[n];
+            if (n + 16 < hi) {
+                const EulerNode3 &a = nodes[n + 16];
+                for (uint32_t j = 0; j < 3; j++)
+                    if (a.to[j] != NONE) __builtin_prefetch(&nodes[a.to[j]]);
+            }
+            EulerNode3 &r = nodes[n];
             const uint32_t d = r.deg < 3 ? r.deg : 3;
+            uint32_t info = 0;
             for (uint32_t j = 0; j < d; j++) {
-                const EulerNode2 &w = nodes[r.to[j]];
-                if (w.deg <= 3) {
-                    r.sub_deg[j] = (uint8_t)w.deg;
-                    for (uint32_t q = 0; q < 3; q++) { r.sub_eid[j][q] = w.eid[q]; r.sub_to[j][q] = w.to[q]; }
+                const EulerNode3 &w = nodes[r.to[j]];
+                const uint32_t c = w.deg < 3 ? w.deg : 3;
+                for (uint32_t q = 0; q < c; q++) { r.sub_eid[j][q] = w.eid[q]; r.sub_to[j][q] = w.to[q]; }
+                info |= (c | (w.deg > 3 ? 4u : 0u)) << (3 * j);
+            }
+            r.sub_info = (uint16_t)info;
+        }
+    }, BUILD_THREADS);
+    const auto t_b = std::chrono::steady_clock::now();
+    // phase C: first 2 positions of each head's heads. The head w = to[j] already holds copies of ITS heads' adjacency
+    // (phase B), so one gather of w's record serves all three (j, q) slots.
+    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++) {
+            if (n + 12 < hi) {
+                const EulerNode3 &a = nodes[n + 12];
+                for (uint32_t j = 0; j < 3; j++)
+                    if (a.to[j] != NONE) {
+                        const char *p = reinterpret_cast<const char *>(&nodes[a.to[j]]);
+                        __builtin_prefetch(p);
+                        __builtin_prefetch(p + 64);
+                    }
+            }
+            EulerNode3 &r = nodes[n];
+            const uint32_t d = r.deg < 3 ? r.deg : 3;
+            uint32_t info = 0;
+            for (uint32_t j = 0; j < d; j++) {
+                const EulerNode3 &w = nodes[r.to[j]];
+                for (uint32_t q = 0; q < r.sub_cnt(j); q++) {
+                    const uint32_t wc = w.sub_cnt(q);  // copied positions of x = w.to[q] (up to 3)
+                    const uint32_t c = wc < 2 ? wc : 2;
+                    for (uint32_t t = 0; t < c; t++) { r.sub2_eid[j][q][t] = w.sub_eid[q][t]; r.sub2_to[j][q][t] = w.sub_to[q][t]; }
+                    info |= (c | ((wc > 2 || w.sub_more(q)) ? 4u : 0u)) << (3 * (3 * j + q));
                 }
             }
+            r.sub2_info = info;
         }
-    });
+    }, BUILD_THREADS);
     const auto t_built = std::chrono::steady_clock::now();
+    if (dbg_t)
+        std::fprintf(stderr, "[mtg] euler_cycles: records: alloc + own adjacency %.3f s, heads %.3f s, heads of heads %.3f s\n",
+                     std::chrono::duration<double>(t_a - t_begin).count(), std::chrono::duration<double>(t_b - t_a).count(),
+                     std::chrono::duration<double>(t_built - t_b).count());
 
     std::vector<uint64_t> used((E / 2 + 63) / 64 + 1, 0);
     auto is_used = [&](uint32_t e) -> bool { return (used[(e >> 1) >> 6] >> ((e >> 1) & 63)) & 1ull; };
     auto set_used = [&](uint32_t e) { used[(e >> 1) >> 6] |= 1ull << ((e >> 1) & 63); };
     // first unused out-edge of `node` in iteration order; j_out = its adjacency position
     auto next_unused = [&](uint32_t node, uint32_t &to_out, uint32_t &j_out) -> uint32_t {
-        EulerNode2 &r = nodes[node];
+        EulerNode3 &r = nodes[node];
         while (r.pos < r.deg) {
             const uint32_t e = r.pos < 3 ? r.eid[r.pos] : ext_eid[r.ext_begin + r.pos - 3];
             if (!is_used(e)) {
@@ -119,7 +177,11 @@ Walks euler_cycles(const HostGraph &g) {
     Walks out;
     out.edges.reserve(E / 2);
     constexpr size_t PF = 12;  // FIFO prefetch distance
-    uint64_t n_walks = 0, n_hinted = 0;
+    uint64_t n_walks = 0, n_hinted = 0, n_full = 0, n_pred_hit = 0;
+    uint32_t last_pf = NONE;
+    double t_walk = 0, t_scan = 0, t_emit = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
     for (uint64_t e0 = 0; e0 < E; e0++) {
         if (is_used((uint32_t)e0)) continue;
@@ -131,11 +193,19 @@ Walks euler_cycles(const HostGraph &g) {
 
         while (start_edge != NONE) {
             n_walks++;
+            const auto tw0 = now();
             const size_t w_begin = n_ent;
             uint32_t e = start_edge, from = start_node, to = start_to;
-            // hint: adjacency of `to`, copied into the record we just left (0xFF: not available)
-            const uint32_t *h_eid = nullptr, *h_to = nullptr;
-            uint32_t h_deg = 0xFF;
+            // hint state: `H` is the last record read; level 2 = `from` is H->to[hj], level 3 = `from` is H->sub_to[hj][hq]
+            const EulerNode3 *H = nullptr;
+            uint32_t level = 0, hj = 0, hq = 0;
+            auto prefetch_record = [&](uint32_t node) {
+                const char *p = reinterpret_cast<const char *>(&nodes[node]);
+                __builtin_prefetch(p);
+                __builtin_prefetch(p + 64);
+                __builtin_prefetch(p + 128);
+                __builtin_prefetch(p + 192);
+            };
             for (;;) {
                 set_used(e);
                 ent_edge[n_ent] = e;
@@ -143,27 +213,49 @@ Walks euler_cycles(const HostGraph &g) {
                 ent_next[n_ent] = (uint32_t)(n_ent + 1);
                 n_ent++;
                 from = to;
-                if (h_deg != 0xFF) {  // no memory access on the critical path for this step
-                    e = NONE;
-                    for (uint32_t q = 0; q < h_deg; q++)
-                        if (!is_used(h_eid[q])) { e = h_eid[q]; to = h_to[q]; break; }
-                    h_deg = 0xFF;
-                    n_hinted++;
-                } else {
+                bool full = true;
+                e = NONE;
+                if (level == 2) {  // no memory access on the critical path: the copy of `from`'s adjacency is in H
+                    const uint32_t cnt = H->sub_cnt(hj);
+                    uint32_t q = 0;
+                    for (; q < cnt; q++)
+                        if (!is_used(H->sub_eid[hj][q])) { e = H->sub_eid[hj][q]; to = H->sub_to[hj][q]; break; }
+                    if (e != NONE) { full = false; level = 3; hq = q; n_hinted++; }
+                    else if (!H->sub_more(hj)) { full = false; level = 0; }  // exhausted: the walk is stuck here
+                } else if (level == 3) {
+                    const uint32_t cnt = H->sub2_cnt(hj, hq);
+                    for (uint32_t t = 0; t < cnt; t++)
+                        if (!is_used(H->sub2_eid[hj][hq][t])) { e = H->sub2_eid[hj][hq][t]; to = H->sub2_to[hj][hq][t]; break; }
+                    if (e != NONE) { full = false; n_hinted++; prefetch_record(to); }
+                    else if (!H->sub2_more(hj, hq)) full = false;
+                    level = 0;
+                }
+                if (full) {
+                    level = 0;
+                    n_full++;
+                    n_pred_hit += (from == last_pf);
                     uint32_t j = 0;
                     e = next_unused(from, to, j);
-                    if (e != NONE && j < 3) {
-                        const EulerNode2 &r = nodes[from];
-                        if (r.sub_deg[j] != 0xFF) {
-                            h_eid = r.sub_eid[j]; h_to = r.sub_to[j]; h_deg = r.sub_deg[j];
-                            // the node after next is one of h_to[*]: start those (<= 3) record fetches and the used-bitmap
-                            // words now, one whole step before the chain needs them
-                            for (uint32_t q = 0; q < h_deg; q++) {
-                                __builtin_prefetch(&nodes[h_to[q]]);
-                                __builtin_prefetch(reinterpret_cast<const char *>(&nodes[h_to[q]]) + 64);
-                                __builtin_prefetch(&used[(h_eid[q] >> 1) >> 6]);
-                            }
-                        }
+                    if (e != NONE) {
+                        if (j < 3) {
+                            H = &nodes[from];
+                            hj = j;
+                            level = 2;
+                            // The record needed three steps from now is the head of the first unused copied edge of the first
+                            // unused copied edge of `to` -- unless used bits change in between. Start its fetch now.
+                            uint32_t pf = to;
+                            const uint32_t c1 = H->sub_cnt(j);
+                            for (uint32_t q = 0; q < c1; q++)
+                                if (!is_used(H->sub_eid[j][q])) {
+                                    pf = H->sub_to[j][q];
+                                    const uint32_t c2 = H->sub2_cnt(j, q);
+                                    for (uint32_t t = 0; t < c2; t++)
+                                        if (!is_used(H->sub2_eid[j][q][t])) { pf = H->sub2_to[j][q][t]; break; }
+                                    break;
+                                }
+                            prefetch_record(pf);
+                            last_pf = pf;
+                        } else { prefetch_record(to); last_pf = to; }
                     }
                 }
                 if (e == NONE) {
@@ -173,6 +265,8 @@ Walks euler_cycles(const HostGraph &g) {
                 }
             }
             const size_t w_end = n_ent;
+            const auto tw1 = now();
+            t_walk += secs(tw0, tw1);
             if (splice_at == NONE) {
                 head = (uint32_t)w_begin;
                 ent_next[w_end - 1] = head;
@@ -192,8 +286,32 @@ Walks euler_cycles(const HostGraph &g) {
                 fifo[fifo_tail++] = x;
                 for (size_t i = w_begin + 1; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
             }
-            // next start edge: first entry in cycle order whose from-node still has an unused out-edge
+            // next start edge: first entry in cycle order whose from-node still has an unused out-edge. A long backlog is
+            // first narrowed down by host threads (read-only: each finds the first such entry of its chunk).
             start_edge = NONE;
+            auto has_unused = [&](uint32_t node) -> bool {  // like next_unused, without moving the node's cursor
+                const EulerNode3 &r = nodes[node];
+                for (uint32_t p = r.pos; p < r.deg; p++)
+                    if (!is_used(p < 3 ? r.eid[p] : ext_eid[r.ext_begin + p - 3])) return true;
+                return false;
+            };
+            while (fifo_tail - fifo_head >= (1u << 18) && start_edge == NONE) {
+                std::atomic<size_t> first_hit{fifo_tail};
+                const size_t base = fifo_head;
+                parallel_ranges(fifo_tail - base, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t i = base + lo; i < base + hi; i++) {
+                        if (i + PF < base + hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
+                        if ((i & 1023) == 0 && first_hit.load(std::memory_order_relaxed) < i) return;
+                        if (has_unused(ent_node[fifo[i]])) {
+                            size_t cur = first_hit.load(std::memory_order_relaxed);
+                            while (i < cur && !first_hit.compare_exchange_weak(cur, (size_t)i)) {}
+                            return;
+                        }
+                    }
+                });
+                fifo_head = first_hit.load();  // everything before it is exhausted; the sequential loop takes it from here
+                break;
+            }
             while (fifo_head < fifo_tail) {
                 if (fifo_head + PF < fifo_tail) __builtin_prefetch(&nodes[ent_node[fifo[fifo_head + PF]]]);
                 const uint32_t ent = fifo[fifo_head];
@@ -203,7 +321,9 @@ Walks euler_cycles(const HostGraph &g) {
                 if (cand != NONE) { start_edge = cand; start_to = to2; start_node = node; splice_at = ent; break; }
                 fifo_head++;
             }
+            t_scan += secs(tw1, now());
         }
+        const auto te0 = now();
         uint32_t ent = head;
         const size_t o0 = out.edges.size();
         out.edges.resize(o0 + n_ent);  // upper bound (the cycle has at most n_ent entries); trimmed below
@@ -214,9 +334,12 @@ Walks euler_cycles(const HostGraph &g) {
         } while (ent != head);
         out.edges.resize(o);
         out.limits.push_back(out.edges.size());
+        t_emit += secs(te0, now());
     }
     if (dbg_t) {
         const auto t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mtg] euler_cycles: walk %.3f s, scan for splice points %.3f s, emit %.3f s; %llu record reads, %.0f%% of them at the predicted node\n",
+                     t_walk, t_scan, t_emit, (unsigned long long)n_full, n_full ? 100.0 * n_pred_hit / n_full : 0.0);
         std::fprintf(stderr, "[mtg] euler_cycles: records %.3f s, walk+splice+emit %.3f s (%llu closed walks, %zu biedges, %.0f%% of steps hinted)\n",
                      std::chrono::duration<double>(t_built - t_begin).count(), std::chrono::duration<double>(t_end - t_built).count(),
                      (unsigned long long)n_walks, out.edges.size(), out.edges.empty() ? 0.0 : 100.0 * n_hinted / out.edges.size());

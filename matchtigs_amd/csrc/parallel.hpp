@@ -9,11 +9,11 @@
 
 namespace mtg {
 
-// Calls f(lo, hi) on disjoint sub-ranges of [0, n) from up to 32 threads (1 thread for small n).
+// Calls f(lo, hi) on disjoint sub-ranges of [0, n) from up to max_threads threads (1 thread for small n).
 template <typename F>
-void parallel_ranges(uint64_t n, F &&f) {
+void parallel_ranges(uint64_t n, F &&f, unsigned max_threads = 32) {
     unsigned t = std::thread::hardware_concurrency();
-    t = std::max(1u, std::min(t, 32u));
+    t = std::max(1u, std::min(t, max_threads));
     if (n < (1u << 16)) t = 1;
     if (t == 1) {
         f(0, n);
