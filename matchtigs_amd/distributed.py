@@ -25,6 +25,22 @@ def partition_sources(n_sources: int, world_size: int) -> list[tuple[int, int]]:
     return out
 
 
+def partition_sources_by_work(work: np.ndarray, world_size: int) -> list[tuple[int, int]]:
+    """Contiguous blocks [lo, hi) of near-equal cumulative estimated work (e.g. 1 + out-degree of each source,
+    in source order) so that ranks finish their SSSP stage together. Deterministic: every rank computes the same split."""
+    n = int(len(work))
+    if n == 0:
+        return [(0, 0)] * world_size
+    cum = np.cumsum(np.asarray(work, dtype=np.int64))
+    total = int(cum[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = (total * r) // world_size
+        cuts.append(max(cuts[-1], int(np.searchsorted(cum, target, side="left"))))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
 def allgather_candidates(start: torch.Tensor, count: torch.Tensor, pool: torch.Tensor, pool_used: int,
                          ranges: list[tuple[int, int]], group=None):
     """All ranks contribute (start[int64 n_r], count[int32 n_r], pool[int64 >= pool_used]) for their source block.

@@ -88,3 +88,22 @@ def test_partition_sources_properties():
             assert len(r) == w and r[0][0] == 0 and r[-1][1] == S
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1 and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_partition_sources_by_work_properties():
+    from matchtigs_amd import distributed as mdist
+
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 1000, 12345):
+        work = rng.integers(1, 6, size=n)
+        for w in (1, 2, 3, 8):
+            r = mdist.partition_sources_by_work(work, w)
+            assert len(r) == w and r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1)) and all(lo <= hi for lo, hi in r)
+            if n >= 1000:
+                loads = [int(work[lo:hi].sum()) for lo, hi in r]
+                assert max(loads) - min(loads) <= 10        # equal work up to one source
+    skew = np.array([1] * 900 + [100] * 100)                 # the heavy tail goes to its own ranks
+    r = mdist.partition_sources_by_work(skew, 4)
+    loads = [int(skew[lo:hi].sum()) for lo, hi in r]
+    assert max(loads) <= 1.1 * sum(loads) / 4
