@@ -1145,12 +1145,14 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
                             bi = better ? (uint32_t)i : bi;
                         }
                         rem &= ~(1u << bi);
-                        if (pos0 + r < a.pool_cap) a.pool[pos0 + r] = bk;
+                        if (pos0 + r < a.pool_cap && !(a.dbg & 16u)) a.pool[pos0 + r] = bk;
                     }
                 }
                 const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
-                a.cand_count[abs_idx - a.src_begin] = c;
+                if (!(a.dbg & 16u)) {  // bit 4 of the what-if switch: no result writes (timing only)
+                    a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
+                    a.cand_count[abs_idx - a.src_begin] = c;
+                }
                 if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
                 active = false;
             }
