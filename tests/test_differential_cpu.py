@@ -162,3 +162,18 @@ def test_oracle_worker_thread_variant_keeps_the_invariants(oracle):
     og.insert_pair_edges(list(zip(pm["out"].tolist(), pm["in"].tolist(), pm["dist"].tolist())))
     og.make_eulerian(31, len(pm))
     assert og.is_eulerian() and og.no_consecutive_dummy_edges(31)
+
+
+@pytest.mark.parametrize("seed,deg,maxdeg", [(4, 5.0, 9), (7, 3.2, 6), (9, 7.0, 12)])
+def test_euler_walk_high_degree_nodes_equal_oracle(oracle, product_lib, seed, deg, maxdeg):
+    """Nodes with more out-edges than the Euler records copy inline (3 own positions, 3 + 2 copied): the spill arrays and the
+    `more` fallbacks of euler_fast.cpp must give the literal algorithm's walks."""
+    bg = synth.g_csr(3000, seed=seed, k=15, mean_out_degree=deg, mean_weight=4.0, max_degree=maxdeg, self_mirror_frac=0.02)
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    og = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    G.make_eulerian(0, 15)
+    og.make_eulerian(15)
+    assert G.euler_cycles() == og.euler_cycles()
+    G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    og2 = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    assert api.EulertigAlgorithm.compute_tigs(G2, api.EulertigAlgorithmConfiguration(15)) == og2.compute_eulertigs(15)

@@ -31,6 +31,7 @@ def _cases():
         ("k31-dense", synth.g_csr(20000, seed=2, k=31, mean_out_degree=2.2, mean_weight=4.0, self_mirror_frac=0.0)),
         ("k31-sparse-many-components", synth.g_csr(20000, seed=4, k=31, mean_out_degree=0.6, self_mirror_frac=0.0)),
         ("k63", synth.g_csr(8000, seed=5, k=63, mean_weight=10.0)),
+        ("k15-high-degree", synth.g_csr(3000, seed=4, k=15, mean_out_degree=5.0, mean_weight=4.0, max_degree=9, self_mirror_frac=0.0)),
     ]
 
 
@@ -52,7 +53,7 @@ def check_bicycles(ex, limits, edges):
     assert (first % 2 == 0).all()
 
 
-@pytest.mark.parametrize("idx", range(6))
+@pytest.mark.parametrize("idx", range(7))
 def test_device_bicycles_on_eulerised_graph(gpu, idx):
     name, bg = _cases()[idx]
     from matchtigs_amd import api
@@ -82,7 +83,7 @@ def _tig_invariants(ex, tigs, k):
     assert (seen[:n_orig] == 1).all()                                   # every unitig exactly once
 
 
-@pytest.mark.parametrize("idx", range(6))
+@pytest.mark.parametrize("idx", range(7))
 def test_greedytigs_with_device_euler_mode(gpu, idx):
     name, bg = _cases()[idx]
     from matchtigs_amd import api
