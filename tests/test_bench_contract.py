@@ -1,0 +1,33 @@
+"""bench.py's output contract (one JSON line with the driver's keys plus roofline and cpu_baseline), on a small graph."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.mark.gpu
+def test_bench_json_line(product_lib):
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-edges", "19",
+                        "--cpu-baseline-seconds", "2"], capture_output=True, text=True, cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["units_per_step"]["relaxed_edges"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and rf["kernels"][0]["kernel"].startswith("sssp_lane_reg_kernel")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["pairs"] == d["config"]["pairs"] and cb["tigs"] == d["config"]["tigs"]   # the CPU port and the GPU path agree
