@@ -1019,16 +1019,16 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
     unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0, st_attempts = 0;
 
     for (;;) {
-        // ---- refill idle lanes ----
-        const unsigned long long need = __ballot(!active);
-        if (need && !exhausted) {
+        // ---- refill idle lanes (a chunk that runs out is topped up from the next one in the same iteration) ----
+        unsigned long long need = __ballot(!active);
+        for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
             if (chunk_lo >= chunk_hi) {
                 unsigned long long c0 = 0;
                 if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
                 c0 = __shfl(c0, 0);
                 chunk_lo = c0 < a.n_items ? c0 : a.n_items;
                 chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
-                if (chunk_lo >= chunk_hi) exhausted = true;
+                if (chunk_lo >= chunk_hi) { exhausted = true; break; }
             }
             const unsigned want = (unsigned)__popcll(need);
             if (!active) {
@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
                 }
             }
             chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
+            need = __ballot(!active);
         }
         if (!__any(active)) {
             if (exhausted) break;
