@@ -11,10 +11,13 @@
  *   mtg_classify                   greedytigs/mod.rs:222-255 (eulertigs :64-97)     GPU (HIP)
  *   mtg_sssp_candidates            greedytigs/mod.rs:324-335 + traitgraph-algo      GPU (HIP)
  *                                  Dijkstra::shortest_path_lens (all sources at once)
- *   mtg_replay_claims              greedytigs/mod.rs:301-523 (1-thread order)       host (C++)
- *   mtg_finish_greedytigs          greedytigs/mod.rs:678-801 + implementation/      host (C++)
- *                                  mod.rs:392-649 + bigraph Euler decomposition
- *   mtg_compute_eulertigs          eulertigs/mod.rs:48-198                          host (C++)
+ *   mtg_replay_claims_device       greedytigs/mod.rs:301-523 (1-thread order)       GPU (HIP)
+ *   mtg_replay_claims              the same loop over host arrays (A/B, tests)      host (C++)
+ *   mtg_finish_greedytigs          greedytigs/mod.rs:678-801 + implementation/      host (C++); Euler bicycles optionally
+ *                                  mod.rs:392-649 + bigraph Euler decomposition     on the GPU (mtg_set_euler_mode)
+ *   mtg_compute_eulertigs          eulertigs/mod.rs:48-198                          host (C++); idem
+ *   mtg_write_walks_fasta / _gfa   bin.rs:466-606 / 667-818                         host (C++)
+ *   mtg_read_bcalm2                bin.rs:902-912 (genome-graph bcalm2 reader)      host (C++)
  *
  * All pointers are plain host pointers unless the name starts with d_ (device pointer in the
  * HBM of the GPU the mtg_device was created on). `stream` is a hipStream_t passed as void*
