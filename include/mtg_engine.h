@@ -199,6 +199,11 @@ uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_
                              const char *unitig_seqs, const uint64_t *seq_offsets, const char *header, char **gfa_out);
 uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
                                  const char *header, const char *path, int compression_level);
+/* Duplication bitvectors (implementation/mod.rs:668-702): one line per tig with `weight` characters per edge, '1' for an
+ * original edge and '0' for a dummy edge (k-mers that repeat ones spelled elsewhere). */
+uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
+                                         char **text_out);
+uint64_t mtg_write_tigs_duplication_bitvector_file(const mtg_graph *g, const mtg_walks *tigs, const char *path);
 
 /* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);

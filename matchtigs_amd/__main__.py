@@ -23,6 +23,8 @@ def main(argv=None) -> int:
     ap.add_argument("--eulertigs-fa-out", help="write eulertigs as fasta (bin.rs:99-101)")
     ap.add_argument("--greedytigs-gfa-out", help="write greedy matchtigs as GFA (bin.rs:107-109, 667-818)")
     ap.add_argument("--eulertigs-gfa-out", help="write eulertigs as GFA (bin.rs:97-99)")
+    ap.add_argument("--greedytigs-duplication-bitvector-out",
+                    help="per greedy matchtig a line of 1 (original k-mer) / 0 (duplicate) characters (bin.rs:129-132)")
     ap.add_argument("--compression-level", type=int, default=6, help="0-9 (bin.rs:203-218)")
     ap.add_argument("--device", type=int, default=0, help="GPU ordinal (not in the reference)")
     args = ap.parse_args(argv)
@@ -38,7 +40,8 @@ def main(argv=None) -> int:
         ap.error("--bcalm-in requires -k")
     if not 0 <= args.compression_level <= 9:
         ap.error("compression level must be in 0..9")
-    if not (args.greedytigs_fa_out or args.eulertigs_fa_out or args.greedytigs_gfa_out or args.eulertigs_gfa_out):
+    if not (args.greedytigs_fa_out or args.eulertigs_fa_out or args.greedytigs_gfa_out or args.eulertigs_gfa_out
+            or args.greedytigs_duplication_bitvector_out):
         ap.error("nothing to do: give --greedytigs-fa-out / --greedytigs-gfa-out and/or --eulertigs-fa-out / --eulertigs-gfa-out")
 
     from . import api
@@ -47,11 +50,13 @@ def main(argv=None) -> int:
     graph, store = api.read_bcalm2(args.bcalm_in, args.k)
     print(f"Loaded {len(store)} unitigs: {graph.node_count()} nodes, {graph.edge_count()} edges in {time.perf_counter() - t0:.1f}s",
           file=sys.stderr)
-    for name, alg, out, gfa in (("eulertigs", 3, args.eulertigs_fa_out, args.eulertigs_gfa_out),
-                                ("greedytigs", 5, args.greedytigs_fa_out, args.greedytigs_gfa_out)):
-        if not (out or gfa):
+    for name, alg, out, gfa, dup in (("eulertigs", 3, args.eulertigs_fa_out, args.eulertigs_gfa_out, None),
+                                     ("greedytigs", 5, args.greedytigs_fa_out, args.greedytigs_gfa_out,
+                                      args.greedytigs_duplication_bitvector_out)):
+        if not (out or gfa or dup):
             continue
-        r = api.compute_tigs_to_fasta_file(graph, store, alg, args.k, out, args.compression_level, args.device, gfa_path=gfa)
+        r = api.compute_tigs_to_fasta_file(graph, store, alg, args.k, out, args.compression_level, args.device, gfa_path=gfa,
+                                           duplication_bitvector_path=dup)
         graph.reset()  # the reference clones the graph per algorithm (bin.rs:1069)
         print(f"Computing {name} took {r['compute_s']:.1f}s and writing took {r['write_s']:.1f}s "
               f"({r['tigs']} tigs, {r['fasta_bytes']} fasta bytes)", file=sys.stderr)

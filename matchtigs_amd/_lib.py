@@ -121,6 +121,8 @@ def load():
         "mtg_unitigs_offsets": (vp, [vp]),
         "mtg_unitigs_free": (None, [vp]),
         "mtg_write_tigs_fasta_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_int]),
+        "mtg_write_duplication_bitvector": (u64, [vp, u64, vp, vp, P(vp)]),
+        "mtg_write_tigs_duplication_bitvector_file": (u64, [vp, vp, C.c_char_p]),
         "mtg_write_walks_gfa": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, C.c_char_p, P(vp)]),
         "mtg_write_tigs_gfa_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_char_p, C.c_int]),
         "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),

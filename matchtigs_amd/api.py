@@ -417,7 +417,7 @@ def read_bcalm2(path: str, k: int):
 
 def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: int, k: int, path: Optional[str],
                                compression_level: int = 6, device_id: int = 0, gfa_path: Optional[str] = None,
-                               gfa_header: Optional[str] = None) -> dict:
+                               gfa_header: Optional[str] = None, duplication_bitvector_path: Optional[str] = None) -> dict:
     """compute (3 = eulertigs, 5 = greedy matchtigs) + spell + write FASTA and/or GFA, all inside the library."""
     import time
 
@@ -432,9 +432,27 @@ def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: in
     if gfa_path:
         gbytes = int(L.mtg_write_tigs_gfa_file(graph.handle, w, k, store.handle, gfa_header.encode() if gfa_header else None,
                                                str(gfa_path).encode(), compression_level))
+    if duplication_bitvector_path:
+        L.mtg_write_tigs_duplication_bitvector_file(graph.handle, w, str(duplication_bitvector_path).encode())
     t2 = time.perf_counter()
     L.mtg_walks_free(w)
     return {"tigs": n_tigs, "fasta_bytes": nbytes, "gfa_bytes": gbytes, "compute_s": t1 - t0, "write_s": t2 - t1}
+
+
+def write_duplication_bitvector(graph: Bigraph, tigs) -> bytes:
+    """implementation/mod.rs:668-702 through the C-ABI: per tig a line of '1' (original k-mer) / '0' (duplicate) characters."""
+    L = _lib.load()
+    if isinstance(tigs, tuple):
+        lim, ed = np.ascontiguousarray(tigs[0], np.uint64), np.ascontiguousarray(tigs[1], np.uint32)
+    else:
+        ed = np.fromiter((e for t in tigs for e in t), dtype=np.uint32)
+        lim = np.cumsum([len(t) for t in tigs], dtype=np.uint64) if len(tigs) else np.zeros(0, np.uint64)
+    out = C.c_void_p()
+    n = L.mtg_write_duplication_bitvector(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None,
+                                          C.byref(out))
+    data = C.string_at(out, n)
+    L.mtg_free(out)
+    return data
 
 
 def write_walks_gfa(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, header: Optional[str] = None) -> bytes:

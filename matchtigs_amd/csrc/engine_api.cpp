@@ -226,6 +226,20 @@ uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_
     return write_walks_text(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, true, header, gfa_out);
 }
 
+uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
+                                         char **text_out) {
+    if (!g || !text_out || (n_walks && (!limits || !edges))) MTG_DIE("mtg_write_duplication_bitvector: null argument");
+    return write_duplication_bitvector(g->g, n_walks, limits, edges, text_out);
+}
+uint64_t mtg_write_tigs_duplication_bitvector_file(const mtg_graph *g, const mtg_walks *tigs, const char *path) {
+    if (!g || !tigs || !path) MTG_DIE("mtg_write_tigs_duplication_bitvector_file: null argument");
+    char *buf = nullptr;
+    const uint64_t n = write_duplication_bitvector(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), &buf);
+    write_file(path, buf, n, 0);  // the reference writes this file uncompressed (implementation/mod.rs:665)
+    std::free(buf);
+    return n;
+}
+
 // ---- f-2: BCALM2 input route + FASTA file output ----
 struct mtg_unitigs { UnitigStore *s; };
 

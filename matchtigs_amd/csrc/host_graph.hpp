@@ -120,6 +120,8 @@ uint64_t write_walks_fasta(const HostGraph &g, uint64_t n_walks, const uint64_t 
 // bin.rs:667-818 when gfa (header = the input file's header line, or null for "H\tKL:Z:{k}"), else bin.rs:466-606
 uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
                           const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, char **out_buf);
+uint64_t write_duplication_bitvector(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
+                                     char **out_buf);  // implementation/mod.rs:668-702
 uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, uint64_t *insert_out, uint64_t *limits);
 
 }  // namespace mtg

@@ -12,6 +12,7 @@
 // embarrassingly parallel over walks; it is a plain loop here and the shape a GPU kernel would take).
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "host_graph.hpp"
 
@@ -113,6 +114,39 @@ uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *
         *p++ = '\n';
         if ((uint64_t)(p - out) != rec_off[i + 1]) MTG_DIE("internal error: record length mismatch");
         begin = end;
+    }
+    out[total] = '\0';
+    *out_buf = out;
+    return total;
+}
+
+// implementation/mod.rs:668-702: per walk one line with, for every edge, `weight` characters: '1' for an original edge
+// (its k-mers are new), '0' for a dummy edge (its k-mers repeat ones spelled elsewhere).
+uint64_t write_duplication_bitvector(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
+                                     char **out_buf) {
+    std::vector<uint64_t> rec_off(n_walks + 1, 0);
+    uint64_t begin = 0;
+    for (uint64_t i = 0; i < n_walks; i++) {
+        const uint64_t end = limits[i];
+        if (end <= begin) MTG_DIE("Found empty walk when writing duplication bitvector (implementation/mod.rs:686)");
+        uint64_t len = 1;  // "\n"
+        for (uint64_t j = begin; j < end; j++) len += g.e_weight[edges[j]];
+        rec_off[i + 1] = rec_off[i] + len;
+        begin = end;
+    }
+    const uint64_t total = rec_off[n_walks];
+    char *out = static_cast<char *>(std::malloc(total + 1));
+    if (!out) MTG_DIE("out of memory (%llu bytes)", (unsigned long long)total);
+    begin = 0;
+    for (uint64_t i = 0; i < n_walks; i++) {
+        char *p = out + rec_off[i];
+        for (uint64_t j = begin; j < limits[i]; j++) {
+            const uint32_t e = edges[j];
+            std::memset(p, g.is_dummy(e) ? '0' : '1', g.e_weight[e]);
+            p += g.e_weight[e];
+        }
+        *p = '\n';
+        begin = limits[i];
     }
     out[total] = '\0';
     *out_buf = out;

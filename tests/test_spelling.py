@@ -65,6 +65,14 @@ def test_greedy_fasta_end_to_end_on_gpu(oracle, product_lib):
     otigs, _ = og.compute_greedytigs(k)
     assert fa == og.fasta(otigs, ug.unitigs, k)
     assert synth.kmer_set_of_tigs(_fasta_seqs(fa), k) == ug.kmers
+    # duplication bitvector (implementation/mod.rs:668-702): one character per spelled k-mer, '0' exactly where a matched
+    # dummy edge repeats k-mers; the '1's add up to the number of distinct k-mers of the input
+    bits = api.write_duplication_bitvector(G, tigs).decode().splitlines()
+    assert [len(b) for b in bits] == [len(s) - k + 1 for s in _fasta_seqs(fa)]
+    assert sum(b.count("1") for b in bits) == len(ug.kmers)
+    ex = G.export()
+    kept_dummy_weight = sum(int(ex["edge_weight"][e]) for t in tigs for e in t if ex["edge_dummy_id"][e])
+    assert sum(b.count("0") for b in bits) == kept_dummy_weight and kept_dummy_weight > 0
 
 
 def test_gfa_records_are_the_fasta_records(product_lib):
@@ -79,3 +87,19 @@ def test_gfa_records_are_the_fasta_records(product_lib):
     assert api.write_walks_gfa(G, tigs, ug.unitigs, k).decode() == want
     custom = api.write_walks_gfa(G, tigs, ug.unitigs, k, header="H\tVN:Z:1.0\tKL:Z:15").decode()
     assert custom == "H\tVN:Z:1.0\tKL:Z:15\n" + want.split("\n", 1)[1]
+
+
+def test_duplication_bitvector(product_lib):
+    """implementation/mod.rs:668-702: per tig, weight x '1' for an original edge and weight x '0' for a dummy edge."""
+    k = 15
+    ug = synth.g_seq(3000, seed=4, k=k, haplotypes=3, sub_rate=0.03)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    tigs = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(k))
+    ex = G.export()
+    want = "".join("".join(("0" if ex["edge_dummy_id"][e] else "1") * int(ex["edge_weight"][e]) for e in t) + "\n" for t in tigs)
+    got = api.write_duplication_bitvector(G, tigs).decode()
+    assert got == want
+    # eulertigs contain no dummy edges (every dummy is a breaking edge and is cut): all ones, one per spelled k-mer
+    assert set(got) <= {"1", "\n"}
+    fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
+    assert [len(l) for l in got.splitlines()] == [len(s) - k + 1 for s in _fasta_seqs(fa)]
