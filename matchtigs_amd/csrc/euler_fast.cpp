@@ -295,7 +295,13 @@ Walks euler_cycles(const HostGraph &g) {
                     if (!is_used(p < 3 ? r.eid[p] : ext_eid[r.ext_begin + p - 3])) return true;
                 return false;
             };
-            while (fifo_tail - fifo_head >= (1u << 18) && start_edge == NONE) {
+            // (the first entries are checked in place: when splice points are frequent the next one is close, and
+            // spawning threads per splice would cost more than the scan)
+            for (size_t probe = 0; probe < 4096 && fifo_head < fifo_tail; probe++) {
+                if (has_unused(ent_node[fifo[fifo_head]])) break;
+                fifo_head++;
+            }
+            while (fifo_tail - fifo_head >= (1u << 18) && !has_unused(ent_node[fifo[fifo_head]])) {
                 std::atomic<size_t> first_hit{fifo_tail};
                 const size_t base = fifo_head;
                 parallel_ranges(fifo_tail - base, [&](uint64_t lo, uint64_t hi) {
