@@ -39,7 +39,7 @@ def traffic_bytes(args, world: int):
     """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement for exactly this workload, else null."""
     if args.traffic_bytes is not None:
         return args.traffic_bytes
-    preset = 5 if args.preset < 0 else args.preset
+    preset = 9 if args.preset < 0 else args.preset
     key = f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:preset={preset}:gpus={world}"
     try:
         return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key, {}).get("traffic_bytes")

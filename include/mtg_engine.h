@@ -120,9 +120,10 @@ int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_
 const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
-/* Kernel tuning: which lane-per-source kernel runs as level 0 (5 = default: 8-entry register tables with seed hand-off;
- * 0 = hash-indexed LDS tables of 32, 1/2/6/7/8 = register tables of 16/12/24/6/10, 3 = scanned LDS tables of 12),
- * 4 = cooperative kernels only; returns the preset in force. */
+/* Kernel tuning: which lane-per-source kernel runs as level 0 (9 = default: table-free path enumeration + sorting post-pass;
+ * 5 = 8-entry register tables with seed hand-off; 0 = hash-indexed LDS tables of 32, 1/2/6/7/8 = register tables of
+ * 16/12/24/6/10, 3 = scanned LDS tables of 12), 4 = cooperative kernels only; returns the preset in
+ * force. */
 int mtg_set_sssp_preset(mtg_device *d, int preset);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified

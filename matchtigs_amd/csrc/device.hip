@@ -14,9 +14,12 @@
 //
 // SSSP stage (integer, gather/latency bound, no MFMA) = a cascade of levels; a source a
 // level cannot finish is appended to a device list by that kernel and re-run from scratch by the next:
-//   level 0   sssp_lane_reg_kernel: one LANE per source, exact Dijkstra over a <=C-entry table held in
-//             VGPRs (compile-time indexed), one 32-byte gather per step, self-refilling lanes, no barrier.
-//             (sssp_lane_kernel / sssp_lane_hash_kernel: the same with LDS tables, kept as presets.)
+//   level 0   sssp_enum_kernel: one LANE per source enumerates the bounded paths depth-first with a private LDS stack (a
+//             (k-1)-ball of a unitig graph is almost a tree, so no visited table is needed); one 32-byte gather per step,
+//             self-refilling lanes, no barrier; results staged per wave and written in bursts; sort_candidates_kernel puts
+//             the lists that are not yet in Dijkstra order in order. Sources beyond its budgets go to level 1+.
+//             (sssp_lane_reg_kernel: exact Dijkstra per lane over a <=C-entry table held in VGPRs, hands its search state
+//             to level 1; sssp_lane_kernel / sssp_lane_hash_kernel: the same with LDS tables. Kept as presets, all tested.)
 //   level 1+  sssp_kernel: a workgroup takes a batch of BSRC sources and runs all their bounded searches
 //             together as ONE label-correcting wavefront over a shared LDS open-addressing table keyed by
 //             (local source, node) -> tentative distance (64-bit entries, ds_cmpst_b64 / ds_min_u64) with
@@ -173,7 +176,8 @@ enum Counter : int {
     C_T_EMIT = 10,
     C_T_CLEAN = 11,
     C_N_ROUNDS = 12,
-    C_COUNT = 13
+    C_FIX = 13,      // enumeration level: number of candidate lists its post-pass has to put in order
+    C_COUNT = 14
 };
 
 struct SsspArgs {
@@ -193,6 +197,7 @@ struct SsspArgs {
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
+    uint32_t *fix_list;          // out (enumeration level): indices (relative to src_begin) of the lists to sort (cursor: C_FIX)
     uint32_t *seed_out;          // out (lane level, optional): search state of every overflowed source, SEED_WORDS per ovf_list entry
     const uint32_t *seed_in;     // in (cooperative level, optional): seeds parallel to src_index -- continue instead of restart
     uint32_t dbg;                // MTG_UNSAFE_TIMING_EXPERIMENT env, never set in production: bits 1/2/8 give WRONG RESULTS (gather from a
@@ -1236,6 +1241,249 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-per-source kernel WITHOUT a table (level 0 of the default plan)
+//
+// The calibration chase (tools/gather_bench.hip) says what limits a lane-per-source kernel: the integer work between a
+// gather's arrival and the next gather's issue (34 G gathers/s at the 368 VALU instructions per step of the register-table
+// kernel, 50 G/s at ~100). A (k-1)-ball of a unitig graph is almost a tree (bench graph: 1.0004 path enumerations per
+// settled node), so the search needs no visited set at all: every lane enumerates the bounded PATHS from its source
+// depth-first with a small private stack in LDS -- pop, gather the 32-byte record, push the <= 4 successors whose distance
+// stays <= k-1, remember the node if it is an in-node. No select-min, no find, no insert. A node reached along two
+// paths is expanded twice (bounded: every edge weighs >= 1 and the path length is capped at k-1), its target hits are
+// de-duplicated (minimum distance) and sorted by (distance, node) by the post-pass below, which makes the output identical
+// to the Dijkstra order. A source whose enumeration exceeds the pop budget, the stack or the hit buffer is handed to the
+// cooperative cascade, which is exact for any ball.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t ENUM_POP_BUDGET = 512;
+
+template <int WPB, int S, int H>
+__global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
+    static_assert((H & (H - 1)) == 0 && H <= 128, "the hit ring is indexed modulo H");
+    constexpr int RQ = 256;  // staged results (finished sources) per wave
+    __shared__ unsigned long long s_stack[WPB][S][64];  // (distance << 32 | node), slot-major / lane-minor: conflict free
+    // Per-lane RING of candidate keys: the hits of the lane's current source follow those of its finished sources, which stay
+    // there until the wave writes its staged results out in one burst. (A store in every iteration would sit in the same
+    // in-order memory counter as the next record gather, so the wave would wait for the store's acknowledgement before it
+    // can use the gather; copying a finished source's hits somewhere else costs a serial loop per iteration. Both measured.)
+    __shared__ unsigned long long s_hits[WPB][H][64];
+    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_cnt[WPB][RQ], s_res_off[WPB][RQ], s_res_ring[WPB][RQ];
+    __shared__ uint32_t s_nkeys[WPB], s_nfix[WPB];
+    __shared__ uint32_t s_fix[WPB][RQ];  // staged sources whose hits are not yet in Dijkstra order
+    __shared__ WaveOvfBuf s_ovf[WPB];
+    __shared__ uint32_t s_src[WPB][LANE_SRC_CHUNK];  // source ids of the wave's current chunk (one coalesced sweep per chunk)
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+
+    unsigned long long chunk_lo = 0, chunk_hi = 0, chunk_base = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    uint32_t n_res = 0;                                                                            // wave-uniform
+    bool exhausted = false;
+    bool active = false;
+    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, n_overflow = 0;
+    uint32_t hit_base = 0, used = 0;      // ring: first slot of the current source's hits, occupied slots
+    unsigned long long prev_key = 0;      // hits already in (distance, node) order and without a repeated node need no post-pass:
+    uint32_t bloom = 0;                   // 32-bit filter over node ids (a set bit seen twice = "maybe repeated")
+    bool unclean = false;
+    uint32_t cur_node = 0, cur_dist = 0;  // the path step in progress; the stack holds the branches still to take
+    unsigned long long item = 0;
+    if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
+
+    auto flush_results = [&]() {
+        const uint32_t n_keys = __shfl(lane == 0 ? s_nkeys[wv] : 0u, 0);
+        if (n_keys && pool_next + n_keys > pool_end) {
+            const unsigned long long grab = n_keys > LANE_POOL_CHUNK ? (unsigned long long)n_keys : LANE_POOL_CHUNK;
+            unsigned long long p0 = 0;
+            if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
+            pool_next = __shfl(p0, 0);
+            pool_end = pool_next + grab;
+        }
+        const uint32_t n_fix = __shfl(lane == 0 ? s_nfix[wv] : 0u, 0);
+        if (n_fix) {  // dense work list for the post-pass (its cursor is taken before this burst's stores are issued)
+            unsigned long long f0 = 0;
+            if (lane == 0) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)n_fix);
+            f0 = __shfl(f0, 0);
+            for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];
+        }
+        for (uint32_t t = lane; t < n_res && !(a.dbg & 64u); t += 64) {  // (what-if bit 6: no result writes at all)
+            const uint32_t i = s_res_idx[wv][t], c = s_res_cnt[wv][t];
+            if (c != CAND_OVERFLOW) {
+                const unsigned long long pos0 = pool_next + s_res_off[wv][t];
+                const uint32_t ring = s_res_ring[wv][t], l = ring & 63u, b = ring >> 8;
+                for (uint32_t r = 0; r < c; r++)
+                    if (pos0 + r < a.pool_cap) a.pool[pos0 + r] = s_hits[wv][(b + r) & (uint32_t)(H - 1)][l];
+                a.cand_start[i] = pos0;
+            }
+            a.cand_count[i] = c;
+        }
+        pool_next += n_keys;
+        n_res = 0;
+        if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
+        used = nhit;  // only the current source's hits stay in the ring
+    };
+
+    for (;;) {
+        // ---- refill idle lanes (a chunk that runs out is topped up from the next one in the same iteration) ----
+        unsigned long long need = __ballot(!active);
+        for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
+            if (chunk_lo >= chunk_hi) {
+                unsigned long long c0 = 0;
+                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
+                c0 = __shfl(c0, 0);
+                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
+                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
+                if (chunk_lo >= chunk_hi) { exhausted = true; break; }
+                chunk_base = chunk_lo;
+                for (unsigned long long t = chunk_lo + lane; t < chunk_hi; t += 64)
+                    s_src[wv][t - chunk_base] = a.sources[a.src_index ? a.src_index[t] : a.src_begin + t];
+            }
+            const unsigned want = (unsigned)__popcll(need);
+            if (!active) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const unsigned long long it = chunk_lo + rank;
+                if (it < chunk_hi) {
+                    item = it;
+                    src_node = s_src[wv][it - chunk_base];
+                    cur_node = src_node; cur_dist = 0;
+                    sp = 0; nhit = 0; pops = 0;
+                    prev_key = 0; bloom = 0; unclean = false;
+                    active = true;
+                }
+            }
+            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
+            need = __ballot(!active);
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        // a step adds at most one hit: make room where a burst write can (finished sources' hits leave the rings)
+        if (n_res + 64 > (uint32_t)RQ || __any(active && used == (uint32_t)H && nhit < (uint32_t)H)) flush_results();
+
+        // ---- one path step per active lane: gather the current node, continue with one successor within the bound (kept
+        // in registers), push the others; a dead end pops the stack ----
+        bool fin = false, ovf = false;
+        if (active) {
+            const uint32_t u = cur_node, d = cur_dist;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);
+            const uint4 lo = rp[0];
+            const uint4 hi = rp[1];
+            const uint32_t flags = (hi.z >> 8) & 0xFFu;
+            if ((flags & F_TARGET) && u != src_node) {  // forbid_source_target, greedytigs/mod.rs:329
+                const unsigned long long key = ((unsigned long long)d << 32) | u;
+                const uint32_t bit = 1u << (u & 31u);
+                unclean |= (key <= prev_key) | ((bloom & bit) != 0u);
+                prev_key = key;
+                bloom |= bit;
+                if (used < (uint32_t)H) {
+                    s_hits[wv][(hit_base + nhit) & (uint32_t)(H - 1)][lane] = key;
+                    used++;
+                } else ovf = true;  // this source alone fills the ring
+                nhit++;
+            }
+            bool have_next = false;
+            auto visit = [&](uint32_t nb, uint32_t w) {
+                const uint32_t nd = d + w;
+                if (nd > a.K1) return;
+                if (!have_next) {  // the first successor is the next step
+                    cur_node = nb; cur_dist = nd; have_next = true;
+                    return;
+                }
+                if (sp < (uint32_t)S) s_stack[wv][sp][lane] = ((unsigned long long)nd << 32) | nb;
+                else ovf = true;
+                sp++;
+            };
+            if (!(flags & F_EXT)) {
+                const uint32_t deg = hi.z & 0xFFu;
+                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < (int)deg) visit(nb[j], ww[j]);
+            } else {
+                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
+                const uint32_t deg = lo.z;
+                for (uint32_t j = 0; j < deg; j++) visit(a.ext_col[eb + j], a.ext_w[eb + j]);
+            }
+            if (++pops > ENUM_POP_BUDGET) ovf = true;
+            if (!have_next && !ovf) {
+                if (sp == 0) fin = true;
+                else {  // dead end: back to the most recent branch
+                    sp--;
+                    const unsigned long long top = s_stack[wv][sp][lane];
+                    cur_node = (uint32_t)top;
+                    cur_dist = (uint32_t)(top >> 32);
+                }
+            }
+        }
+
+        // ---- finished / overflowed lanes stage their result (hits as they are: the post-pass de-duplicates and sorts) ----
+        const unsigned long long donemask = __ballot(fin || ovf);
+        if (donemask && (a.dbg & 32u)) {  // (what-if bit 5: finished lanes just go idle)
+            if (fin || ovf) { active = false; nhit = 0; used = 0; }
+        } else if (donemask) {
+            if (fin || ovf) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(donemask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donemask, 0u));
+                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
+                const uint32_t c = fin ? nhit : 0u;
+                s_res_idx[wv][n_res + rank] = (uint32_t)(abs_idx - a.src_begin);
+                s_res_cnt[wv][n_res + rank] = ovf ? CAND_OVERFLOW : c;
+                if (fin && unclean && c > 1) s_fix[wv][atomicAdd(&s_nfix[wv], 1u)] = (uint32_t)(abs_idx - a.src_begin);
+                s_res_off[wv][n_res + rank] = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
+                s_res_ring[wv][n_res + rank] = (uint32_t)lane | (hit_base << 8);
+                if (fin) hit_base = (hit_base + nhit) & (uint32_t)(H - 1);  // the finished source's hits stay until the next burst
+                else used -= (nhit < (uint32_t)H ? nhit : (uint32_t)H);     // an overflowed source's hits are dropped
+                nhit = 0;
+                active = false;
+            }
+            n_res += (uint32_t)__popcll(donemask);
+            uint32_t ovf_idx = 0;
+            if (ovf) ovf_idx = (uint32_t)(a.src_index ? a.src_index[item] : a.src_begin + item);
+            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
+        }
+    }
+    flush_results();
+    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
+}
+
+// Post-pass of the enumeration level: a source's hits arrive in discovery order and may name a node more than once (one
+// hit per path). Keep the smallest distance per node and order by (distance, node) -- what Dijkstra's pop order gives
+// (SURVEY App. A.1). Lists written by the cooperative levels are already in that form and pass through unchanged.
+template <int H>
+__global__ __launch_bounds__(256) void sort_candidates_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
+                                                              uint32_t *cand_count, const uint32_t *fix_list, const unsigned long long *n_fix) {
+    __shared__ unsigned long long s_k[H][256];
+    const unsigned long long n = *n_fix;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (unsigned long long)gridDim.x * 256) {
+    const uint32_t i = fix_list[p];
+    const uint32_t c = cand_count[i];
+    if (c < 2 || c > (uint32_t)H) continue;
+    const unsigned long long st = cand_start[i];
+    if (st + c > pool_cap) continue;  // pool too small: the host retries with a larger one
+    const int t = threadIdx.x;
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)H; r++)  // all loads in flight at once (a load per sorting step would serialise their latencies)
+        if (r < c) s_k[r][t] = pool[st + r];
+    for (uint32_t r = 1; r < c; r++) {  // insertion sort by key = (distance, node)
+        const unsigned long long key = s_k[r][t];
+        uint32_t q = r;
+        while (q > 0 && s_k[q - 1][t] > key) {
+            s_k[q][t] = s_k[q - 1][t];
+            q--;
+        }
+        s_k[q][t] = key;
+    }
+    uint32_t m = 0;  // keep the first (= smallest distance) occurrence of every node
+    for (uint32_t r = 0; r < c; r++) {
+        const unsigned long long key = s_k[r][t];
+        bool dup = false;
+        for (uint32_t q = 0; q < m; q++) dup |= (uint32_t)s_k[q][t] == (uint32_t)key;
+        if (!dup) s_k[m++][t] = key;
+    }
+    for (uint32_t r = 0; r < m; r++) pool[st + r] = s_k[r][t];
+    if (m != c) cand_count[i] = m;
+    }
+}
+
 #include "replay_kernels.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1270,7 +1518,7 @@ struct Device {
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
     std::string last_level_name[8];
-    int preset = 5;  // lane kernel with 8-entry per-lane register tables, then the cooperative cascade
+    int preset = 9;  // table-free path enumeration per lane, then the cooperative cascade for the ~1 % heaviest sources
     int n_cu = 256;
     uint64_t graph_bytes = 0;
 };
@@ -1299,7 +1547,7 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-static const int N_PRESETS = 9;
+static const int N_PRESETS = 10;
 // Level plan: lane-per-source kernel (per-lane table of C entries) -> cooperative kernel, 64 sources per
 // workgroup -> cooperative kernel, 1 source per workgroup with a 128 KB LDS table -> cooperative kernel with
 // a 32 MB global-memory table. `preset` picks the lane kernel's table size (4 = skip the lane level).
@@ -1310,12 +1558,15 @@ struct LaneCfg {
     int max_occ = 0;  // workgroups per CU to launch at most (0 = what fits)
     const char *kind = "";
     int c = 0;
+    int hits = 0;  // > 0: enumeration kernel (c = stack slots, hits = hit-buffer slots), followed by sort_candidates_kernel
     std::string name() const {
         char b[96];
-        std::snprintf(b, sizeof b, "%s<%d,%d>", kind, block / 64, c);
+        if (hits) std::snprintf(b, sizeof b, "%s<%d,%d,%d> + sort_candidates_kernel", kind, block / 64, c, hits);
+        else std::snprintf(b, sizeof b, "%s<%d,%d>", kind, block / 64, c);
         return b;
     }
 };
+constexpr int ENUM_STACK = 8, ENUM_HITS = 16;
 template <int WPB, int C>
 static LaneCfg make_lane_cfg() {
     return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_kernel", C};
@@ -1330,6 +1581,11 @@ static LaneCfg make_lane_hash_cfg() {
 }
 static LaneCfg lane_cfg(int preset) {
     switch (preset) {
+        case 9: {  // table-free path enumeration; counting runs use the register-table kernel (it counts DISTINCT nodes)
+            LaneCfg c{sssp_enum_kernel<4, ENUM_STACK, ENUM_HITS>, sssp_lane_reg_kernel<4, 8, true>, 256, 0, "sssp_enum_kernel", ENUM_STACK,
+                      ENUM_HITS};
+            return c;
+        }
         case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane LDS table, 32 entries
         case 1: return make_lane_reg_cfg<4, 16>();   // register tables, 16 entries
         case 2: return make_lane_reg_cfg<4, 12>();   // register tables, 12 entries
@@ -1348,7 +1604,7 @@ static LaneCfg lane_cfg(int preset) {
 // Cascade of cooperative levels: 64 sources per workgroup, then 8, then 1 (128 KB LDS table), then a 32 MB
 // global-memory table. A level re-runs the sources whose batch overflowed the previous level's tables.
 static const int N_COOP_LEVELS = 5;
-static LevelCfg coop_level(int i) {
+static LevelCfg coop_level(int i, bool enum_plan = false) {
     // tuning experiments for the first cooperative level: MTG_L1=<n>
     static const int exp_l1 = std::getenv("MTG_L1") ? std::atoi(std::getenv("MTG_L1")) : 0;
     if (i == 0 && exp_l1 == 1) return make_cfg<256, 12, 2048, 1024, 64, false>();  // the round-1 geometry before seeds
@@ -1361,7 +1617,11 @@ static LevelCfg coop_level(int i) {
         // log early and are re-run by the next level (measured: 0.93 + 0.10 ms against 1.17 + 0.04 ms for 64 sources
         // per workgroup with a 4096-entry table)
         case 0: return make_cfg<256, 11, 1024, 512, 32, false>();
-        case 1: return make_cfg<256, 12, 4096, 1024, 16, false>();
+        case 1:
+            // what the enumeration level hands on are its ~1 % heaviest sources: 8 per workgroup in 29 KB of LDS (5 workgroups
+            // per CU) measured 0.18 ms against 0.27 ms for 16 per workgroup in 58 KB
+            if (enum_plan) return make_cfg<256, 11, 2048, 512, 8, false>();
+            return make_cfg<256, 12, 4096, 1024, 16, false>();
         case 2: return make_cfg<256, 13, 8192, 2048, 8, false>();
         case 3: return make_cfg<256, 14, 4096, 1024, 1, false>();
         default: return make_cfg<256, 22, 1 << 22, 1 << 21, 1, true>();
@@ -1389,6 +1649,12 @@ static void launch_lane(Device *d, hipStream_t st, const LaneCfg &cfg, bool coun
     HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
     HIP_CHECK(hipGetLastError());
+    if (cfg.hits && !count) {
+        hipLaunchKernelGGL(sort_candidates_kernel<ENUM_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
+                           dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start, args.cand_count, args.fix_list,
+                           args.counters + C_FIX);
+        HIP_CHECK(hipGetLastError());
+    }
     HIP_CHECK(hipEventRecord(d->ev1, st));
 }
 
@@ -1455,6 +1721,7 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     const bool seeded = d->use_seeds && !seeds_off && d->preset == 5;  // only the 8-entry register kernel writes seeds
     a.seed_out = seeded ? d->d_seed : nullptr;
     a.seed_in = nullptr;
+    a.fix_list = d->d_seed;  // (the enumeration plan writes no seeds: the buffer holds its post-pass work list instead)
     { const char *e = std::getenv("MTG_UNSAFE_TIMING_EXPERIMENT"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
     double total_ms = 0.0;
     const bool use_lane = d->preset != 4;
@@ -1475,8 +1742,9 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
     // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
     // to the other of two ping-pong lists
     int cur_list = 0;
-    for (int li = use_lane ? 0 : 1; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
-        const LevelCfg next = coop_level(li);
+    // (what the enumeration level hands on are the heavy balls: batches of 32 of them do not fit the first cooperative level)
+    for (int li = !use_lane || d->preset == 9 ? 1 : 0; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
+        const LevelCfg next = coop_level(li, d->preset == 9);
         const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
         HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVERFLOW], 0, sizeof(unsigned long long), st));
         SsspArgs b = a;

@@ -27,7 +27,7 @@ def test_bench_json_line(product_lib):
     assert abs(d["value"] - d["units_per_step"]["relaxed_edges"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and rf["kernels"][0]["kernel"].startswith("sssp_lane_reg_kernel")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and rf["kernels"][0]["kernel"].startswith("sssp_enum_kernel")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert cb["pairs"] == d["config"]["pairs"] and cb["tigs"] == d["config"]["tigs"]   # the CPU port and the GPU path agree

@@ -74,7 +74,7 @@ def test_classification_matches_oracle(gpu, oracle, idx):
     assert np.array_equal(li, o_live), name
 
 
-@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4, 5, 6])  # lane kernels: 0 hash/LDS, 1/2/5/6 register tables, 3 LDS scan; 4 = cooperative only
+@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4, 5, 6, 9])  # lane kernels: 0 hash/LDS, 1/2/5/6 register tables, 3 LDS scan, 9 table-free enumeration; 4 = cooperative only
 @pytest.mark.parametrize("idx", range(5))
 def test_t1_candidate_lists(gpu, oracle, idx, preset):
     name, bg = graphs()[idx]
@@ -139,7 +139,7 @@ def test_t2_t3_t4_pairs_and_tigs(gpu, oracle, idx):
     assert (ex["edge_weight"][matched] >= 1).all()
 
 
-@pytest.mark.parametrize("preset", [0, 5])
+@pytest.mark.parametrize("preset", [0, 5, 9])
 def test_overflow_levels_big_balls(gpu, oracle, preset):
     """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 tables: the larger levels must agree
     (preset 5 = the default plan, where the lane level hands its search state to the first cooperative level)."""
@@ -156,7 +156,7 @@ def test_overflow_levels_big_balls(gpu, oracle, preset):
     assert cnt["settled_nodes"] == st["settled_nodes"] and cnt["relaxed_edges"] == st["relaxed_edges"]
 
 
-@pytest.mark.parametrize("preset", [0, 5])
+@pytest.mark.parametrize("preset", [0, 5, 9])
 def test_deepest_levels_huge_balls(gpu, oracle, preset):
     """Balls above 16384 nodes only fit the last level (table in a global workspace): a unit-weight graph whose
     (k-1)-balls cover most of its 36000 nodes, on a slice of the sources (the oracle would need minutes for all)."""
@@ -166,7 +166,7 @@ def test_deepest_levels_huge_balls(gpu, oracle, preset):
     lo, hi = 100, 148
     G, dev, S, start, count, pool = _gpu_candidates(bg, preset, lo, hi)
     levels = dev.last_sssp_levels()
-    assert len(levels) == 6, levels          # lane + every cooperative level down to the global-workspace one
+    assert len(levels) == (5 if preset == 9 else 6), levels   # lane + every cooperative level (the enumeration plan skips the first) down to the global-workspace one
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k, lo, hi)
     assert st["settled_nodes"] > 16384 * 8   # the balls really are that large
     assert np.array_equal(count.astype(np.uint64), np.diff(off)[lo:hi])
@@ -174,7 +174,7 @@ def test_deepest_levels_huge_balls(gpu, oracle, preset):
     assert np.array_equal(got, keys)
 
 
-@pytest.mark.parametrize("preset", [0, 5])
+@pytest.mark.parametrize("preset", [0, 5, 9])
 def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, preset):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
     from matchtigs_amd import synth
