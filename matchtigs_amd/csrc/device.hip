@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
 // to the Dijkstra order. A source whose enumeration exceeds the pop budget, the stack or the hit buffer is handed to the
 // cooperative cascade, which is exact for any ball.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t ENUM_POP_BUDGET = 512;
+constexpr uint32_t ENUM_POP_BUDGET = 256;
 
 template <int WPB, int S, int H>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
