@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     // in-order memory counter as the next record gather, so the wave would wait for the store's acknowledgement before it
     // can use the gather; copying a finished source's hits somewhere else costs a serial loop per iteration. Both measured.)
     __shared__ unsigned long long s_hits[WPB][H][64];
-    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_cnt[WPB][RQ], s_res_off[WPB][RQ], s_res_ring[WPB][RQ];
+    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_off[WPB][RQ], s_res_misc[WPB][RQ];  // misc: count:8 | lane:8 | ring base:8 | overflow:1
     __shared__ uint32_t s_nkeys[WPB], s_nfix[WPB];
     __shared__ uint32_t s_fix[WPB][RQ];  // staged sources whose hits are not yet in Dijkstra order
     __shared__ WaveOvfBuf s_ovf[WPB];
@@ -1305,10 +1305,11 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];
         }
         for (uint32_t t = lane; t < n_res && !(a.dbg & 64u); t += 64) {  // (what-if bit 6: no result writes at all)
-            const uint32_t i = s_res_idx[wv][t], c = s_res_cnt[wv][t];
+            const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
+            const uint32_t c = (misc >> 24) ? CAND_OVERFLOW : (misc & 0xFFu);
             if (c != CAND_OVERFLOW) {
                 const unsigned long long pos0 = pool_next + s_res_off[wv][t];
-                const uint32_t ring = s_res_ring[wv][t], l = ring & 63u, b = ring >> 8;
+                const uint32_t l = (misc >> 8) & 0xFFu, b = (misc >> 16) & 0xFFu;
                 for (uint32_t r = 0; r < c; r++)
                     if (pos0 + r < a.pool_cap) a.pool[pos0 + r] = s_hits[wv][(b + r) & (uint32_t)(H - 1)][l];
                 a.cand_start[i] = pos0;
@@ -1426,10 +1427,9 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                 const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
                 const uint32_t c = fin ? nhit : 0u;
                 s_res_idx[wv][n_res + rank] = (uint32_t)(abs_idx - a.src_begin);
-                s_res_cnt[wv][n_res + rank] = ovf ? CAND_OVERFLOW : c;
+                s_res_misc[wv][n_res + rank] = c | ((uint32_t)lane << 8) | (hit_base << 16) | (ovf ? 1u << 24 : 0u);
                 if (fin && unclean && c > 1) s_fix[wv][atomicAdd(&s_nfix[wv], 1u)] = (uint32_t)(abs_idx - a.src_begin);
                 s_res_off[wv][n_res + rank] = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
-                s_res_ring[wv][n_res + rank] = (uint32_t)lane | (hit_base << 8);
                 if (fin) hit_base = (hit_base + nhit) & (uint32_t)(H - 1);  // the finished source's hits stay until the next burst
                 else used -= (nhit < (uint32_t)H ? nhit : (uint32_t)H);     // an overflowed source's hits are dropped
                 nhit = 0;
@@ -1566,7 +1566,7 @@ struct LaneCfg {
         return b;
     }
 };
-constexpr int ENUM_STACK = 8, ENUM_HITS = 16;
+constexpr int ENUM_STACK = 10, ENUM_HITS = 16;
 template <int WPB, int C>
 static LaneCfg make_lane_cfg() {
     return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_kernel", C};
