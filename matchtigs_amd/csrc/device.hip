@@ -1286,6 +1286,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     bool unclean = false;
     uint32_t cur_node = 0, cur_dist = 0;  // the path step in progress; the stack holds the branches still to take
     unsigned long long item = 0;
+    unsigned long long dbg_iters = 0, dbg_lanes = 0;
     if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
 
     auto flush_results = [&]() {
@@ -1362,6 +1363,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
 
         // ---- one path step per active lane: gather the current node, continue with one successor within the bound (kept
         // in registers), push the others; a dead end pops the stack ----
+        if (a.dbg & 256u) { dbg_iters++; dbg_lanes += (uint32_t)__popcll(__ballot(active)); }  // lane-utilisation probe
         bool fin = false, ovf = false;
         if (active) {
             const uint32_t u = cur_node, d = cur_dist;
@@ -1443,6 +1445,10 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     }
     flush_results();
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
+    if ((a.dbg & 256u) && lane == 0) {
+        atomicAdd(&a.counters[C_T_INIT], dbg_iters);
+        atomicAdd(&a.counters[C_T_ROUNDS], dbg_lanes);
+    }
 }
 
 // Post-pass of the enumeration level: a source's hits arrive in discovery order and may name a node more than once (one
@@ -1735,6 +1741,9 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
         d->last_level_name[0] = use_lane ? lane_cfg(d->preset).name() : coop_level(0).name();
     }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
+    if (debug && n && (a.dbg & 256u))
+        std::fprintf(stderr, "[mtg] level0 lane utilisation: %llu wave iterations, %.1f active lanes per iteration\n",
+                     (unsigned long long)d->h_counters[C_T_INIT], d->h_counters[C_T_INIT] ? (double)d->h_counters[C_T_ROUNDS] / d->h_counters[C_T_INIT] : 0.0);
     if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_lane ? "lane" : "coop level 0",
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
     uint64_t total_overflow = d->h_counters[C_OVERFLOW];
