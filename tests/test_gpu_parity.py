@@ -142,7 +142,8 @@ def test_t2_t3_t4_pairs_and_tigs(gpu, oracle, idx):
 @pytest.mark.parametrize("preset", [0, 5, 9])
 def test_overflow_levels_big_balls(gpu, oracle, preset):
     """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 tables: the larger levels must agree
-    (preset 5 = the default plan, where the lane level hands its search state to the first cooperative level)."""
+    (preset 9 = the default plan: table-free enumeration level; preset 5 = register-table lane level that hands its search state
+    to the first cooperative level)."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01)
