@@ -993,7 +993,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-per-source kernel, tables in registers (level 0, default)
+// Lane-per-source kernel, tables in registers (level 0 of preset 5, the previous default plan; counting runs use it)
 //
 // PMC on sssp_lane_kernel (LDS tables): ~640 wave-instructions and ~12 us per wave iteration, most of it waiting on
 // the dependent ds_read -> compare chains of the table scans. With C <= 16 the whole per-lane table fits in VGPRs:
