@@ -1256,6 +1256,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
 // cooperative cascade, which is exact for any ball.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ENUM_POP_BUDGET = 256;
+constexpr unsigned long long ENUM_POOL_CHUNK = 1024;  // keys per wave-local pool chunk (a burst needs ~250)
 
 template <int WPB, int S, int H>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
@@ -1291,20 +1292,22 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
 
     auto flush_results = [&]() {
         const uint32_t n_keys = __shfl(lane == 0 ? s_nkeys[wv] : 0u, 0);
-        if (n_keys && pool_next + n_keys > pool_end) {
-            const unsigned long long grab = n_keys > LANE_POOL_CHUNK ? (unsigned long long)n_keys : LANE_POOL_CHUNK;
-            unsigned long long p0 = 0;
-            if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
-            pool_next = __shfl(p0, 0);
+        const uint32_t n_fix = __shfl(lane == 0 ? s_nfix[wv] : 0u, 0);
+        // both cursors are taken by one lane back to back (one memory round trip, not two) and before this burst's stores
+        const bool need_pool = n_keys && pool_next + n_keys > pool_end;
+        const unsigned long long grab = n_keys > ENUM_POOL_CHUNK ? (unsigned long long)n_keys : ENUM_POOL_CHUNK;
+        unsigned long long p0 = 0, f0 = 0;
+        if (lane == 0) {
+            if (need_pool) p0 = atomicAdd(&a.counters[C_POOL], grab);
+            if (n_fix) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)n_fix);
+        }
+        p0 = __shfl(p0, 0);
+        f0 = __shfl(f0, 0);
+        if (need_pool) {
+            pool_next = p0;
             pool_end = pool_next + grab;
         }
-        const uint32_t n_fix = __shfl(lane == 0 ? s_nfix[wv] : 0u, 0);
-        if (n_fix) {  // dense work list for the post-pass (its cursor is taken before this burst's stores are issued)
-            unsigned long long f0 = 0;
-            if (lane == 0) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)n_fix);
-            f0 = __shfl(f0, 0);
-            for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];
-        }
+        for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];  // dense work list for the post-pass
         for (uint32_t t = lane; t < n_res && !(a.dbg & 64u); t += 64) {  // (what-if bit 6: no result writes at all)
             const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
             const uint32_t c = (misc >> 24) ? CAND_OVERFLOW : (misc & 0xFFu);
