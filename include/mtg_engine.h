@@ -14,7 +14,7 @@
  *   mtg_replay_claims_device       greedytigs/mod.rs:301-523 (1-thread order)       GPU (HIP)
  *   mtg_replay_claims              the same loop over host arrays (A/B, tests)      host (C++)
  *   mtg_finish_greedytigs          greedytigs/mod.rs:678-801 + implementation/      host (C++); Euler bicycles optionally
- *                                  mod.rs:392-649 + bigraph Euler decomposition     on the GPU (mtg_set_euler_mode)
+ *                                  mod.rs:392-649 + bigraph Euler decomposition     on the GPU (mtg_config.euler_mode)
  *   mtg_compute_eulertigs          eulertigs/mod.rs:48-198                          host (C++); idem
  *   mtg_write_walks_fasta / _gfa   bin.rs:466-606 / 667-818                         host (C++)
  *   mtg_read_bcalm2                bin.rs:902-912 (genome-graph bcalm2 reader)      host (C++)
@@ -56,6 +56,50 @@ typedef struct {
     uint64_t relax_attempts;   /* edge relaxations the label-correcting kernel really performed */
     uint64_t overflow_sources; /* sources that needed a larger kernel level */
 } mtg_sssp_stats;
+
+/* Engine configuration = the fields of GreedytigAlgorithmConfiguration (greedytigs/mod.rs:40-73; the C-ABI fixes
+ * them at clib.rs:378-389, the CLI fills them from bin.rs:1074-1082) plus what only this engine has.
+ * threads / staged_parallelism_divisor / resource_limit_factor / node_weight_array_type / heap_type select CPU data
+ * structures and scheduling in the reference and never change its 1-thread result; the engine validates and otherwise
+ * ignores them (results always equal the reference's 1-thread order, its only deterministic one). */
+enum { MTG_NODE_WEIGHT_EPOCH_ARRAY = 0, MTG_NODE_WEIGHT_HASHBROWN_HASH_MAP = 1 }; /* implementation/mod.rs:61-81 */
+enum { MTG_HEAP_STD_BINARY_HEAP = 0 };                                            /* implementation/mod.rs:83-102 */
+enum { MTG_PERFORMANCE_DATA_NONE = 0, MTG_PERFORMANCE_DATA_COMPLETE = 1 };        /* implementation/mod.rs:104-126 */
+enum { MTG_EULER_HOST_REFERENCE_ORDER = 0, MTG_EULER_DEVICE = 1 };
+#define MTG_MAX_DEVICES 8
+typedef struct {
+    uint64_t threads;                  /* greedytigs/mod.rs:42 */
+    uint64_t k;                        /* :44 */
+    double staged_parallelism_divisor; /* :47, 0 = None */
+    uint64_t resource_limit_factor;    /* :49 */
+    int32_t node_weight_array_type;    /* :51 */
+    int32_t heap_type;                 /* :53 */
+    int32_t performance_data_type;     /* :55; COMPLETE additionally runs the counting kernels (mtg_last_performance_data) */
+    int32_t euler_mode;                /* MTG_EULER_HOST_REFERENCE_ORDER (bit-exact tigs) or MTG_EULER_DEVICE (valid walks, same
+                                          #tigs / cumulative length, different order) */
+    int32_t n_devices;                 /* GPUs to shard the SSSP sources over; >= 1 */
+    int32_t device_ids[MTG_MAX_DEVICES];
+} mtg_config;
+/* GreedytigAlgorithmConfiguration::new(threads, k) (greedytigs/mod.rs:62-72): staged None, factor 0, HashbrownHashMap,
+ * StdBinaryHeap, performance data None; engine fields: host Euler walk, one device (id 0). */
+void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k);
+
+/* The reference's Dijkstra performance counters (logged at greedytigs/mod.rs:647-673; DijkstraPerformanceData of
+ * traitgraph-algo) in the engine's terms, over all queries of the last greedy run with performance_data_type COMPLETE.
+ * The engine searches the FULL (k-1)-ball of every source with a label-correcting wavefront, one source per workgroup in
+ * this mode: iterations = expansions of a settled (source,node) pair; heap pushes = frontier-log items; unnecessary heap
+ * elements = log items superseded by a shorter distance before they were expanded (the analogue of a stale heap entry);
+ * max heap size of a query = its frontier-log length; max distance array size of a query = its table entries. */
+typedef struct {
+    uint64_t dijkstras;                 /* number of queries */
+    uint64_t iterations;
+    uint64_t heap_pushes;
+    uint64_t unnecessary_heap_elements;
+    uint64_t max_max_heap_size;
+    uint64_t max_max_distance_array_size;
+    uint64_t sum_max_heap_size;           /* average_max_heap_size = sum / dijkstras */
+    uint64_t sum_max_distance_array_size; /* average_max_distance_array_size = sum / dijkstras */
+} mtg_dijkstra_performance_data;
 
 /* Library / device probes. */
 const char *mtg_version(void);
@@ -120,11 +164,10 @@ int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_
 const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
-/* Kernel tuning: which lane-per-source kernel runs as level 0 (9 = default: table-free path enumeration + sorting post-pass;
- * 5 = 8-entry register tables with seed hand-off; 0 = hash-indexed LDS tables of 32, 1/2/6/7/8 = register tables of
- * 16/12/24/6/10, 3 = scanned LDS tables of 12), 4 = cooperative kernels only; returns the preset in
- * force. */
-int mtg_set_sssp_preset(mtg_device *d, int preset);
+/* Which SSSP level plan runs: 0 = default (table-free path enumeration per lane + sorting post-pass, then the cooperative
+ * cascade for the sources it hands on), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the
+ * counting kernels use). Returns the plan in force. */
+int mtg_set_sssp_plan(mtg_device *d, int plan);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified
  * sources (device arrays indexed by absolute source index, e.g. straight from mtg_sssp_candidates or an all-gather):
@@ -159,9 +202,10 @@ mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t 
  * boundaries differ while #tigs and cumulative length stay the same (SURVEY 8a invariance note). Opt-in:
  * mode 0 (default) = host walk in the reference's order, mode 1 = this. Aborts without a GPU. */
 mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id);
-void mtg_set_euler_mode(int mode, int device_id); /* used by mtg_finish_greedytigs / mtg_compute_eulertigs / mtg_compute_tigs */
-int mtg_get_euler_mode(void);
-double mtg_last_euler_kernel_ms(void);
+double mtg_last_euler_kernel_ms(void); /* of the last device decomposition on this thread */
+/* The two finishing paths with an explicit configuration (euler_mode, device_ids[0] for the device decomposition). */
+mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
+mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg);
 
 uint64_t mtg_walks_count(const mtg_walks *w);
 uint64_t mtg_walks_total_edges(const mtg_walks *w);
@@ -206,8 +250,13 @@ uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, c
                                          char **text_out);
 uint64_t mtg_write_tigs_duplication_bitvector_file(const mtg_graph *g, const mtg_walks *tigs, const char *path);
 
-/* Whole path on one GPU: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. */
+/* Whole path: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. matchtigs_compute_tigs builds the configuration from
+ * clib.rs:378-389's constants and calls this. */
+mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg);
+/* The same with mtg_config_init(threads = 1, k) on GPU `device_id`. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);
+/* Counters of the last mtg_compute_tigs_cfg(5) on this thread run with MTG_PERFORMANCE_DATA_COMPLETE (zeros otherwise). */
+void mtg_last_performance_data(mtg_dijkstra_performance_data *out);
 
 /* Phase timings (seconds) of the last mtg_compute_tigs on this thread:
  * [0] device build+upload, [1] classify, [2] sssp (all levels), [3] download, [4] replay,

@@ -34,6 +34,42 @@ class MtgSsspStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+MTG_MAX_DEVICES = 8
+
+
+class MtgConfig(C.Structure):
+    """mtg_config (include/mtg_engine.h): the fields of GreedytigAlgorithmConfiguration + euler_mode / device_ids."""
+
+    _fields_ = [
+        ("threads", C.c_uint64),
+        ("k", C.c_uint64),
+        ("staged_parallelism_divisor", C.c_double),
+        ("resource_limit_factor", C.c_uint64),
+        ("node_weight_array_type", C.c_int32),
+        ("heap_type", C.c_int32),
+        ("performance_data_type", C.c_int32),
+        ("euler_mode", C.c_int32),
+        ("n_devices", C.c_int32),
+        ("device_ids", C.c_int32 * MTG_MAX_DEVICES),
+    ]
+
+
+class MtgDijkstraPerformanceData(C.Structure):
+    _fields_ = [
+        ("dijkstras", C.c_uint64),
+        ("iterations", C.c_uint64),
+        ("heap_pushes", C.c_uint64),
+        ("unnecessary_heap_elements", C.c_uint64),
+        ("max_max_heap_size", C.c_uint64),
+        ("max_max_distance_array_size", C.c_uint64),
+        ("sum_max_heap_size", C.c_uint64),
+        ("sum_max_distance_array_size", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 def declared_symbols() -> list[str]:
     """Every function name declared in include/*.h (used by the symbol-export test)."""
     names: list[str] = []
@@ -94,7 +130,7 @@ def load():
         "mtg_last_sssp_levels": (C.c_int, [vp, P(C.c_double), P(u64), C.c_int]),
         "mtg_last_sssp_level_name": (C.c_char_p, [vp, C.c_int]),
         "mtg_sssp_count": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
-        "mtg_set_sssp_preset": (C.c_int, [vp, C.c_int]),
+        "mtg_set_sssp_plan": (C.c_int, [vp, C.c_int]),
         "mtg_replay_claims_device": (u64, [vp, vp, u64, vp, vp, vp, P(P(MtgPair))]),
         "mtg_last_replay_rounds": (C.c_int, [vp]),
         "mtg_replay_claims": (u64, [vp, u64, vp, vp, vp, vp, vp, vp, P(P(MtgPair))]),
@@ -106,8 +142,11 @@ def load():
         "mtg_euler_cycles": (vp, [vp]),
         "mtg_cut_cycles": (vp, [vp, vp, u64]),
         "mtg_euler_cycles_device": (vp, [vp, C.c_int]),
-        "mtg_set_euler_mode": (None, [C.c_int, C.c_int]),
-        "mtg_get_euler_mode": (C.c_int, []),
+        "mtg_config_init": (None, [P(MtgConfig), u64, u64]),
+        "mtg_finish_greedytigs_cfg": (vp, [vp, vp, u64, P(MtgConfig)]),
+        "mtg_compute_eulertigs_cfg": (vp, [vp, P(MtgConfig)]),
+        "mtg_compute_tigs_cfg": (vp, [vp, u64, P(MtgConfig)]),
+        "mtg_last_performance_data": (None, [P(MtgDijkstraPerformanceData)]),
         "mtg_last_euler_kernel_ms": (C.c_double, []),
         "mtg_walks_count": (u64, [vp]),
         "mtg_walks_total_edges": (u64, [vp]),

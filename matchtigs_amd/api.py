@@ -59,11 +59,20 @@ class PerformanceDataType(_FromStr):
 PerformanceDataType._label = "performance data type"
 
 
+class EulerMode(enum.IntEnum):
+    """Engine-only option (mtg_config.euler_mode): HostReferenceOrder = the reference's walk order (bit-exact tigs);
+    Device = parallel Euler bicycles on the GPU (valid walks, same #tigs / cumulative length, different order)."""
+
+    HostReferenceOrder = 0
+    Device = 1
+
+
 @dataclass
 class GreedytigAlgorithmConfiguration:
     """greedytigs/mod.rs:40-73. heap / node-weight-array / staged-parallelism settings select CPU data
-    structures in the reference and never change results; the MI355X engine accepts and ignores them.
-    ``threads`` likewise: results always equal the reference's 1-thread order (its only deterministic one)."""
+    structures in the reference and never change results; the MI355X engine validates and otherwise ignores them.
+    ``threads`` likewise: results always equal the reference's 1-thread order (its only deterministic one).
+    ``euler_mode`` / ``device_ids`` are engine-only fields (mtg_config)."""
 
     threads: int
     k: int
@@ -72,17 +81,38 @@ class GreedytigAlgorithmConfiguration:
     node_weight_array_type: NodeWeightArrayType = NodeWeightArrayType.HashbrownHashMap
     heap_type: HeapType = HeapType.StdBinaryHeap
     performance_data_type: PerformanceDataType = PerformanceDataType.None_
+    euler_mode: EulerMode = EulerMode.HostReferenceOrder
+    device_ids: Sequence[int] = (0,)
 
     @classmethod
     def new(cls, threads: int, k: int) -> "GreedytigAlgorithmConfiguration":
         return cls(threads, k)
 
+    def to_c(self) -> "_lib.MtgConfig":
+        c = _lib.MtgConfig()
+        _lib.load().mtg_config_init(C.byref(c), self.threads, self.k)
+        c.staged_parallelism_divisor = float(self.staged_parallelism_divisor or 0.0)
+        c.resource_limit_factor = self.resource_limit_factor
+        c.node_weight_array_type = list(NodeWeightArrayType).index(self.node_weight_array_type)
+        c.heap_type = list(HeapType).index(self.heap_type)
+        c.performance_data_type = list(PerformanceDataType).index(self.performance_data_type)
+        c.euler_mode = int(self.euler_mode)
+        c.n_devices = len(self.device_ids)
+        for i, dv in enumerate(self.device_ids):
+            c.device_ids[i] = int(dv)
+        return c
+
 
 @dataclass
 class EulertigAlgorithmConfiguration:
-    """eulertigs/mod.rs:42-45."""
+    """eulertigs/mod.rs:42-45 (+ the engine-only euler_mode / device_id)."""
 
     k: int
+    euler_mode: EulerMode = EulerMode.HostReferenceOrder
+    device_id: int = 0
+
+    def to_c(self) -> "_lib.MtgConfig":
+        return GreedytigAlgorithmConfiguration(1, self.k, euler_mode=self.euler_mode, device_ids=(self.device_id,)).to_c()
 
 
 # ---- edge payload view (implementation/mod.rs:287-317; clib.rs:45-85) -------------------------
@@ -338,8 +368,9 @@ class DeviceGraph:
         self._L.mtg_sssp_count(self._d, stream, src_begin, src_end, C.byref(st))
         return st.as_dict()
 
-    def set_preset(self, preset: int) -> int:
-        return int(self._L.mtg_set_sssp_preset(self._d, preset))
+    def set_plan(self, plan: int) -> int:
+        """0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only."""
+        return int(self._L.mtg_set_sssp_plan(self._d, plan))
 
 
 class TigAlgorithm:
@@ -358,9 +389,10 @@ class GreedytigAlgorithm(TigAlgorithm):
     Configuration = GreedytigAlgorithmConfiguration
 
     @classmethod
-    def compute_tigs(cls, graph: Bigraph, configuration: GreedytigAlgorithmConfiguration, device_id: int = 0):
+    def compute_tigs(cls, graph: Bigraph, configuration: GreedytigAlgorithmConfiguration):
         L = _lib.load()
-        return _take_walks(L, L.mtg_compute_tigs(graph.handle, 5, configuration.k, device_id))
+        c = configuration.to_c()
+        return _take_walks(L, L.mtg_compute_tigs_cfg(graph.handle, 5, C.byref(c)))
 
 
 class EulertigAlgorithm(TigAlgorithm):
@@ -371,14 +403,30 @@ class EulertigAlgorithm(TigAlgorithm):
     @classmethod
     def compute_tigs(cls, graph: Bigraph, configuration: EulertigAlgorithmConfiguration):
         L = _lib.load()
-        return _take_walks(L, L.mtg_compute_eulertigs(graph.handle, configuration.k))
+        c = configuration.to_c()
+        return _take_walks(L, L.mtg_compute_eulertigs_cfg(graph.handle, C.byref(c)))
+
+    @classmethod
+    def compute_tigs_np(cls, graph: Bigraph, configuration: EulertigAlgorithmConfiguration):
+        L = _lib.load()
+        c = configuration.to_c()
+        return _take_walks_np(L, L.mtg_compute_eulertigs_cfg(graph.handle, C.byref(c)))
 
 
-def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int):
-    """mtg_finish_greedytigs returning flat numpy walks (limits, edges) -- for large graphs."""
+def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
+                         device_id: int = 0):
+    """mtg_finish_greedytigs_cfg returning flat numpy walks (limits, edges) -- for large graphs."""
     L = _lib.load()
     p = np.ascontiguousarray(pairs)
-    return _take_walks_np(L, L.mtg_finish_greedytigs(graph.handle, _ptr(p), len(p), k))
+    c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,)).to_c()
+    return _take_walks_np(L, L.mtg_finish_greedytigs_cfg(graph.handle, _ptr(p), len(p), C.byref(c)))
+
+
+def last_performance_data() -> dict:
+    """greedytigs/mod.rs:647-673 counters of the last greedy run with PerformanceDataType.Complete."""
+    out = _lib.MtgDijkstraPerformanceData()
+    _lib.load().mtg_last_performance_data(C.byref(out))
+    return out.as_dict()
 
 
 class UnitigStore:
@@ -417,13 +465,15 @@ def read_bcalm2(path: str, k: int):
 
 def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: int, k: int, path: Optional[str],
                                compression_level: int = 6, device_id: int = 0, gfa_path: Optional[str] = None,
-                               gfa_header: Optional[str] = None, duplication_bitvector_path: Optional[str] = None) -> dict:
+                               gfa_header: Optional[str] = None, duplication_bitvector_path: Optional[str] = None,
+                               configuration: Optional[GreedytigAlgorithmConfiguration] = None) -> dict:
     """compute (3 = eulertigs, 5 = greedy matchtigs) + spell + write FASTA and/or GFA, all inside the library."""
     import time
 
     L = _lib.load()
     t0 = time.perf_counter()
-    w = L.mtg_compute_tigs(graph.handle, algorithm, k, device_id)
+    c = (configuration or GreedytigAlgorithmConfiguration(1, k, device_ids=(device_id,))).to_c()
+    w = L.mtg_compute_tigs_cfg(graph.handle, algorithm, C.byref(c))
     t1 = time.perf_counter()
     n_tigs = int(L.mtg_walks_count(w))
     nbytes = gbytes = 0
@@ -482,15 +532,6 @@ def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, _gfa
     data = C.string_at(out, n)
     L.mtg_free(out)
     return data
-
-
-def set_euler_mode(mode: int, device_id: int = 0) -> None:
-    """0 = host Euler walk in the reference's order (default), 1 = parallel Euler bicycles on the GPU (f-3)."""
-    _lib.load().mtg_set_euler_mode(mode, device_id)
-
-
-def get_euler_mode() -> int:
-    return int(_lib.load().mtg_get_euler_mode())
 
 
 def last_euler_kernel_ms() -> float:

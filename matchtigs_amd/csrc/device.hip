@@ -18,8 +18,6 @@
 //             (k-1)-ball of a unitig graph is almost a tree, so no visited table is needed); one 32-byte gather per step,
 //             self-refilling lanes, no barrier; results staged per wave and written in bursts; sort_candidates_kernel puts
 //             the lists that are not yet in Dijkstra order in order. Sources beyond its budgets go to level 1+.
-//             (sssp_lane_reg_kernel: exact Dijkstra per lane over a <=C-entry table held in VGPRs, hands its search state
-//             to level 1; sssp_lane_kernel / sssp_lane_hash_kernel: the same with LDS tables. Kept as presets, all tested.)
 //   level 1+  sssp_kernel: a workgroup takes a batch of BSRC sources and runs all their bounded searches
 //             together as ONE label-correcting wavefront over a shared LDS open-addressing table keyed by
 //             (local source, node) -> tentative distance (64-bit entries, ds_cmpst_b64 / ds_min_u64) with
@@ -171,13 +169,11 @@ enum Counter : int {
     C_EMITTED = 5,
     C_ATTEMPTS = 6,
     C_OVF_LIST = 7,  // cursor of the overflow source list
-    C_T_INIT = 8,    // MTG_UNSAFE_TIMING_EXPERIMENT=3: wall-clock ticks (100 MHz) thread 0 of every block spent per phase, and rounds
-    C_T_ROUNDS = 9,
-    C_T_EMIT = 10,
-    C_T_CLEAN = 11,
-    C_N_ROUNDS = 12,
-    C_FIX = 13,      // enumeration level: number of candidate lists its post-pass has to put in order
-    C_COUNT = 14
+    C_FIX = 8,       // enumeration level: number of candidate lists its post-pass has to put in order
+    C_PUSHES = 9,    // COUNT: frontier-log items of all finished batches
+    C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
+    C_MAX_ENT = 11,  // COUNT: most table entries of one batch
+    C_COUNT = 16
 };
 
 struct SsspArgs {
@@ -198,17 +194,7 @@ struct SsspArgs {
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
     uint32_t *fix_list;          // out (enumeration level): indices (relative to src_begin) of the lists to sort (cursor: C_FIX)
-    uint32_t *seed_out;          // out (lane level, optional): search state of every overflowed source, SEED_WORDS per ovf_list entry
-    const uint32_t *seed_in;     // in (cooperative level, optional): seeds parallel to src_index -- continue instead of restart
-    uint32_t dbg;                // MTG_UNSAFE_TIMING_EXPERIMENT env, never set in production: bits 1/2/8 give WRONG RESULTS (gather from a
-                                 // 32 KB window / skip emission writes: what-if timings), 3 = per-phase clocks of the cooperative kernel
 };
-
-// Seed = the state of a lane-level Dijkstra at the moment its table overflowed, so that the cooperative level
-// continues the search instead of repeating it: word 0..7 node, 8..11 distances (u16 pairs), 12 = n | settled << 8 |
-// targets << 16 (the node whose relaxation was interrupted is stored as unsettled), 13..15 unused (64-byte records).
-constexpr int SEED_WORDS = 16;
-constexpr int SEED_C = 8;
 
 template <bool GLOBAL_WS>
 struct Mem {
@@ -286,6 +272,7 @@ struct SsspLds {
     unsigned long long chunk_next, chunk_end;   // block-local pool chunk
     unsigned long long bt_settled, bt_relaxed, bt_attempts;              // per batch (COUNT)
     unsigned long long st_settled, st_relaxed, st_attempts, st_emitted;  // per block (COUNT)
+    unsigned long long st_pushes, st_max_log, st_max_ent;
 };
 
 template <int BLOCK, int LOGH, int QCAP, int SCAP, int BSRC, bool COUNT, bool GLOBAL_WS>
@@ -324,68 +311,34 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
     if (tid == 0) {
         s.chunk_next = 0; s.chunk_end = 0;
         s.st_settled = 0; s.st_relaxed = 0; s.st_attempts = 0; s.st_emitted = 0;
+        s.st_pushes = 0; s.st_max_log = 0; s.st_max_ent = 0;
     }
     __syncthreads();
 
     for (uint64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
         const uint64_t item0 = batch * BSRC;
         const int nsrc = (int)min((uint64_t)BSRC, a.n_items - item0);
-        const bool prof = a.dbg == 3 && tid == 0;
-        unsigned long long tp0 = prof ? wall_clock64() : 0ull, tp1 = 0, tp2 = 0, tp3 = 0;
-
         // ---- init (the table is clean here) ----
         if (tid < BSRC) { s.cnt[tid] = 0; s.fill[tid] = 0; }
-        if (tid == 0) { s.tail = a.seed_in ? 0u : (uint32_t)nsrc; s.ovf = 0; s.bt_settled = 0; s.bt_relaxed = 0; s.bt_attempts = 0; }
+        if (tid == 0) { s.tail = (uint32_t)nsrc; s.ovf = 0; s.bt_settled = 0; s.bt_relaxed = 0; s.bt_attempts = 0; }
         __syncthreads();
         uint32_t begin = 0;
-        if (!a.seed_in) {
-            if (tid < nsrc) {
-                const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
-                const uint32_t node = a.sources[abs_idx];
-                s.srcnode[tid] = node;
-                uint32_t slot = 0;
-                const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
-                if (r < 0) s.ovf = 1;
-                M::st(&log[tid], (slot << HINT_BITS) | 0u);
-            }
-            __syncthreads();
-            if (tid == 0) s.end = s.ovf ? 0u : (uint32_t)nsrc;  // loop bounds are only ever published between two barriers
-            __syncthreads();
-        } else {
-            // continue the lane level's searches: its settled entries go to the log first (never expanded again, but
-            // walked by emission and clean-up), its open entries form the first frontier
-            if (tid < nsrc) s.srcnode[tid] = a.sources[a.src_index[item0 + tid]];
-            for (int pass = 0; pass < 2; pass++) {
-                for (uint32_t w = tid; w < (uint32_t)nsrc * SEED_C; w += BLOCK) {
-                    const uint32_t t = w / SEED_C, j = w % SEED_C;
-                    const uint32_t *sd = a.seed_in + (item0 + t) * SEED_WORDS;
-                    const uint32_t meta = sd[12];
-                    if (j >= (meta & 0xFFu)) continue;
-                    const bool is_settled = (meta >> (8 + j)) & 1u;
-                    if (is_settled != (pass == 0)) continue;
-                    const uint32_t node = sd[j];
-                    const uint32_t dist = (sd[8 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
-                    uint32_t slot = 0;
-                    const int r = tbl_relax<LOGH, GLOBAL_WS>(table, t, node, dist, slot);
-                    if (r <= 0) { s.ovf = 1; continue; }  // table full (a seed never holds a node twice)
-                    if (is_settled && ((meta >> (16 + j)) & 1u)) M::fand(&table[slot], ~1ull);  // confirmed in-node
-                    const uint32_t pos = atomicAdd(&s.tail, 1u);
-                    if (pos < (uint32_t)QCAP) M::st(&log[pos], (slot << HINT_BITS) | (dist & HINT_MASK));
-                    else s.ovf = 1;
-                }
-                __syncthreads();
-                if (tid == 0) s.end = s.ovf ? 0u : min(s.tail, (uint32_t)QCAP);
-                __syncthreads();
-                if (pass == 0) begin = s.end;
-            }
-            if (s.ovf) begin = 0;  // uniform (s.ovf is stable after the barrier): no rounds
+        if (tid < nsrc) {
+            const uint64_t abs_idx = a.src_index ? a.src_index[item0 + tid] : a.src_begin + item0 + tid;
+            const uint32_t node = a.sources[abs_idx];
+            s.srcnode[tid] = node;
+            uint32_t slot = 0;
+            const int r = tbl_relax<LOGH, GLOBAL_WS>(table, (uint32_t)tid, node, 0u, slot);
+            if (r < 0) s.ovf = 1;
+            M::st(&log[tid], (slot << HINT_BITS) | 0u);
         }
+        __syncthreads();
+        if (tid == 0) s.end = s.ovf ? 0u : (uint32_t)nsrc;  // loop bounds are only ever published between two barriers
+        __syncthreads();
 
         // ---- label-correcting rounds: round r processes log[begin, end), pushes append at tail ----
         uint32_t end = s.end;
-        if (prof) tp1 = wall_clock64();
-        int n_rounds = 0;
-        for (int round = 0; begin < end; round++, n_rounds++) {  // uniform: `end` is a snapshot published by thread 0
+        for (int round = 0; begin < end; round++) {  // uniform: `end` is a snapshot published by thread 0
             // one lane per (frontier item, inline edge j): the four lanes of an item read the same 32-byte record
             // (one memory request) and each relaxes one edge, instead of one lane running four divergent table updates
             for (uint32_t w = begin * 4 + tid; w < end * 4; w += BLOCK) {
@@ -438,7 +391,6 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
         }
         __syncthreads();
         const uint32_t n_log = min(s.tail, (uint32_t)QCAP);
-        if (prof) tp2 = wall_clock64();
 
         // visits every live table entry exactly once: f(entry)
         auto for_each_entry = [&](auto &&f) {
@@ -537,6 +489,9 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 if (tid == 0) {
                     s.st_settled += s.bt_settled; s.st_relaxed += s.bt_relaxed; s.st_attempts += s.bt_attempts;
                     s.st_emitted += s.total;
+                    s.st_pushes += n_log;
+                    if (n_log > s.st_max_log) s.st_max_log = n_log;
+                    if (s.bt_settled > s.st_max_ent) s.st_max_ent = s.bt_settled;
                 }
             }
         } else {
@@ -549,7 +504,6 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             }
         }
         __syncthreads();
-        if (prof) tp3 = wall_clock64();
 
         // ---- clean the table for the next batch ----
         if (LOG_EMIT && !s.ovf) {
@@ -558,14 +512,6 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             for (uint32_t i = tid; i < H; i += BLOCK) M::st(&table[i], TBL_EMPTY);
         }
         __syncthreads();
-        if (prof) {
-            const unsigned long long tp4 = wall_clock64();
-            atomicAdd(&a.counters[C_T_INIT], tp1 - tp0);
-            atomicAdd(&a.counters[C_T_ROUNDS], tp2 - tp1);
-            atomicAdd(&a.counters[C_T_EMIT], tp3 - tp2);
-            atomicAdd(&a.counters[C_T_CLEAN], tp4 - tp3);
-            atomicAdd(&a.counters[C_N_ROUNDS], (unsigned long long)n_rounds);
-        }
     }
 
     if constexpr (COUNT) {
@@ -574,22 +520,14 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
             atomicAdd(&a.counters[C_RELAXED], s.st_relaxed);
             atomicAdd(&a.counters[C_ATTEMPTS], s.st_attempts);
             atomicAdd(&a.counters[C_EMITTED], s.st_emitted);
+            atomicAdd(&a.counters[C_PUSHES], s.st_pushes);
+            atomicMax(&a.counters[C_MAX_LOG], s.st_max_log);
+            atomicMax(&a.counters[C_MAX_ENT], s.st_max_ent);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Lane-per-source kernel (level 0 for small balls)
-//
-// Measured on the cooperative kernel above (profiles/r01_v2_pmc.md): 79 % of wave cycles waiting, ~15 of
-// 64 lanes active per VMEM instruction, 12 waves per CU -- latency bound, because a (k-1)-ball in a unitig
-// graph is typically a handful of nodes. Here every LANE runs its own exact Dijkstra (select the unsettled
-// minimum by scanning its <= C-entry private table) and refills itself with the next source the moment it
-// finishes, so all 64 lanes keep one 32-byte record gather in flight each, with no barrier anywhere.
-// Per-lane tables live in LDS as node[C][64] (u32) + dist[C][64] (u16): index-major / lane-minor, so any
-// per-lane index is bank-conflict free. A source whose ball exceeds C entries is flagged and re-run by the
-// cooperative kernel. Each settled node is expanded exactly once (work-efficient).
-// ------------------------------------------------------------------------------------------------
+// Wave-level helpers shared by the lane-per-source level
 constexpr unsigned long long LANE_SRC_CHUNK = 512;  // sources a wave takes per global atomic
 
 // Overflowed sources of a wave are buffered in LDS and appended to the global overflow list 64 at a time, so the
@@ -621,625 +559,6 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
     if ((uint32_t)lane < nbuf) a.ovf_list[p0 + lane] = w.buf[lane];
 }
 constexpr unsigned long long LANE_POOL_CHUNK = 256; // keys per wave-local pool chunk
-
-template <int WPB, int C, bool COUNT>
-__global__ __launch_bounds__(WPB * 64) void sssp_lane_kernel(SsspArgs a) {
-    static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
-    __shared__ uint32_t s_node[WPB][C][64];
-    __shared__ uint16_t s_dist[WPB][C][64];
-    __shared__ WaveOvfBuf s_ovf[WPB];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t(*node)[64] = s_node[wv];
-    uint16_t(*dist)[64] = s_dist[wv];
-
-    // wave-uniform state
-    unsigned long long chunk_lo = 0, chunk_hi = 0;  // source items [lo, hi) this wave still owns
-    unsigned long long pool_next = 0, pool_end = 0; // wave-local pool chunk
-    bool exhausted = false;
-    // lane state
-    bool active = false;
-    uint32_t n = 0, settled = 0, targets = 0, cur_relaxed = 0;
-    unsigned long long item = 0;
-    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0;
-    uint32_t n_overflow = 0;
-
-    for (;;) {
-        // ---- refill idle lanes ----
-        const unsigned long long need = __ballot(!active);
-        if (need && !exhausted) {
-            if (chunk_lo >= chunk_hi) {
-                unsigned long long c0 = 0;
-                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
-                c0 = __shfl(c0, 0);
-                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
-                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
-                if (chunk_lo >= chunk_hi) exhausted = true;
-            }
-            const unsigned want = (unsigned)__popcll(need);
-            if (!active) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const unsigned long long it = chunk_lo + rank;
-                if (it < chunk_hi) {
-                    item = it;
-                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
-                    node[0][lane] = a.sources[abs_idx];
-                    dist[0][lane] = 0;
-                    n = 1; settled = 0; targets = 0; cur_relaxed = 0;
-                    active = true;
-                }
-            }
-            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
-        }
-        if (!__any(active)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- one Dijkstra step per active lane ----
-        bool fin = false, ovf = false;
-        if (active) {
-            uint32_t best = 0, bestd = 0xFFFFFFFFu;
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t di = dist[i][lane];
-                if (!((settled >> i) & 1u) && di < bestd) { bestd = di; best = i; }
-            }
-            settled |= 1u << best;
-            const uint32_t u = node[best][lane];
-            const uint32_t d = bestd;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((a.dbg & 1u) ? (u & 1023u) : u));  // one aligned 32-byte gather
-            const uint4 lo = rp[0];
-            const uint4 hi = rp[1];
-            const uint32_t flags = (hi.z >> 8) & 0xFFu;
-            if ((flags & F_TARGET) && best != 0) targets |= 1u << best;  // entry 0 is the source itself (forbid_source_target)
-            auto relax = [&](uint32_t nb, uint32_t w) {
-                const uint32_t nd = d + w;
-                if (nd > a.K1) return;
-                int f = -1;
-                for (uint32_t i = 0; i < n; i++)
-                    if (node[i][lane] == nb) f = (int)i;
-                if (f >= 0) {
-                    if (nd < dist[f][lane]) dist[f][lane] = (uint16_t)nd;  // a settled entry already has dist <= d < nd
-                } else if (n < (uint32_t)C) {
-                    node[n][lane] = nb;
-                    dist[n][lane] = (uint16_t)nd;
-                    n++;
-                } else ovf = true;
-            };
-            uint32_t deg;
-            if (!(flags & F_EXT)) {
-                deg = hi.z & 0xFFu;
-                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
-                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < (int)deg) relax(nb[j], ww[j]);
-            } else {
-                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
-                deg = lo.z;
-                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
-            }
-            cur_relaxed += deg;
-            const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
-            fin = !ovf && settled == all;
-        }
-
-        // ---- lanes whose search is complete emit (wave-collective pool allocation) ----
-        const unsigned long long finmask = __ballot(fin);
-        if (finmask) {
-            const uint32_t c = fin ? (uint32_t)__popc(targets) : 0u;
-            uint32_t incl = c;
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t t = __shfl_up(incl, dd);
-                if (lane >= dd) incl += t;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            if constexpr (!COUNT) {
-                if (total && pool_next + total > pool_end) {
-                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
-                    unsigned long long p0 = 0;
-                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
-                    pool_next = __shfl(p0, 0);
-                    pool_end = pool_next + grab;
-                }
-            }
-            if (fin) {
-                const unsigned long long pos0 = pool_next + (incl - c);
-                if constexpr (!COUNT) {
-                    uint32_t rem = targets;
-                    for (uint32_t r = 0; r < c; r++) {  // selection sort by (distance, node)
-                        unsigned long long bk = ~0ull;
-                        uint32_t bi = 0;
-                        for (uint32_t i = 1; i < n; i++) {
-                            const unsigned long long key = ((unsigned long long)dist[i][lane] << 32) | node[i][lane];
-                            if (((rem >> i) & 1u) && key < bk) { bk = key; bi = i; }
-                        }
-                        rem &= ~(1u << bi);
-                        if (pos0 + r < a.pool_cap && !(a.dbg & 2u)) a.pool[pos0 + r] = bk;
-                    }
-                }
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                if (!(a.dbg & 2u)) {
-                    a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
-                    a.cand_count[abs_idx - a.src_begin] = c;
-                }
-                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
-                active = false;
-            }
-            pool_next += total;
-        }
-        {   // ball larger than the per-lane table: hand the source to the cooperative level
-            uint32_t ovf_idx = 0;
-            if (ovf) {
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-                ovf_idx = (uint32_t)abs_idx;
-                active = false;
-            }
-            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
-        }
-    }
-    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
-
-    if constexpr (COUNT) {
-        // wave reduction, one atomic per wave and counter
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            st_settled += __shfl_down(st_settled, dd);
-            st_relaxed += __shfl_down(st_relaxed, dd);
-            st_emitted += __shfl_down(st_emitted, dd);
-        }
-        if (lane == 0) {
-            atomicAdd(&a.counters[C_SETTLED], st_settled);
-            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
-            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed);
-            atomicAdd(&a.counters[C_EMITTED], st_emitted);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Lane-per-source kernel, hash-indexed (level 0)
-//
-// Same idea as sssp_lane_kernel above (every lane runs its own search and refills itself, so all 64 lanes keep a
-// 32-byte gather in flight and nothing ever waits at a barrier), but the per-lane table is indexed by a per-lane
-// open-addressing byte table (HS = 2C slots holding entry numbers) and the search is label-correcting with a
-// `pending` bitmask, so a step costs O(degree) LDS probes instead of O(n) scans: the table can be 32..64 entries
-// without slowing the small searches that share the wave, and far fewer sources overflow to the cooperative levels.
-// LDS per lane: node[C] u32 + dist[C] u16 + hidx[2C] u8 = 8C bytes (C = 32: 16 KB per wave).
-// ------------------------------------------------------------------------------------------------
-template <int WPB, int C, bool COUNT>
-__global__ __launch_bounds__(WPB * 64) void sssp_lane_hash_kernel(SsspArgs a) {
-    static_assert(C >= 8 && C <= 64 && (C & (C - 1)) == 0, "C must be a power of two <= 64 (64-bit masks)");
-    constexpr int HS = 2 * C;  // hash slots per lane
-    __shared__ uint32_t s_node[WPB][C][64];
-    __shared__ uint16_t s_dist[WPB][C][64];
-    __shared__ uint8_t s_hidx[WPB][HS][64];
-    __shared__ WaveOvfBuf s_ovf[WPB];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t(*node)[64] = s_node[wv];
-    uint16_t(*dist)[64] = s_dist[wv];
-    uint8_t(*hidx)[64] = s_hidx[wv];
-
-    unsigned long long chunk_lo = 0, chunk_hi = 0, pool_next = 0, pool_end = 0;  // wave-uniform
-    bool exhausted = false;
-    bool active = false;  // lane state
-    uint32_t n = 0, cur_relaxed = 0, n_overflow = 0;
-    unsigned long long pending = 0, targets = 0, expanded = 0, item = 0;
-    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0, st_attempts = 0;
-
-    auto hslot = [](uint32_t nb) -> uint32_t { return ((nb * 0x9E3779B1u) >> 16) & (uint32_t)(HS - 1); };
-
-    for (;;) {
-        // ---- refill idle lanes ----
-        const unsigned long long need = __ballot(!active);
-        if (need && !exhausted) {
-            if (chunk_lo >= chunk_hi) {
-                unsigned long long c0 = 0;
-                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
-                c0 = __shfl(c0, 0);
-                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
-                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
-                if (chunk_lo >= chunk_hi) exhausted = true;
-            }
-            const unsigned want = (unsigned)__popcll(need);
-            if (!active) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const unsigned long long it = chunk_lo + rank;
-                if (it < chunk_hi) {
-                    item = it;
-                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
-                    const uint32_t sn = a.sources[abs_idx];
-#pragma unroll 4
-                    for (int h = 0; h < HS; h++) hidx[h][lane] = 0xFF;
-                    node[0][lane] = sn;
-                    dist[0][lane] = 0;
-                    hidx[hslot(sn)][lane] = 0;
-                    n = 1; pending = 1ull; targets = 0; expanded = 0; cur_relaxed = 0;
-                    active = true;
-                }
-            }
-            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
-        }
-        if (!__any(active)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- one expansion per active lane ----
-        bool fin = false, ovf = false;
-        if (active) {
-            const uint32_t i = (uint32_t)__builtin_ctzll(pending);  // lowest pending entry (discovery order)
-            pending &= pending - 1ull;
-            const uint32_t u = node[i][lane];
-            const uint32_t d = dist[i][lane];
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);  // one aligned 32-byte gather
-            const uint4 lo = rp[0];
-            const uint4 hi = rp[1];
-            const uint32_t flags = (hi.z >> 8) & 0xFFu;
-            if ((flags & F_TARGET) && i != 0) targets |= 1ull << i;  // entry 0 is the source itself (forbid_source_target)
-            auto relax = [&](uint32_t nb, uint32_t w) {
-                const uint32_t nd = d + w;
-                if (nd > a.K1) return;
-                uint32_t h = hslot(nb);
-                for (int probe = 0; probe < HS; probe++) {
-                    const uint32_t idx = hidx[h][lane];
-                    if (idx == 0xFFu) {  // new node
-                        if (n < (uint32_t)C) {
-                            hidx[h][lane] = (uint8_t)n;
-                            node[n][lane] = nb;
-                            dist[n][lane] = (uint16_t)nd;
-                            pending |= 1ull << n;
-                            n++;
-                        } else ovf = true;
-                        return;
-                    }
-                    if (node[idx][lane] == nb) {
-                        if (nd < dist[idx][lane]) { dist[idx][lane] = (uint16_t)nd; pending |= 1ull << idx; }
-                        return;
-                    }
-                    h = (h + 1) & (uint32_t)(HS - 1);
-                }
-                ovf = true;
-            };
-            uint32_t deg;
-            if (!(flags & F_EXT)) {
-                deg = hi.z & 0xFFu;
-                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
-                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < (int)deg) relax(nb[j], ww[j]);
-            } else {
-                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
-                deg = lo.z;
-                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
-            }
-            if (!((expanded >> i) & 1ull)) { cur_relaxed += deg; expanded |= 1ull << i; }  // algorithmic edges: once per node
-            if constexpr (COUNT) st_attempts += deg;
-            fin = !ovf && pending == 0ull;
-        }
-
-        // ---- finished lanes emit (wave-collective pool allocation) ----
-        const unsigned long long finmask = __ballot(fin);
-        if (finmask) {
-            const uint32_t c = fin ? (uint32_t)__popcll(targets) : 0u;
-            uint32_t incl = c;
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t t = __shfl_up(incl, dd);
-                if (lane >= dd) incl += t;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            if constexpr (!COUNT) {
-                if (total && pool_next + total > pool_end) {
-                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
-                    unsigned long long p0 = 0;
-                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
-                    pool_next = __shfl(p0, 0);
-                    pool_end = pool_next + grab;
-                }
-            }
-            if (fin) {
-                const unsigned long long pos0 = pool_next + (incl - c);
-                if constexpr (!COUNT) {
-                    unsigned long long rem = targets;
-                    for (uint32_t r = 0; r < c; r++) {  // selection sort of the (few) targets by (distance, node)
-                        unsigned long long bk = ~0ull, scan = rem;
-                        uint32_t bi = 0;
-                        while (scan) {
-                            const uint32_t i = (uint32_t)__builtin_ctzll(scan);
-                            scan &= scan - 1ull;
-                            const unsigned long long key = ((unsigned long long)dist[i][lane] << 32) | node[i][lane];
-                            if (key < bk) { bk = key; bi = i; }
-                        }
-                        rem &= ~(1ull << bi);
-                        if (pos0 + r < a.pool_cap && !(a.dbg & 2u)) a.pool[pos0 + r] = bk;
-                    }
-                }
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
-                a.cand_count[abs_idx - a.src_begin] = c;
-                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
-                active = false;
-            }
-            pool_next += total;
-        }
-        {   // ball larger than the per-lane table: hand the source to the cooperative level
-            uint32_t ovf_idx = 0;
-            if (ovf) {
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-                ovf_idx = (uint32_t)abs_idx;
-                active = false;
-            }
-            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
-        }
-    }
-    wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
-    if constexpr (COUNT) {
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            st_settled += __shfl_down(st_settled, dd);
-            st_relaxed += __shfl_down(st_relaxed, dd);
-            st_emitted += __shfl_down(st_emitted, dd);
-            st_attempts += __shfl_down(st_attempts, dd);
-        }
-        if (lane == 0) {
-            atomicAdd(&a.counters[C_SETTLED], st_settled);
-            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
-            atomicAdd(&a.counters[C_ATTEMPTS], st_attempts);
-            atomicAdd(&a.counters[C_EMITTED], st_emitted);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Lane-per-source kernel, tables in registers (level 0 of preset 5, the previous default plan; counting runs use it)
-//
-// PMC on sssp_lane_kernel (LDS tables): ~640 wave-instructions and ~12 us per wave iteration, most of it waiting on
-// the dependent ds_read -> compare chains of the table scans. With C <= 16 the whole per-lane table fits in VGPRs:
-// node[C] / dist[C] are register arrays that are only ever indexed with compile-time constants (fully unrolled
-// compare / v_cndmask chains for "read entry best", "find nb", "write entry n"), so a step has NO LDS traffic and
-// no dependent memory latency besides its one 32-byte record gather, and occupancy is bounded by VGPRs alone.
-// Exact Dijkstra per lane (select the unsettled minimum), dynamic lane refill, wave-collective pool allocation:
-// as in sssp_lane_kernel. Only the overflow buffer of a wave lives in LDS.
-// ------------------------------------------------------------------------------------------------
-template <int WPB, int C, bool COUNT>
-__global__ __launch_bounds__(WPB * 64) void sssp_lane_reg_kernel(SsspArgs a) {
-    static_assert(C >= 4 && C <= 32, "per-lane masks are 32-bit");
-    constexpr bool SEEDED = (C == SEED_C);  // the 8-entry instantiation can hand its state to the cooperative level
-    __shared__ WaveOvfBuf s_ovf[WPB];
-    __shared__ uint32_t s_seed[SEEDED ? WPB : 1][SEEDED ? 128 * SEED_WORDS : 1];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const bool seeding = SEEDED && a.seed_out != nullptr;
-
-    unsigned long long chunk_lo = 0, chunk_hi = 0, pool_next = 0, pool_end = 0;  // wave-uniform
-    bool exhausted = false;
-    bool active = false;  // lane state
-    uint32_t node[C], dist[C];
-#pragma unroll
-    for (int i = 0; i < C; i++) { node[i] = 0; dist[i] = 0; }
-    uint32_t n = 0, settled = 0, targets = 0, cur_relaxed = 0, n_overflow = 0;
-    unsigned long long item = 0;
-    unsigned long long st_settled = 0, st_relaxed = 0, st_emitted = 0, st_attempts = 0;
-
-    for (;;) {
-        // ---- refill idle lanes (a chunk that runs out is topped up from the next one in the same iteration) ----
-        unsigned long long need = __ballot(!active);
-        for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
-            if (chunk_lo >= chunk_hi) {
-                unsigned long long c0 = 0;
-                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
-                c0 = __shfl(c0, 0);
-                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
-                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
-                if (chunk_lo >= chunk_hi) { exhausted = true; break; }
-            }
-            const unsigned want = (unsigned)__popcll(need);
-            if (!active) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const unsigned long long it = chunk_lo + rank;
-                if (it < chunk_hi) {
-                    item = it;
-                    const uint64_t abs_idx = a.src_index ? a.src_index[it] : a.src_begin + it;
-                    node[0] = a.sources[abs_idx];
-                    dist[0] = 0;
-                    n = 1; settled = 0; targets = 0; cur_relaxed = 0;
-                    active = true;
-                }
-            }
-            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
-            need = __ballot(!active);
-        }
-        if (!__any(active)) {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- one Dijkstra step per active lane (registers only, one 32-byte gather) ----
-        bool fin = false, ovf = false;
-        uint32_t popped = 0;
-        if (active) {
-            uint32_t best = 0, bestd = 0xFFFFFFFFu, u = 0;
-#pragma unroll
-            for (int i = 0; i < C; i++) {
-                const bool cand = (uint32_t)i < n && !((settled >> i) & 1u) && dist[i] < bestd;
-                bestd = cand ? dist[i] : bestd;
-                best = cand ? (uint32_t)i : best;
-                u = cand ? node[i] : u;
-            }
-            settled |= 1u << best;
-            popped = best;
-            const uint32_t d = bestd;
-            // MTG_UNSAFE_TIMING_EXPERIMENT bit 3 (timing experiments only, wrong results): gather from a 32 KB window = no DRAM latency
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((a.dbg & 8u) ? (u & 1023u) : u));
-            const uint4 lo = rp[0];
-            const uint4 hi = rp[1];
-            const uint32_t flags = (hi.z >> 8) & 0xFFu;
-            if ((flags & F_TARGET) && best != 0) targets |= 1u << best;  // entry 0 is the source itself
-            auto relax = [&](uint32_t nb, uint32_t w) {
-                const uint32_t nd = d + w;
-                if (nd > a.K1) return;
-                bool found = false;
-#pragma unroll
-                for (int i = 0; i < C; i++) {
-                    const bool hit = (uint32_t)i < n && node[i] == nb;
-                    found |= hit;
-                    dist[i] = (hit && nd < dist[i]) ? nd : dist[i];  // a settled entry already has dist <= d < nd
-                }
-                if (!found) {
-                    if (n < (uint32_t)C) {
-#pragma unroll
-                        for (int i = 0; i < C; i++) {
-                            const bool here = (uint32_t)i == n;
-                            node[i] = here ? nb : node[i];
-                            dist[i] = here ? nd : dist[i];
-                        }
-                        n++;
-                    } else ovf = true;
-                }
-            };
-            uint32_t deg;
-            if (!(flags & F_EXT)) {
-                deg = hi.z & 0xFFu;
-                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
-                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < (int)deg) relax(nb[j], ww[j]);
-            } else {
-                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
-                deg = lo.z;
-                for (uint32_t j = 0; j < deg; j++) relax(a.ext_col[eb + j], a.ext_w[eb + j]);
-            }
-            cur_relaxed += deg;
-            const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
-            fin = !ovf && settled == all;
-        }
-
-        // ---- finished lanes emit (wave-collective pool allocation) ----
-        const unsigned long long finmask = __ballot(fin);
-        if (finmask) {
-            const uint32_t c = fin ? (uint32_t)__popc(targets) : 0u;
-            uint32_t incl = c;
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t t = __shfl_up(incl, dd);
-                if (lane >= dd) incl += t;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            if constexpr (!COUNT) {
-                if (total && pool_next + total > pool_end) {
-                    const unsigned long long grab = total > LANE_POOL_CHUNK ? (unsigned long long)total : LANE_POOL_CHUNK;
-                    unsigned long long p0 = 0;
-                    if (lane == 0) p0 = atomicAdd(&a.counters[C_POOL], grab);
-                    pool_next = __shfl(p0, 0);
-                    pool_end = pool_next + grab;
-                }
-            }
-            if (fin) {
-                const unsigned long long pos0 = pool_next + (incl - c);
-                if constexpr (!COUNT) {
-                    uint32_t rem = targets;
-                    for (uint32_t r = 0; r < c; r++) {  // selection sort of the (few) targets by (distance, node)
-                        unsigned long long bk = ~0ull;
-                        uint32_t bi = 0;
-#pragma unroll
-                        for (int i = 1; i < C; i++) {
-                            const unsigned long long key = ((unsigned long long)dist[i] << 32) | node[i];
-                            const bool better = ((rem >> i) & 1u) && key < bk;
-                            bk = better ? key : bk;
-                            bi = better ? (uint32_t)i : bi;
-                        }
-                        rem &= ~(1u << bi);
-                        if (pos0 + r < a.pool_cap && !(a.dbg & 16u)) a.pool[pos0 + r] = bk;
-                    }
-                }
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                if (!(a.dbg & 16u)) {  // bit 4 of the what-if switch: no result writes (timing only)
-                    a.cand_start[abs_idx - a.src_begin] = COUNT ? 0ull : pos0;
-                    a.cand_count[abs_idx - a.src_begin] = c;
-                }
-                if constexpr (COUNT) { st_settled += n; st_emitted += c; st_relaxed += cur_relaxed; }
-                active = false;
-            }
-            pool_next += total;
-        }
-        {   // ball larger than the per-lane table: hand the source (and, if asked, the search state) to the cooperative level
-            const unsigned long long om = __ballot(ovf);
-            if (om) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
-                if (ovf) {
-                    const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                    a.cand_count[abs_idx - a.src_begin] = CAND_OVERFLOW;
-                    const uint32_t slot = n_overflow + rank;
-                    s_ovf[wv].buf[slot] = (uint32_t)abs_idx;
-                    if constexpr (SEEDED) {
-                        if (seeding) {
-                            uint32_t *sd = &s_seed[wv][slot * SEED_WORDS];
-#pragma unroll
-                            for (int i = 0; i < C; i++) sd[i] = node[i];
-#pragma unroll
-                            for (int i = 0; i < C; i += 2) sd[8 + i / 2] = (dist[i] & 0xFFFFu) | (dist[i + 1] << 16);
-                            // the node popped in this step was not fully relaxed: it stays open
-                            sd[12] = n | ((settled & ~(1u << popped)) << 8) | (targets << 16);
-                        }
-                    }
-                    if constexpr (COUNT) st_attempts += cur_relaxed;
-                    active = false;
-                }
-                n_overflow += (uint32_t)__popcll(om);
-                if (n_overflow >= 64) {
-                    unsigned long long p0 = 0;
-                    if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], 64ull);
-                    p0 = __shfl(p0, 0);
-                    a.ovf_list[p0 + lane] = s_ovf[wv].buf[lane];
-                    const uint32_t rest = s_ovf[wv].buf[64 + lane];
-                    s_ovf[wv].buf[lane] = rest;
-                    if constexpr (SEEDED) {
-                        if (seeding) {
-                            uint32_t *out = a.seed_out + p0 * SEED_WORDS;
-#pragma unroll
-                            for (int w = 0; w < SEED_WORDS; w++) out[w * 64 + lane] = s_seed[wv][w * 64 + lane];
-#pragma unroll
-                            for (int w = 0; w < SEED_WORDS; w++) {
-                                const uint32_t v = s_seed[wv][64 * SEED_WORDS + w * 64 + lane];
-                                s_seed[wv][w * 64 + lane] = v;
-                            }
-                        }
-                    }
-                    n_overflow -= 64;
-                }
-            }
-        }
-    }
-    if (n_overflow) {
-        unsigned long long p0 = 0;
-        if (lane == 0) p0 = atomicAdd(&a.counters[C_OVERFLOW], (unsigned long long)n_overflow);
-        p0 = __shfl(p0, 0);
-        if ((uint32_t)lane < n_overflow) a.ovf_list[p0 + lane] = s_ovf[wv].buf[lane];
-        if constexpr (SEEDED) {
-            if (seeding) {
-                uint32_t *out = a.seed_out + p0 * SEED_WORDS;
-                for (uint32_t w = lane; w < n_overflow * SEED_WORDS; w += 64) out[w] = s_seed[wv][w];
-            }
-        }
-    }
-
-    if constexpr (COUNT) {
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            st_settled += __shfl_down(st_settled, dd);
-            st_relaxed += __shfl_down(st_relaxed, dd);
-            st_emitted += __shfl_down(st_emitted, dd);
-            st_attempts += __shfl_down(st_attempts, dd);
-        }
-        if (lane == 0) {
-            atomicAdd(&a.counters[C_SETTLED], st_settled);
-            atomicAdd(&a.counters[C_RELAXED], st_relaxed);
-            atomicAdd(&a.counters[C_ATTEMPTS], st_relaxed + st_attempts);
-            atomicAdd(&a.counters[C_EMITTED], st_emitted);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Lane-per-source kernel WITHOUT a table (level 0 of the default plan)
@@ -1287,7 +606,6 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     bool unclean = false;
     uint32_t cur_node = 0, cur_dist = 0;  // the path step in progress; the stack holds the branches still to take
     unsigned long long item = 0;
-    unsigned long long dbg_iters = 0, dbg_lanes = 0;
     if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
 
     auto flush_results = [&]() {
@@ -1308,7 +626,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             pool_end = pool_next + grab;
         }
         for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];  // dense work list for the post-pass
-        for (uint32_t t = lane; t < n_res && !(a.dbg & 64u); t += 64) {  // (what-if bit 6: no result writes at all)
+        for (uint32_t t = lane; t < n_res; t += 64) {
             const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
             const uint32_t c = (misc >> 24) ? CAND_OVERFLOW : (misc & 0xFFu);
             if (c != CAND_OVERFLOW) {
@@ -1366,7 +684,6 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
 
         // ---- one path step per active lane: gather the current node, continue with one successor within the bound (kept
         // in registers), push the others; a dead end pops the stack ----
-        if (a.dbg & 256u) { dbg_iters++; dbg_lanes += (uint32_t)__popcll(__ballot(active)); }  // lane-utilisation probe
         bool fin = false, ovf = false;
         if (active) {
             const uint32_t u = cur_node, d = cur_dist;
@@ -1424,9 +741,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
 
         // ---- finished / overflowed lanes stage their result (hits as they are: the post-pass de-duplicates and sorts) ----
         const unsigned long long donemask = __ballot(fin || ovf);
-        if (donemask && (a.dbg & 32u)) {  // (what-if bit 5: finished lanes just go idle)
-            if (fin || ovf) { active = false; nhit = 0; used = 0; }
-        } else if (donemask) {
+        if (donemask) {
             if (fin || ovf) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(donemask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donemask, 0u));
                 const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
@@ -1448,10 +763,6 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     }
     flush_results();
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
-    if ((a.dbg & 256u) && lane == 0) {
-        atomicAdd(&a.counters[C_T_INIT], dbg_iters);
-        atomicAdd(&a.counters[C_T_ROUNDS], dbg_lanes);
-    }
 }
 
 // Post-pass of the enumeration level: a source's hits arrive in discovery order and may name a node more than once (one
@@ -1498,6 +809,17 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(unsigned long long
 // ------------------------------------------------------------------------------------------------
 // Host side of the device stage
 // ------------------------------------------------------------------------------------------------
+// Work arrays of the GPU claim replay (replay_kernels.inc); owned by the Device they were allocated on.
+struct ReplayWork {
+    uint64_t cap_v = 0, cap_s = 0, cap_slots = 0, cap_blocks = 0;
+    int32_t *mult = nullptr;
+    uint8_t *live = nullptr;
+    unsigned long long *resv = nullptr;
+    uint32_t *demand0 = nullptr, *pair_count = nullptr, *pending[2] = {nullptr, nullptr};
+    unsigned long long *pair_off = nullptr, *final_off = nullptr, *block_sums = nullptr;
+    mtg_pair *slots = nullptr;
+};
+
 struct Device {
     int dev = 0;
     uint64_t k = 0;
@@ -1517,19 +839,19 @@ struct Device {
     unsigned long long *h_counters = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
-    uint64_t last_level0_overflow = 0;
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
+    uint32_t *d_fix = nullptr;                // enumeration level: candidate lists its post-pass has to put in order
     uint64_t ovf_cap = 0;
-    uint32_t *d_seed = nullptr;               // lane-level search states of the overflowed sources (SEED_WORDS each)
-    bool use_seeds = true;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
     std::string last_level_name[8];
-    int preset = 9;  // table-free path enumeration per lane, then the cooperative cascade for the ~1 % heaviest sources
+    int plan = 0;  // 0 = table-free path enumeration per lane, then the cooperative cascade for the heaviest sources; 1 = cascade only
     int n_cu = 256;
     uint64_t graph_bytes = 0;
+    ReplayWork replay;
+    int last_replay_rounds = 0;
 };
 
 typedef void (*sssp_fn)(SsspArgs);
@@ -1556,80 +878,26 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-static const int N_PRESETS = 10;
-// Level plan: lane-per-source kernel (per-lane table of C entries) -> cooperative kernel, 64 sources per
-// workgroup -> cooperative kernel, 1 source per workgroup with a 128 KB LDS table -> cooperative kernel with
-// a 32 MB global-memory table. `preset` picks the lane kernel's table size (4 = skip the lane level).
-struct LaneCfg {
-    sssp_fn fn;
-    sssp_fn fn_count;
-    int block;
-    int max_occ = 0;  // workgroups per CU to launch at most (0 = what fits)
-    const char *kind = "";
-    int c = 0;
-    int hits = 0;  // > 0: enumeration kernel (c = stack slots, hits = hit-buffer slots), followed by sort_candidates_kernel
-    std::string name() const {
-        char b[96];
-        if (hits) std::snprintf(b, sizeof b, "%s<%d,%d,%d> + sort_candidates_kernel", kind, block / 64, c, hits);
-        else std::snprintf(b, sizeof b, "%s<%d,%d>", kind, block / 64, c);
-        return b;
-    }
-};
-constexpr int ENUM_STACK = 10, ENUM_HITS = 16;
-template <int WPB, int C>
-static LaneCfg make_lane_cfg() {
-    return LaneCfg{sssp_lane_kernel<WPB, C, false>, sssp_lane_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_kernel", C};
+constexpr int ENUM_WPB = 4, ENUM_STACK = 10, ENUM_HITS = 16;
+static std::string enum_level_name() {
+    char b[96];
+    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d> + sort_candidates_kernel", ENUM_WPB, ENUM_STACK, ENUM_HITS);
+    return b;
 }
-template <int WPB, int C>
-static LaneCfg make_lane_reg_cfg() {
-    return LaneCfg{sssp_lane_reg_kernel<WPB, C, false>, sssp_lane_reg_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_reg_kernel", C};
-}
-template <int WPB, int C>
-static LaneCfg make_lane_hash_cfg() {
-    return LaneCfg{sssp_lane_hash_kernel<WPB, C, false>, sssp_lane_hash_kernel<WPB, C, true>, WPB * 64, 0, "sssp_lane_hash_kernel", C};
-}
-static LaneCfg lane_cfg(int preset) {
-    switch (preset) {
-        case 9: {  // table-free path enumeration; counting runs use the register-table kernel (it counts DISTINCT nodes)
-            LaneCfg c{sssp_enum_kernel<4, ENUM_STACK, ENUM_HITS>, sssp_lane_reg_kernel<4, 8, true>, 256, 0, "sssp_enum_kernel", ENUM_STACK,
-                      ENUM_HITS};
-            return c;
-        }
-        case 0: return make_lane_hash_cfg<4, 32>();  // hash-indexed per-lane LDS table, 32 entries
-        case 1: return make_lane_reg_cfg<4, 16>();   // register tables, 16 entries
-        case 2: return make_lane_reg_cfg<4, 12>();   // register tables, 12 entries
-        case 5: {  // default: register tables, 8 entries; measured best at 12 waves per CU (0.52 ms vs 0.56 at 16)
-            LaneCfg c = make_lane_reg_cfg<4, 8>();
-            c.max_occ = 3;
-            return c;
-        }
-        case 6: return make_lane_reg_cfg<4, 24>();
-        case 7: return make_lane_reg_cfg<4, 6>();
-        case 8: return make_lane_reg_cfg<4, 10>();
-        default: return make_lane_cfg<4, 12>();      // preset 3: scan-based per-lane LDS table, 12 entries
-    }
-}
-//                                              BLOCK LOGH  QCAP  SCAP BSRC
-// Cascade of cooperative levels: 64 sources per workgroup, then 8, then 1 (128 KB LDS table), then a 32 MB
+
+// Cascade of cooperative levels: 32 sources per workgroup, then 8, then 1 (128 KB LDS table), then a 32 MB
 // global-memory table. A level re-runs the sources whose batch overflowed the previous level's tables.
 static const int N_COOP_LEVELS = 5;
-static LevelCfg coop_level(int i, bool enum_plan = false) {
-    // tuning experiments for the first cooperative level: MTG_L1=<n>
-    static const int exp_l1 = std::getenv("MTG_L1") ? std::atoi(std::getenv("MTG_L1")) : 0;
-    if (i == 0 && exp_l1 == 1) return make_cfg<256, 12, 2048, 1024, 64, false>();  // the round-1 geometry before seeds
-    if (i == 0 && exp_l1 == 2) return make_cfg<256, 11, 2048, 512, 32, false>();
-    if (i == 0 && exp_l1 == 3) return make_cfg<256, 11, 1024, 512, 24, false>();
-    if (i == 0 && exp_l1 == 4) return make_cfg<512, 12, 2048, 512, 64, false>();
+static LevelCfg coop_level(int i, bool after_enum) {
     switch (i) {  //                    BLOCK LOGH  QCAP  SCAP BSRC
         // 25 KB of LDS per workgroup -> 6 workgroups per CU: the level is bound by rounds x gather latency per batch
         // (4 us per round, ~10 rounds), so concurrency per CU is what counts; its heavy batches overflow the 1024-item
-        // log early and are re-run by the next level (measured: 0.93 + 0.10 ms against 1.17 + 0.04 ms for 64 sources
-        // per workgroup with a 4096-entry table)
+        // log early and are re-run by the next level
         case 0: return make_cfg<256, 11, 1024, 512, 32, false>();
         case 1:
             // what the enumeration level hands on are its ~1 % heaviest sources: 8 per workgroup in 29 KB of LDS (5 workgroups
             // per CU) measured 0.18 ms against 0.27 ms for 16 per workgroup in 58 KB
-            if (enum_plan) return make_cfg<256, 11, 2048, 512, 8, false>();
+            if (after_enum) return make_cfg<256, 11, 2048, 512, 8, false>();
             return make_cfg<256, 12, 4096, 1024, 16, false>();
         case 2: return make_cfg<256, 13, 8192, 2048, 8, false>();
         case 3: return make_cfg<256, 14, 4096, 1024, 1, false>();
@@ -1643,27 +911,22 @@ static float elapsed_ms(Device *d) {
     return ms;
 }
 
-static void launch_lane(Device *d, hipStream_t st, const LaneCfg &cfg, bool count, SsspArgs args) {
+static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     if (args.n_items == 0) return;
-    sssp_fn fn = count ? cfg.fn_count : cfg.fn;
+    sssp_fn fn = sssp_enum_kernel<ENUM_WPB, ENUM_STACK, ENUM_HITS>;
     int occ = 1;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, cfg.block, 0));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, ENUM_WPB * 64, 0));
     if (occ < 1) occ = 1;
     const uint64_t waves_needed = (args.n_items + 63) / 64;
-    const uint64_t wpb = (uint64_t)cfg.block / 64;
-    if (cfg.max_occ > 0) occ = std::min(occ, cfg.max_occ);
-    if (const char *e = std::getenv("MTG_LANE_OCC")) occ = std::max(1, std::atoi(e));  // tuning experiments
-    uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + wpb - 1) / wpb);
+    uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + ENUM_WPB - 1) / ENUM_WPB);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(cfg.block), 0, st, args);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    if (cfg.hits && !count) {
-        hipLaunchKernelGGL(sort_candidates_kernel<ENUM_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
-                           dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start, args.cand_count, args.fix_list,
-                           args.counters + C_FIX);
-        HIP_CHECK(hipGetLastError());
-    }
+    hipLaunchKernelGGL(sort_candidates_kernel<ENUM_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
+                       dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start, args.cand_count, args.fix_list,
+                       args.counters + C_FIX);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(d->ev1, st));
 }
 
@@ -1704,66 +967,59 @@ static void read_counters(Device *d, hipStream_t st) {
 }
 
 // runs level 0 over [src_begin, src_end) and larger levels over whatever overflowed
-static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin, uint64_t src_end, unsigned long long *d_pool,
+static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, uint64_t src_end, unsigned long long *d_pool,
                       uint64_t pool_cap, unsigned long long *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed,
                       mtg_sssp_stats *stats) {
     if (!d->classified) MTG_DIE("mtg_sssp_candidates: call mtg_classify first");
     if (src_end > d->n_sources || src_begin > src_end) MTG_DIE("mtg_sssp_candidates: source range out of bounds");
     const uint64_t n = src_end - src_begin;
+    const bool count = count_mode != 0;   // 1 = unit counters (cooperative plan), 2 = per-query performance data (one source per workgroup)
+    const int first_coop = count_mode == 2 ? 3 : 0;
     HIP_CHECK(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), st));
     SsspArgs a{};
     a.recs = d->d_recs; a.ext_col = d->d_ext_col; a.ext_w = d->d_ext_w;
     a.sources = d->d_out_nodes; a.src_index = nullptr; a.n_items = n; a.src_begin = src_begin;
     a.K1 = d->K1; a.pool = d_pool; a.pool_cap = pool_cap; a.cand_start = d_cand_start; a.cand_count = d_cand_count;
     a.counters = d->d_counters;
-    if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each
+    if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each + the post-pass work list
         for (int i = 0; i < 2; i++) {
             if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
-        if (d->d_seed) HIP_CHECK(hipFree(d->d_seed));
-        HIP_CHECK(hipMalloc(&d->d_seed, std::max<uint64_t>(n, 1) * SEED_WORDS * sizeof(uint32_t)));
+        if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
+        HIP_CHECK(hipMalloc(&d->d_fix, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
-    static const bool seeds_off = std::getenv("MTG_NO_SEEDS") != nullptr;  // A/B: restart overflowed sources from scratch
-    const bool seeded = d->use_seeds && !seeds_off && d->preset == 5;  // only the 8-entry register kernel writes seeds
-    a.seed_out = seeded ? d->d_seed : nullptr;
-    a.seed_in = nullptr;
-    a.fix_list = d->d_seed;  // (the enumeration plan writes no seeds: the buffer holds its post-pass work list instead)
-    { const char *e = std::getenv("MTG_UNSAFE_TIMING_EXPERIMENT"); a.dbg = e ? (uint32_t)std::atoi(e) : 0u; }
+    a.fix_list = d->d_fix;
     double total_ms = 0.0;
-    const bool use_lane = d->preset != 4;
-    if (use_lane) launch_lane(d, st, lane_cfg(d->preset), count, a);
-    else launch_level(d, st, coop_level(0), count, a);
+    // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
+    // settled nodes, an enumeration counts path steps
+    const bool use_enum = d->plan == 0 && !count;
+    if (use_enum) launch_enum(d, st, a);
+    else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
-    if (n) total_ms += elapsed_ms(d);
     d->last_n_levels = 0;
     if (n) {
+        total_ms += elapsed_ms(d);
         d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1;
-        d->last_level_name[0] = use_lane ? lane_cfg(d->preset).name() : coop_level(0).name();
+        d->last_level_name[0] = use_enum ? enum_level_name() : coop_level(first_coop, false).name();
     }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
-    if (debug && n && (a.dbg & 256u))
-        std::fprintf(stderr, "[mtg] level0 lane utilisation: %llu wave iterations, %.1f active lanes per iteration\n",
-                     (unsigned long long)d->h_counters[C_T_INIT], d->h_counters[C_T_INIT] ? (double)d->h_counters[C_T_ROUNDS] / d->h_counters[C_T_INIT] : 0.0);
-    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_lane ? "lane" : "coop level 0",
+    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_enum ? "enum" : "coop level 0",
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
-    uint64_t total_overflow = d->h_counters[C_OVERFLOW];
-    d->last_level0_overflow = total_overflow;
+    const uint64_t total_overflow = d->h_counters[C_OVERFLOW];
     // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
     // to the other of two ping-pong lists
     int cur_list = 0;
     // (what the enumeration level hands on are the heavy balls: batches of 32 of them do not fit the first cooperative level)
-    for (int li = !use_lane || d->preset == 9 ? 1 : 0; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
-        const LevelCfg next = coop_level(li, d->preset == 9);
+    for (int li = first_coop + 1; li < N_COOP_LEVELS && d->h_counters[C_OVERFLOW] > 0; li++) {
+        const LevelCfg next = coop_level(li, use_enum);
         const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
         HIP_CHECK(hipMemsetAsync(&d->d_counters[C_OVERFLOW], 0, sizeof(unsigned long long), st));
         SsspArgs b = a;
         b.src_index = d->d_ovf[cur_list];
         b.ovf_list = d->d_ovf[cur_list ^ 1];
-        b.seed_out = nullptr;
-        b.seed_in = (seeded && use_lane && li == 0) ? d->d_seed : nullptr;  // seeds are parallel to the lane level's list
         cur_list ^= 1;
         b.n_items = n_ovf;
         launch_level(d, st, next, count, b);
@@ -1775,15 +1031,10 @@ static int run_levels(Device *d, hipStream_t st, bool count, uint64_t src_begin,
             d->last_level_name[d->last_n_levels] = next.name();
             d->last_n_levels++;
         }
-        if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li + 1,
+        if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li,
                                 next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
-        if (debug && a.dbg == 3)
-            std::fprintf(stderr, "[mtg]   cumulative block-time (10 ns ticks): init %llu rounds %llu emit %llu clean %llu; rounds %llu\n",
-                         (unsigned long long)d->h_counters[C_T_INIT], (unsigned long long)d->h_counters[C_T_ROUNDS],
-                         (unsigned long long)d->h_counters[C_T_EMIT], (unsigned long long)d->h_counters[C_T_CLEAN],
-                         (unsigned long long)d->h_counters[C_N_ROUNDS]);
     }
-    d->last_kernel_ms = total_ms;
+    if (!count) d->last_kernel_ms = total_ms;
     if (d->h_counters[C_OVERFLOW] > 0)
         MTG_DIE("bounded search from %llu source(s) exceeds every kernel level (ball larger than 2^22 table entries)",
                 (unsigned long long)d->h_counters[C_OVERFLOW]);
@@ -1888,7 +1139,10 @@ void device_free(Device *d) {
     void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
-    (void)hipFree(d->d_seed);
+    (void)hipFree(d->d_fix);
+    ReplayWork &w = d->replay;
+    void *rb[] = {w.mult, w.live, w.resv, w.demand0, w.pair_count, w.pending[0], w.pending[1], w.pair_off, w.final_off, w.block_sums, w.slots};
+    for (void *b : rb) (void)hipFree(b);
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
@@ -1943,7 +1197,7 @@ uint64_t device_n_sources(const Device *d) { return d->n_sources; }
 int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, uint64_t *d_pool, uint64_t pool_cap,
                 uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed) {
     HIP_CHECK(hipSetDevice(d->dev));
-    return run_levels(d, (hipStream_t)stream, false, src_begin, src_end, (unsigned long long *)d_pool, pool_cap,
+    return run_levels(d, (hipStream_t)stream, 0, src_begin, src_end, (unsigned long long *)d_pool, pool_cap,
                       (unsigned long long *)d_cand_start, d_cand_count, pool_needed, nullptr);
 }
 
@@ -1955,10 +1209,32 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
     HIP_CHECK(hipMalloc(&d_start, std::max<uint64_t>(n, 1) * 8));
     HIP_CHECK(hipMalloc(&d_count, std::max<uint64_t>(n, 1) * 4));
     const double keep_ms = d->last_kernel_ms;
-    run_levels(d, (hipStream_t)stream, true, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
+    run_levels(d, (hipStream_t)stream, 1, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
     d->last_kernel_ms = keep_ms;
     HIP_CHECK(hipFree(d_start));
     HIP_CHECK(hipFree(d_count));
+}
+
+// greedytigs/mod.rs:647-673 counters in the engine's terms (see mtg_dijkstra_performance_data): one source per workgroup
+void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t n = d->n_sources;
+    unsigned long long *d_start = nullptr;
+    uint32_t *d_count = nullptr;
+    HIP_CHECK(hipMalloc(&d_start, std::max<uint64_t>(n, 1) * 8));
+    HIP_CHECK(hipMalloc(&d_count, std::max<uint64_t>(n, 1) * 4));
+    mtg_sssp_stats st{};
+    run_levels(d, (hipStream_t)stream, 2, 0, n, nullptr, 0, d_start, d_count, nullptr, &st);
+    HIP_CHECK(hipFree(d_start));
+    HIP_CHECK(hipFree(d_count));
+    out->dijkstras = n;
+    out->iterations = st.settled_nodes;
+    out->heap_pushes = d->h_counters[C_PUSHES];
+    out->unnecessary_heap_elements = d->h_counters[C_PUSHES] - st.settled_nodes;
+    out->max_max_heap_size = d->h_counters[C_MAX_LOG];
+    out->max_max_distance_array_size = d->h_counters[C_MAX_ENT];
+    out->sum_max_heap_size = d->h_counters[C_PUSHES];
+    out->sum_max_distance_array_size = st.settled_nodes;
 }
 
 double device_last_kernel_ms(const Device *d) { return d->last_kernel_ms; }
@@ -1974,16 +1250,6 @@ int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) 
 // ------------------------------------------------------------------------------------------------
 // GPU claim replay (replay_kernels.inc): host driver
 // ------------------------------------------------------------------------------------------------
-struct ReplayWork {
-    uint64_t cap_v = 0, cap_s = 0, cap_slots = 0, cap_blocks = 0;
-    int32_t *mult = nullptr;
-    uint8_t *live = nullptr;
-    unsigned long long *resv = nullptr;
-    uint32_t *demand0 = nullptr, *pair_count = nullptr, *pending[2] = {nullptr, nullptr};
-    unsigned long long *pair_off = nullptr, *final_off = nullptr, *block_sums = nullptr;
-    mtg_pair *slots = nullptr;
-};
-
 static void scan_u32(Device *d, hipStream_t st, ReplayWork &w, const uint32_t *in, uint64_t n, unsigned long long *out,
                      unsigned long long *d_total) {
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -2006,10 +1272,11 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(d->dev));
     if (!d->classified || n_sources != d->n_sources) MTG_DIE("mtg_replay_claims_device: classify first; n_sources must be all sources");
-    static ReplayWork w;  // one engine per process in practice; buffers are re-used across calls
+    ReplayWork &w = d->replay;  // buffers are re-used across calls on this device
     const uint64_t V = d->V, S = n_sources;
     if (S == 0) {
         *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        d->last_replay_rounds = 0;
         if (rounds_out) *rounds_out = 0;
         return 0;
     }
@@ -2085,6 +1352,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
     }
+    d->last_replay_rounds = rounds;
     if (rounds_out) *rounds_out = rounds;
 
     // compaction in source order
@@ -2106,10 +1374,11 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     return n_pairs;
 }
 
-int device_set_preset(Device *d, int preset) {
-    if (preset >= 0 && preset < N_PRESETS) d->preset = preset;
-    return d->preset;
+int device_set_plan(Device *d, int plan) {
+    if (plan == 0 || plan == 1) d->plan = plan;
+    return d->plan;
 }
+int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
 
 // one-shot path: SSSP candidates for all sources into engine-owned device buffers (pool grown on demand), then the
 // claim replay on the GPU; only the matched pairs travel to the host.
@@ -2130,7 +1399,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     for (;;) {
         HIP_CHECK(hipMalloc(&d_pool, cap * 8));
         uint64_t needed = 0;
-        if (run_levels(d, st, false, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr) == 0) break;
+        if (run_levels(d, st, 0, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr) == 0) break;
         HIP_CHECK(hipFree(d_pool));
         d_pool = nullptr;
         cap = needed + needed / 8 + 1024;
@@ -2160,7 +1429,7 @@ void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &c
     for (;;) {
         HIP_CHECK(hipMalloc(&d_pool, cap * 8));
         uint64_t needed = 0;
-        const int rc = run_levels(d, st, false, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr);
+        const int rc = run_levels(d, st, 0, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr);
         if (rc == 0) {
             pool.resize(needed);
             if (needed) HIP_CHECK(hipMemcpyAsync(pool.data(), d_pool, needed * 8, hipMemcpyDeviceToHost, st));

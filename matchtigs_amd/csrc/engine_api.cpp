@@ -23,13 +23,23 @@ struct MatchtigsData { mtg_graph graph; };
 
 static thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static bool g_log_initialised = false;
-static thread_local int g_last_replay_rounds = 0;
-static int g_euler_mode = 0;    // 0 = host walk in the reference's order, 1 = GPU (euler_device.hip)
-static int g_euler_device = 0;
 static thread_local double g_last_euler_kernel_ms = 0;
+static thread_local mtg_dijkstra_performance_data g_last_perf = {};
 
-static Walks euler_cycles_by_mode(const HostGraph &g) {
-    if (g_euler_mode == 1) return device_euler_cycles(g, g_euler_device, &g_last_euler_kernel_ms);
+static void check_config(const mtg_config *cfg, const char *who) {
+    if (!cfg) MTG_DIE("%s: null configuration", who);
+    if (cfg->k < 1) MTG_DIE("%s: k must be >= 1", who);
+    if (cfg->n_devices < 1 || cfg->n_devices > MTG_MAX_DEVICES) MTG_DIE("%s: n_devices = %d is out of range [1, %d]", who, cfg->n_devices, MTG_MAX_DEVICES);
+    if (cfg->euler_mode != MTG_EULER_HOST_REFERENCE_ORDER && cfg->euler_mode != MTG_EULER_DEVICE) MTG_DIE("%s: unknown euler_mode %d", who, cfg->euler_mode);
+    if (cfg->node_weight_array_type != MTG_NODE_WEIGHT_EPOCH_ARRAY && cfg->node_weight_array_type != MTG_NODE_WEIGHT_HASHBROWN_HASH_MAP)
+        MTG_DIE("Unknown node weight array type: %d", cfg->node_weight_array_type);       // implementation/mod.rs:78
+    if (cfg->heap_type != MTG_HEAP_STD_BINARY_HEAP) MTG_DIE("Unknown heap type: %d", cfg->heap_type);  // implementation/mod.rs:99
+    if (cfg->performance_data_type != MTG_PERFORMANCE_DATA_NONE && cfg->performance_data_type != MTG_PERFORMANCE_DATA_COMPLETE)
+        MTG_DIE("Unknown performance data type: %d", cfg->performance_data_type);          // implementation/mod.rs:123
+}
+
+static Walks euler_cycles_by_mode(const HostGraph &g, const mtg_config &cfg) {
+    if (cfg.euler_mode == MTG_EULER_DEVICE) return device_euler_cycles(g, cfg.device_ids[0], &g_last_euler_kernel_ms);
     return euler_cycles(g);
 }
 
@@ -126,13 +136,13 @@ const char *mtg_last_sssp_level_name(const mtg_device *d, int level) { return de
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
     device_sssp_count(d->d, stream, src_begin, src_end, stats);
 }
-int mtg_set_sssp_preset(mtg_device *d, int preset) { return device_set_preset(d->d, preset); }
+int mtg_set_sssp_plan(mtg_device *d, int plan) { return device_set_plan(d->d, plan); }
 uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
                                   const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out) {
     if (!d || !pairs_out) MTG_DIE("mtg_replay_claims_device: null argument");
-    return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, &g_last_replay_rounds);
+    return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
-int mtg_last_replay_rounds(const mtg_device *) { return g_last_replay_rounds; }
+int mtg_last_replay_rounds(const mtg_device *d) { return device_last_replay_rounds(d->d); }
 
 // ---- host stages ----
 uint64_t mtg_replay_claims(const mtg_graph *g, uint64_t n_sources, const uint32_t *out_nodes, const int32_t *multiplicity,
@@ -156,18 +166,13 @@ mtg_walks *mtg_euler_cycles(const mtg_graph *g) { return new mtg_walks{euler_cyc
 mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id) {
     return new mtg_walks{device_euler_cycles(g->g, device_id, &g_last_euler_kernel_ms)};
 }
-void mtg_set_euler_mode(int mode, int device_id) {
-    if (mode != 0 && mode != 1) MTG_DIE("mtg_set_euler_mode: unknown mode %d", mode);
-    g_euler_mode = mode;
-    g_euler_device = device_id;
-}
-int mtg_get_euler_mode(void) { return g_euler_mode; }
 double mtg_last_euler_kernel_ms(void) { return g_last_euler_kernel_ms; }
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k) {
     return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
 }
 
-static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
+static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, const mtg_config &cfg) {
+    const uint64_t k = cfg.k;
     double t0 = now_s();
     log_info("Making graph Eulerian by adding breaking dummy edges");
     make_eulerian(g, dummy_edge_id, k);
@@ -175,7 +180,7 @@ static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, uint64_
     double t1 = now_s();
     g_phase[5] += t1 - t0;
     log_info("Finding Eulerian bicycle");
-    Walks cycles = euler_cycles_by_mode(g);
+    Walks cycles = euler_cycles_by_mode(g, cfg);
     double t2 = now_s();
     g_phase[6] = t2 - t1;
     log_info("Found %zu Eulerian bicycles", cycles.limits.size());
@@ -184,19 +189,48 @@ static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, uint64_
     return tigs;
 }
 
-mtg_walks *mtg_finish_greedytigs(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, uint64_t k) {
+void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k) {  // GreedytigAlgorithmConfiguration::new, greedytigs/mod.rs:62-72
+    if (!cfg) MTG_DIE("mtg_config_init: null configuration");
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->threads = threads;
+    cfg->k = k;
+    cfg->staged_parallelism_divisor = 0.0;
+    cfg->resource_limit_factor = 0;
+    cfg->node_weight_array_type = MTG_NODE_WEIGHT_HASHBROWN_HASH_MAP;
+    cfg->heap_type = MTG_HEAP_STD_BINARY_HEAP;
+    cfg->performance_data_type = MTG_PERFORMANCE_DATA_NONE;
+    cfg->euler_mode = MTG_EULER_HOST_REFERENCE_ORDER;
+    cfg->n_devices = 1;
+    cfg->device_ids[0] = 0;
+}
+
+mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg) {
+    check_config(cfg, "mtg_finish_greedytigs_cfg");
+    if (!g || !g->g.built) MTG_DIE("mtg_finish_greedytigs_cfg: graph is not built");
     double t0 = now_s();
     const uint64_t dummy_edge_id = insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);
     g_phase[5] = now_s() - t0;
-    mtg_walks *tigs = eulerise_and_cut(g->g, dummy_edge_id, k);
+    mtg_walks *tigs = eulerise_and_cut(g->g, dummy_edge_id, *cfg);
     log_info("Found %zu greedytigs", tigs->w.limits.size());
     return tigs;
 }
-mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k) {
+mtg_walks *mtg_finish_greedytigs(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, uint64_t k) {
+    mtg_config cfg;
+    mtg_config_init(&cfg, 1, k);
+    return mtg_finish_greedytigs_cfg(g, pairs, n_pairs, &cfg);
+}
+mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg) {
+    check_config(cfg, "mtg_compute_eulertigs_cfg");
+    if (!g || !g->g.built) MTG_DIE("mtg_compute_eulertigs_cfg: graph is not built");
     g_phase[5] = 0;
-    mtg_walks *tigs = eulerise_and_cut(g->g, 0, k);  // eulertigs/mod.rs:101-102
+    mtg_walks *tigs = eulerise_and_cut(g->g, 0, *cfg);  // eulertigs/mod.rs:101-102
     log_info("Found %zu eulertigs", tigs->w.limits.size());
     return tigs;
+}
+mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k) {
+    mtg_config cfg;
+    mtg_config_init(&cfg, 1, k);
+    return mtg_compute_eulertigs_cfg(g, &cfg);
 }
 
 uint64_t mtg_walks_count(const mtg_walks *w) { return w->w.limits.size(); }
@@ -282,9 +316,12 @@ uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint
     return n;
 }
 
-mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {
+mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg) {
+    check_config(cfg, "mtg_compute_tigs_cfg");
     if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs: graph is not built");
     for (double &p : g_phase) p = 0;
+    g_last_perf = mtg_dijkstra_performance_data{};
+    const uint64_t k = cfg->k;
     switch (tig_algorithm) {
         case 1: {  // clib.rs:351-361: one walk per forward unitig edge
             mtg_walks *w = new mtg_walks();
@@ -295,10 +332,10 @@ mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, in
             return w;
         }
         case 3:
-            return mtg_compute_eulertigs(g, k);
+            return mtg_compute_eulertigs_cfg(g, cfg);
         case 5: {
             double t0 = now_s();
-            mtg_device *dev = mtg_device_create(g, k, device_id);
+            mtg_device *dev = mtg_device_create(g, k, cfg->device_ids[0]);
             double t1 = now_s();
             g_phase[0] = t1 - t0;
             log_info("Collecting nodes with missing incoming or outgoing edges");
@@ -308,12 +345,24 @@ mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, in
             log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
             // SSSP candidates and the claim loop both run on the GPU; only the matched pairs come back
             mtg_pair *pairs = nullptr;
-            const uint64_t n_pairs = device_pairs(dev->d, nullptr, &pairs, &g_last_replay_rounds);
+            const uint64_t n_pairs = device_pairs(dev->d, nullptr, &pairs, nullptr);
             double t3 = now_s();
             g_phase[2] = t3 - t2;  // SSSP + replay + pair download
+            if (cfg->performance_data_type == MTG_PERFORMANCE_DATA_COMPLETE) {  // greedytigs/mod.rs:647-673
+                device_performance_data(dev->d, nullptr, &g_last_perf);
+                const mtg_dijkstra_performance_data &p = g_last_perf;
+                if (p.iterations)
+                    log_info("Dijkstras had a factor of %.3f unnecessary heap elements", (double)p.unnecessary_heap_elements / (double)p.iterations);
+                log_info("Dijktras had a maximum maximum heap size of %llu", (unsigned long long)p.max_max_heap_size);
+                log_info("Dijktras had a maximum maximum distance array size of %llu", (unsigned long long)p.max_max_distance_array_size);
+                if (p.dijkstras) {
+                    log_info("Dijktras had an average maximum heap size of %.0f", (double)p.sum_max_heap_size / (double)p.dijkstras);
+                    log_info("Dijktras had an average maximum heap size of %.0f", (double)p.sum_max_distance_array_size / (double)p.dijkstras);  // sic, :669-671
+                }
+            }
             mtg_device_free(dev);
             log_info("Found %llu shortest paths", (unsigned long long)n_pairs);
-            mtg_walks *tigs = mtg_finish_greedytigs(g, pairs, n_pairs, k);
+            mtg_walks *tigs = mtg_finish_greedytigs_cfg(g, pairs, n_pairs, cfg);
             std::free(pairs);
             return tigs;
         }
@@ -326,6 +375,17 @@ mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, in
             MTG_DIE("Unknown tigs algorithm identifier %llu", (unsigned long long)tig_algorithm);  // clib.rs:390
     }
     return nullptr;
+}
+
+mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {
+    mtg_config cfg;
+    mtg_config_init(&cfg, 1, k);
+    cfg.device_ids[0] = device_id;
+    return mtg_compute_tigs_cfg(g, tig_algorithm, &cfg);
+}
+
+void mtg_last_performance_data(mtg_dijkstra_performance_data *out) {
+    if (out) *out = g_last_perf;
 }
 
 void mtg_last_phase_seconds(double out[8]) {
@@ -373,7 +433,11 @@ size_t matchtigs_compute_tigs(MatchtigsData *data, size_t tig_algorithm, size_t 
     if (!tigs_insert_out) MTG_DIE("assertion failed: !tigs_insert_out.is_null() (clib.rs:339)");
     if (!tigs_out_limits) MTG_DIE("assertion failed: !tigs_out_limits.is_null() (clib.rs:345)");
     static_assert(sizeof(ptrdiff_t) == sizeof(int64_t), "64-bit only");
-    mtg_walks *tigs = mtg_compute_tigs(&data->graph, tig_algorithm, k, 0);
+    mtg_config cfg;  // clib.rs:378-389: staged None, factor 1, StdBinaryHeap, EpochNodeWeightArray, performance data None
+    mtg_config_init(&cfg, threads, k);
+    cfg.resource_limit_factor = 1;
+    cfg.node_weight_array_type = MTG_NODE_WEIGHT_EPOCH_ARRAY;
+    mtg_walks *tigs = mtg_compute_tigs_cfg(&data->graph, tig_algorithm, &cfg);
     const uint64_t n = flatten_clib(data->graph.g, tigs->w, reinterpret_cast<int64_t *>(tigs_edge_out),
                                     reinterpret_cast<uint64_t *>(tigs_insert_out),
                                     reinterpret_cast<uint64_t *>(tigs_out_limits));

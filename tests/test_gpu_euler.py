@@ -93,15 +93,11 @@ def test_greedytigs_with_device_euler_mode(gpu, idx):
     G0 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     ref_tigs = api.GreedytigAlgorithm.compute_tigs(G0, cfg)            # host walk, reference order
     w0 = G0.export()["edge_weight"]
-    api.set_euler_mode(1)
-    try:
-        assert api.get_euler_mode() == 1
-        G1 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
-        tigs = api.GreedytigAlgorithm.compute_tigs(G1, cfg)
-        G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
-        etigs = api.EulertigAlgorithm.compute_tigs(G2, api.EulertigAlgorithmConfiguration(k))
-    finally:
-        api.set_euler_mode(0)
+    dcfg = api.GreedytigAlgorithmConfiguration(1, k, euler_mode=api.EulerMode.Device)
+    G1 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    tigs = api.GreedytigAlgorithm.compute_tigs(G1, dcfg)
+    G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    etigs = api.EulertigAlgorithm.compute_tigs(G2, api.EulertigAlgorithmConfiguration(k, euler_mode=api.EulerMode.Device))
     ex = G1.export()
     _tig_invariants(ex, tigs, k)
     _tig_invariants(G2.export(), etigs, k)
@@ -121,24 +117,37 @@ def test_device_euler_real_dbg_kmer_set(gpu):
 
     ug = synth.g_seq(3000, seed=7, k=15)
     G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
-    api.set_euler_mode(1)
-    try:
-        tigs = api.GreedytigAlgorithm.compute_tigs(G, api.GreedytigAlgorithmConfiguration.new(1, ug.k))
-    finally:
-        api.set_euler_mode(0)
+    tigs = api.GreedytigAlgorithm.compute_tigs(G, api.GreedytigAlgorithmConfiguration(1, ug.k, euler_mode=api.EulerMode.Device))
     fasta = api.write_walks_fasta(G, tigs, ug.unitigs, ug.k).decode()
     seqs = [l for l in fasta.splitlines() if l and not l.startswith(">")]
     assert synth.kmer_set_of_tigs(seqs, ug.k) == ug.kmers
 
 
 def test_device_euler_full_bench_size(gpu):
+    """BASELINE configs[2] shape (Eulertigs only) at |E| = 2^24: the device decomposition is a valid set of bicycles, and
+    after the unchanged cutter it gives the same number of tigs and the same cumulative length as the reference-order
+    host walk (T3; the graph has no self-mirror nodes, so the invariance note of SURVEY 8a applies exactly)."""
     from matchtigs_amd import api, synth
 
-    bg = synth.g_csr(5_592_405, seed=1, k=31)
+    k = 31
+    bg = synth.g_csr(5_592_405, seed=1, k=k, self_mirror_frac=0.0)
     G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
-    G.make_eulerian(0, bg.k)
+    G.make_eulerian(0, k)
     limits, edges = G.euler_cycles_device_np()
-    check_bicycles(G.export(), limits, edges)
+    ex = G.export()
+    check_bicycles(ex, limits, edges)
+    G.reset()
+    lim_h, ed_h = api.EulertigAlgorithm.compute_tigs_np(G, api.EulertigAlgorithmConfiguration(k))
+    w_h = G.export()["edge_weight"]
+    G.reset()
+    lim_d, ed_d = api.EulertigAlgorithm.compute_tigs_np(G, api.EulertigAlgorithmConfiguration(k, euler_mode=api.EulerMode.Device))
+    w_d = G.export()["edge_weight"]
+    assert len(lim_d) == len(lim_h)                                                  # T3: #tigs
+    assert int(w_d[ed_d].sum()) + (k - 1) * len(lim_d) == int(w_h[ed_h].sum()) + (k - 1) * len(lim_h)  # T3: cumulative length
+    n_orig = bg.n_edges
+    for lim, ed in ((lim_h, ed_h), (lim_d, ed_d)):
+        orig = ed[ed < n_orig]
+        assert len(orig) == n_orig // 2 and len(np.unique(orig >> 1)) == n_orig // 2   # every unitig exactly once
 
 
 def test_device_euler_is_reproducible(gpu):

@@ -44,12 +44,12 @@ def _oracle(oracle, bg):
     return oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
 
 
-def _gpu_candidates(bg, preset=0, lo=None, hi=None):
+def _gpu_candidates(bg, plan=0, lo=None, hi=None):
     from matchtigs_amd import api, torch_glue
 
     G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     dev = api.DeviceGraph(G, bg.k)
-    dev.set_preset(preset)
+    dev.set_plan(plan)
     S = dev.classify(torch_glue.current_stream_ptr())
     lo = 0 if lo is None else lo
     hi = S if hi is None else hi
@@ -74,11 +74,11 @@ def test_classification_matches_oracle(gpu, oracle, idx):
     assert np.array_equal(li, o_live), name
 
 
-@pytest.mark.parametrize("preset", [0, 1, 2, 3, 4, 5, 6, 9])  # lane kernels: 0 hash/LDS, 1/2/5/6 register tables, 3 LDS scan, 9 table-free enumeration; 4 = cooperative only
+@pytest.mark.parametrize("plan", [0, 1])  # 0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only
 @pytest.mark.parametrize("idx", range(5))
-def test_t1_candidate_lists(gpu, oracle, idx, preset):
+def test_t1_candidate_lists(gpu, oracle, idx, plan):
     name, bg = graphs()[idx]
-    G, dev, S, start, count, pool = _gpu_candidates(bg, preset)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
     assert S == len(o_on)
     assert np.array_equal(count.astype(np.uint64), np.diff(off)), name
@@ -139,17 +139,15 @@ def test_t2_t3_t4_pairs_and_tigs(gpu, oracle, idx):
     assert (ex["edge_weight"][matched] >= 1).all()
 
 
-@pytest.mark.parametrize("preset", [0, 5, 9])
-def test_overflow_levels_big_balls(gpu, oracle, preset):
-    """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 tables: the larger levels must agree
-    (preset 9 = the default plan: table-free enumeration level; preset 5 = register-table lane level that hands its search state
-    to the first cooperative level)."""
+@pytest.mark.parametrize("plan", [0, 1])
+def test_overflow_levels_big_balls(gpu, oracle, plan):
+    """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 budgets: the larger levels must agree."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01)
-    G, dev, S, start, count, pool = _gpu_candidates(bg, preset)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
+    assert len(dev.last_sssp_levels()) > 1, "test graph should overflow level 0"
     cnt = dev.sssp_count(0, S)
-    assert cnt["overflow_sources"] > 0, "test graph should overflow level 0"
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
     assert np.array_equal(count.astype(np.uint64), np.diff(off))
     got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])
@@ -157,17 +155,18 @@ def test_overflow_levels_big_balls(gpu, oracle, preset):
     assert cnt["settled_nodes"] == st["settled_nodes"] and cnt["relaxed_edges"] == st["relaxed_edges"]
 
 
-@pytest.mark.parametrize("preset", [0, 5, 9])
-def test_deepest_levels_huge_balls(gpu, oracle, preset):
+@pytest.mark.parametrize("plan", [0, 1])
+def test_deepest_levels_huge_balls(gpu, oracle, plan):
     """Balls above 16384 nodes only fit the last level (table in a global workspace): a unit-weight graph whose
     (k-1)-balls cover most of its 36000 nodes, on a slice of the sources (the oracle would need minutes for all)."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(18000, seed=21, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.0)
     lo, hi = 100, 148
-    G, dev, S, start, count, pool = _gpu_candidates(bg, preset, lo, hi)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan, lo, hi)
     levels = dev.last_sssp_levels()
-    assert len(levels) == (5 if preset == 9 else 6), levels   # lane + every cooperative level (the enumeration plan skips the first) down to the global-workspace one
+    assert len(levels) == 5, levels   # level 0 + every later cooperative level down to the global-workspace one
+    assert levels[-1]["kernel"].endswith(",global>")
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k, lo, hi)
     assert st["settled_nodes"] > 16384 * 8   # the balls really are that large
     assert np.array_equal(count.astype(np.uint64), np.diff(off)[lo:hi])
@@ -175,15 +174,15 @@ def test_deepest_levels_huge_balls(gpu, oracle, preset):
     assert np.array_equal(got, keys)
 
 
-@pytest.mark.parametrize("preset", [0, 5, 9])
-def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, preset):
+@pytest.mark.parametrize("plan", [0, 1])
+def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, plan):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
     from matchtigs_amd import synth
 
     bg = synth.g_csr(2000, seed=4, k=15, mean_out_degree=5.0, mean_weight=4.0, max_degree=9)
     deg = np.bincount(bg.edge_from, minlength=bg.n_nodes)
     assert deg.max() > 4
-    G, dev, S, start, count, pool = _gpu_candidates(bg, preset)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
     o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
     assert np.array_equal(count.astype(np.uint64), np.diff(off))
     got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])

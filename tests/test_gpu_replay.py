@@ -11,14 +11,14 @@ def _pairs_equal(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in ("out", "in", "dist"))
 
 
-def _run(bg, preset=None):
+def _run(bg, plan=None):
     import torch  # noqa: F401
     from matchtigs_amd import api, torch_glue
 
     G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     dev = api.DeviceGraph(G, bg.k)
-    if preset is not None:
-        dev.set_preset(preset)
+    if plan is not None:
+        dev.set_plan(plan)
     S = dev.classify(torch_glue.current_stream_ptr())
     bufs = torch_glue.run_sssp(dev, 0, S)
     gpu_pairs = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(),

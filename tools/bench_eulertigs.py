@@ -18,12 +18,11 @@ bg = synth.g_csr(int((1 << args.log2_edges) / 1.5 / 2), seed=1, k=args.k)
 G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
 L = api._lib.load()
 results = {}
-for mode, name in ((0, "host"), (1, "device")):
-    api.set_euler_mode(mode)
+for mode, name in ((api.EulerMode.HostReferenceOrder, "host"), (api.EulerMode.Device, "device")):
     times, phases = [], []
     for it in range(args.steps + 1):
         t0 = time.perf_counter()
-        lim, ed = api._take_walks_np(L, L.mtg_compute_eulertigs(G.handle, args.k))
+        lim, ed = api.EulertigAlgorithm.compute_tigs_np(G, api.EulertigAlgorithmConfiguration(args.k, euler_mode=mode))
         t1 = time.perf_counter()
         if it:  # first iteration = warm-up
             times.append(t1 - t0)
@@ -38,5 +37,4 @@ for mode, name in ((0, "host"), (1, "device")):
                       "cumulative_length": cum,
                       "phases_s": {k: round(float(np.mean([p[k] for p in phases])), 4) for k in ("eulerise", "euler", "cut")},
                       "device_kernels_ms": round(api.last_euler_kernel_ms(), 3) if mode else None}), flush=True)
-api.set_euler_mode(0)
 assert results["host"] == results["device"], results   # same number of tigs and cumulative length in both modes

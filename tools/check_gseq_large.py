@@ -12,9 +12,8 @@ otigs, _ = og.compute_greedytigs(31)
 print("tigs", len(tigs), len(otigs), "fasta identical:", fa == og.fasta(otigs, ug.unitigs, 31))
 seqs = [l for l in fa.splitlines() if l and not l.startswith(">")]
 print("kmer set preserved:", synth.kmer_set_of_tigs(seqs, 31) == ug.kmers, "cum len", sum(len(s) for s in seqs), "vs unitigs", sum(len(u) for u in ug.unitigs))
-api.set_euler_mode(1)
 G2 = api.Bigraph.from_unitig_links(ug.weights, ug.links)
-t2 = api.GreedytigAlgorithm.compute_tigs(G2, api.GreedytigAlgorithmConfiguration.new(1, 31))
+t2 = api.GreedytigAlgorithm.compute_tigs(G2, api.GreedytigAlgorithmConfiguration(1, 31, euler_mode=api.EulerMode.Device))
 fa2 = api.write_walks_fasta(G2, t2, ug.unitigs, 31).decode()
 s2 = [l for l in fa2.splitlines() if l and not l.startswith(">")]
 print("device euler: tigs", len(t2), "kmer set preserved:", synth.kmer_set_of_tigs(s2, 31) == ug.kmers, "cum len", sum(len(s) for s in s2))
