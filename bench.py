@@ -35,16 +35,32 @@ def algorithmic_bytes(stats: dict) -> int:
     return 5 * stats["relaxed_edges"] + 12 * stats["settled_nodes"] + 12 * stats["emitted"]
 
 
+def workload_key(args, world: int) -> str:
+    if args.workload == "g_seq":
+        return f"g_seq:length={args.genome_length}:k={args.k}:seed={args.seed}:plan={args.plan}:gpus={world}"
+    return f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:plan={args.plan}:gpus={world}"
+
+
 def traffic_bytes(args, world: int):
-    """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement for exactly this workload, else null."""
+    """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement (separate rocprofv3 --pmc passes of this
+    very command, profiles/traffic.json) for exactly this workload, else null."""
     if args.traffic_bytes is not None:
         return args.traffic_bytes
-    preset = 9 if args.preset < 0 else args.preset
-    key = f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:preset={preset}:gpus={world}"
     try:
-        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key, {}).get("traffic_bytes")
+        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(workload_key(args, world), {}).get("traffic_bytes")
     except (OSError, ValueError):
         return None
+
+
+def size_label(log2_edges: int) -> str:
+    """BASELINE.json config the G-csr size stands in for (real genomes are not shippable)."""
+    if log2_edges <= 21:
+        return "E. coli-like"
+    if log2_edges <= 25:
+        return "C. elegans-like"
+    if log2_edges <= 29:
+        return "human-like"
+    return "human-like (full) / pangenome-like"
 
 
 def main():
@@ -52,10 +68,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2-edges", type=int, default=24, help="|E| ~ 2^x directed unitig edges per GPU-equivalent")
+    ap.add_argument("--workload", choices=["g_csr", "g_seq"], default="g_csr",
+                    help="g_csr = random bidirected unitig graph of 2^x edges (SURVEY 8d; the default, human-like at 2^27); "
+                         "g_seq = REAL compacted de Bruijn graph of a random genome with haplotype bubbles (--genome-length)")
+    ap.add_argument("--log2-edges", type=int, default=27, help="G-csr: |E| ~ 2^x directed unitig edges (whole graph)")
+    ap.add_argument("--genome-length", type=int, default=4_600_000, help="G-seq: genome length (4 haplotypes, 2 %% substitutions)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--preset", type=int, default=-1, help="SSSP kernel geometry preset (default: library default)")
+    ap.add_argument("--plan", type=int, default=0, help="SSSP level plan: 0 = default (enumeration level + cascade), 1 = cascade only")
+    ap.add_argument("--euler-device-steps", type=int, default=1,
+                    help="untimed extra steps in device Euler mode after the timed region, reported as euler_device_ms_per_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
@@ -72,8 +94,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the matchtigs_amd hot path has no CPU fallback")
     if args.single_device:
@@ -88,15 +109,24 @@ def main():
 
     k = args.k
     # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned
-    n_binodes = int((1 << args.log2_edges) / 1.5 / 2)
     t_gen = time.perf_counter()
-    bg = synth.g_csr(n_binodes, seed=args.seed, k=k)
-    graph = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    if args.workload == "g_seq":
+        ua = synth.g_seq_arrays(args.genome_length, seed=args.seed, k=k, haplotypes=4, sub_rate=0.02)
+        graph = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
+        ex = graph.export()
+        bg = synth.Bigraph(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"], k)
+        workload = (f"G-seq REAL compacted de Bruijn graph: random genome L={args.genome_length}, 4 haplotypes, 2% substitutions, "
+                    f"k={k}, {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers (clib.rs graph construction), seed={args.seed}")
+        del ua, ex
+    else:
+        bg = synth.g_csr(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k)
+        graph = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        workload = (f"G-csr random bidirected de Bruijn-like unitig graph ({size_label(args.log2_edges)}, 2^{args.log2_edges} nominal "
+                    f"edges), k={k}, seed={args.seed}")
+    t_graph = time.perf_counter() - t_gen
     dev = api.DeviceGraph(graph, k, local_rank)  # H2D: inputs resident in HBM before any timed region
-    if args.preset >= 0:
-        dev.set_preset(args.preset)
-    if args.euler == "device":
-        api.set_euler_mode(1, local_rank)
+    dev.set_plan(args.plan)
+    euler_mode = api.EulerMode.Device if args.euler == "device" else api.EulerMode.HostReferenceOrder
     t_gen = time.perf_counter() - t_gen
     stream = torch_glue.current_stream_ptr()
 
@@ -119,6 +149,8 @@ def main():
         on0, _, _ = dev.classify_download(stream)
         outdeg = np.bincount(bg.edge_from, minlength=bg.n_nodes)
         ranges_by_work = mdist.partition_sources_by_work(1 + outdeg[on0[:S0]], world)
+
+    euler_mode_now = [euler_mode]
 
     def step(record: bool):
         nonlocal bufs
@@ -160,12 +192,12 @@ def main():
                 result_info["replay_rounds"] = dev.last_replay_rounds()
             t5 = time.perf_counter()
             ph["replay"] = t5 - t4
-            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k)
+            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, euler_mode_now[0], local_rank)
             t6 = time.perf_counter()
             ph["eulerise_euler_cut"] = t6 - t5
             hp = api.last_phase_seconds()
             ph["host_eulerise"], ph["host_euler"], ph["host_cut"] = hp["eulerise"], hp["euler"], hp["cut"]
-            if args.euler == "device":
+            if euler_mode_now[0] == api.EulerMode.Device:
                 ph["euler_device_kernels"] = api.last_euler_kernel_ms() * 1e-3
             result_info.update(S=int(S), pairs=int(len(pairs)), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
                                candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
@@ -188,6 +220,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
+
+    # ---- secondary figure: the same step with the parallel Euler decomposition on the GPU (untimed region) ----
+    euler_device_ms = None
+    if args.euler == "host" and args.euler_device_steps > 0:
+        euler_mode_now[0] = api.EulerMode.Device
+        step(False)
+        sync_barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.euler_device_steps):
+            step(False)
+        sync_barrier()
+        euler_device_ms = (time.perf_counter() - t0) / args.euler_device_steps * 1e3
+        euler_mode_now[0] = euler_mode
 
     # ---- units of work (untimed counting kernel over this rank's block) ----
     S = dev.n_sources
@@ -227,22 +272,25 @@ def main():
         }
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = run_cpu_baseline(bg, k, args.cpu_baseline_seconds)
+            cpu_baseline = run_cpu_baseline(bg, k, args.cpu_baseline_seconds, dev, stream, total_stats["relaxed_edges"])
+            gpu_stage_s = sum(phases_acc.get(kk, 0.0) for kk in ("classify", "sssp", "allgather", "download", "replay")) / max(args.steps, 1)
+            cpu_baseline["gpu_same_stage_edges_per_s"] = round(total_stats["relaxed_edges"] / max(gpu_stage_s, 1e-9), 1)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {
             "metric": "greedy-matchtigs SSSP edges/s (whole hot-path step: classify+SSSP+claim+Euler+cut)",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "wall_clock_s": round(ms_per_step / 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
-            "config": {"workload": f"G-csr random bidirected de Bruijn-like unitig graph (C. elegans-like), k={k}, "
-                                   f"|V|={bg.n_nodes}, |E|={bg.n_edges}, seed={args.seed}; sources block-partitioned over ranks",
+            "config": {"workload": f"{workload}; |V|={bg.n_nodes}, |E|={bg.n_edges}; sources block-partitioned over ranks",
                        "V": bg.n_nodes, "E": bg.n_edges, "k": k, "sources": result_info.get("S"),
                        "pairs": result_info.get("pairs"), "tigs": result_info.get("tigs"),
                        "candidates": result_info.get("candidates"), "parallelism": f"sources/{world}"},
             "units_per_step": total_stats,
             "phases_ms": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in phases_acc.items()},
             "euler_mode": args.euler,
-            "setup_s": round(t_gen, 2),
+            "euler_device_ms_per_step": None if euler_device_ms is None else round(euler_device_ms, 3),
+            "level0_finish_rate": (round(1.0 - kernels[1]["sources"] / max(kernels[0]["sources"], 1), 6) if len(kernels) > 1 else 1.0) if kernels else None,
+            "setup_s": round(t_gen, 2), "setup_graph_s": round(t_graph, 2),
             "device_graph_bytes": dev.graph_bytes(),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
@@ -253,10 +301,13 @@ def main():
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(bg, k: int, budget_s: float) -> dict:
+def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_all: int) -> dict:
     """Oracle (C restatement of the reference's 1-thread CPU path) timed on the same workload, bounded to ~budget_s:
     the WHOLE path (claim loop + Eulerisation + Euler decomposition + cut) when the graph is small enough to finish in
-    the budget (it is for the default workload), else the Dijkstra+claim phase on a prefix of the sources."""
+    the budget, else the Dijkstra + claim phase on a prefix of the sources. `value` is in the unit of the headline value:
+    FULL-BALL SSSP edges of the sampled sources (counted by the GPU's counting kernel -- the work the sample stands for)
+    per CPU second, so value(GPU) / value(CPU) is a ratio of seconds for the same work. The CPU's own truncated searches
+    examine fewer edges (reference semantics: stop after demand + 1 hits); that figure is reported beside it."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
 
@@ -270,26 +321,31 @@ def run_cpu_baseline(bg, k: int, budget_s: float) -> dict:
         stages, st = og.whole_path_timed(k)
         total = sum(stages.values())
         return {
-            "value": round(st["relaxed_edges"] / total, 1), "unit": "edges/s", "cores": 1, "kind": "port",
+            "value": round(full_ball_edges_all / total, 1), "unit": "edges/s", "cores": 1, "kind": "port",
             "sample": f"the same graph, whole path on 1 core (oracle/mtg_oracle.c: reference-style truncated Dijkstra + claim "
-                      f"loop, Eulerisation, literal Hierholzer, cut), {total:.1f} s; edges = the {st['relaxed_edges']} out-edges the "
-                      f"truncated CPU search examines (the GPU explores full balls: see units_per_step)",
+                      f"loop, Eulerisation, literal Hierholzer, cut), {total:.1f} s; value = the graph's {full_ball_edges_all} "
+                      f"full-ball SSSP edges (the unit of the headline value) / those seconds",
             "seconds": round(total, 2), "stage_seconds": {kk: round(v, 3) for kk, v in stages.items()},
-            "dijkstra_phase_edges_per_s": round(st["relaxed_edges"] / stages["dijkstra_claim"], 1),
-            "relaxed_edges": st["relaxed_edges"], "settled_nodes": st["settled_nodes"], "queries": st["queries"],
-            "pairs": st["pairs"], "tigs": st["tigs"],
+            "cpu_examined_edges": st["relaxed_edges"],
+            "cpu_examined_edges_per_s_dijkstra_phase": round(st["relaxed_edges"] / stages["dijkstra_claim"], 1),
+            "settled_nodes": st["settled_nodes"], "queries": st["queries"], "pairs": st["pairs"], "tigs": st["tigs"],
             "multi_thread": run_cpu_baseline_mt(bg, k, stages),
         }
     n = int(min(n_sources, max(50000, 50000 * budget_s / dt)))
     t0 = time.perf_counter()
     _, st = og.greedy_pairs_np(k, n)
     dt = time.perf_counter() - t0
+    full_ball_prefix = dev.sssp_count(0, n, stream)["relaxed_edges"]
     return {
-        "value": round(st["relaxed_edges"] / dt, 1), "unit": "edges/s", "cores": 1, "kind": "port",
-        "sample": f"first {n} of {n_sources} sources of the same graph, reference-style truncated Dijkstra + claim loop only "
-                  f"(oracle/mtg_oracle.c og_greedy_pairs_prefix), {dt:.1f} s",
-        "sources_per_s": round(n / dt, 1), "relaxed_edges": st["relaxed_edges"], "settled_nodes": st["settled_nodes"],
-        "queries": st["queries"], "seconds": round(dt, 2),
+        "value": round(full_ball_prefix / dt, 1), "unit": "edges/s", "cores": 1, "kind": "port",
+        "sample": f"Dijkstra + claim stage only (greedytigs/mod.rs:276-526, oracle og_greedy_pairs_prefix) on the first {n} of "
+                  f"{n_sources} sources of the same graph, {dt:.1f} s on 1 core; value = the {full_ball_prefix} full-ball SSSP edges "
+                  f"of those sources / those seconds; compare with gpu_same_stage_edges_per_s (the GPU's classify + SSSP + claim "
+                  f"stages over ALL sources), not with the whole-step headline value",
+        "stage": "dijkstra_claim", "sources": n, "sources_per_s": round(n / dt, 1), "seconds": round(dt, 2),
+        "whole_stage_seconds_estimate": round(dt * n_sources / n, 1),
+        "cpu_examined_edges": st["relaxed_edges"], "cpu_examined_edges_per_s": round(st["relaxed_edges"] / dt, 1),
+        "settled_nodes": st["settled_nodes"], "queries": st["queries"],
     }
 
 
@@ -306,7 +362,7 @@ def run_cpu_baseline_mt(bg, k: int, stages_1core: dict) -> dict:
     dt = time.perf_counter() - t0
     rest = sum(v for kk, v in stages_1core.items() if kk != "dijkstra_claim")
     return {"cores": cores, "dijkstra_claim_seconds": round(dt, 3), "whole_path_seconds_estimate": round(dt + rest, 2),
-            "dijkstra_phase_edges_per_s": round(st["relaxed_edges"] / dt, 1), "pairs": int(len(pairs))}
+            "cpu_examined_edges_per_s_dijkstra_phase": round(st["relaxed_edges"] / dt, 1), "pairs": int(len(pairs))}
 
 
 if __name__ == "__main__":

@@ -115,6 +115,8 @@ mtg_graph *mtg_graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64
 /* The clib.rs builder as three calls (matchtigs.h wraps exactly these). */
 mtg_graph *mtg_graph_builder_new(uint64_t unitig_amount);
 void mtg_graph_builder_merge(mtg_graph *g, uint64_t unitig_a, int strand_a, uint64_t unitig_b, int strand_b);
+/* n links at once: row i = (unitig_a, strand_a, unitig_b, strand_b) as int64; the same unions in the same order as n merges. */
+void mtg_graph_builder_merge_links(mtg_graph *g, uint64_t n_links, const int64_t *links);
 void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights);
 void mtg_graph_free(mtg_graph *g);
 /* Removes every dummy edge again (undoes what compute_tigs appended), restoring the adjacency order of the
@@ -212,6 +214,8 @@ uint64_t mtg_walks_total_edges(const mtg_walks *w);
 /* limits[i] = exclusive end of walk i in edges[] (edge ids into the mutated graph). */
 void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges);
 void mtg_walks_free(mtg_walks *w);
+/* Walks from caller arrays (copied), e.g. externally computed Euler cycles for mtg_cut_cycles. */
+mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const uint32_t *edges);
 
 /* clib.rs:393-407 flattening into caller arrays sized as clib.rs:332-348. Returns #tigs. */
 uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out,

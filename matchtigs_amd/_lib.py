@@ -113,6 +113,7 @@ def load():
         "mtg_graph_from_edges": (vp, [u64, vp, u64, vp, vp, vp]),
         "mtg_graph_builder_new": (vp, [u64]),
         "mtg_graph_builder_merge": (None, [vp, u64, C.c_int, u64, C.c_int]),
+        "mtg_graph_builder_merge_links": (None, [vp, u64, vp]),
         "mtg_graph_builder_build": (None, [vp, vp]),
         "mtg_graph_free": (None, [vp]),
         "mtg_graph_reset": (None, [vp]),
@@ -152,6 +153,7 @@ def load():
         "mtg_walks_total_edges": (u64, [vp]),
         "mtg_walks_export": (None, [vp, vp, vp]),
         "mtg_walks_free": (None, [vp]),
+        "mtg_walks_from_arrays": (vp, [u64, vp, vp]),
         "mtg_flatten_clib": (u64, [vp, vp, vp, vp, vp]),
         "mtg_write_walks_fasta": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, P(vp)]),
         "mtg_read_bcalm2": (vp, [C.c_char_p, u64, P(vp)]),

@@ -188,6 +188,19 @@ class Bigraph:
         L.mtg_graph_builder_build(h, _ptr(w))
         return cls(h)
 
+    @classmethod
+    def from_unitig_links_arrays(cls, unitig_weights, links) -> "Bigraph":
+        """The clib.rs builder over an int array [n, 4] of links (one call instead of one per link)."""
+        L = _lib.load()
+        w = np.ascontiguousarray(unitig_weights, dtype=np.uint64)
+        lk = np.ascontiguousarray(links, dtype=np.int64)
+        if lk.ndim != 2 or (len(lk) and lk.shape[1] != 4):
+            raise ValueError("links must have shape [n, 4]")
+        h = L.mtg_graph_builder_new(len(w))
+        L.mtg_graph_builder_merge_links(h, len(lk), _ptr(lk) if len(lk) else None)
+        L.mtg_graph_builder_build(h, _ptr(w))
+        return cls(h)
+
     @property
     def handle(self) -> int:
         return self._h
@@ -255,6 +268,16 @@ class Bigraph:
     def euler_cycles_device_np(self, device_id: int = 0):
         """(limits, edges) arrays of the GPU Euler bicycles."""
         return _take_walks_np(self._L, self._L.mtg_euler_cycles_device(self._h, device_id))
+
+    def cut_cycles(self, cycles: list[list[int]], k: int) -> list[list[int]]:
+        """greedytigs/mod.rs:726-789 on given closed walks (edge ids into this graph)."""
+        ed = np.fromiter((e for c in cycles for e in c), dtype=np.uint32)
+        lim = np.cumsum([len(c) for c in cycles], dtype=np.uint64) if len(cycles) else np.zeros(0, np.uint64)
+        w = self._L.mtg_walks_from_arrays(len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None)
+        try:
+            return _take_walks(self._L, self._L.mtg_cut_cycles(self._h, w, k))
+        finally:
+            self._L.mtg_walks_free(w)
 
     def finish_greedytigs(self, pairs: np.ndarray, k: int) -> list[list[int]]:
         p = np.ascontiguousarray(pairs)

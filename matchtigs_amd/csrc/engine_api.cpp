@@ -80,6 +80,13 @@ void mtg_graph_builder_merge(mtg_graph *g, uint64_t ua, int sa, uint64_t ub, int
     if (!g) MTG_DIE("mtg_graph_builder_merge: null graph");
     builder_merge(&g->g, ua, sa != 0, ub, sb != 0);
 }
+void mtg_graph_builder_merge_links(mtg_graph *g, uint64_t n_links, const int64_t *links) {
+    if (!g || (n_links && !links)) MTG_DIE("mtg_graph_builder_merge_links: null argument");
+    for (uint64_t i = 0; i < n_links; i++) {
+        if (links[4 * i] < 0 || links[4 * i + 2] < 0) MTG_DIE("mtg_graph_builder_merge_links: negative unitig id in row %llu", (unsigned long long)i);
+        builder_merge(&g->g, (uint64_t)links[4 * i], links[4 * i + 1] != 0, (uint64_t)links[4 * i + 2], links[4 * i + 3] != 0);
+    }
+}
 void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights) {
     if (!g) MTG_DIE("mtg_graph_builder_build: null graph");
     builder_build(&g->g, unitig_weights);
@@ -240,6 +247,18 @@ void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges) {
     if (edges && !w->w.edges.empty()) std::memcpy(edges, w->w.edges.data(), w->w.edges.size() * 4);
 }
 void mtg_walks_free(mtg_walks *w) { delete w; }
+mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const uint32_t *edges) {
+    if (n_walks && (!limits || !edges)) MTG_DIE("mtg_walks_from_arrays: null argument");
+    mtg_walks *w = new mtg_walks();
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < n_walks; i++) {
+        if (limits[i] < prev) MTG_DIE("mtg_walks_from_arrays: limits must be non-decreasing");
+        prev = limits[i];
+    }
+    w->w.limits.assign(limits, limits + n_walks);
+    w->w.edges.assign(edges, edges + prev);
+    return w;
+}
 
 uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out, uint64_t *tigs_insert_out,
                           uint64_t *tigs_out_limits) {

@@ -216,3 +216,219 @@ def kmer_set_of_tigs(tigs: list[str], k: int) -> set[str]:
         for i in range(len(t) - k + 1):
             out.add(canonical(t[i:i + k]))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# G-seq at scale: the same construction as g_seq, vectorised (2-bit packed k-mers in uint64, k <= 31)
+# --------------------------------------------------------------------------------------
+@dataclass
+class UnitigArrays:
+    """Node-centric compacted dBG in the clib.rs input form, as flat arrays (same content as UnitigGraph)."""
+
+    k: int
+    seq: np.ndarray      # uint8 ASCII, concatenated forward sequences
+    off: np.ndarray      # uint64 [U + 1]
+    links: np.ndarray    # int64 [n_links, 4]: (unitig_a, strand_a, unitig_b, strand_b), in g_seq's link order
+    kmers: np.ndarray    # sorted canonical k-mer codes (2 bits per base, A < C < G < T)
+
+    @property
+    def n_unitigs(self) -> int:
+        return int(len(self.off) - 1)
+
+    @property
+    def weights(self) -> np.ndarray:
+        return (np.diff(self.off.astype(np.int64)) + 1 - self.k).astype(np.uint64)
+
+    def unitig_list(self) -> list[str]:
+        s = self.seq.tobytes().decode()
+        o = self.off.astype(np.int64)
+        return [s[o[i]:o[i + 1]] for i in range(self.n_unitigs)]
+
+    def bcalm2_text(self) -> bytes:
+        """BCALM2-style unitig FASTA (`>id LN:i:.. L:<s>:<id>:<s>`), the `--bcalm-in` input of the reference."""
+        o = self.off.astype(np.int64)
+        lk = self.links
+        order = np.argsort(lk[:, 0], kind="stable") if len(lk) else np.zeros(0, np.int64)
+        first = np.searchsorted(lk[order, 0], np.arange(self.n_unitigs + 1)) if len(lk) else np.zeros(self.n_unitigs + 1, np.int64)
+        s = self.seq.tobytes().decode()
+        out = []
+        for u in range(self.n_unitigs):
+            tags = "".join(f" L:{'+' if lk[j, 1] else '-'}:{int(lk[j, 2])}:{'+' if lk[j, 3] else '-'}" for j in order[first[u]:first[u + 1]])
+            out.append(f">{u} LN:i:{o[u + 1] - o[u]}{tags}\n{s[o[u]:o[u + 1]]}\n")
+        return "".join(out).encode()
+
+
+def _kmer_codes(b: np.ndarray, k: int):
+    """forward and reverse-complement codes of every k-mer of the base array b (values 0..3)."""
+    n = len(b) - k + 1
+    fwd = np.zeros(n, np.uint64)
+    rc = np.zeros(n, np.uint64)
+    b64 = b.astype(np.uint64)
+    for j in range(k):
+        x = b64[j:j + n]
+        fwd |= x << np.uint64(2 * (k - 1 - j))
+        rc |= (np.uint64(3) - x) << np.uint64(2 * j)
+    return fwd, rc
+
+
+def kmer_codes_of_sequences(seq: np.ndarray, off: np.ndarray, k: int) -> np.ndarray:
+    """Sorted distinct canonical k-mer codes of ASCII sequences (concatenated `seq`, offsets `off`)."""
+    lut = np.full(256, 255, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    b = lut[seq]
+    if (b == 255).any():
+        raise ValueError("non-ACGT character")
+    fwd, rc = _kmer_codes(b, k)
+    o = off.astype(np.int64)
+    lens = np.diff(o)
+    valid = np.zeros(len(fwd) + 1, np.int64)      # k-mers that do not straddle a sequence boundary
+    np.add.at(valid, o[:-1], 1)
+    np.add.at(valid, np.maximum(o[1:] - k + 1, o[:-1]), -1)
+    ok = np.cumsum(valid[: len(fwd)]) > 0
+    ok &= np.repeat(lens >= k, lens)[: len(fwd)] if len(lens) else ok
+    return np.unique(np.minimum(fwd, rc)[ok])
+
+
+def g_seq_arrays(length: int, seed: int = 1, k: int = 31, haplotypes: int = 4, sub_rate: float = 0.02) -> UnitigArrays:
+    """g_seq for large genomes: identical unitigs, unitig order, orientations and link order (checked against g_seq in the
+    tests), built with array operations. Raises on the degenerate shapes g_seq handles by its visit order (a unitig that
+    is a cycle or runs into its own reverse complement); they do not occur in random genomes of useful k."""
+    if k > 31 or k % 2 == 0:
+        raise ValueError("k must be odd and <= 31")
+    g = (splitmix64(seed, length, 10) % np.uint64(4)).astype(np.int64)
+    canon_all = []
+    for h in range(haplotypes):
+        if h == 0:
+            gh = g
+        else:
+            mut = _uniform01(splitmix64(seed, length, 20 + h)) < sub_rate
+            shift = (splitmix64(seed, length, 40 + h) % np.uint64(3)).astype(np.int64) + 1
+            gh = np.where(mut, (g + shift) % 4, g)
+        fwd, rc = _kmer_codes(gh.astype(np.uint8), k)
+        canon_all.append(np.minimum(fwd, rc))
+        del fwd, rc
+    K = np.unique(np.concatenate(canon_all))
+    del canon_all
+    N = len(K)
+    mask = np.uint64((1 << (2 * k)) - 1)
+
+    def revcomp_code(c):  # reverse the 2-bit groups of the complemented word, drop the 64 - 2k pad bits
+        x = ~c
+        for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+            mm = np.uint64(m)
+            x = ((x >> np.uint64(sh)) & mm) | ((x & mm) << np.uint64(sh))
+        x = (x >> np.uint64(32)) | (x << np.uint64(32))
+        return x >> np.uint64(64 - 2 * k)
+
+    code = np.empty(2 * N, np.uint64)        # oriented k-mer x = 2 * index + (0 canonical orientation, 1 reverse complement)
+    code[0::2] = K
+    code[1::2] = revcomp_code(K)
+    # successors by a merge join: x -> y iff the (k-1)-suffix of x is the (k-1)-prefix of y
+    s_order = np.argsort(code)            # oriented k-mers by code = by (prefix, last base)
+    S = code[s_order]
+    pref = S >> np.uint64(2)
+    first = np.r_[True, pref[1:] != pref[:-1]]
+    g_start = np.nonzero(first)[0]
+    g_pref = pref[g_start]
+    g_end = np.r_[g_start[1:], len(S)]
+    suf = code & np.uint64((1 << (2 * (k - 1))) - 1)
+    a_order = np.argsort(suf)
+    pos = np.searchsorted(g_pref, suf[a_order])           # ascending needles
+    pos_c = np.minimum(pos, len(g_pref) - 1)
+    hit = g_pref[pos_c] == suf[a_order]
+    succ = np.full((2 * N, 4), -1, np.int64)              # oriented successor by appended base
+    xs = a_order[hit]
+    gs = pos_c[hit]
+    for t in range(4):
+        idx = g_start[gs] + t
+        ok = idx < g_end[gs]
+        ii = idx[ok]
+        succ[xs[ok], (S[ii] & np.uint64(3)).astype(np.int64)] = s_order[ii]
+    del S, pref, first, suf, a_order, pos, pos_c, hit, xs, gs
+    out_deg = (succ >= 0).sum(axis=1)
+    in_deg = out_deg.reshape(N, 2)[:, ::-1].reshape(2 * N)   # predecessors of x = reverse complements of the successors of x ^ 1
+    only = np.where(out_deg == 1, succ.max(axis=1), -1)
+    internal = (only >= 0) & (in_deg[np.maximum(only, 0)] == 1)
+    nxt = np.where(internal, only, -1)
+    prv = np.full(2 * N, -1, np.int64)
+    prv[nxt[internal]] = np.nonzero(internal)[0]
+    if (nxt == (np.arange(2 * N) ^ 1)).any():
+        raise NotImplementedError("a unitig runs into its own reverse complement")
+    # head, position and the smallest member of every oriented path, by pointer jumping over prv
+    jump = prv.copy()
+    rank = (prv >= 0).astype(np.int64)      # invariant: rank[x] = steps from x back to jump[x]
+    mn = np.arange(2 * N)                   # invariant: mn[x] = smallest member of the path segment (jump[x], x]
+    for _ in range(64):
+        live = np.nonzero(jump >= 0)[0]
+        j = jump[live]
+        jj = jump[j]
+        upd = jj >= 0
+        if not upd.any():
+            break
+        idx = live[upd]
+        rank[idx] += rank[j[upd]]
+        mn[idx] = np.minimum(mn[idx], mn[j[upd]])
+        jump[idx] = jj[upd]
+    else:
+        raise NotImplementedError("a unitig is a cycle")
+    head = np.where(jump >= 0, jump, np.arange(2 * N))
+    is_tail = nxt < 0
+    minx = np.full(2 * N, 2 * N, np.int64)  # per head: smallest member of its path
+    minx[head[is_tail]] = np.minimum(mn[is_tail], head[is_tail])
+
+    # orientation and order as g_seq: it visits canonical k-mers ascending and spells the unitig of the first unused one in
+    # that k-mer's canonical orientation, so a unitig = the oriented path whose smallest member x = 2 * index + orientation is even
+    is_head = head == np.arange(2 * N)
+    sel_heads = np.nonzero(is_head & (minx % 2 == 0) & (minx < 2 * N))[0]
+    sel_heads = sel_heads[np.argsort(minx[sel_heads], kind="stable")]
+    U = len(sel_heads)
+    uid_of_head = np.full(2 * N, -1, np.int64)
+    uid_of_head[sel_heads] = np.arange(U)
+    uid = uid_of_head[head]                    # -1 for members of the reverse-complement paths
+    members = np.nonzero(uid >= 0)[0]
+    if len(members) != N:
+        raise NotImplementedError("a unitig runs into its own reverse complement")
+    m = np.bincount(uid[members], minlength=U)                 # k-mers per unitig
+    off = np.zeros(U + 1, np.int64)
+    off[1:] = np.cumsum(m + k - 1)
+    seq = np.zeros(int(off[-1]), np.uint8)
+    seq[off[uid[members]] + k - 1 + rank[members]] = (code[members] & np.uint64(3)).astype(np.uint8)
+    hc = code[sel_heads]
+    for t in range(k - 1):
+        seq[off[:-1] + t] = ((hc >> np.uint64(2 * (k - 1 - t))) & np.uint64(3)).astype(np.uint8)
+    ascii_seq = np.frombuffer(b"ACGT", np.uint8)[seq]
+
+    # links in g_seq's order: for unitig i ascending, strand True then False: every oriented unitig (j, sb) whose first k-mer
+    # follows the last k-mer of (i, sa), ordered by (j, True before False)
+    tails = np.empty(U, np.int64)
+    last = rank[members] == m[uid[members]] - 1
+    tails[uid[members[last]]] = members[last]
+    start_of = np.full(2 * N, -1, np.int64)
+    start_of[sel_heads] = 2 * np.arange(U)
+    start_of[tails ^ 1] = 2 * np.arange(U) + 1
+    ends = np.empty(2 * U, np.int64)
+    ends[0::2] = tails
+    ends[1::2] = sel_heads ^ 1
+    sy = succ[ends]                                              # [2U, 4]
+    so = np.where(sy >= 0, start_of[np.maximum(sy, 0)], -1)
+    if ((sy >= 0) & (so < 0)).any():
+        raise NotImplementedError("a unitig end is followed by the inside of a unitig (cycle / hairpin shapes)")
+    big = np.iinfo(np.int64).max
+    so_sorted = np.sort(np.where(so >= 0, so, big), axis=1)
+    valid = so_sorted != big
+    e_idx = np.repeat(np.arange(2 * U), 4).reshape(2 * U, 4)[valid]
+    tgt = so_sorted[valid]
+    links = np.stack([e_idx >> 1, (e_idx & 1) == 0, tgt >> 1, (tgt & 1) == 0], axis=1).astype(np.int64)
+    return UnitigArrays(k, ascii_seq, off.astype(np.uint64), links, K)
+
+
+def unitig_graph_of_arrays(ua: UnitigArrays) -> UnitigGraph:
+    """The same graph in g_seq's object form (small sizes: builds Python strings and a set)."""
+    bases = "ACGT"
+
+    def decode(c):
+        return "".join(bases[(int(c) >> (2 * (ua.k - 1 - j))) & 3] for j in range(ua.k))
+
+    return UnitigGraph(ua.k, ua.unitig_list(), [(int(a), bool(b), int(c), bool(d)) for a, b, c, d in ua.links],
+                       {decode(c) for c in ua.kmers})

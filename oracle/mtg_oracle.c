@@ -245,6 +245,11 @@ void og_builder_merge_nodes(og_builder *b, uint64_t ua, int sa, uint64_t ub, int
     uf_union(b, out_a, in_b);
     uf_union(b, mirror_in_a, mirror_out_b);
 }
+/* the same, once per row (unitig_a, strand_a, unitig_b, strand_b) of an int64 table: test convenience only */
+void og_builder_merge_nodes_many(og_builder *b, uint64_t n, const int64_t *links) {
+    for (uint64_t i = 0; i < n; i++)
+        og_builder_merge_nodes(b, (uint64_t)links[4 * i], links[4 * i + 1] != 0, (uint64_t)links[4 * i + 2], links[4 * i + 3] != 0);
+}
 static int cmp_u64(const void *a, const void *b) {
     uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
     return x < y ? -1 : x > y;

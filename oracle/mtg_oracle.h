@@ -59,7 +59,8 @@ int og_verify_edge_mirror_property(const og_graph *g);
 typedef struct og_builder og_builder;
 og_builder *og_builder_new(uint64_t unitig_amount);                         /* clib.rs:97-102 */
 void og_builder_merge_nodes(og_builder *b, uint64_t unitig_a, int strand_a,
-                            uint64_t unitig_b, int strand_b);               /* clib.rs:135-170 */
+                            uint64_t unitig_b, int strand_b);
+void og_builder_merge_nodes_many(og_builder *b, uint64_t n, const int64_t *links);               /* clib.rs:135-170 */
 og_graph *og_builder_build(og_builder *b, const uint64_t *unitig_weights);  /* clib.rs:180-259; frees b */
 
 /* ---- bigraph::algo::eulerian restatements ---- */

@@ -48,3 +48,19 @@ def product_pairs_from_oracle_lists(G, og, k):
     _, live, mult, _, _ = og.classify()
     pr = G.replay_claims(on, mult.astype(np.int32), live, off[:-1], np.diff(off).astype(np.uint32), keys)
     return pr
+
+
+def links_of_bigraph(mirror, unitigs):
+    """clib.rs input form of an abstract bigraph: one link per (unitig end, unitig start) meeting at the same node."""
+    ends, starts = {}, {}
+    for u, (a, b, _) in enumerate(unitigs):
+        starts.setdefault(a, []).append((u, True))
+        ends.setdefault(b, []).append((u, True))
+        starts.setdefault(mirror[b], []).append((u, False))   # the backwards strand runs mirror(b) -> mirror(a)
+        ends.setdefault(mirror[a], []).append((u, False))
+    links = []
+    for n in sorted(ends):
+        for (ua, sa) in ends[n]:
+            for (ub, sb) in starts.get(n, []):
+                links.append((ua, sa, ub, sb))
+    return links

@@ -76,6 +76,7 @@ def lib():
         "og_builder_new": (vp, [u64]),
         "og_builder_merge_nodes": (None, [vp, u64, C.c_int, u64, C.c_int]),
         "og_builder_build": (vp, [vp, P(u64)]),
+        "og_builder_merge_nodes_many": (None, [vp, u64, P(i64)]),
         "og_superfluous_out_biedges": (i64, [vp, u32]),
         "og_find_non_eulerian": (u32, [vp, P(u32), P(i64)]),
         "og_classify": (u32, [vp, P(u32), P(C.c_uint8), P(i64), P(u32), P(u32)]),
@@ -166,6 +167,17 @@ class OracleGraph:
         b = L.og_builder_new(len(w))
         for (ua, sa, ub, sb) in links:
             L.og_builder_merge_nodes(b, int(ua), 1 if sa else 0, int(ub), 1 if sb else 0)
+        g = L.og_builder_build(b, w.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return cls(g)
+
+    @classmethod
+    def from_unitig_links_arrays(cls, unitig_weights, links):
+        """The same builder over an int array [n, 4] of links (one call instead of one per link)."""
+        L = lib()
+        w = np.ascontiguousarray(unitig_weights, dtype=np.uint64)
+        lk = np.ascontiguousarray(links, dtype=np.int64)
+        b = L.og_builder_new(len(w))
+        L.og_builder_merge_nodes_many(b, len(lk), lk.ctypes.data_as(C.POINTER(C.c_int64)))
         g = L.og_builder_build(b, w.ctypes.data_as(C.POINTER(C.c_uint64)))
         return cls(g)
 
@@ -312,6 +324,20 @@ class OracleGraph:
         w = self.L.og_euler_cycles(self.h)
         out = _walks_to_lists(w)
         self.L.og_walks_free(w)
+        return out
+
+    def cut_cycles(self, cycles, k):
+        """og_cut_cycles on given closed walks (lists of edge ids)."""
+        limits, edges = [], []
+        for c in cycles:
+            edges.extend(c)
+            limits.append(len(edges))
+        la = (C.c_uint64 * max(len(limits), 1))(*limits)
+        ea = (C.c_uint32 * max(len(edges), 1))(*edges)
+        w = Walks(len(limits), len(edges), la, ea)
+        t = self.L.og_cut_cycles(self.h, C.byref(w), k, None)
+        out = _walks_to_lists(t)
+        self.L.og_walks_free(t)
         return out
 
     def compute_greedytigs(self, k):

@@ -10,7 +10,7 @@ import helpers
 import pyref
 
 KATS = json.loads((Path(__file__).parent / "golden" / "kats.json").read_text())
-UNITIG_KATS = [k for k in KATS if "unitigs" in k]
+UNITIG_KATS = [k for k in KATS if "unitigs" in k and "pairs" in k["expect"]]
 
 
 def test_kat_e_euleriser(oracle, product_lib):
@@ -71,3 +71,76 @@ def test_kat1_tigs(oracle, product_lib):
     G2 = helpers.product_graph(mirror, frm, to, w)
     pr = np.array([tuple(p) for p in exp["pairs"]], dtype=[("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
     assert G2.finish_greedytigs(pr, k) == tigs
+
+
+T4_KATS = [k for k in KATS if "unitigs" in k and any(x in k["expect"] for x in ("greedy_tigs", "euler_tigs"))]
+
+
+@pytest.mark.parametrize("kat", T4_KATS, ids=[k["name"] for k in T4_KATS])
+def test_kat_t4_euler_order_and_cut(kat, oracle, product_lib):
+    """T4: hand-derived Euler cycles (walk order policies of App. A.2/A.3) and tigs (rotation + cut, greedytigs/mod.rs:726-789)
+    against the oracle, the independent Python restatement and the product's host stages."""
+    from matchtigs_amd import api
+
+    k, exp = kat["k"], kat["expect"]
+    mirror, frm, to, w = helpers.unitigs_to_arrays(kat["mirror"], kat["unitigs"])
+    pairs = [tuple(p) for p in exp["pairs"]]
+    pr = np.array(pairs, dtype=[("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+    if "greedy_tigs" in exp:
+        og = helpers.oracle_graph(mirror, frm, to, w)
+        did = og.insert_pair_edges(pairs)
+        og.make_eulerian(k, did)
+        assert og.euler_cycles() == exp["greedy_euler_cycles"], "oracle cycles"
+        assert og.cut_cycles(exp["greedy_euler_cycles"], k) == exp["greedy_tigs"], "oracle cut"
+        pg = helpers.py_graph(mirror, frm, to, w)
+        pyref.make_eulerian(pg, pyref.insert_pair_edges(pg, pairs), k)
+        assert pyref.euler_cycles(pg) == exp["greedy_euler_cycles"], "pyref cycles"
+        assert pyref.cut_cycles(pg, exp["greedy_euler_cycles"], k) == exp["greedy_tigs"], "pyref cut"
+        G = helpers.product_graph(mirror, frm, to, w)
+        G.make_eulerian(G.insert_pair_edges(pr), k)
+        assert G.euler_cycles() == exp["greedy_euler_cycles"], "product cycles"
+        assert G.cut_cycles(exp["greedy_euler_cycles"], k) == exp["greedy_tigs"], "product cut"
+        G2 = helpers.product_graph(mirror, frm, to, w)
+        assert G2.finish_greedytigs(pr, k) == exp["greedy_tigs"], "product finish_greedytigs"
+    if "euler_tigs" in exp:
+        og = helpers.oracle_graph(mirror, frm, to, w)
+        og.make_eulerian(k, 0)
+        assert og.euler_cycles() == exp["euler_euler_cycles"]
+        assert helpers.oracle_graph(mirror, frm, to, w).compute_eulertigs(k) == exp["euler_tigs"]
+        assert pyref.compute_eulertigs(helpers.py_graph(mirror, frm, to, w), k) == exp["euler_tigs"]
+        G = helpers.product_graph(mirror, frm, to, w)
+        assert api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(k)) == exp["euler_tigs"]
+
+
+def test_kat_c_cutter(oracle, product_lib):
+    kat = next(k for k in KATS if k["name"].startswith("KAT-C"))
+    k, exp = kat["k"], kat["expect"]
+    mirror, frm, to, w = helpers.unitigs_to_arrays(kat["mirror"], kat["unitigs"])
+    pairs = [tuple(p) for p in kat["dummy_pairs"]]
+    og = helpers.oracle_graph(mirror, frm, to, w)
+    og.insert_pair_edges(pairs)
+    assert og.cut_cycles(kat["cycles"], k) == exp["cut_tigs"], "oracle"
+    pg = helpers.py_graph(mirror, frm, to, w)
+    pyref.insert_pair_edges(pg, pairs)
+    assert pyref.cut_cycles(pg, [list(c) for c in kat["cycles"]], k) == exp["cut_tigs"], "pyref"
+    G = helpers.product_graph(mirror, frm, to, w)
+    G.insert_pair_edges(np.array(pairs, dtype=[("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)]))
+    assert G.cut_cycles(kat["cycles"], k) == exp["cut_tigs"], "product"
+
+
+CLIB_EULER_KATS = [k for k in KATS if "clib" in k.get("expect", {}) and k["expect"]["pairs"] == []]
+
+
+@pytest.mark.parametrize("kat", CLIB_EULER_KATS, ids=[k["name"] for k in CLIB_EULER_KATS])
+def test_kat_clib_route_eulertigs(kat, oracle, product_lib):
+    """The clib.rs route (initialise_graph -> merge_nodes -> build_graph -> compute_tigs(3)) on the balanced KATs: the
+    flattened output arrays (signed unitig ids, inserts, exclusive limits; clib.rs:393-407) typed in by hand."""
+    from matchtigs_amd import api
+
+    exp = kat["expect"]["clib"]
+    uw = np.array([u[2] for u in kat["unitigs"]], dtype=np.uint64)
+    links = helpers.links_of_bigraph(kat["mirror"], kat["unitigs"])
+    n, eo, io, lo = api.clib_compute_tigs(uw, links, 3, 1, kat["k"])
+    assert (n, eo.tolist(), io.tolist(), lo.tolist()) == (len(exp["tigs_out_limits"]), exp["tigs_edge_out"], exp["tigs_insert_out"], exp["tigs_out_limits"])
+    n2, eo2, io2, lo2 = oracle.OracleGraph.from_unitig_links(uw, links).clib_compute_tigs(3, kat["k"])
+    assert (n2, eo2.tolist(), io2.tolist(), lo2.tolist()) == (n, eo.tolist(), io.tolist(), lo.tolist())

@@ -28,3 +28,38 @@ def test_kmer_set_preserved_and_fasta_matches_pyref(seed, k, length, oracle):
     assert unitig_len >= sum(map(len, eseqs)) >= sum(map(len, seqs))
     # an Euler tiling repeats nothing: total k-mers in eulertigs == distinct k-mers
     assert sum(len(s) - k + 1 for s in eseqs) == len(ug.kmers)
+
+
+def test_g_seq_arrays_equals_g_seq():
+    """The vectorised generator (used for the E. coli-sized GPU test and the real-dBG bench workload) builds exactly
+    g_seq's unitigs, unitig order, orientations, links and link order."""
+    from matchtigs_amd import synth
+
+    for (L, seed, k, H, p) in [(3000, 7, 15, 4, 0.02), (6000, 3, 15, 4, 0.03), (8000, 5, 31, 4, 0.02), (6000, 9, 21, 3, 0.03)]:
+        a = synth.g_seq(L, seed=seed, k=k, haplotypes=H, sub_rate=p)
+        b = synth.g_seq_arrays(L, seed=seed, k=k, haplotypes=H, sub_rate=p)
+        assert b.unitig_list() == a.unitigs
+        assert [(int(x[0]), bool(x[1]), int(x[2]), bool(x[3])) for x in b.links] == a.links
+        assert synth.unitig_graph_of_arrays(b).kmers == a.kmers
+        assert (b.weights == a.weights).all()
+
+
+def test_real_dbg_eulertigs_at_scale_cpu(tmp_path, oracle, product_lib):
+    """BCALM2 file route + eulertigs (host-only path) on a 10^5-bp genome: FASTA bytes equal the oracle's, k-mer set preserved."""
+    import numpy as np
+    from matchtigs_amd import api, synth
+
+    k = 31
+    ua = synth.g_seq_arrays(100_000, seed=5, k=k, haplotypes=4, sub_rate=0.02)
+    inp, out = tmp_path / "u.fa", tmp_path / "e.fa"
+    inp.write_bytes(ua.bcalm2_text())
+    G, store = api.read_bcalm2(str(inp), k)
+    res = api.compute_tigs_to_fasta_file(G, store, 3, k, str(out))
+    og = oracle.OracleGraph.from_unitig_links_arrays(ua.weights, ua.links)
+    want = og.fasta(og.compute_eulertigs(k), ua.unitig_list(), k).encode()
+    fa = out.read_bytes()
+    assert fa == want and res["tigs"] > 0
+    lines = fa.split(b"\n")[1::2]
+    off = np.zeros(len(lines) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in lines])
+    assert np.array_equal(synth.kmer_codes_of_sequences(np.frombuffer(b"".join(lines), np.uint8), off, k), ua.kmers)
