@@ -68,10 +68,12 @@ __device__ __forceinline__ uint32_t rec_degree(const NodeRec &r) { return (r.fla
 constexpr int CLS_BLOCK = 256;
 
 __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(NodeRec *recs, uint32_t n_nodes, int32_t *mult,
-                                                             uint32_t *block_counts) {
+                                                             uint32_t *block_counts, uint32_t *block_demand) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
+    __shared__ uint32_t wave_dem[CLS_BLOCK / 64];
     const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
     bool is_source = false;
+    uint32_t pos = 0;
     if (n < n_nodes) {
         const NodeRec r = recs[n];
         const uint32_t out_d = rec_degree(r);
@@ -89,28 +91,35 @@ __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(NodeRec *recs, uint
         else if (diff > 0) fl |= F_TARGET;                                       // :237-240
         else if (diff < 0) { fl |= F_SOURCE; is_source = true; }                 // :241-244
         mult[n] = diff;  // 0 for balanced nodes
+        pos = diff > 0 ? (uint32_t)diff : 0u;
         recs[n].flags = fl;  // byte store; degree/mirror bytes that other threads read are untouched
     }
     const unsigned long long b = __ballot(is_source);
-    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    for (int dd = 32; dd >= 1; dd >>= 1) pos += __shfl_down(pos, dd);
+    if ((threadIdx.x & 63) == 0) { wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b); wave_dem[threadIdx.x >> 6] = pos; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t s = 0;
-        for (int i = 0; i < CLS_BLOCK / 64; i++) s += wave_cnt[i];
+        uint32_t s = 0, dm = 0;
+        for (int i = 0; i < CLS_BLOCK / 64; i++) { s += wave_cnt[i]; dm += wave_dem[i]; }
         block_counts[blockIdx.x] = s;
+        block_demand[blockIdx.x] = dm;
     }
 }
 
-// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uint32_t n, unsigned long long *total_out) {
+// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out; sum of block_demand in *demand_out
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uint32_t n, unsigned long long *total_out,
+                                                           const uint32_t *block_demand, unsigned long long *demand_out) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ unsigned long long dem_sum;
+    if (threadIdx.x == 0) { carry = 0; dem_sum = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long dem = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < n ? counts[i] : 0;
+        dem += i < n ? block_demand[i] : 0u;
         uint32_t incl = v;
         for (int d = 1; d < 64; d <<= 1) {
             uint32_t t = __shfl_up(incl, d);
@@ -126,7 +135,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uin
         if (threadIdx.x == 1023) carry = c + wave_off + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    for (int dd = 32; dd >= 1; dd >>= 1) dem += __shfl_down(dem, dd);
+    if (lane == 0 && dem) atomicAdd(&dem_sum, dem);
+    __syncthreads();
+    if (threadIdx.x == 0) { *total_out = carry; *demand_out = dem_sum; }
 }
 
 __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const NodeRec *recs, uint32_t n_nodes,
@@ -173,6 +185,7 @@ enum Counter : int {
     C_PUSHES = 9,    // COUNT: frontier-log items of all finished batches
     C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
     C_MAX_ENT = 11,  // COUNT: most table entries of one batch
+    C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
     C_COUNT = 16
 };
 
@@ -810,14 +823,20 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(unsigned long long
 // Host side of the device stage
 // ------------------------------------------------------------------------------------------------
 // Work arrays of the GPU claim replay (replay_kernels.inc); owned by the Device they were allocated on.
+
 struct ReplayWork {
-    uint64_t cap_v = 0, cap_s = 0, cap_slots = 0, cap_blocks = 0;
-    int32_t *mult = nullptr;
-    uint8_t *live = nullptr;
-    unsigned long long *resv = nullptr;
-    uint32_t *demand0 = nullptr, *pair_count = nullptr, *pending[2] = {nullptr, nullptr};
-    unsigned long long *pair_off = nullptr, *final_off = nullptr, *block_sums = nullptr;
-    mtg_pair *slots = nullptr;
+    uint64_t cap_v = 0, cap_s = 0, cap_spill = 0, cap_blocks = 0, cap_out = 0;
+    unsigned long long *state = nullptr;      // [V] working node states {mirror, multiplicity, live}
+    unsigned long long *resv[2] = {nullptr, nullptr};
+    uint32_t tag_base = 0xFFFFFFFFu;          // reservation tags used so far (the arrays are never cleared between calls)
+    Touch *touch = nullptr;
+    uint8_t *big = nullptr;
+    unsigned long long *claims = nullptr;
+    uint32_t *pair_count = nullptr, *pending[2] = {nullptr, nullptr}, *spill = nullptr;
+    unsigned long long *final_off = nullptr, *block_sums = nullptr;
+    unsigned long long *ctl = nullptr, *h_ctl = nullptr;  // control block (device / pinned host copy)
+    mtg_pair *out = nullptr;
+    unsigned grid = 0;                        // co-resident workgroups of the cooperative launch
 };
 
 struct Device {
@@ -834,6 +853,7 @@ struct Device {
     uint32_t *d_block_counts = nullptr;
     uint64_t n_cls_blocks = 0;
     uint64_t n_sources = 0;
+    uint64_t total_demand = 0;  // sum of the positive multiplicities (classification)
     bool classified = false;
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
@@ -1084,6 +1104,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         NodeRec &r = recs[n];
         std::memset(&r, 0, sizeof r);
         r.mirror = g.mirror[n];
+        if (odeg[n] > 32767) MTG_DIE("node %llu has %u out-edges: the device stage keeps multiplicities in 16 bits", (unsigned long long)n, odeg[n]);
         if (odeg[n] > 4) {
             r.flags = F_EXT;
             r.nbr[0] = (uint32_t)(ext_total & 0xFFFFFFFFu);
@@ -1124,7 +1145,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     if (V) HIP_CHECK(hipMemcpy(d->d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4));
     d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
-    HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4));  // source counts | positive multiplicities per block
     HIP_CHECK(hipMalloc(&d->d_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
@@ -1141,8 +1162,10 @@ void device_free(Device *d) {
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
     ReplayWork &w = d->replay;
-    void *rb[] = {w.mult, w.live, w.resv, w.demand0, w.pair_count, w.pending[0], w.pending[1], w.pair_off, w.final_off, w.block_sums, w.slots};
+    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.big, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
+                  w.final_off, w.block_sums, w.ctl, w.out};
     for (void *b : rb) (void)hipFree(b);
+    (void)hipHostFree(w.h_ctl);
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
@@ -1157,16 +1180,17 @@ uint64_t device_classify(Device *d, void *stream) {
     d->n_sources = 0;
     if (d->V) {
         hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs, (uint32_t)d->V,
-                           d->d_mult, d->d_block_counts);
+                           d->d_mult, d->d_block_counts, d->d_block_counts + d->n_cls_blocks);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
-                           &d->d_counters[C_OVF_LIST]);
+                           &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND]);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs,
                            (uint32_t)d->V, d->d_block_counts, d->d_out_nodes);
         HIP_CHECK(hipGetLastError());
         read_counters(d, st);
         d->n_sources = d->h_counters[C_OVF_LIST];
+        d->total_demand = d->h_counters[C_DEMAND];
     }
     d->classified = true;
     return d->n_sources;
@@ -1281,74 +1305,92 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         return 0;
     }
     if (V > w.cap_v) {
-        if (w.mult) { HIP_CHECK(hipFree(w.mult)); HIP_CHECK(hipFree(w.live)); HIP_CHECK(hipFree(w.resv)); }
-        HIP_CHECK(hipMalloc(&w.mult, V * 4));
-        HIP_CHECK(hipMalloc(&w.live, V));
-        HIP_CHECK(hipMalloc(&w.resv, V * 8));
+        if (w.state) { HIP_CHECK(hipFree(w.state)); HIP_CHECK(hipFree(w.resv[0])); HIP_CHECK(hipFree(w.resv[1])); }
+        HIP_CHECK(hipMalloc(&w.state, V * 8));
+        HIP_CHECK(hipMalloc(&w.resv[0], V * 8));
+        HIP_CHECK(hipMalloc(&w.resv[1], V * 8));
         w.cap_v = V;
+        w.tag_base = 0xFFFFFFFFu;  // forces the clear below
     }
     if (S > w.cap_s) {
-        if (w.demand0) {
-            HIP_CHECK(hipFree(w.demand0)); HIP_CHECK(hipFree(w.pair_count)); HIP_CHECK(hipFree(w.pending[0]));
-            HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.pair_off)); HIP_CHECK(hipFree(w.final_off));
+        if (w.touch) {
+            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.big)); HIP_CHECK(hipFree(w.claims)); HIP_CHECK(hipFree(w.pair_count));
+            HIP_CHECK(hipFree(w.pending[0])); HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.final_off));
         }
-        HIP_CHECK(hipMalloc(&w.demand0, S * 4));
+        HIP_CHECK(hipMalloc(&w.touch, S * sizeof(Touch)));
+        HIP_CHECK(hipMalloc(&w.big, S));
+        HIP_CHECK(hipMalloc(&w.claims, S * 8));
         HIP_CHECK(hipMalloc(&w.pair_count, S * 4));
         HIP_CHECK(hipMalloc(&w.pending[0], S * 4));
         HIP_CHECK(hipMalloc(&w.pending[1], S * 4));
-        HIP_CHECK(hipMalloc(&w.pair_off, S * 8));
         HIP_CHECK(hipMalloc(&w.final_off, S * 8));
         w.cap_s = S;
     }
-    // working copies of the classification state
-    HIP_CHECK(hipMemcpyAsync(w.mult, d->d_mult, V * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_recs, (uint32_t)V, w.live);
-    HIP_CHECK(hipMemsetAsync(w.resv, 0xFF, V * 8, st));
-    unsigned long long *cnt = &d->d_counters[C_OVF_LIST];  // scratch counters: [C_OVF_LIST] and [C_BATCH]
-    unsigned long long *cnt2 = &d->d_counters[C_BATCH];
-    HIP_CHECK(hipMemsetAsync(d->d_counters, 0, C_COUNT * sizeof(unsigned long long), st));
+    const uint64_t spill_need = std::max<uint64_t>(d->total_demand, 1);  // a source emits at most its demand (classification)
+    if (spill_need > w.cap_spill) {
+        if (w.spill) HIP_CHECK(hipFree(w.spill));
+        HIP_CHECK(hipMalloc(&w.spill, spill_need * 4));
+        w.cap_spill = spill_need;
+    }
+    if (!w.ctl) {
+        HIP_CHECK(hipMalloc(&w.ctl, RC_COUNT * 8));
+        HIP_CHECK(hipHostMalloc(&w.h_ctl, RC_COUNT * 8));
+    }
+    // reservation tags decrease with every round of every call, so the two reservation arrays are never cleared; only when
+    // the 32-bit tag space is used up (or the arrays are new)
+    if ((uint64_t)w.tag_base + REPLAY_MAX_ROUNDS + 8 >= 0xFFFFFFF0ull) {
+        HIP_CHECK(hipMemsetAsync(w.resv[0], 0xFF, V * 8, st));
+        HIP_CHECK(hipMemsetAsync(w.resv[1], 0xFF, V * 8, st));
+        w.tag_base = 0;
+    }
+    // working copy of the classification state; per-source outputs start at "nothing claimed"
+    hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_recs, V, w.state);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(w.pair_count, 0, S * 4, st));
+    HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
 
     ReplayArgs a{};
-    a.out_nodes = d->d_out_nodes; a.mirror = d->d_mirror; a.mult = w.mult; a.live = w.live;
+    a.out_nodes = d->d_out_nodes; a.state = w.state;
     a.cand_start = (const unsigned long long *)d_cand_start; a.cand_count = d_cand_count; a.pool = (const unsigned long long *)d_pool;
-    a.resv = w.resv; a.pair_off = w.pair_off; a.pair_count = w.pair_count; a.n_sources = S;
-    const unsigned sb = (unsigned)((S + 255) / 256);
-    hipLaunchKernelGGL(replay_init_kernel, dim3(sb), dim3(256), 0, st, a, w.demand0, w.pending[0], cnt);
-    HIP_CHECK(hipGetLastError());
-    scan_u32(d, st, w, w.demand0, S, w.pair_off, cnt2);
-    read_counters(d, st);
-    uint64_t n_pending = d->h_counters[C_OVF_LIST];
-    const uint64_t n_slots = d->h_counters[C_BATCH];
-    if (n_slots > w.cap_slots) {
-        if (w.slots) HIP_CHECK(hipFree(w.slots));
-        HIP_CHECK(hipMalloc(&w.slots, std::max<uint64_t>(n_slots, 1) * sizeof(mtg_pair)));
-        w.cap_slots = n_slots;
-    }
-    a.slots = w.slots;
+    a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.big = w.big; a.claims = w.claims; a.pair_count = w.pair_count;
+    a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
+    a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
 
-    int cur = 0, rounds = 0;
-    constexpr int MAX_ROUNDS = 256;
-    static const bool replay_debug = std::getenv("MTG_DEBUG_REPLAY") != nullptr;
-    while (n_pending > 0 && rounds < MAX_ROUNDS) {
-        const unsigned pb = (unsigned)((n_pending + 255) / 256);
-        HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
-        a.round_tag = (unsigned long long)(0xFFFFFFFFu - (uint32_t)rounds) << 32;
-        hipLaunchKernelGGL(replay_reserve_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending);
-        hipLaunchKernelGGL(replay_commit_kernel, dim3(pb), dim3(256), 0, st, a, w.pending[cur], n_pending, w.pending[cur ^ 1], cnt);
-        HIP_CHECK(hipGetLastError());
-        read_counters(d, st);
-        n_pending = d->h_counters[C_OVF_LIST];
-        cur ^= 1;
-        rounds++;
-        if (replay_debug) std::fprintf(stderr, "[mtg] replay round %d: %llu pending\n", rounds, (unsigned long long)n_pending);
+    // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
+    // deadlock; fewer, larger workgroups keep the barrier cheap
+    if (w.grid == 0) {
+        int coop = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, d->dev));
+        if (!coop) MTG_DIE("device %d does not support cooperative launches (needed by the claim replay's grid barrier)", d->dev);
+        int occ = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, replay_rounds_kernel, REPLAY_BLOCK, 0));
+        if (occ < 1) MTG_DIE("replay_rounds_kernel does not fit a compute unit");
+        w.grid = (unsigned)d->n_cu * (unsigned)std::min(occ, 2);
     }
-    if (n_pending > 0) {  // very long priority chain: finish the rest in order on one GPU thread
-        std::vector<uint32_t> rest(n_pending);
-        HIP_CHECK(hipMemcpyAsync(rest.data(), w.pending[cur], n_pending * 4, hipMemcpyDeviceToHost, st));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(w.grid, (S + REPLAY_BLOCK - 1) / REPLAY_BLOCK));
+    void *kargs[] = {&a};
+    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
+    HIP_CHECK(hipMemcpyAsync(w.h_ctl, w.ctl, RC_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (w.h_ctl[RC_ABORT]) MTG_DIE("claim replay: a workgroup never reached the grid barrier (watchdog)");
+    const int rounds = (int)w.h_ctl[RC_ROUNDS];
+    w.tag_base += (uint32_t)rounds + 2;
+    static const bool replay_debug = std::getenv("MTG_DEBUG") != nullptr;
+    if (replay_debug) {
+        std::fprintf(stderr, "[mtg] replay: %d rounds, %llu left; per round (pending, us since kernel start):", rounds, (unsigned long long)w.h_ctl[RC_LEFT]);
+        for (int r = 0; r < rounds && r < RC_TRACE_ROUNDS; r++)
+            std::fprintf(stderr, " (%llu, %.0f)", (unsigned long long)w.h_ctl[RC_TRACE + 2 * r], (double)(w.h_ctl[RC_TRACE + 2 * r + 1] - w.h_ctl[RC_LEFT_PAR + 2]) * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+    uint64_t n_left = w.h_ctl[RC_LEFT];
+    if (n_left > 0) {  // very long priority chain: finish the rest in order on one GPU thread
+        uint32_t *lst = w.pending[w.h_ctl[RC_LEFT_PAR] & 1];
+        std::vector<uint32_t> rest(n_left);
+        HIP_CHECK(hipMemcpyAsync(rest.data(), lst, n_left * 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         std::sort(rest.begin(), rest.end());
-        HIP_CHECK(hipMemcpyAsync(w.pending[cur], rest.data(), n_pending * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(replay_tail_kernel, dim3(1), dim3(64), 0, st, a, w.pending[cur], n_pending);
+        HIP_CHECK(hipMemcpyAsync(lst, rest.data(), n_left * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(replay_tail_kernel, dim3(1), dim3(64), 0, st, a, lst, n_left);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -1356,19 +1398,22 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (rounds_out) *rounds_out = rounds;
 
     // compaction in source order
+    unsigned long long *cnt = &d->d_counters[C_OVF_LIST];
     scan_u32(d, st, w, w.pair_count, S, w.final_off, cnt);
     read_counters(d, st);
     const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
     mtg_pair *host = (mtg_pair *)std::malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
     if (!host) MTG_DIE("out of memory");
     if (n_pairs) {
-        mtg_pair *d_out = nullptr;
-        HIP_CHECK(hipMalloc(&d_out, n_pairs * sizeof(mtg_pair)));
-        hipLaunchKernelGGL(replay_compact_kernel, dim3(sb), dim3(256), 0, st, w.slots, w.pair_off, w.pair_count, w.final_off, S, d_out);
+        if (n_pairs > w.cap_out) {
+            if (w.out) HIP_CHECK(hipFree(w.out));
+            HIP_CHECK(hipMalloc(&w.out, n_pairs * sizeof(mtg_pair)));
+            w.cap_out = n_pairs;
+        }
+        hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(host, d_out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(host, w.out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        HIP_CHECK(hipFree(d_out));
     }
     *pairs_out = host;
     return n_pairs;
