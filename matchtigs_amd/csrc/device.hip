@@ -5,10 +5,11 @@
 //   * Dijkstra::shortest_path_lens (bounded)   call site greedytigs/mod.rs:324-335 (traitgraph-algo 8.1.2)
 //
 // Data layout in HBM (DESIGN.md "Data layout"):
-//   NodeRec[V]   32-byte record per node: <=4 inline (neighbour, clamped weight) pairs, degree, flags,
-//                mirror node. One aligned 32-byte gather per settled node fetches everything the
-//                relaxation needs (neighbours, weights, is-target flag). Nodes with more than 4
-//                out-edges (never the case in a de Bruijn graph) spill to a CSR side array.
+//   NodeBlock[V] 64-byte family block per node: <=4 inline (neighbour, clamped weight) pairs, degree, in-node flag,
+//                its children's in-node flags and, while they fit, its children's out-edges. One aligned gather
+//                fetches everything a path enumeration needs about a node AND its embedded children (the
+//                cooperative levels read the first 32 bytes only). Nodes with more than 4 out-edges (never the
+//                case in a de Bruijn graph) spill to a CSR side array. Built on the GPU from the edge arrays.
 //   out_nodes[S] ascending source list (u32), mult[V] (i32) from classification.
 //   pool[]       candidate keys (distance << 32 | node), per source contiguous and ascending.
 //
@@ -36,6 +37,7 @@
 #include <vector>
 
 #include "device.hpp"
+#include "parallel.hpp"
 
 namespace mtg {
 
@@ -50,49 +52,55 @@ namespace mtg {
 // ------------------------------------------------------------------------------------------------
 enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
 
-struct alignas(32) NodeRec {
-    uint32_t nbr[4];  // inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
-    uint16_t w[4];    // weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path)
-    uint8_t deg;      // inline degree 0..4 (0 if F_EXT)
-    uint8_t flags;
-    uint16_t pad;
-    uint32_t mirror;
+// One 64-byte "family" block per node: the node's own <= 4 out-edges (first 32 bytes: what the cooperative levels read) AND, for as
+// many of its children as fit, the child's in-node flag and the child's out-edges (grandchildren of the node). A path enumeration
+// therefore spends ONE 64-byte gather on a node and its embedded children instead of one gather each: 1.8 visited nodes per gather
+// on the bench graph (35 fetched bytes per visited node instead of 64; a 32-byte record costs a 64-byte request anyway).
+// Everything in it is a function of the graph alone, so it is built once with the device graph (build kernels below).
+struct alignas(64) NodeBlock {
+    uint32_t nbr[4];   // words 0-3: inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
+    uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path)
+    uint8_t deg;       // word 6: inline degree 0..4 (0 if F_EXT)
+    uint8_t flags;     //         F_TARGET (initial in-node, greedytigs/mod.rs:231-240) | F_EXT
+    uint16_t cmeta;    //         4 bits per child j: [2:0] = number of its out-edges embedded below (7 = child not embedded), [3] = child is an in-node
+    uint32_t gnbr[6];  // words 7-12: out-neighbours of the embedded children, children in order, each child's edges in order
+    uint16_t gw[6];    // words 13-15: their weights
 };
-static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+static_assert(sizeof(NodeBlock) == 64, "NodeBlock must be 64 bytes");
+constexpr int GSLOTS = 6;
+constexpr uint32_t CHILD_NOT_EMBEDDED = 7;
 
-__device__ __forceinline__ uint32_t rec_degree(const NodeRec &r) { return (r.flags & F_EXT) ? r.nbr[2] : r.deg; }
+// compute_eulerian_superfluous_out_biedges (bigraph) and the classification rule of greedytigs/mod.rs:229-245
+struct NodeClass { int32_t diff; uint8_t cls; };
+__device__ __forceinline__ NodeClass classify_node(uint32_t out_deg, uint32_t out_deg_mirror, bool self_mirror) {
+    NodeClass c;
+    c.diff = self_mirror ? (int32_t)(out_deg & 1u) : (int32_t)out_deg - (int32_t)out_deg_mirror;  // in_degree(n) == out_degree(mirror(n))
+    c.cls = self_mirror ? F_SELF_MIRROR : 0;
+    if (self_mirror && c.diff != 0) c.cls |= F_TARGET | F_SOURCE;  // :231-236
+    else if (c.diff > 0) c.cls |= F_TARGET;                        // :237-240
+    else if (c.diff < 0) c.cls |= F_SOURCE;                        // :241-244
+    return c;
+}
 
 // ------------------------------------------------------------------------------------------------
-// Classification kernels (greedytigs/mod.rs:229-245)
+// Classification kernels (greedytigs/mod.rs:229-245): compact arrays only (out-degree, mirror -> multiplicity, class byte)
 // ------------------------------------------------------------------------------------------------
 constexpr int CLS_BLOCK = 256;
 
-__global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(NodeRec *recs, uint32_t n_nodes, int32_t *mult,
-                                                             uint32_t *block_counts, uint32_t *block_demand) {
+__global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *odeg, const uint32_t *mirror, uint32_t n_nodes, int32_t *mult,
+                                                             uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
     __shared__ uint32_t wave_dem[CLS_BLOCK / 64];
     const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
     bool is_source = false;
     uint32_t pos = 0;
     if (n < n_nodes) {
-        const NodeRec r = recs[n];
-        const uint32_t out_d = rec_degree(r);
-        int32_t diff;
-        bool sm = (r.mirror == n);
-        if (sm) {
-            diff = (int32_t)(out_d & 1u);  // compute_eulerian_superfluous_out_biedges, self-mirror case
-        } else {
-            const NodeRec rm = recs[r.mirror];
-            diff = (int32_t)out_d - (int32_t)rec_degree(rm);  // in_degree(n) == out_degree(mirror(n))
-        }
-        uint8_t fl = r.flags & (uint8_t)~(F_TARGET | F_SOURCE | F_SELF_MIRROR);
-        if (sm) fl |= F_SELF_MIRROR;
-        if (sm && diff != 0) { fl |= F_TARGET | F_SOURCE; is_source = true; }   // :231-236
-        else if (diff > 0) fl |= F_TARGET;                                       // :237-240
-        else if (diff < 0) { fl |= F_SOURCE; is_source = true; }                 // :241-244
-        mult[n] = diff;  // 0 for balanced nodes
-        pos = diff > 0 ? (uint32_t)diff : 0u;
-        recs[n].flags = fl;  // byte store; degree/mirror bytes that other threads read are untouched
+        const uint32_t m = mirror[n];
+        const NodeClass c = classify_node(odeg[n], m == n ? 0u : odeg[m], m == n);
+        is_source = c.cls & F_SOURCE;
+        mult[n] = c.diff;  // 0 for balanced nodes
+        cls[n] = c.cls;
+        pos = c.diff > 0 ? (uint32_t)c.diff : 0u;
     }
     const unsigned long long b = __ballot(is_source);
     for (int dd = 32; dd >= 1; dd >>= 1) pos += __shfl_down(pos, dd);
@@ -141,11 +149,11 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uin
     if (threadIdx.x == 0) { *total_out = carry; *demand_out = dem_sum; }
 }
 
-__global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const NodeRec *recs, uint32_t n_nodes,
+__global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_t *cls, uint32_t n_nodes,
                                                                     const uint32_t *block_offsets, uint32_t *out_nodes) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
     const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
-    const bool is_source = n < n_nodes && (recs[n].flags & F_SOURCE);
+    const bool is_source = n < n_nodes && (cls[n] & F_SOURCE);
     const unsigned long long b = __ballot(is_source);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(b);
@@ -158,9 +166,113 @@ __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const NodeRe
     }
 }
 
-__global__ void export_live_kernel(const NodeRec *recs, uint32_t n_nodes, uint8_t *live) {
+__global__ void export_live_kernel(const uint8_t *cls, uint32_t n_nodes, uint8_t *live) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < n_nodes) live[n] = (recs[n].flags & F_TARGET) ? 1 : 0;
+    if (n < n_nodes) live[n] = (cls[n] & F_TARGET) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device graph build: original edge arrays -> family blocks (+ CSR spill for nodes with more than 4 out-edges)
+// Out-edges are kept in edge-id order per node (slots are claimed in any order, then sorted by edge id), so the content is
+// independent of thread timing.
+// ------------------------------------------------------------------------------------------------
+__global__ void build_count_kernel(const uint32_t *e_from, uint64_t n_edges, uint32_t *odeg) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) atomicAdd(&odeg[e_from[e]], 1u);
+}
+__global__ void build_ext_need_kernel(const uint32_t *odeg, uint64_t n_nodes, uint32_t *ext_need) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_nodes) ext_need[n] = odeg[n] > 4 ? odeg[n] : 0u;
+}
+// every edge claims a slot of its from-node and leaves its EDGE ID there (inline slot or spill position)
+__global__ void build_fill_kernel(const uint32_t *e_from, uint64_t n_edges, const uint32_t *odeg, const unsigned long long *ext_off,
+                                  uint32_t *fill, NodeBlock *blocks, uint32_t *ext_col) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint32_t f = e_from[e];
+    const uint32_t slot = atomicAdd(&fill[f], 1u);
+    if (odeg[f] > 4) ext_col[ext_off[f] + slot] = (uint32_t)e;
+    else blocks[f].nbr[slot] = (uint32_t)e;
+}
+// per node: edge ids ascending -> (neighbour, clamped weight); degree, own class flag
+__global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const uint32_t *mirror, const unsigned long long *ext_off,
+                                   const uint32_t *e_to, const uint16_t *e_w, NodeBlock *blocks, uint32_t *ext_col, uint16_t *ext_w) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint32_t dg = odeg[n];
+    const uint32_t m = mirror[n];
+    const NodeClass c = classify_node(dg, m == n ? 0u : odeg[m], m == n);
+    NodeBlock b;
+    uint32_t *bw = reinterpret_cast<uint32_t *>(&b);
+#pragma unroll
+    for (int i = 0; i < 16; i++) bw[i] = 0;
+    b.flags = c.cls & F_TARGET;
+    b.cmeta = 0x7777;  // no child embedded (build_children_kernel fills this in)
+    if (dg <= 4) {
+        uint32_t ids[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (uint32_t j = 0; j < dg; j++) ids[j] = blocks[n].nbr[j];
+        auto cswap = [&](int x, int y) { if (ids[x] > ids[y]) { const uint32_t t = ids[x]; ids[x] = ids[y]; ids[y] = t; } };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+        for (uint32_t j = 0; j < dg; j++) { b.nbr[j] = e_to[ids[j]]; b.w[j] = e_w[ids[j]]; }
+        b.deg = (uint8_t)dg;
+    } else {
+        const unsigned long long off = ext_off[n];
+        for (uint32_t i = 1; i < dg; i++) {  // insertion sort of the spill segment by edge id
+            const uint32_t key = ext_col[off + i];
+            uint32_t q = i;
+            while (q > 0 && ext_col[off + q - 1] > key) { ext_col[off + q] = ext_col[off + q - 1]; q--; }
+            ext_col[off + q] = key;
+        }
+        for (uint32_t i = 0; i < dg; i++) {
+            const uint32_t e = ext_col[off + i];
+            ext_col[off + i] = e_to[e];
+            ext_w[off + i] = e_w[e];
+        }
+        b.flags |= F_EXT;
+        b.nbr[0] = (uint32_t)(off & 0xFFFFFFFFull);
+        b.nbr[1] = (uint32_t)(off >> 32);
+        b.nbr[2] = dg;
+    }
+    blocks[n] = b;
+}
+// second half of every block: the children's in-node flags and, while they fit, the children's out-edges
+__global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint32_t *me = reinterpret_cast<const uint32_t *>(blocks + n);
+    const uint32_t meta = me[6];
+    if ((meta >> 8) & F_EXT) return;
+    const uint32_t dg = meta & 0xFFu;
+    uint32_t cmeta = 0, used = 0;
+    uint32_t gn[GSLOTS];
+    uint16_t gwt[GSLOTS];
+#pragma unroll
+    for (int i = 0; i < GSLOTS; i++) { gn[i] = 0; gwt[i] = 0; }
+    bool open = true;  // children are embedded in order while they fit (prefix rule: the decoder walks the slots in child order)
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t cm = CHILD_NOT_EMBEDDED;
+        if (j < dg) {
+            const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + me[j]);  // first half only: never written by this kernel
+            const uint32_t cmt = ch[6];
+            const uint32_t cflags = (cmt >> 8) & 0xFFu, cdeg = cmt & 0xFFu;
+            if (cflags & F_TARGET) cm |= 8u;
+            if (open && !(cflags & F_EXT) && used + cdeg <= (uint32_t)GSLOTS) {
+                for (uint32_t t = 0; t < cdeg; t++) {
+                    gn[used + t] = ch[t];
+                    gwt[used + t] = (uint16_t)((ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu);
+                }
+                used += cdeg;
+                cm = (cm & 8u) | cdeg;
+            } else open = false;
+        }
+        cmeta |= cm << (4 * j);
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(blocks + n);
+    out[6] = (meta & 0xFFFFu) | (cmeta << 16);
+#pragma unroll
+    for (int i = 0; i < GSLOTS; i++) out[7 + i] = gn[i];
+#pragma unroll
+    for (int i = 0; i < GSLOTS / 2; i++) out[13 + i] = (uint32_t)gwt[2 * i] | ((uint32_t)gwt[2 * i + 1] << 16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -186,11 +298,13 @@ enum Counter : int {
     C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
     C_MAX_ENT = 11,  // COUNT: most table entries of one batch
     C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
-    C_COUNT = 16
+    C_SRC0 = 16,     // enumeration level: N_SRC_CTR source cursors, one per slice of the source range (a single cursor for 2048 waves
+                     // is a same-address atomic every ~25 ns: the waves queue up behind it)
+    C_COUNT = 32
 };
 
 struct SsspArgs {
-    const NodeRec *recs;
+    const NodeBlock *recs;  // family blocks (the cooperative levels read the first 32 bytes of each)
     const uint32_t *ext_col;
     const uint16_t *ext_w;
     const uint32_t *sources;     // out_nodes (ascending)
@@ -541,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 }
 
 // Wave-level helpers shared by the lane-per-source level
-constexpr unsigned long long LANE_SRC_CHUNK = 512;  // sources a wave takes per global atomic
+constexpr unsigned long long LANE_SRC_CHUNK = 256;  // sources a wave takes per global atomic (LDS budget: two workgroups per CU)
 
 // Overflowed sources of a wave are buffered in LDS and appended to the global overflow list 64 at a time, so the
 // list cursor sees one atomic per 64 sources instead of one per overflow event.
@@ -571,7 +685,6 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
     p0 = __shfl(p0, 0);
     if ((uint32_t)lane < nbuf) a.ovf_list[p0 + lane] = w.buf[lane];
 }
-constexpr unsigned long long LANE_POOL_CHUNK = 256; // keys per wave-local pool chunk
 
 // ------------------------------------------------------------------------------------------------
 // Lane-per-source kernel WITHOUT a table (level 0 of the default plan)
@@ -580,15 +693,19 @@ constexpr unsigned long long LANE_POOL_CHUNK = 256; // keys per wave-local pool 
 // gather's arrival and the next gather's issue (34 G gathers/s at the 368 VALU instructions per step of the register-table
 // kernel, 50 G/s at ~100). A (k-1)-ball of a unitig graph is almost a tree (bench graph: 1.0004 path enumerations per
 // settled node), so the search needs no visited set at all: every lane enumerates the bounded PATHS from its source
-// depth-first with a small private stack in LDS -- pop, gather the 32-byte record, push the <= 4 successors whose distance
-// stays <= k-1, remember the node if it is an in-node. No select-min, no find, no insert. A node reached along two
+// depth-first with a small private stack in LDS -- pop, gather the node's 64-byte family block (the node, its children's
+// in-node flags and the embedded children's out-edges), remember the in-nodes among the node and its children, push the
+// grandchildren (and not-embedded children) whose distance stays <= k-1. No select-min, no find, no insert. A node reached along two
 // paths is expanded twice (bounded: every edge weighs >= 1 and the path length is capped at k-1), its target hits are
 // de-duplicated (minimum distance) and sorted by (distance, node) by the post-pass below, which makes the output identical
 // to the Dijkstra order. A source whose enumeration exceeds the pop budget, the stack or the hit buffer is handed to the
 // cooperative cascade, which is exact for any ball.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ENUM_POP_BUDGET = 256;
-constexpr unsigned long long ENUM_POOL_CHUNK = 1024;  // keys per wave-local pool chunk (a burst needs ~250)
+constexpr unsigned long long ENUM_POOL_CHUNK = 4096;  // keys per wave-local pool chunk (a burst needs ~250; fewer same-address atomics)
+constexpr unsigned long long ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
+constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
+constexpr int N_SRC_CTR = 16;
 
 template <int WPB, int S, int H>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
@@ -608,7 +725,10 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
 
-    unsigned long long chunk_lo = 0, chunk_hi = 0, chunk_base = 0, pool_next = 0, pool_end = 0;  // wave-uniform
+    unsigned long long chunk_lo = 0, chunk_hi = 0, chunk_base = 0, pool_next = 0, pool_end = 0, fix_next = 0, fix_end = 0;  // wave-uniform
+    // the source range is cut into N_SRC_CTR slices with a cursor each; a wave starts at "its" slice and moves on when one runs dry
+    const unsigned long long slice = ((a.n_items + N_SRC_CTR - 1) / N_SRC_CTR + LANE_SRC_CHUNK - 1) / LANE_SRC_CHUNK * LANE_SRC_CHUNK;
+    int cur_ctr = (int)((blockIdx.x * WPB + wv) % N_SRC_CTR), dry = 0;  // wave-uniform
     uint32_t n_res = 0;                                                                            // wave-uniform
     bool exhausted = false;
     bool active = false;
@@ -617,7 +737,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     unsigned long long prev_key = 0;      // hits already in (distance, node) order and without a repeated node need no post-pass:
     uint32_t bloom = 0;                   // 32-bit filter over node ids (a set bit seen twice = "maybe repeated")
     bool unclean = false;
-    uint32_t cur_node = 0, cur_dist = 0;  // the path step in progress; the stack holds the branches still to take
+    uint32_t cur_node = 0, cur_dist = 0;  // the step in progress; the stack holds the branches still to take
+    bool cur_chk = false;                 // the node's own in-node flag was already evaluated from its parent's block
     unsigned long long item = 0;
     if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
 
@@ -627,10 +748,11 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         // both cursors are taken by one lane back to back (one memory round trip, not two) and before this burst's stores
         const bool need_pool = n_keys && pool_next + n_keys > pool_end;
         const unsigned long long grab = n_keys > ENUM_POOL_CHUNK ? (unsigned long long)n_keys : ENUM_POOL_CHUNK;
+        const bool need_fix = n_fix && fix_next + n_fix > fix_end;
         unsigned long long p0 = 0, f0 = 0;
         if (lane == 0) {
             if (need_pool) p0 = atomicAdd(&a.counters[C_POOL], grab);
-            if (n_fix) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)n_fix);
+            if (need_fix) f0 = atomicAdd(&a.counters[C_FIX], ENUM_FIX_CHUNK);
         }
         p0 = __shfl(p0, 0);
         f0 = __shfl(f0, 0);
@@ -638,7 +760,13 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             pool_next = p0;
             pool_end = pool_next + grab;
         }
-        for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[f0 + t] = s_fix[wv][t];  // dense work list for the post-pass
+        if (need_fix) {  // (a burst stages at most RQ <= ENUM_FIX_CHUNK lists); the rest of the old chunk is marked unused
+            for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
+            fix_next = f0;
+            fix_end = f0 + ENUM_FIX_CHUNK;
+        }
+        for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[fix_next + t] = s_fix[wv][t];  // (almost) dense work list for the post-pass
+        fix_next += n_fix;
         for (uint32_t t = lane; t < n_res; t += 64) {
             const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
             const uint32_t c = (misc >> 24) ? CAND_OVERFLOW : (misc & 0xFFu);
@@ -657,56 +785,156 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         used = nhit;  // only the current source's hits stay in the ring
     };
 
-    for (;;) {
-        // ---- refill idle lanes (a chunk that runs out is topped up from the next one in the same iteration) ----
-        unsigned long long need = __ballot(!active);
+    // Software-pipelined main loop. An iteration (1) decodes the block that arrived for every active lane just far enough to
+    // know where the lane goes next -- a successor within the bound, else the top of its stack, else a NEW source --, (2) issues
+    // the gather of that next block straight away, and only then (3) records the in-node hits, pushes the other successors and
+    // stages finished sources, i.e. the bulk of the integer and LDS work runs while the next gather is in flight. (Measured
+    // before this form: a wave spent memory latency + ~600 instructions per step back to back, 5 us per step at 8 waves/CU.)
+    uint4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;  // family block of cur_node (valid for active lanes)
+    auto load_block = [&](uint32_t node, uint4 &o0, uint4 &o1, uint4 &o2, uint4 &o3) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
+        o0 = rp[0]; o1 = rp[1]; o2 = rp[2]; o3 = rp[3];
+    };
+    // hands out source indices to the lanes in `need` (wave-uniform chunk of LANE_SRC_CHUNK sources per global atomic, source
+    // ids staged in LDS with one coalesced sweep per chunk; a chunk that runs out is topped up from the next one)
+    auto take_sources = [&](bool want, unsigned long long &new_item, uint32_t &new_src) -> bool {
+        bool got = false;
+        unsigned long long need = __ballot(want);
         for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
             if (chunk_lo >= chunk_hi) {
-                unsigned long long c0 = 0;
-                if (lane == 0) c0 = atomicAdd(&a.counters[C_BATCH], LANE_SRC_CHUNK);
-                c0 = __shfl(c0, 0);
-                chunk_lo = c0 < a.n_items ? c0 : a.n_items;
-                chunk_hi = (c0 + LANE_SRC_CHUNK) < a.n_items ? (c0 + LANE_SRC_CHUNK) : a.n_items;
+                while (dry < N_SRC_CTR) {
+                    const unsigned long long s_lo = (unsigned long long)cur_ctr * slice;
+                    const unsigned long long s_hi = (s_lo + slice) < a.n_items ? (s_lo + slice) : a.n_items;
+                    unsigned long long c0 = 0;
+                    if (lane == 0 && s_lo < s_hi) c0 = atomicAdd(&a.counters[C_SRC0 + cur_ctr], LANE_SRC_CHUNK);
+                    c0 = __shfl(c0, 0) + s_lo;
+                    if (s_lo < s_hi && c0 < s_hi) {
+                        chunk_lo = c0;
+                        chunk_hi = (c0 + LANE_SRC_CHUNK) < s_hi ? (c0 + LANE_SRC_CHUNK) : s_hi;
+                        break;
+                    }
+                    cur_ctr = (cur_ctr + 1) % N_SRC_CTR;  // this slice is dry (it stays dry: cursors only grow)
+                    dry++;
+                }
                 if (chunk_lo >= chunk_hi) { exhausted = true; break; }
                 chunk_base = chunk_lo;
                 for (unsigned long long t = chunk_lo + lane; t < chunk_hi; t += 64)
                     s_src[wv][t - chunk_base] = a.sources[a.src_index ? a.src_index[t] : a.src_begin + t];
             }
-            const unsigned want = (unsigned)__popcll(need);
-            if (!active) {
+            const unsigned n_want = (unsigned)__popcll(need);
+            if (want && !got) {
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 const unsigned long long it = chunk_lo + rank;
                 if (it < chunk_hi) {
-                    item = it;
-                    src_node = s_src[wv][it - chunk_base];
-                    cur_node = src_node; cur_dist = 0;
-                    sp = 0; nhit = 0; pops = 0;
-                    prev_key = 0; bloom = 0; unclean = false;
-                    active = true;
+                    new_item = it;
+                    new_src = s_src[wv][it - chunk_base];
+                    got = true;
                 }
             }
-            chunk_lo = (chunk_lo + want) < chunk_hi ? (chunk_lo + want) : chunk_hi;
-            need = __ballot(!active);
+            chunk_lo = (chunk_lo + n_want) < chunk_hi ? (chunk_lo + n_want) : chunk_hi;
+            need = __ballot(want && !got);
         }
+        return got;
+    };
+
+    {  // prologue: first sources and their blocks
+        unsigned long long ni = 0;
+        uint32_t ns = 0;
+        if (take_sources(true, ni, ns)) {
+            item = ni; src_node = ns; cur_node = ns; cur_dist = 0; cur_chk = false;
+            active = true;
+            load_block(cur_node, b0, b1, b2, b3);
+        }
+    }
+    for (;;) {
         if (!__any(active)) {
             if (exhausted) break;
+            unsigned long long ni = 0;  // (all lanes idle although sources remain: only after a wave-wide overflow)
+            uint32_t ns = 0;
+            if (take_sources(true, ni, ns)) {
+                item = ni; src_node = ns; cur_node = ns; cur_dist = 0; cur_chk = false;
+                sp = 0; nhit = 0; pops = 0; prev_key = 0; bloom = 0; unclean = false;
+                active = true;
+                load_block(cur_node, b0, b1, b2, b3);
+            }
             continue;
         }
-        // a step adds at most one hit: make room where a burst write can (finished sources' hits leave the rings)
-        if (n_res + 64 > (uint32_t)RQ || __any(active && used == (uint32_t)H && nhit < (uint32_t)H)) flush_results();
+        // a step adds at most five hits (the node and its four children): make room where a burst write can (finished sources'
+        // hits leave the rings)
+        if (n_res + 64 > (uint32_t)RQ || __any(active && used + 5 > (uint32_t)H && used > nhit)) flush_results();
 
-        // ---- one path step per active lane: gather the current node, continue with one successor within the bound (kept
-        // in registers), push the others; a dead end pops the stack ----
+        // ---- (1) where does every lane go next? ----
+        const uint32_t u = cur_node, d = cur_dist;
+        const uint32_t meta = b1.z;
+        const uint32_t flags = (meta >> 8) & 0xFFu;
+        const bool ext = active && (flags & F_EXT);
+        const uint32_t deg = meta & 0xFFu, cmeta = meta >> 16;
+        const uint32_t nb[4] = {b0.x, b0.y, b0.z, b0.w};
+        const uint32_t ww[4] = {b1.x & 0xFFFFu, b1.x >> 16, b1.y & 0xFFFFu, b1.y >> 16};
+        const uint32_t gn[GSLOTS] = {b1.w, b2.x, b2.y, b2.z, b2.w, b3.x};
+        const uint32_t gwt[GSLOTS] = {b3.y & 0xFFFFu, b3.y >> 16, b3.z & 0xFFFFu, b3.z >> 16, b3.w & 0xFFFFu, b3.w >> 16};
+        uint32_t dc[4];            // distance of child j (0xFFFFFFFF = absent or beyond the bound)
+        uint32_t succ_d[4 + GSLOTS];  // successors that need their own block: not-embedded children [0,4), grandchildren [4,10)
+        uint32_t bound[4];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t cg = (cmeta >> (4 * j)) & 7u;
+            const bool present = active && !ext && j < (int)deg;
+            const uint32_t dj = d + ww[j];
+            const bool within = present && dj <= a.K1;
+            dc[j] = within ? dj : 0xFFFFFFFFu;
+            succ_d[j] = (within && cg == CHILD_NOT_EMBEDDED) ? dj : 0xFFFFFFFFu;
+            acc += (present && cg != CHILD_NOT_EMBEDDED) ? cg : 0u;
+            bound[j] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < GSLOTS; t++) {
+            const uint32_t pd = (uint32_t)t < bound[0] ? dc[0] : (uint32_t)t < bound[1] ? dc[1] : (uint32_t)t < bound[2] ? dc[2] : dc[3];
+            const uint32_t nd = pd + gwt[t];
+            succ_d[4 + t] = ((uint32_t)t < acc && pd != 0xFFFFFFFFu && nd <= a.K1) ? nd : 0xFFFFFFFFu;
+        }
+        bool have_next = false;
+        uint32_t nx_node = 0, nx_dist = 0;
+        bool nx_chk = false;
+        int nx_slot = -1;
+#pragma unroll
+        for (int t = 4 + GSLOTS - 1; t >= 0; t--) {  // lowest slot wins
+            if (succ_d[t] != 0xFFFFFFFFu) { have_next = true; nx_slot = t; nx_dist = succ_d[t]; nx_node = t < 4 ? nb[t] : gn[t - 4]; nx_chk = t < 4; }
+        }
+        uint64_t ext_begin = 0;
+        uint32_t ext_deg = 0;
+        if (ext) {  // spilled adjacency (more than 4 out-edges): the first successor within the bound
+            ext_begin = ((uint64_t)b0.y << 32) | b0.x;
+            ext_deg = b0.z;
+            for (uint32_t j = 0; j < ext_deg && !have_next; j++) {
+                const uint32_t nd = d + a.ext_w[ext_begin + j];
+                if (nd <= a.K1) { have_next = true; nx_slot = (int)j; nx_dist = nd; nx_node = a.ext_col[ext_begin + j]; nx_chk = false; }
+            }
+        }
+        bool popped = false;
+        if (active && !have_next && sp > 0) {  // dead end: back to the most recent branch (nothing is pushed in such a step)
+            const unsigned long long top = s_stack[wv][sp - 1][lane];
+            nx_node = (uint32_t)top;
+            nx_dist = (uint32_t)(top >> 32) & 0x7FFFFFFFu;
+            nx_chk = (top >> 63) != 0;
+            popped = true;
+        }
+        const bool will_end = active && !have_next && !popped;  // the source finishes (or overflows) in this step
+        unsigned long long new_item = 0;
+        uint32_t new_src = 0;
+        const bool got_new = take_sources(!active || will_end, new_item, new_src);
+        if (got_new) { nx_node = new_src; nx_dist = 0; nx_chk = false; }
+        // ---- (2) the next gather leaves now ----
+        uint4 n0 = b0, n1 = b1, n2 = b2, n3 = b3;
+        if (have_next || popped || got_new) load_block(nx_node, n0, n1, n2, n3);
+
+        // ---- (3) the rest of this step, while that gather is in flight ----
         bool fin = false, ovf = false;
         if (active) {
-            const uint32_t u = cur_node, d = cur_dist;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + u);
-            const uint4 lo = rp[0];
-            const uint4 hi = rp[1];
-            const uint32_t flags = (hi.z >> 8) & 0xFFu;
-            if ((flags & F_TARGET) && u != src_node) {  // forbid_source_target, greedytigs/mod.rs:329
-                const unsigned long long key = ((unsigned long long)d << 32) | u;
-                const uint32_t bit = 1u << (u & 31u);
+            auto hit = [&](uint32_t node, uint32_t dist) {
+                const unsigned long long key = ((unsigned long long)dist << 32) | node;
+                const uint32_t bit = 1u << (node & 31u);
                 unclean |= (key <= prev_key) | ((bloom & bit) != 0u);
                 prev_key = key;
                 bloom |= bit;
@@ -715,41 +943,31 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                     used++;
                 } else ovf = true;  // this source alone fills the ring
                 nhit++;
-            }
-            bool have_next = false;
-            auto visit = [&](uint32_t nb, uint32_t w) {
-                const uint32_t nd = d + w;
-                if (nd > a.K1) return;
-                if (!have_next) {  // the first successor is the next step
-                    cur_node = nb; cur_dist = nd; have_next = true;
-                    return;
-                }
-                if (sp < (uint32_t)S) s_stack[wv][sp][lane] = ((unsigned long long)nd << 32) | nb;
+            };
+            auto push = [&](uint32_t nbn, uint32_t nd, bool chk) {
+                if (sp < (uint32_t)S) s_stack[wv][sp][lane] = ((unsigned long long)(nd | (chk ? 0x80000000u : 0u)) << 32) | nbn;
                 else ovf = true;
                 sp++;
             };
-            if (!(flags & F_EXT)) {
-                const uint32_t deg = hi.z & 0xFFu;
-                const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
-                const uint32_t ww[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+            if (!cur_chk && (flags & F_TARGET) && u != src_node) hit(u, d);  // forbid_source_target, greedytigs/mod.rs:329
+            if (!ext) {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (j < (int)deg) visit(nb[j], ww[j]);
+                for (int j = 0; j < 4; j++) {
+                    if (dc[j] != 0xFFFFFFFFu && ((cmeta >> (4 * j)) & 8u) && nb[j] != src_node) hit(nb[j], dc[j]);
+                    if (succ_d[j] != 0xFFFFFFFFu && nx_slot != j) push(nb[j], succ_d[j], true);  // its in-node flag is done
+                }
+#pragma unroll
+                for (int t = 0; t < GSLOTS; t++)
+                    if (succ_d[4 + t] != 0xFFFFFFFFu && nx_slot != 4 + t) push(gn[t], succ_d[4 + t], false);
             } else {
-                const uint64_t eb = ((uint64_t)lo.y << 32) | lo.x;
-                const uint32_t deg = lo.z;
-                for (uint32_t j = 0; j < deg; j++) visit(a.ext_col[eb + j], a.ext_w[eb + j]);
-            }
-            if (++pops > ENUM_POP_BUDGET) ovf = true;
-            if (!have_next && !ovf) {
-                if (sp == 0) fin = true;
-                else {  // dead end: back to the most recent branch
-                    sp--;
-                    const unsigned long long top = s_stack[wv][sp][lane];
-                    cur_node = (uint32_t)top;
-                    cur_dist = (uint32_t)(top >> 32);
+                for (uint32_t j = (uint32_t)(nx_slot + 1); have_next && j < ext_deg; j++) {
+                    const uint32_t nd = d + a.ext_w[ext_begin + j];
+                    if (nd <= a.K1) push(a.ext_col[ext_begin + j], nd, false);
                 }
             }
+            if (popped) sp--;
+            if (++pops > ENUM_POP_BUDGET) ovf = true;
+            if (will_end && !ovf) fin = true;
         }
 
         // ---- finished / overflowed lanes stage their result (hits as they are: the post-pass de-duplicates and sorts) ----
@@ -765,16 +983,31 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                 s_res_off[wv][n_res + rank] = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
                 if (fin) hit_base = (hit_base + nhit) & (uint32_t)(H - 1);  // the finished source's hits stay until the next burst
                 else used -= (nhit < (uint32_t)H ? nhit : (uint32_t)H);     // an overflowed source's hits are dropped
-                nhit = 0;
-                active = false;
             }
             n_res += (uint32_t)__popcll(donemask);
             uint32_t ovf_idx = 0;
             if (ovf) ovf_idx = (uint32_t)(a.src_index ? a.src_index[item] : a.src_begin + item);
             wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
         }
+
+        // ---- commit: every lane moves to its next block ----
+        if (fin || ovf || !active) {
+            if (got_new) {
+                item = new_item; src_node = new_src;
+                cur_node = new_src; cur_dist = 0; cur_chk = false;
+                sp = 0; nhit = 0; pops = 0; prev_key = 0; bloom = 0; unclean = false;
+                active = true;
+            } else {
+                nhit = 0;
+                active = false;
+            }
+        } else {
+            cur_node = nx_node; cur_dist = nx_dist; cur_chk = nx_chk;
+        }
+        b0 = n0; b1 = n1; b2 = n2; b3 = n3;
     }
     flush_results();
+    for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
 }
 
@@ -788,6 +1021,7 @@ __global__ __launch_bounds__(256) void sort_candidates_kernel(unsigned long long
     const unsigned long long n = *n_fix;
     for (unsigned long long p = (unsigned long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (unsigned long long)gridDim.x * 256) {
     const uint32_t i = fix_list[p];
+    if (i == FIX_NONE) continue;
     const uint32_t c = cand_count[i];
     if (c < 2 || c > (uint32_t)H) continue;
     const unsigned long long st = cand_start[i];
@@ -844,7 +1078,9 @@ struct Device {
     uint64_t k = 0;
     uint32_t K1 = 0;
     uint64_t V = 0;
-    NodeRec *d_recs = nullptr;
+    NodeBlock *d_recs = nullptr;              // [V] family blocks
+    uint32_t *d_odeg = nullptr;               // [V] out-degree (classification)
+    uint8_t *d_cls = nullptr;                 // [V] class byte of the last classification (F_TARGET | F_SOURCE | F_SELF_MIRROR)
     uint32_t *d_ext_col = nullptr;
     uint16_t *d_ext_w = nullptr;
     uint64_t ext_n = 0;
@@ -875,6 +1111,8 @@ struct Device {
 };
 
 typedef void (*sssp_fn)(SsspArgs);
+static void scan_u32(Device *d, hipStream_t st, ReplayWork &w, const uint32_t *in, uint64_t n, unsigned long long *out,
+                     unsigned long long *d_total);
 
 struct LevelCfg {
     sssp_fn fn;
@@ -898,7 +1136,7 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-constexpr int ENUM_WPB = 4, ENUM_STACK = 10, ENUM_HITS = 16;
+constexpr int ENUM_WPB = 4, ENUM_STACK = 12, ENUM_HITS = 16;
 static std::string enum_level_name() {
     char b[96];
     std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d> + sort_candidates_kernel", ENUM_WPB, ENUM_STACK, ENUM_HITS);
@@ -1007,7 +1245,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
         if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
-        HIP_CHECK(hipMalloc(&d->d_fix, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&d->d_fix, (std::max<uint64_t>(n, 1) + (uint64_t)d->n_cu * 8 * ENUM_WPB * ENUM_FIX_CHUNK) * sizeof(uint32_t)));  // + chunk slack per wave
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
@@ -1094,55 +1332,28 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
     d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    // node records are built from the ORIGINAL edges only (the search runs before any dummy edge exists, :678)
+    // The device graph is built ON the GPU from the ORIGINAL edges only (the search runs before any dummy edge exists, :678):
+    // the host uploads from / to / clamped weight / mirror, the build kernels make the family blocks.
     const uint64_t V = d->V, E = g.n_original_edges;
-    std::vector<NodeRec> recs(V);
-    std::vector<uint32_t> odeg(V, 0);
-    for (uint64_t e = 0; e < E; e++) odeg[g.e_from[e]]++;
-    uint64_t ext_total = 0;
-    for (uint64_t n = 0; n < V; n++) {
-        NodeRec &r = recs[n];
-        std::memset(&r, 0, sizeof r);
-        r.mirror = g.mirror[n];
-        if (odeg[n] > 32767) MTG_DIE("node %llu has %u out-edges: the device stage keeps multiplicities in 16 bits", (unsigned long long)n, odeg[n]);
-        if (odeg[n] > 4) {
-            r.flags = F_EXT;
-            r.nbr[0] = (uint32_t)(ext_total & 0xFFFFFFFFu);
-            r.nbr[1] = (uint32_t)(ext_total >> 32);
-            r.nbr[2] = 0;  // filled below
-            ext_total += odeg[n];
-        }
-    }
-    std::vector<uint32_t> ext_col(ext_total);
-    std::vector<uint16_t> ext_w(ext_total);
-    for (uint64_t e = 0; e < E; e++) {
-        const uint32_t f = g.e_from[e];
-        NodeRec &r = recs[f];
-        const uint64_t w = g.e_weight[e];
-        const uint16_t wc = (uint16_t)std::min<uint64_t>(w, k);
-        if (r.flags & F_EXT) {
-            const uint64_t b = ((uint64_t)r.nbr[1] << 32) | r.nbr[0];
-            ext_col[b + r.nbr[2]] = g.e_to[e];
-            ext_w[b + r.nbr[2]] = wc;
-            r.nbr[2]++;
-        } else {
-            r.nbr[r.deg] = g.e_to[e];
-            r.w[r.deg] = wc;
-            r.deg++;
-        }
-    }
-    HIP_CHECK(hipMalloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeRec)));
-    HIP_CHECK(hipMemcpy(d->d_recs, recs.data(), V * sizeof(NodeRec), hipMemcpyHostToDevice));
-    d->ext_n = ext_total;
-    HIP_CHECK(hipMalloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4));
-    HIP_CHECK(hipMalloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2));
-    if (ext_total) {
-        HIP_CHECK(hipMemcpy(d->d_ext_col, ext_col.data(), ext_total * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(d->d_ext_w, ext_w.data(), ext_total * 2, hipMemcpyHostToDevice));
-    }
+    PodVec<uint16_t> wclamp(E);
+    parallel_ranges(E, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t e = lo; e < hi; e++) wclamp[e] = (uint16_t)std::min<uint64_t>(g.e_weight[e], k);
+    });
+    hipStream_t st = nullptr;
+    uint32_t *d_from = nullptr, *d_to = nullptr, *d_fill = nullptr, *d_need = nullptr;
+    uint16_t *d_w = nullptr;
+    unsigned long long *d_ext_off = nullptr;
+    HIP_CHECK(hipMalloc(&d_from, std::max<uint64_t>(E, 1) * 4));
+    HIP_CHECK(hipMalloc(&d_to, std::max<uint64_t>(E, 1) * 4));
+    HIP_CHECK(hipMalloc(&d_w, std::max<uint64_t>(E, 1) * 2));
+    HIP_CHECK(hipMalloc(&d_fill, std::max<uint64_t>(V, 1) * 4));
+    HIP_CHECK(hipMalloc(&d_need, std::max<uint64_t>(V, 1) * 4));
+    HIP_CHECK(hipMalloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8));
+    HIP_CHECK(hipMalloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeBlock)));
+    HIP_CHECK(hipMalloc(&d->d_odeg, std::max<uint64_t>(V, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_cls, std::max<uint64_t>(V, 1)));
     HIP_CHECK(hipMalloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4));
     HIP_CHECK(hipMalloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4));
-    if (V) HIP_CHECK(hipMemcpy(d->d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4));
     d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
     HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4));  // source counts | positive multiplicities per block
@@ -1150,14 +1361,44 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
-    d->graph_bytes = V * sizeof(NodeRec) + ext_total * 6 + V * 8;
+    if (E) {
+        HIP_CHECK(hipMemcpyAsync(d_from, g.e_from.data(), E * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_to, g.e_to.data(), E * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_w, wclamp.data(), E * 2, hipMemcpyHostToDevice, st));
+    }
+    if (V) HIP_CHECK(hipMemcpyAsync(d->d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, st));
+    HIP_CHECK(hipMemsetAsync(d_fill, 0, std::max<uint64_t>(V, 1) * 4, st));
+    const unsigned eb = (unsigned)((E + 255) / 256), vb = (unsigned)((V + 255) / 256);
+    uint64_t ext_total = 0;
+    if (V) {
+        if (E) hipLaunchKernelGGL(build_count_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg);
+        hipLaunchKernelGGL(build_ext_need_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, V, d_need);
+        HIP_CHECK(hipGetLastError());
+        scan_u32(d, st, d->replay, d_need, V, d_ext_off, &d->d_counters[C_OVF_LIST]);
+        read_counters(d, st);
+        ext_total = d->h_counters[C_OVF_LIST];
+    }
+    d->ext_n = ext_total;
+    HIP_CHECK(hipMalloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4));
+    HIP_CHECK(hipMalloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2));
+    if (V) {
+        if (E) hipLaunchKernelGGL(build_fill_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_ext_off, d_fill, d->d_recs, d->d_ext_col);
+        hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_to, d_w, d->d_recs,
+                           d->d_ext_col, d->d_ext_w);
+        hipLaunchKernelGGL(build_children_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (void *p : {(void *)d_from, (void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
+    d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13;
     return d;
 }
 
 void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
-    void *bufs[] = {d->d_recs, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
+    void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
@@ -1179,13 +1420,13 @@ uint64_t device_classify(Device *d, void *stream) {
     HIP_CHECK(hipSetDevice(d->dev));
     d->n_sources = 0;
     if (d->V) {
-        hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs, (uint32_t)d->V,
-                           d->d_mult, d->d_block_counts, d->d_block_counts + d->n_cls_blocks);
+        hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_odeg, d->d_mirror, (uint32_t)d->V,
+                           d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
                            &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND]);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_recs,
+        hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_cls,
                            (uint32_t)d->V, d->d_block_counts, d->d_out_nodes);
         HIP_CHECK(hipGetLastError());
         read_counters(d, st);
@@ -1206,7 +1447,7 @@ void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int3
     if (live && d->V) {
         uint8_t *d_live = nullptr;
         HIP_CHECK(hipMalloc(&d_live, d->V));
-        hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((d->V + 255) / 256)), dim3(256), 0, st, d->d_recs, (uint32_t)d->V, d_live);
+        hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((d->V + 255) / 256)), dim3(256), 0, st, d->d_cls, (uint32_t)d->V, d_live);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(live, d_live, d->V, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1344,7 +1585,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         w.tag_base = 0;
     }
     // working copy of the classification state; per-source outputs start at "nothing claimed"
-    hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_recs, V, w.state);
+    hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(w.pair_count, 0, S * 4, st));
     HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
@@ -1440,7 +1681,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     uint32_t *d_count = nullptr;
     HIP_CHECK(hipMalloc(&d_start, S * 8));
     HIP_CHECK(hipMalloc(&d_count, S * 4));
-    uint64_t cap = std::max<uint64_t>(S * 2 + (uint64_t)d->n_cu * 32 * LANE_POOL_CHUNK, 1024);
+    uint64_t cap = std::max<uint64_t>(S * 2 + std::min<uint64_t>((S + 63) / 64, (uint64_t)d->n_cu * 8) * ENUM_POOL_CHUNK, 1024);  // keys + per-wave chunk slack
     for (;;) {
         HIP_CHECK(hipMalloc(&d_pool, cap * 8));
         uint64_t needed = 0;

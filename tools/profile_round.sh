@@ -4,7 +4,7 @@
 set -u
 OUT=${1:-gpurun_out/prof}
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH=${BENCH:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --euler-device-steps 0"}
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc1" -- $BENCH > /dev/null 2> "$OUT/pmc1.err"
