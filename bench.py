@@ -331,7 +331,11 @@ def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_a
             "settled_nodes": st["settled_nodes"], "queries": st["queries"], "pairs": st["pairs"], "tigs": st["tigs"],
             "multi_thread": run_cpu_baseline_mt(bg, k, stages),
         }
-    n = int(min(n_sources, max(50000, 50000 * budget_s / dt)))
+    n1 = int(min(n_sources, 400000))          # second calibration sample: the first 50 000 sources run on cold caches
+    t0 = time.perf_counter()
+    og.greedy_pairs_np(k, n1)
+    rate = n1 / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(n_sources, max(50000, rate * budget_s)))
     t0 = time.perf_counter()
     _, st = og.greedy_pairs_np(k, n)
     dt = time.perf_counter() - t0

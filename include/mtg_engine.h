@@ -180,6 +180,18 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
 /* Reservation rounds the last mtg_replay_claims_device needed. */
 int mtg_last_replay_rounds(const mtg_device *d);
 
+/* ---- multi-GPU ------------------------------------------------------------- */
+/* SSSP + gather + claim replay over ALL classified sources of n_devices resident copies of the SAME graph (each created
+ * with mtg_device_create on its GPU and classified): the ascending source list is cut into contiguous blocks of equal
+ * estimated work (1 + out-degree of the source), device i searches block i from its own host thread, the candidate lists
+ * are gathered on devices[0] with peer copies over xGMI (concatenation in device order is the replay order) and the claim
+ * loop runs there. The pair list is identical for every n_devices. *pairs_out: host memory, free with mtg_free.
+ * mtg_compute_tigs_cfg does exactly this for mtg_config.device_ids. */
+uint64_t mtg_compute_pairs(mtg_device *const *devices, int n_devices, mtg_pair **pairs_out);
+double mtg_last_gather_ms(void); /* wall-clock of the peer-copy gather of the last mtg_compute_pairs on this thread */
+/* The block boundaries that split uses: cuts_out[0..parts], cuts_out[0] = 0, cuts_out[parts] = number of sources. */
+void mtg_partition_sources(mtg_device *d, int parts, uint64_t *cuts_out);
+
 /* ---- host stages ----------------------------------------------------------------------- */
 /* Replays the reference's claim loop over the candidate lists in ascending source order.
  * cand_start/cand_count index `pool`. multiplicity / is_in_node are the classification
@@ -248,6 +260,15 @@ uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_
                              const char *unitig_seqs, const uint64_t *seq_offsets, const char *header, char **gfa_out);
 uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
                                  const char *header, const char *path, int compression_level);
+/* The same text (FASTA when gfa == 0, else GFA with `gfa_header` or "H\tKL:Z:{k}") spelled ON THE GPU `device_id`: the unitig
+ * store is packed to 2 bits per base on the device and one kernel writes the characters at prefix-summed offsets. Byte-identical to
+ * mtg_write_walks_fasta / _gfa for upper-case ACGT input (lower case is accepted and written upper case; any other character
+ * aborts, like the reference's DnaAlphabet store). mtg_write_tigs_fasta_file / _gfa_file use this path whenever a GPU is present. */
+uint64_t mtg_write_walks_text_device(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                                     const char *unitig_seqs, const uint64_t *seq_offsets, int gfa, const char *gfa_header, int device_id,
+                                     char **text_out);
+double mtg_last_spell_kernel_ms(void); /* HIP-event time of the last spelling kernel on this thread */
+uint64_t mtg_last_spell_bytes(void);   /* HBM bytes it moved (text written + packed bases + per-position metadata) */
 /* Duplication bitvectors (implementation/mod.rs:668-702): one line per tig with `weight` characters per edge, '1' for an
  * original edge and '0' for a dummy edge (k-mers that repeat ones spelled elsewhere). */
 uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,

@@ -134,6 +134,9 @@ def load():
         "mtg_set_sssp_plan": (C.c_int, [vp, C.c_int]),
         "mtg_replay_claims_device": (u64, [vp, vp, u64, vp, vp, vp, P(P(MtgPair))]),
         "mtg_last_replay_rounds": (C.c_int, [vp]),
+        "mtg_compute_pairs": (u64, [P(vp), C.c_int, P(P(MtgPair))]),
+        "mtg_last_gather_ms": (C.c_double, []),
+        "mtg_partition_sources": (None, [vp, C.c_int, P(u64)]),
         "mtg_replay_claims": (u64, [vp, u64, vp, vp, vp, vp, vp, vp, P(P(MtgPair))]),
         "mtg_free": (None, [vp]),
         "mtg_finish_greedytigs": (vp, [vp, vp, u64, u64]),
@@ -162,6 +165,9 @@ def load():
         "mtg_unitigs_offsets": (vp, [vp]),
         "mtg_unitigs_free": (None, [vp]),
         "mtg_write_tigs_fasta_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_int]),
+        "mtg_write_walks_text_device": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, C.c_int, C.c_char_p, C.c_int, P(vp)]),
+        "mtg_last_spell_kernel_ms": (C.c_double, []),
+        "mtg_last_spell_bytes": (u64, []),
         "mtg_write_duplication_bitvector": (u64, [vp, u64, vp, vp, P(vp)]),
         "mtg_write_tigs_duplication_bitvector_file": (u64, [vp, vp, C.c_char_p]),
         "mtg_write_walks_gfa": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, C.c_char_p, P(vp)]),

@@ -396,6 +396,26 @@ class DeviceGraph:
         return int(self._L.mtg_set_sssp_plan(self._d, plan))
 
 
+def compute_pairs(devices: Sequence[DeviceGraph]) -> np.ndarray:
+    """mtg_compute_pairs: SSSP sharded over the given (classified) device copies of one graph, gather on the first, claim replay."""
+    L = _lib.load()
+    arr = (C.c_void_p * len(devices))(*[d.handle for d in devices])
+    pp = C.POINTER(_lib.MtgPair)()
+    n = L.mtg_compute_pairs(arr, len(devices), C.byref(pp))
+    dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+    out = np.zeros(n, dt)
+    if n:
+        C.memmove(out.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
+    L.mtg_free(pp)
+    return out
+
+
+def partition_sources(device: DeviceGraph, parts: int) -> list[int]:
+    cuts = (C.c_uint64 * (parts + 1))()
+    _lib.load().mtg_partition_sources(device.handle, parts, cuts)
+    return [int(x) for x in cuts]
+
+
 class TigAlgorithm:
     """implementation/mod.rs:49-59."""
 
@@ -531,6 +551,35 @@ def write_duplication_bitvector(graph: Bigraph, tigs) -> bytes:
 def write_walks_gfa(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, header: Optional[str] = None) -> bytes:
     """bin.rs:667-818 through the C-ABI: GFA1 text (header line, then one S record per tig)."""
     return write_walks_fasta(graph, tigs, unitigs, k, _gfa=True, _header=header)
+
+
+def write_walks_text_device(graph: Bigraph, tigs, unitigs, k: int, gfa: bool = False, header: Optional[str] = None,
+                            device_id: int = 0) -> bytes:
+    """The same text spelled on the GPU (mtg_write_walks_text_device). unitigs: list of str, or (uint8 array, offsets)."""
+    L = _lib.load()
+    if isinstance(tigs, tuple):
+        lim, ed = np.ascontiguousarray(tigs[0], np.uint64), np.ascontiguousarray(tigs[1], np.uint32)
+    else:
+        ed = np.fromiter((e for t in tigs for e in t), dtype=np.uint32)
+        lim = np.cumsum([len(t) for t in tigs], dtype=np.uint64) if len(tigs) else np.zeros(0, np.uint64)
+    if isinstance(unitigs, tuple):
+        cat = np.ascontiguousarray(unitigs[0], np.uint8).tobytes()
+        off = np.ascontiguousarray(unitigs[1], np.uint64)
+    else:
+        cat = "".join(unitigs).encode()
+        off = np.zeros(len(unitigs) + 1, np.uint64)
+        off[1:] = np.cumsum([len(u) for u in unitigs])
+    out = C.c_void_p()
+    n = L.mtg_write_walks_text_device(graph.handle, len(lim), _ptr(lim) if len(lim) else None, _ptr(ed) if len(ed) else None, k, cat,
+                                      _ptr(off), 1 if gfa else 0, header.encode() if header else None, device_id, C.byref(out))
+    data = C.string_at(out, n)
+    L.mtg_free(out)
+    return data
+
+
+def last_spell_kernel() -> dict:
+    L = _lib.load()
+    return {"ms": float(L.mtg_last_spell_kernel_ms()), "bytes": int(L.mtg_last_spell_bytes())}
 
 
 def write_walks_fasta(graph: Bigraph, tigs, unitigs: Sequence[str], k: int, _gfa: bool = False,

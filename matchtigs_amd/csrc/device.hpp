@@ -31,8 +31,15 @@ void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_d
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
                        const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out);
 uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out);
+// SURVEY 8e inside the library: sources block-partitioned by work over the devices, candidate lists gathered on devs[0]
+uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out, int *rounds_out, double *gather_ms_out);
+std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int parts);
 // euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
 Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out);
+// spell_device.hip: tig spelling on the GPU (bin.rs:466-606 / 667-818), byte-identical to spell.cpp for ACGT input
+uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                                 const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, int device_id,
+                                 char **out_buf, double *kernel_ms_out, uint64_t *bytes_out);
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
                                std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);
 

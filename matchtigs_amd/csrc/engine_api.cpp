@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/matchtigs.h"
 #include "../../include/mtg_engine.h"
@@ -24,6 +26,7 @@ struct MatchtigsData { mtg_graph graph; };
 static thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static bool g_log_initialised = false;
 static thread_local double g_last_euler_kernel_ms = 0;
+static thread_local double g_last_gather_ms = 0;
 static thread_local mtg_dijkstra_performance_data g_last_perf = {};
 
 static void check_config(const mtg_config *cfg, const char *who) {
@@ -150,6 +153,21 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
     return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
 int mtg_last_replay_rounds(const mtg_device *d) { return device_last_replay_rounds(d->d); }
+uint64_t mtg_compute_pairs(mtg_device *const *devices, int n_devices, mtg_pair **pairs_out) {
+    if (!devices || n_devices < 1 || n_devices > MTG_MAX_DEVICES || !pairs_out) MTG_DIE("mtg_compute_pairs: bad argument");
+    std::vector<Device *> dv;
+    for (int i = 0; i < n_devices; i++) {
+        if (!devices[i]) MTG_DIE("mtg_compute_pairs: null device %d", i);
+        dv.push_back(devices[i]->d);
+    }
+    return device_pairs_multi(dv.data(), n_devices, pairs_out, nullptr, &g_last_gather_ms);
+}
+double mtg_last_gather_ms(void) { return g_last_gather_ms; }
+void mtg_partition_sources(mtg_device *d, int parts, uint64_t *cuts_out) {
+    if (!d || parts < 1 || !cuts_out) MTG_DIE("mtg_partition_sources: bad argument");
+    const std::vector<uint64_t> c = device_partition_sources(d->d, nullptr, parts);
+    for (int i = 0; i <= parts; i++) cuts_out[i] = c[(size_t)i];
+}
 
 // ---- host stages ----
 uint64_t mtg_replay_claims(const mtg_graph *g, uint64_t n_sources, const uint32_t *out_nodes, const int32_t *multiplicity,
@@ -279,6 +297,20 @@ uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_
     return write_walks_text(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, true, header, gfa_out);
 }
 
+// f-1 on the device: the same text from spell_device.hip (2-bit packed store, output-centric kernel)
+static thread_local double g_last_spell_kernel_ms = 0;
+static thread_local uint64_t g_last_spell_bytes = 0;
+uint64_t mtg_write_walks_text_device(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
+                                     const char *unitig_seqs, const uint64_t *seq_offsets, int gfa, const char *gfa_header, int device_id,
+                                     char **text_out) {
+    if (!g || !text_out || (n_walks && (!limits || !edges)) || !unitig_seqs || !seq_offsets)
+        MTG_DIE("mtg_write_walks_text_device: null argument");
+    return device_write_walks_text(g->g, n_walks, limits, edges, k, unitig_seqs, seq_offsets, gfa != 0, gfa_header, device_id, text_out,
+                                   &g_last_spell_kernel_ms, &g_last_spell_bytes);
+}
+double mtg_last_spell_kernel_ms(void) { return g_last_spell_kernel_ms; }
+uint64_t mtg_last_spell_bytes(void) { return g_last_spell_bytes; }
+
 uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
                                          char **text_out) {
     if (!g || !text_out || (n_walks && (!limits || !edges))) MTG_DIE("mtg_write_duplication_bitvector: null argument");
@@ -317,8 +349,11 @@ uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, ui
                                    const char *path, int compression_level) {
     if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_fasta_file: null argument");
     char *buf = nullptr;
-    const uint64_t n = write_walks_fasta(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
-                                         unitigs->s->data.data(), unitigs->s->off.data(), &buf);
+    const uint64_t n = device_count() > 0
+                           ? device_write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k, unitigs->s->data.data(),
+                                                     unitigs->s->off.data(), false, nullptr, 0, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
+                           : write_walks_fasta(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                                               unitigs->s->data.data(), unitigs->s->off.data(), &buf);
     write_file(path, buf, n, compression_level);
     std::free(buf);
     return n;
@@ -328,8 +363,11 @@ uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint
                                  const char *header, const char *path, int compression_level) {
     if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_gfa_file: null argument");
     char *buf = nullptr;
-    const uint64_t n = write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
-                                        unitigs->s->data.data(), unitigs->s->off.data(), true, header, &buf);
+    const uint64_t n = device_count() > 0
+                           ? device_write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k, unitigs->s->data.data(),
+                                                     unitigs->s->off.data(), true, header, 0, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
+                           : write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                                              unitigs->s->data.data(), unitigs->s->off.data(), true, header, &buf);
     write_file(path, buf, n, compression_level);
     std::free(buf);
     return n;
@@ -354,19 +392,35 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
             return mtg_compute_eulertigs_cfg(g, cfg);
         case 5: {
             double t0 = now_s();
-            mtg_device *dev = mtg_device_create(g, k, cfg->device_ids[0]);
+            // one resident copy of the graph per configured GPU (replicas + source sharding), built concurrently
+            const int n_dev = cfg->n_devices;
+            std::vector<mtg_device *> devs((size_t)n_dev, nullptr);
+            {
+                std::vector<std::thread> th;
+                for (int i = 1; i < n_dev; i++) th.emplace_back([&, i]() { devs[(size_t)i] = mtg_device_create(g, k, cfg->device_ids[i]); });
+                devs[0] = mtg_device_create(g, k, cfg->device_ids[0]);
+                for (auto &t : th) t.join();
+            }
+            mtg_device *dev = devs[0];
             double t1 = now_s();
             g_phase[0] = t1 - t0;
             log_info("Collecting nodes with missing incoming or outgoing edges");
-            const uint64_t S = mtg_classify(dev, nullptr);
+            uint64_t S = 0;
+            {
+                std::vector<std::thread> th;
+                for (int i = 1; i < n_dev; i++) th.emplace_back([&, i]() { (void)mtg_classify(devs[(size_t)i], nullptr); });
+                S = mtg_classify(dev, nullptr);
+                for (auto &t : th) t.join();
+            }
             double t2 = now_s();
             g_phase[1] = t2 - t1;
             log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
-            // SSSP candidates and the claim loop both run on the GPU; only the matched pairs come back
+            // SSSP candidates (sharded over the devices) and the claim loop both run on the GPU; only the matched pairs come back
             mtg_pair *pairs = nullptr;
-            const uint64_t n_pairs = device_pairs(dev->d, nullptr, &pairs, nullptr);
+            const uint64_t n_pairs = mtg_compute_pairs(devs.data(), n_dev, &pairs);
             double t3 = now_s();
-            g_phase[2] = t3 - t2;  // SSSP + replay + pair download
+            g_phase[2] = t3 - t2;  // SSSP + gather + replay + pair download
+            for (int i = 1; i < n_dev; i++) mtg_device_free(devs[(size_t)i]);
             if (cfg->performance_data_type == MTG_PERFORMANCE_DATA_COMPLETE) {  // greedytigs/mod.rs:647-673
                 device_performance_data(dev->d, nullptr, &g_last_perf);
                 const mtg_dijkstra_performance_data &p = g_last_perf;

@@ -103,3 +103,51 @@ def test_duplication_bitvector(product_lib):
     assert set(got) <= {"1", "\n"}
     fa = api.write_walks_fasta(G, tigs, ug.unitigs, k).decode()
     assert [len(l) for l in got.splitlines()] == [len(s) - k + 1 for s in _fasta_seqs(fa)]
+
+
+@pytest.mark.gpu
+def test_device_spelling_is_byte_identical(oracle, product_lib):
+    """SURVEY f-1 on the device (spell_device.hip): FASTA and GFA bytes equal the host speller's and the oracle's, for greedy
+    matchtigs (dummy overlaps), eulertigs and plain unitigs, on real tiny dBGs incl. backwards edges."""
+    from matchtigs_amd import api, synth
+
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU")
+    for seed, k in ((3, 11), (5, 21), (8, 31)):
+        ug = synth.g_seq(6000, seed=seed, k=k, haplotypes=4, sub_rate=0.03)
+        for alg in ("greedy", "euler", "unitigs"):
+            G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+            if alg == "greedy":
+                tigs = api.GreedytigAlgorithm.compute_tigs(G, api.GreedytigAlgorithmConfiguration.new(1, k))
+            elif alg == "euler":
+                tigs = api.EulertigAlgorithm.compute_tigs(G, api.EulertigAlgorithmConfiguration(k))
+            else:
+                tigs = [[2 * u] for u in range(len(ug.unitigs))] + [[2 * u + 1] for u in range(0, len(ug.unitigs), 7)]
+            host = api.write_walks_fasta(G, tigs, ug.unitigs, k)
+            dev = api.write_walks_text_device(G, tigs, ug.unitigs, k)
+            assert dev == host, (seed, k, alg)
+            assert api.write_walks_text_device(G, tigs, ug.unitigs, k, gfa=True) == api.write_walks_gfa(G, tigs, ug.unitigs, k)
+            assert api.write_walks_text_device(G, tigs, ug.unitigs, k, gfa=True, header="H\tVN:Z:1.0") == \
+                api.write_walks_gfa(G, tigs, ug.unitigs, k, header="H\tVN:Z:1.0")
+    # empty input and lower-case input
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    assert api.write_walks_text_device(G, [], ug.unitigs, k) == b""
+    assert api.write_walks_text_device(G, [[0]], [u.lower() for u in ug.unitigs], k) == api.write_walks_fasta(G, [[0]], ug.unitigs, k)
+
+
+@pytest.mark.gpu
+def test_device_spelling_at_scale(product_lib):
+    """E. coli-sized real dBG (config[0] stand-in): greedy matchtigs spelled on the GPU == host speller; prints the kernel's HBM rate."""
+    import numpy as np
+    from matchtigs_amd import api, synth
+
+    k = 31
+    ua = synth.g_seq_arrays(1_000_000, seed=3, k=k, haplotypes=4, sub_rate=0.02)
+    G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
+    lim, ed = api._take_walks_np(api._lib.load(), api._lib.load().mtg_compute_tigs(G.handle, 5, k, 0))
+    units = (ua.seq, ua.off)
+    dev = api.write_walks_text_device(G, (lim, ed), units, k)
+    info = api.last_spell_kernel()
+    host = api.write_walks_fasta(G, (lim, ed), ua.unitig_list(), k)
+    assert dev == host
+    print(f"device spelling: {len(dev)} bytes, kernel {info['ms']:.3f} ms, {info['bytes'] / max(info['ms'], 1e-9) / 1e6:.1f} GB/s")
