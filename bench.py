@@ -190,6 +190,7 @@ def main():
                 pairs = dev.replay_claims_device(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
                 po = pool_all
                 result_info["replay_rounds"] = dev.last_replay_rounds()
+                result_info["replay_visits"] = dev.last_replay_visits()
             t5 = time.perf_counter()
             ph["replay"] = t5 - t4
             tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, euler_mode_now[0], local_rank)
@@ -293,6 +294,11 @@ def main():
             "setup_s": round(t_gen, 2), "setup_graph_s": round(t_graph, 2),
             "device_graph_bytes": dev.graph_bytes(),
             "roofline": roofline,
+            # claim replay (one cooperative kernel): cost model = source visits x (32-B touch record + 8-B state and 8-B reservation
+            # word for the source's own binode and for each of its ~1.2 live candidates) + 64-bit atomics of the failed visits
+            "replay": {"rounds": result_info.get("replay_rounds"), "source_visits": result_info.get("replay_visits"),
+                       "model_bytes": None if result_info.get("replay_visits") is None else int(result_info["replay_visits"] * (32 + 16 + 1.2 * 16)),
+                       "ms": round(phases_acc.get("replay", 0.0) / max(args.steps, 1) * 1e3, 3)},
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

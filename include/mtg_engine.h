@@ -179,6 +179,8 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
                                   const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out);
 /* Reservation rounds the last mtg_replay_claims_device needed. */
 int mtg_last_replay_rounds(const mtg_device *d);
+/* Source visits of those rounds (sum of the pending-list lengths): the unit of the replay's cost model. */
+uint64_t mtg_last_replay_visits(const mtg_device *d);
 
 /* ---- multi-GPU ------------------------------------------------------------- */
 /* SSSP + gather + claim replay over ALL classified sources of n_devices resident copies of the SAME graph (each created

@@ -134,6 +134,7 @@ def load():
         "mtg_set_sssp_plan": (C.c_int, [vp, C.c_int]),
         "mtg_replay_claims_device": (u64, [vp, vp, u64, vp, vp, vp, P(P(MtgPair))]),
         "mtg_last_replay_rounds": (C.c_int, [vp]),
+        "mtg_last_replay_visits": (u64, [vp]),
         "mtg_compute_pairs": (u64, [P(vp), C.c_int, P(P(MtgPair))]),
         "mtg_last_gather_ms": (C.c_double, []),
         "mtg_partition_sources": (None, [vp, C.c_int, P(u64)]),

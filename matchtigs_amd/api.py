@@ -379,6 +379,9 @@ class DeviceGraph:
     def last_replay_rounds(self) -> int:
         return int(self._L.mtg_last_replay_rounds(self._d))
 
+    def last_replay_visits(self) -> int:
+        return int(self._L.mtg_last_replay_visits(self._d))
+
     def last_sssp_levels(self) -> list[dict]:
         ms = (C.c_double * 8)()
         src = (C.c_uint64 * 8)()

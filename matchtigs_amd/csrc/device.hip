@@ -1109,6 +1109,7 @@ struct Device {
     uint64_t graph_bytes = 0;
     ReplayWork replay;
     int last_replay_rounds = 0;
+    uint64_t last_replay_visits = 0;  // sum over the rounds of the pending-list lengths (first RC_TRACE_ROUNDS rounds)
 };
 
 typedef void (*sssp_fn)(SsspArgs);
@@ -1617,6 +1618,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (w.h_ctl[RC_ABORT]) MTG_DIE("claim replay: a workgroup never reached the grid barrier (watchdog)");
     const int rounds = (int)w.h_ctl[RC_ROUNDS];
     w.tag_base += (uint32_t)rounds + 2;
+    d->last_replay_visits = 0;
+    for (int r = 0; r < rounds && r < RC_TRACE_ROUNDS; r++) d->last_replay_visits += w.h_ctl[RC_TRACE + 2 * r];
     static const bool replay_debug = std::getenv("MTG_DEBUG") != nullptr;
     if (replay_debug) {
         std::fprintf(stderr, "[mtg] replay: %d rounds, %llu left; per round (pending, us since kernel start):", rounds, (unsigned long long)w.h_ctl[RC_LEFT]);
@@ -1666,6 +1669,7 @@ int device_set_plan(Device *d, int plan) {
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
+uint64_t device_last_replay_visits(const Device *d) { return d->last_replay_visits; }
 
 // one-shot path: SSSP candidates for all sources into engine-owned device buffers (pool grown on demand), then the
 // claim replay on the GPU; only the matched pairs travel to the host.

@@ -27,6 +27,7 @@ const char *device_last_level_name(const Device *d, int level);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_plan(Device *d, int plan);
 int device_last_replay_rounds(const Device *d);
+uint64_t device_last_replay_visits(const Device *d);
 void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out);
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
                        const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out);

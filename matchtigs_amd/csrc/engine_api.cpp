@@ -153,6 +153,7 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
     return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
 int mtg_last_replay_rounds(const mtg_device *d) { return device_last_replay_rounds(d->d); }
+uint64_t mtg_last_replay_visits(const mtg_device *d) { return device_last_replay_visits(d->d); }
 uint64_t mtg_compute_pairs(mtg_device *const *devices, int n_devices, mtg_pair **pairs_out) {
     if (!devices || n_devices < 1 || n_devices > MTG_MAX_DEVICES || !pairs_out) MTG_DIE("mtg_compute_pairs: bad argument");
     std::vector<Device *> dv;

@@ -94,30 +94,60 @@ void HostGraph::reset_to_original() {
 void HostGraph::validate_pairing() const {
     // graph.verify_node_pairing(), clib.rs:251
     const uint64_t n = mirror.size();
-    for (uint64_t i = 0; i < n; i++) {
-        uint32_t m = mirror[i];
-        if (m == NONE || m >= n || mirror[m] != i)
-            MTG_DIE("assertion failed: graph.verify_node_pairing() (node %llu)", (unsigned long long)i);
-    }
+    parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint32_t m = mirror[i];
+            if (m == NONE || m >= n || mirror[m] != i)
+                MTG_DIE("assertion failed: graph.verify_node_pairing() (node %llu)", (unsigned long long)i);
+        }
+    });
+}
+
+// per-node adjacency lists over edges [0, n_edges) in insertion order (newest first, like petgraph's per-node edge list), linked by
+// node range from host threads: every node's edges are prepended in ascending edge id by exactly one thread
+static void link_adjacency(HostGraph &g, uint64_t n_edges) {
+    parallel_ranges(g.node_count(), [&](uint64_t nlo, uint64_t nhi) {
+        for (uint64_t e = 0; e < n_edges; e++) {
+            const uint32_t f = g.e_from[e];
+            if (f < nlo || f >= nhi) continue;
+            g.e_next_out[e] = g.head_out[f];
+            g.head_out[f] = (uint32_t)e;
+            g.out_deg[f]++;
+        }
+    });
 }
 
 HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *from,
                             const uint32_t *to, const uint64_t *weight) {
     if ((n_nodes && !mirror) || (n_edges && (!from || !to || !weight))) MTG_DIE("mtg_graph_from_edges: null array");
     if (n_edges % 2) MTG_DIE("mtg_graph_from_edges: edges must come in (forward, mirror) pairs");
+    if (n_edges >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
     HostGraph *g = new HostGraph();
     g->init_nodes(n_nodes);
-    for (uint64_t i = 0; i < n_nodes; i++) g->mirror[i] = mirror[i];
+    parallel_ranges(n_nodes, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) g->mirror[i] = mirror[i];
+    });
     g->validate_pairing();
-    g->reserve_edges(n_edges);
-    for (uint64_t e = 0; e < n_edges; e += 2) {
-        uint32_t f = from[e], t = to[e];
-        if (f >= n_nodes || t >= n_nodes) MTG_DIE("edge %llu: node id out of range", (unsigned long long)e);
-        // graph.verify_edge_mirror_property(), clib.rs:252: the partner must be mirror(to) -> mirror(from)
-        if (from[e + 1] != g->mirror[t] || to[e + 1] != g->mirror[f] || weight[e + 1] != weight[e])
-            MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (edge %llu)", (unsigned long long)e);
-        g->add_biedge(f, t, weight[e], 0, e / 2);
-    }
+    // bulk form of n_edges / 2 add_biedge calls: arrays filled by host threads, adjacency linked by node range
+    g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
+    g->e_weight.resize(n_edges); g->e_dummy.resize(n_edges); g->e_unitig.resize(n_edges); g->e_fwd.resize(n_edges);
+    parallel_ranges(n_edges / 2, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t u = lo; u < hi; u++) {
+            const uint64_t e = 2 * u;
+            const uint32_t f = from[e], t = to[e];
+            if (f >= n_nodes || t >= n_nodes) MTG_DIE("edge %llu: node id out of range", (unsigned long long)e);
+            // graph.verify_edge_mirror_property(), clib.rs:252: the partner must be mirror(to) -> mirror(from)
+            if (from[e + 1] != g->mirror[t] || to[e + 1] != g->mirror[f] || weight[e + 1] != weight[e])
+                MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (edge %llu)", (unsigned long long)e);
+            g->e_from[e] = f; g->e_to[e] = t;
+            g->e_from[e + 1] = from[e + 1]; g->e_to[e + 1] = to[e + 1];
+            g->e_weight[e] = g->e_weight[e + 1] = weight[e];
+            g->e_dummy[e] = g->e_dummy[e + 1] = 0;
+            g->e_unitig[e] = g->e_unitig[e + 1] = u;
+            g->e_fwd[e] = 1; g->e_fwd[e + 1] = 0;
+        }
+    });
+    link_adjacency(*g, n_edges);
     g->n_original_edges = n_edges;
     g->built = true;
     return g;
@@ -182,17 +212,31 @@ void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
             node_of_root[i] = (uint32_t)n_nodes++;
         }
     g->init_nodes(n_nodes);
-    g->reserve_edges(g->unitig_amount * 2);
-    for (uint64_t u = 0; u < g->unitig_amount; u++) {
-        const uint32_t n1 = node_of_root[uf_root(g, u * 4)];
-        const uint32_t n2 = node_of_root[uf_root(g, u * 4 + 2)];
-        const uint32_t mirror_n2 = node_of_root[uf_root(g, u * 4 + 3)];
-        const uint32_t mirror_n1 = node_of_root[uf_root(g, u * 4 + 1)];
-        g->mirror[n1] = mirror_n1; g->mirror[mirror_n1] = n1;   // set_mirror_nodes, clib.rs:236
+    const uint64_t U = g->unitig_amount, n_edges = 2 * U;
+    if (n_edges >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
+    for (uint64_t i = 0; i < slots; i++) (void)uf_root(g, i);  // full compression once: the parallel fill below only reads parents
+    g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
+    g->e_weight.resize(n_edges); g->e_dummy.resize(n_edges); g->e_unitig.resize(n_edges); g->e_fwd.resize(n_edges);
+    auto node_of = [&](uint64_t slot) { return node_of_root[g->uf_parent[slot]]; };
+    // set_mirror_nodes (clib.rs:236-237) is an assignment in unitig order: a later unitig re-pairs a node an earlier one
+    // paired differently (then verify_node_pairing fails below, as in the reference); kept sequential for that order
+    for (uint64_t u = 0; u < U; u++) {
+        const uint32_t n1 = node_of(u * 4), n2 = node_of(u * 4 + 2), mirror_n2 = node_of(u * 4 + 3), mirror_n1 = node_of(u * 4 + 1);
+        g->mirror[n1] = mirror_n1; g->mirror[mirror_n1] = n1;   // clib.rs:236
         g->mirror[n2] = mirror_n2; g->mirror[mirror_n2] = n2;   // clib.rs:237
-        push_edge(*g, n1, n2, unitig_weights[u], 0, u, true);                // clib.rs:239-243
-        push_edge(*g, mirror_n2, mirror_n1, unitig_weights[u], 0, u, false); // clib.rs:244-248
     }
+    parallel_ranges(U, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t u = lo; u < hi; u++) {
+            const uint64_t e = 2 * u;
+            g->e_from[e] = node_of(u * 4); g->e_to[e] = node_of(u * 4 + 2);              // clib.rs:239-243
+            g->e_from[e + 1] = node_of(u * 4 + 3); g->e_to[e + 1] = node_of(u * 4 + 1);  // clib.rs:244-248
+            g->e_weight[e] = g->e_weight[e + 1] = unitig_weights[u];
+            g->e_dummy[e] = g->e_dummy[e + 1] = 0;
+            g->e_unitig[e] = g->e_unitig[e + 1] = u;
+            g->e_fwd[e] = 1; g->e_fwd[e + 1] = 0;
+        }
+    });
+    link_adjacency(*g, n_edges);
     g->validate_pairing();  // clib.rs:251
     // clib.rs:252 verify_edge_mirror_property: with a valid pairing the two edges of a unitig are mirrors of
     // each other by construction only if later set_mirror_nodes calls did not re-pair their endpoints.

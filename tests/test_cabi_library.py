@@ -121,3 +121,32 @@ def test_weight_zero_rejected_at_the_boundary(product_lib):
         _lib.load().mtg_device_create(G.handle, 5, 0)
     """)
     assert r.returncode != 0 and "weight 0" in r.stderr
+
+
+def test_config_struct_defaults_and_validation(product_lib):
+    """mtg_config mirrors GreedytigAlgorithmConfiguration (greedytigs/mod.rs:40-73): ::new() defaults, enum parsing errors."""
+    import ctypes as C
+    import subprocess
+    import sys
+
+    from matchtigs_amd import _lib, api
+
+    c = _lib.MtgConfig()
+    product_lib.mtg_config_init(C.byref(c), 7, 31)
+    assert (c.threads, c.k, c.staged_parallelism_divisor, c.resource_limit_factor) == (7, 31, 0.0, 0)          # :62-72
+    assert (c.node_weight_array_type, c.heap_type, c.performance_data_type) == (1, 0, 0)                         # HashbrownHashMap, StdBinaryHeap, None
+    assert (c.euler_mode, c.n_devices, c.device_ids[0]) == (0, 1, 0)
+    cfg = api.GreedytigAlgorithmConfiguration(3, 21, staged_parallelism_divisor=2.0, resource_limit_factor=5,
+                                              node_weight_array_type=api.NodeWeightArrayType.EpochNodeWeightArray,
+                                              performance_data_type=api.PerformanceDataType.Complete, euler_mode=api.EulerMode.Device,
+                                              device_ids=(2, 5)).to_c()
+    assert (cfg.threads, cfg.k, cfg.staged_parallelism_divisor, cfg.resource_limit_factor, cfg.node_weight_array_type,
+            cfg.performance_data_type, cfg.euler_mode, cfg.n_devices, cfg.device_ids[0], cfg.device_ids[1]) == (3, 21, 2.0, 5, 0, 1, 1, 2, 2, 5)
+    with pytest.raises(ValueError, match="Unknown heap type: Fibonacci"):
+        api.HeapType.from_str("Fibonacci")                                                                         # implementation/mod.rs:99
+    # an invalid enum value aborts with the reference's message (panic => abort), checked in a child process
+    code = ("import ctypes as C, numpy as np\nfrom matchtigs_amd import _lib, api\nL = _lib.load()\n"
+            "G = api.Bigraph.from_edges(np.array([1,0],np.uint32), np.array([0,0],np.uint32), np.array([1,1],np.uint32), np.array([3,3],np.uint64))\n"
+            "c = _lib.MtgConfig(); L.mtg_config_init(C.byref(c), 1, 5); c.heap_type = 9\nL.mtg_compute_eulertigs_cfg(G.handle, C.byref(c))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(_lib.REPO_DIR))
+    assert r.returncode != 0 and "Unknown heap type" in r.stderr

@@ -259,3 +259,27 @@ def test_full_bench_size_properties(gpu, oracle):
     # cumulative length identity: sum of unitig k-mers + kept dummy weights + (k-1) * #tigs
     cum = int(ex["edge_weight"][edges].sum()) + (k - 1) * len(lim)
     assert cum == int(bg.edge_weight[0::2].sum()) + int(w.sum()) + (k - 1) * len(lim)
+
+
+def test_dijkstra_performance_data(gpu, oracle):
+    """performance_data_type = Complete (greedytigs/mod.rs:176-197, 647-673): counters in the engine's terms, tied to the
+    oracle's full-ball Dijkstra: one query per source, iterations = settled (source, node) pairs."""
+    from matchtigs_amd import api
+
+    name, bg = graphs()[2]
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    cfg = api.GreedytigAlgorithmConfiguration(4, bg.k, performance_data_type=api.PerformanceDataType.Complete,
+                                              node_weight_array_type=api.NodeWeightArrayType.EpochNodeWeightArray)
+    tigs = api.GreedytigAlgorithm.compute_tigs(G, cfg)
+    pd = api.last_performance_data()
+    og = _oracle(oracle, bg)
+    o_on, off, keys, st = og.candidate_lists(bg.k)
+    assert pd["dijkstras"] == len(o_on)
+    assert pd["iterations"] == st["settled_nodes"] == pd["sum_max_distance_array_size"]
+    assert pd["heap_pushes"] >= pd["iterations"] and pd["unnecessary_heap_elements"] == pd["heap_pushes"] - pd["iterations"]
+    assert 1 <= pd["max_max_distance_array_size"] <= pd["max_max_heap_size"] <= pd["heap_pushes"]
+    want, _ = _oracle(oracle, bg).compute_greedytigs(bg.k)
+    assert tigs == want          # the counters never change results
+    G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    api.GreedytigAlgorithm.compute_tigs(G2, api.GreedytigAlgorithmConfiguration.new(1, bg.k))
+    assert api.last_performance_data()["dijkstras"] == 0   # None: nothing is collected
