@@ -1581,7 +1581,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     // reservation tags decrease with every round of every call, so the two reservation arrays are never cleared; only when
     // the 32-bit tag space is used up (or the arrays are new)
-    if ((uint64_t)w.tag_base + REPLAY_MAX_ROUNDS + 8 >= 0xFFFFFFF0ull) {
+    if ((uint64_t)w.tag_base + REPLAY_MAX_ROUNDS + 128 >= 0xFFFFFFF0ull) {
         HIP_CHECK(hipMemsetAsync(w.resv[0], 0xFF, V * 8, st));
         HIP_CHECK(hipMemsetAsync(w.resv[1], 0xFF, V * 8, st));
         w.tag_base = 0;
@@ -1598,6 +1598,12 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.big = w.big; a.claims = w.claims; a.pair_count = w.pair_count;
     a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
     a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
+    // index-ordered admission windows: ~256 K sources each, between 4 and 64 of them (a round costs a grid barrier plus one
+    // dependent-access chain, ~30-50 us, so tiny windows are latency bound; huge ones bring the waiting visits back)
+    {
+        const uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(64, (S + (1u << 18) - 1) >> 18));
+        a.window = std::max<uint64_t>((S + n_win - 1) / n_win, REPLAY_BLOCK);
+    }
 
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
     // deadlock; fewer, larger workgroups keep the barrier cheap
