@@ -299,9 +299,7 @@ enum Counter : int {
     C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
     C_MAX_ENT = 11,  // COUNT: most table entries of one batch
     C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
-    C_SRC0 = 16,     // enumeration level: N_SRC_CTR source cursors, one per slice of the source range (a single cursor for 2048 waves
-                     // is a same-address atomic every ~25 ns: the waves queue up behind it)
-    C_COUNT = 32
+    C_COUNT = 16
 };
 
 struct SsspArgs {
@@ -656,7 +654,6 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
 }
 
 // Wave-level helpers shared by the lane-per-source level
-constexpr unsigned long long LANE_SRC_CHUNK = 256;  // sources a wave takes per global atomic (LDS budget: two workgroups per CU)
 
 // Overflowed sources of a wave are buffered in LDS and appended to the global overflow list 64 at a time, so the
 // list cursor sees one atomic per 64 sources instead of one per overflow event.
@@ -706,45 +703,45 @@ constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr unsigned long long ENUM_POOL_CHUNK = 4096;  // keys per wave-local pool chunk (a burst needs ~250; fewer same-address atomics)
 constexpr unsigned long long ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
-constexpr int N_SRC_CTR = 16;
+
 
 template <int WPB, int S, int H>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
-    static_assert((H & (H - 1)) == 0 && H <= 128, "the hit ring is indexed modulo H");
-    constexpr int RQ = 256;  // staged results (finished sources) per wave
-    __shared__ unsigned long long s_stack[WPB][S][64];  // (distance << 32 | node), slot-major / lane-minor: conflict free
-    // Per-lane RING of candidate keys: the hits of the lane's current source follow those of its finished sources, which stay
-    // there until the wave writes its staged results out in one burst. (A store in every iteration would sit in the same
-    // in-order memory counter as the next record gather, so the wave would wait for the store's acknowledgement before it
-    // can use the gather; copying a finished source's hits somewhere else costs a serial loop per iteration. Both measured.)
-    __shared__ unsigned long long s_hits[WPB][H][64];
-    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_off[WPB][RQ], s_res_misc[WPB][RQ];  // misc: count:8 | lane:8 | ring base:8 | overflow:1
-    __shared__ uint32_t s_nkeys[WPB], s_nfix[WPB];
+    // LDS budget: the level is a dependent gather chain per lane, so its throughput is lanes in flight / step latency. The
+    // random-line ceiling of the memory system (tools/gather_bench64: 54 G lines/s for 16, 32 and 64 bytes per lane alike, flat
+    // from 8 to 32 waves per CU) is only reached with >= 12-16 waves per CU at this kernel's ~5 us per step, i.e. <= 10-13 KB
+    // of LDS per wave: 6-byte stack and hit entries, hits of the CURRENT source only per lane, finished sources' keys compacted
+    // into one wave-shared buffer.
+    constexpr int RQ = 128;       // staged results (finished sources) per wave
+    constexpr int OB = 512;       // staged candidate keys per wave (a step that would stage more hands its last sources to the cascade)
+    __shared__ uint32_t s_stk_node[WPB][S][64];   // slot-major / lane-minor: conflict free
+    __shared__ uint16_t s_stk_dist[WPB][S][64];   // distance | own-flag-done << 15
+    __shared__ uint32_t s_hit_node[WPB][H][64];   // in-node hits of the lane's current source, discovery order
+    __shared__ uint16_t s_hit_dist[WPB][H][64];
+    __shared__ unsigned long long s_out[WPB][OB]; // keys of finished sources, compact, until the wave's next burst
+    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_misc[WPB][RQ];  // misc: offset in s_out:12 | count:8 | overflow:1 << 31
+    __shared__ uint32_t s_nfix[WPB];
     __shared__ uint32_t s_fix[WPB][RQ];  // staged sources whose hits are not yet in Dijkstra order
     __shared__ WaveOvfBuf s_ovf[WPB];
-    __shared__ uint32_t s_src[WPB][LANE_SRC_CHUNK];  // source ids of the wave's current chunk (one coalesced sweep per chunk)
+    __shared__ uint32_t s_src[WPB][64];  // source ids of the wave's current chunk
+    __shared__ uint32_t s_nkeys[WPB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
 
     unsigned long long chunk_lo = 0, chunk_hi = 0, chunk_base = 0, pool_next = 0, pool_end = 0, fix_next = 0, fix_end = 0;  // wave-uniform
-    // the source range is cut into N_SRC_CTR slices with a cursor each; a wave starts at "its" slice and moves on when one runs dry
-    const unsigned long long slice = ((a.n_items + N_SRC_CTR - 1) / N_SRC_CTR + LANE_SRC_CHUNK - 1) / LANE_SRC_CHUNK * LANE_SRC_CHUNK;
-    int cur_ctr = (int)((blockIdx.x * WPB + wv) % N_SRC_CTR), dry = 0;  // wave-uniform
-    uint32_t n_res = 0;                                                                            // wave-uniform
+    uint32_t n_res = 0, n_keys = 0;                                       // wave-uniform
     bool exhausted = false;
     bool active = false;
     uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, n_overflow = 0;
-    uint32_t hit_base = 0, used = 0;      // ring: first slot of the current source's hits, occupied slots
     unsigned long long prev_key = 0;      // hits already in (distance, node) order and without a repeated node need no post-pass:
     uint32_t bloom = 0;                   // 32-bit filter over node ids (a set bit seen twice = "maybe repeated")
     bool unclean = false;
     uint32_t cur_node = 0, cur_dist = 0;  // the step in progress; the stack holds the branches still to take
     bool cur_chk = false;                 // the node's own in-node flag was already evaluated from its parent's block
     unsigned long long item = 0;
-    if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
+    if (lane == 0) { s_nfix[wv] = 0; s_nkeys[wv] = 0; }
 
     auto flush_results = [&]() {
-        const uint32_t n_keys = __shfl(lane == 0 ? s_nkeys[wv] : 0u, 0);
         const uint32_t n_fix = __shfl(lane == 0 ? s_nfix[wv] : 0u, 0);
         // both cursors are taken by one lane back to back (one memory round trip, not two) and before this burst's stores
         const bool need_pool = n_keys && pool_next + n_keys > pool_end;
@@ -768,59 +765,56 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         }
         for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[fix_next + t] = s_fix[wv][t];  // (almost) dense work list for the post-pass
         fix_next += n_fix;
+        for (uint32_t t = lane; t < n_keys; t += 64)                                            // the keys: one coalesced copy
+            if (pool_next + t < a.pool_cap) a.pool[pool_next + t] = s_out[wv][t];
         for (uint32_t t = lane; t < n_res; t += 64) {
             const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
-            const uint32_t c = (misc >> 24) ? CAND_OVERFLOW : (misc & 0xFFu);
-            if (c != CAND_OVERFLOW) {
-                const unsigned long long pos0 = pool_next + s_res_off[wv][t];
-                const uint32_t l = (misc >> 8) & 0xFFu, b = (misc >> 16) & 0xFFu;
-                for (uint32_t r = 0; r < c; r++)
-                    if (pos0 + r < a.pool_cap) a.pool[pos0 + r] = s_hits[wv][(b + r) & (uint32_t)(H - 1)][l];
-                a.cand_start[i] = pos0;
+            if (misc >> 31) a.cand_count[i] = CAND_OVERFLOW;
+            else {
+                a.cand_start[i] = pool_next + (misc & 0xFFFu);
+                a.cand_count[i] = (misc >> 12) & 0xFFu;
             }
-            a.cand_count[i] = c;
         }
         pool_next += n_keys;
         n_res = 0;
-        if (lane == 0) { s_nkeys[wv] = 0; s_nfix[wv] = 0; }
-        used = nhit;  // only the current source's hits stay in the ring
+        n_keys = 0;
+        if (lane == 0) s_nfix[wv] = 0;
     };
 
     // Software-pipelined main loop. An iteration (1) decodes the block that arrived for every active lane just far enough to
     // know where the lane goes next -- a successor within the bound, else the top of its stack, else a NEW source --, (2) issues
     // the gather of that next block straight away, and only then (3) records the in-node hits, pushes the other successors and
-    // stages finished sources, i.e. the bulk of the integer and LDS work runs while the next gather is in flight. (Measured
-    // before this form: a wave spent memory latency + ~600 instructions per step back to back, 5 us per step at 8 waves/CU.)
+    // stages finished sources.
     uint4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;  // family block of cur_node (valid for active lanes)
     auto load_block = [&](uint32_t node, uint4 &o0, uint4 &o1, uint4 &o2, uint4 &o3) {
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
         o0 = rp[0]; o1 = rp[1]; o2 = rp[2]; o3 = rp[3];
     };
-    // hands out source indices to the lanes in `need` (wave-uniform chunk of LANE_SRC_CHUNK sources per global atomic, source
-    // ids staged in LDS with one coalesced sweep per chunk; a chunk that runs out is topped up from the next one)
+    // Hands out source indices to the lanes in `want`. Waves take chunks of 64 sources in a STATIC stride (chunk c belongs to wave
+    // c mod n_waves): no atomic, and the ids of the wave's NEXT chunk are loaded one chunk ahead (a register per lane), so a
+    // refill costs neither a same-address atomic nor a memory round trip (measured before: a quarter of the kernel's time went
+    // into the two dependent round trips of a dynamic chunk grab). The searches are short and the per-wave totals close, so the
+    // static split loses less at the tail than the dynamic one lost in queues.
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB, my_wave = (unsigned long long)blockIdx.x * WPB + wv;
+    unsigned long long next_chunk = my_wave;  // chunk whose ids are in `ahead` (wave-uniform)
+    uint32_t ahead = 0;
+    auto prefetch_ids = [&]() {
+        const unsigned long long t = next_chunk * 64 + lane;
+        ahead = t < a.n_items ? a.sources[a.src_index ? a.src_index[t] : a.src_begin + t] : 0u;
+    };
+    prefetch_ids();
     auto take_sources = [&](bool want, unsigned long long &new_item, uint32_t &new_src) -> bool {
         bool got = false;
         unsigned long long need = __ballot(want);
         for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
             if (chunk_lo >= chunk_hi) {
-                while (dry < N_SRC_CTR) {
-                    const unsigned long long s_lo = (unsigned long long)cur_ctr * slice;
-                    const unsigned long long s_hi = (s_lo + slice) < a.n_items ? (s_lo + slice) : a.n_items;
-                    unsigned long long c0 = 0;
-                    if (lane == 0 && s_lo < s_hi) c0 = atomicAdd(&a.counters[C_SRC0 + cur_ctr], LANE_SRC_CHUNK);
-                    c0 = __shfl(c0, 0) + s_lo;
-                    if (s_lo < s_hi && c0 < s_hi) {
-                        chunk_lo = c0;
-                        chunk_hi = (c0 + LANE_SRC_CHUNK) < s_hi ? (c0 + LANE_SRC_CHUNK) : s_hi;
-                        break;
-                    }
-                    cur_ctr = (cur_ctr + 1) % N_SRC_CTR;  // this slice is dry (it stays dry: cursors only grow)
-                    dry++;
-                }
-                if (chunk_lo >= chunk_hi) { exhausted = true; break; }
-                chunk_base = chunk_lo;
-                for (unsigned long long t = chunk_lo + lane; t < chunk_hi; t += 64)
-                    s_src[wv][t - chunk_base] = a.sources[a.src_index ? a.src_index[t] : a.src_begin + t];
+                const unsigned long long lo = next_chunk * 64;
+                if (lo >= a.n_items) { exhausted = true; break; }
+                chunk_lo = chunk_base = lo;
+                chunk_hi = (lo + 64) < a.n_items ? (lo + 64) : a.n_items;
+                s_src[wv][lane] = ahead;      // the ids loaded one chunk ago
+                next_chunk += n_waves;
+                prefetch_ids();               // in flight while this chunk is being consumed
             }
             const unsigned n_want = (unsigned)__popcll(need);
             if (want && !got) {
@@ -860,9 +854,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             }
             continue;
         }
-        // a step adds at most five hits (the node and its four children): make room where a burst write can (finished sources'
-        // hits leave the rings)
-        if (n_res + 64 > (uint32_t)RQ || __any(active && used + 5 > (uint32_t)H && used > nhit)) flush_results();
+        // room for the result records of every source that can finish in this step (key space is checked where they are staged)
+        if (n_res + 64 > (uint32_t)RQ) flush_results();
 
         // ---- (1) where does every lane go next? ----
         const uint32_t u = cur_node, d = cur_dist;
@@ -915,10 +908,10 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         }
         bool popped = false;
         if (active && !have_next && sp > 0) {  // dead end: back to the most recent branch (nothing is pushed in such a step)
-            const unsigned long long top = s_stack[wv][sp - 1][lane];
-            nx_node = (uint32_t)top;
-            nx_dist = (uint32_t)(top >> 32) & 0x7FFFFFFFu;
-            nx_chk = (top >> 63) != 0;
+            nx_node = s_stk_node[wv][sp - 1][lane];
+            const uint32_t dd = s_stk_dist[wv][sp - 1][lane];
+            nx_dist = dd & 0x7FFFu;
+            nx_chk = (dd >> 15) != 0;
             popped = true;
         }
         const bool will_end = active && !have_next && !popped;  // the source finishes (or overflows) in this step
@@ -939,15 +932,17 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                 unclean |= (key <= prev_key) | ((bloom & bit) != 0u);
                 prev_key = key;
                 bloom |= bit;
-                if (used < (uint32_t)H) {
-                    s_hits[wv][(hit_base + nhit) & (uint32_t)(H - 1)][lane] = key;
-                    used++;
-                } else ovf = true;  // this source alone fills the ring
+                if (nhit < (uint32_t)H) {
+                    s_hit_node[wv][nhit][lane] = node;
+                    s_hit_dist[wv][nhit][lane] = (uint16_t)dist;
+                } else ovf = true;  // more in-nodes than a lane keeps: the cascade takes this source
                 nhit++;
             };
             auto push = [&](uint32_t nbn, uint32_t nd, bool chk) {
-                if (sp < (uint32_t)S) s_stack[wv][sp][lane] = ((unsigned long long)(nd | (chk ? 0x80000000u : 0u)) << 32) | nbn;
-                else ovf = true;
+                if (sp < (uint32_t)S) {
+                    s_stk_node[wv][sp][lane] = nbn;
+                    s_stk_dist[wv][sp][lane] = (uint16_t)(nd | (chk ? 0x8000u : 0u));
+                } else ovf = true;
                 sp++;
             };
             if (!cur_chk && (flags & F_TARGET) && u != src_node) hit(u, d);  // forbid_source_target, greedytigs/mod.rs:329
@@ -971,20 +966,34 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             if (will_end && !ovf) fin = true;
         }
 
-        // ---- finished / overflowed lanes stage their result (hits as they are: the post-pass de-duplicates and sorts) ----
+        // ---- finished / overflowed lanes stage their result: keys compacted into the wave's buffer (hits as they are: the
+        // post-pass de-duplicates and sorts) ----
         const unsigned long long donemask = __ballot(fin || ovf);
         if (donemask) {
+            uint32_t c = fin ? nhit : 0u;
+            uint32_t total = 0;  // keys this step stages: sum over the wave, bit plane by bit plane (scalar work only)
+#pragma unroll
+            for (int bit = 0; bit < 5; bit++) total += (uint32_t)__popcll(__ballot((c >> bit) & 1u)) << bit;
+            if (n_keys && n_keys + total > (uint32_t)OB) flush_results();  // wave-uniform
+            if (lane == 0) s_nkeys[wv] = n_keys;
             if (fin || ovf) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(donemask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donemask, 0u));
                 const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                const uint32_t c = fin ? nhit : 0u;
+                uint32_t off = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
+                if (off + c > (uint32_t)OB) { ovf = true; fin = false; c = 0; off = 0; }  // (only if ONE step stages more than OB keys)
+                unsigned long long keys[H];
+#pragma unroll
+                for (int r = 0; r < H; r++)  // all reads in flight, then all writes (a dependent read -> write pair per key would serialise)
+                    keys[r] = (uint32_t)r < c ? (((unsigned long long)s_hit_dist[wv][r][lane] << 32) | s_hit_node[wv][r][lane]) : 0ull;
+#pragma unroll
+                for (int r = 0; r < H; r++)
+                    if ((uint32_t)r < c) s_out[wv][off + r] = keys[r];
                 s_res_idx[wv][n_res + rank] = (uint32_t)(abs_idx - a.src_begin);
-                s_res_misc[wv][n_res + rank] = c | ((uint32_t)lane << 8) | (hit_base << 16) | (ovf ? 1u << 24 : 0u);
+                s_res_misc[wv][n_res + rank] = off | (c << 12) | (ovf ? 0x80000000u : 0u);
                 if (fin && unclean && c > 1) s_fix[wv][atomicAdd(&s_nfix[wv], 1u)] = (uint32_t)(abs_idx - a.src_begin);
-                s_res_off[wv][n_res + rank] = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
-                if (fin) hit_base = (hit_base + nhit) & (uint32_t)(H - 1);  // the finished source's hits stay until the next burst
-                else used -= (nhit < (uint32_t)H ? nhit : (uint32_t)H);     // an overflowed source's hits are dropped
             }
+            n_keys = __shfl(lane == 0 ? s_nkeys[wv] : 0u, 0);
+            if (n_keys > (uint32_t)OB) n_keys = (uint32_t)OB;
             n_res += (uint32_t)__popcll(donemask);
             uint32_t ovf_idx = 0;
             if (ovf) ovf_idx = (uint32_t)(a.src_index ? a.src_index[item] : a.src_begin + item);
@@ -1138,7 +1147,7 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-constexpr int ENUM_WPB = 4, ENUM_STACK = 12, ENUM_HITS = 16;
+constexpr int ENUM_WPB = 4, ENUM_STACK = 12, ENUM_HITS = 16;  // 68 KB of LDS per workgroup: 2 workgroups = 8 waves per CU
 static std::string enum_level_name() {
     char b[96];
     std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d> + sort_candidates_kernel", ENUM_WPB, ENUM_STACK, ENUM_HITS);
@@ -1255,7 +1264,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
-    const bool use_enum = d->plan == 0 && !count;
+    const bool use_enum = d->plan == 0 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
     if (use_enum) launch_enum(d, st, a);
     else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
