@@ -707,11 +707,10 @@ constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 
 template <int WPB, int S, int H>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
-    // LDS budget: the level is a dependent gather chain per lane, so its throughput is lanes in flight / step latency. The
-    // random-line ceiling of the memory system (tools/gather_bench64: 54 G lines/s for 16, 32 and 64 bytes per lane alike, flat
-    // from 8 to 32 waves per CU) is only reached with >= 12-16 waves per CU at this kernel's ~5 us per step, i.e. <= 10-13 KB
-    // of LDS per wave: 6-byte stack and hit entries, hits of the CURRENT source only per lane, finished sources' keys compacted
-    // into one wave-shared buffer.
+    // LDS: 6-byte stack and hit entries, hits of the CURRENT source only per lane, finished sources' keys compacted into one
+    // wave-shared buffer: 17 KB per wave, 2 workgroups (8 waves) per CU. Measured alternatives: 12 waves per CU with
+    // 9-10 stack / 8-12 hit slots run this level 10-20 % faster at 2^24 but hand 2-6 x more sources to the cascade, which costs more
+    // than it saves at 2^27, where the gathers are bound by address translation (tools/gather_bench64 with a 5.7-GB table).
     constexpr int RQ = 128;       // staged results (finished sources) per wave
     constexpr int OB = 512;       // staged candidate keys per wave (a step that would stage more hands its last sources to the cascade)
     __shared__ uint32_t s_stk_node[WPB][S][64];   // slot-major / lane-minor: conflict free

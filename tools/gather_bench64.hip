@@ -40,8 +40,9 @@ static void run(const uint4 *d, uint32_t n_blk, uint32_t *o) {
     }
 }
 
-int main() {
-    const uint32_t n_blk = 11190402;  // 716 MB of 64-byte blocks
+int main(int argc, char **argv) {
+    const uint32_t n_blk = argc > 1 ? (uint32_t)atoll(argv[1]) : 11190402;  // default: 716 MB of 64-byte blocks (the 2^24 graph); 89523223 = the 2^27 graph (5.7 GB)
+    printf("table: %u blocks of 64 bytes = %.2f GB\n", n_blk, n_blk * 64.0 / 1e9);
     std::vector<uint4> h((size_t)n_blk * 4);
     uint64_t x = 88172645463325252ull;
     for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v.x = (uint32_t)x; v.y = (uint32_t)(x >> 32); v.z = v.x * 3; v.w = v.y * 5; }
