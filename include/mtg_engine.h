@@ -79,6 +79,9 @@ typedef struct {
                                           #tigs / cumulative length, different order) */
     int32_t n_devices;                 /* GPUs to shard the SSSP sources over; >= 1 */
     int32_t device_ids[MTG_MAX_DEVICES];
+    /* MatchtigAlgorithmConfiguration (matchtigs/mod.rs:33-45), tig algorithm 4 only; may be NULL otherwise */
+    const char *matching_file_prefix; /* the instance goes to <prefix>.minimalperfectmatching, the matcher writes <that>.solution */
+    const char *matcher_path;         /* blossom5-compatible executable: `<matcher> -e <instance> -w <solution>` */
 } mtg_config;
 /* GreedytigAlgorithmConfiguration::new(threads, k) (greedytigs/mod.rs:62-72): staged None, factor 0, HashbrownHashMap,
  * StdBinaryHeap, performance data None; engine fields: host Euler walk, one device (id 0). */
@@ -193,6 +196,42 @@ uint64_t mtg_compute_pairs(mtg_device *const *devices, int n_devices, mtg_pair *
 double mtg_last_gather_ms(void); /* wall-clock of the peer-copy gather of the last mtg_compute_pairs on this thread */
 /* The block boundaries that split uses: cuts_out[0..parts], cuts_out[0] = 0, cuts_out[parts] = number of sources. */
 void mtg_partition_sources(mtg_device *d, int parts, uint64_t *cuts_out);
+
+/* ---- optimal matchtigs around the external matcher ---------------------------- */
+/* matchtigs/mod.rs:150-940 minus the matcher itself. The reference runs one bounded Dijkstra per out-node with
+ * target_amount = #in-nodes (:235-246) -- exactly the candidate lists of mtg_sssp_candidates -- and folds them into a
+ * minimum-perfect-matching instance: collapsed matching nodes (GraphMatchingNodeMap, implementation/mod.rs:188-250), the
+ * (min, max) -> (weight, out, target) edge map, two copies of that graph joined by weight-(k-1) edges, four extra nodes per
+ * weakly connected component. The lists come from the GPU (cfg->device_ids[0]); the instance equals the reference's
+ * threads == 1 result (with more threads the reference's node numbering depends on thread timing). */
+typedef struct mtg_matching mtg_matching;
+typedef struct {
+    uint64_t transformed_node_count; /* matching nodes of one copy (:531) */
+    uint64_t edge_count;             /* edges.len() (:535) */
+    uint64_t wcc_amount;             /* WCCs that contain a matching node (:565) */
+    uint64_t matching_node_count;    /* first number of the instance file (:598) */
+    uint64_t matching_edge_count;    /* second number (:600) */
+    uint64_t mirror_biedges, mirror_expanded_biedges; /* the two counts logged at :537-540 */
+} mtg_matching_stats;
+mtg_matching *mtg_matching_instance(const mtg_graph *g, const mtg_config *cfg);
+/* The host stage alone, over candidate lists the caller holds (layout of mtg_replay_claims; multiplicity as downloaded by
+ * mtg_classify_download: negative for out-nodes). */
+mtg_matching *mtg_matching_instance_from_lists(const mtg_graph *g, uint64_t k, uint64_t n_sources, const uint32_t *out_nodes,
+                                               const int32_t *multiplicity, const uint64_t *cand_start,
+                                               const uint32_t *cand_count, const uint64_t *pool);
+void mtg_matching_get_stats(const mtg_matching *m, mtg_matching_stats *out);
+/* Writes the instance text (:591-719) to `path`; returns the bytes written. */
+uint64_t mtg_matching_write(const mtg_matching *m, const char *path);
+/* Reads a matcher solution (:746-812): the matched pairs (original out-node, in-node, weight) in file order, ready for
+ * mtg_finish_matchtigs_cfg. *pairs_out: malloc'd, free with mtg_free. Aborts on an edge that is not in the instance (:794). */
+uint64_t mtg_matching_read_solution(const mtg_matching *m, const char *solution_path, mtg_pair **pairs_out);
+void mtg_matching_free(mtg_matching *m);
+/* Inserts the matched edges, Eulerises, walks and cuts (:797-935): mtg_finish_greedytigs_cfg plus the reference's assertion
+ * that every bicycle with a dummy edge holds a breaking edge (:883). */
+mtg_walks *mtg_finish_matchtigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
+/* The whole algorithm (tig algorithm 4 of mtg_compute_tigs_cfg): instance -> cfg->matcher_path as a child process ->
+ * solution -> matchtigs. */
+mtg_walks *mtg_compute_matchtigs_cfg(mtg_graph *g, const mtg_config *cfg);
 
 /* ---- host stages ----------------------------------------------------------------------- */
 /* Replays the reference's claim loop over the candidate lists in ascending source order.

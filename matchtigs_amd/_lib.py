@@ -51,7 +51,24 @@ class MtgConfig(C.Structure):
         ("euler_mode", C.c_int32),
         ("n_devices", C.c_int32),
         ("device_ids", C.c_int32 * MTG_MAX_DEVICES),
+        ("matching_file_prefix", C.c_char_p),
+        ("matcher_path", C.c_char_p),
     ]
+
+
+class MtgMatchingStats(C.Structure):
+    _fields_ = [
+        ("transformed_node_count", C.c_uint64),
+        ("edge_count", C.c_uint64),
+        ("wcc_amount", C.c_uint64),
+        ("matching_node_count", C.c_uint64),
+        ("matching_edge_count", C.c_uint64),
+        ("mirror_biedges", C.c_uint64),
+        ("mirror_expanded_biedges", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class MtgDijkstraPerformanceData(C.Structure):
@@ -150,6 +167,14 @@ def load():
         "mtg_config_init": (None, [P(MtgConfig), u64, u64]),
         "mtg_finish_greedytigs_cfg": (vp, [vp, vp, u64, P(MtgConfig)]),
         "mtg_compute_eulertigs_cfg": (vp, [vp, P(MtgConfig)]),
+        "mtg_matching_instance": (vp, [vp, P(MtgConfig)]),
+        "mtg_matching_instance_from_lists": (vp, [vp, u64, u64, vp, vp, vp, vp, vp]),
+        "mtg_matching_get_stats": (None, [vp, P(MtgMatchingStats)]),
+        "mtg_matching_write": (u64, [vp, C.c_char_p]),
+        "mtg_matching_read_solution": (u64, [vp, C.c_char_p, P(P(MtgPair))]),
+        "mtg_matching_free": (None, [vp]),
+        "mtg_finish_matchtigs_cfg": (vp, [vp, vp, u64, P(MtgConfig)]),
+        "mtg_compute_matchtigs_cfg": (vp, [vp, P(MtgConfig)]),
         "mtg_compute_tigs_cfg": (vp, [vp, u64, P(MtgConfig)]),
         "mtg_last_performance_data": (None, [P(MtgDijkstraPerformanceData)]),
         "mtg_last_euler_kernel_ms": (C.c_double, []),

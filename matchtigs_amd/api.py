@@ -115,6 +115,25 @@ class EulertigAlgorithmConfiguration:
         return GreedytigAlgorithmConfiguration(1, self.k, euler_mode=self.euler_mode, device_ids=(self.device_id,)).to_c()
 
 
+@dataclass
+class MatchtigAlgorithmConfiguration:
+    """matchtigs/mod.rs:33-45 (+ the engine-only euler_mode / device_id). ``matcher_path`` is the external blossom5-compatible
+    executable (`<matcher> -e <instance> -w <solution>`); the instance goes to ``<matching_file_prefix>.minimalperfectmatching``."""
+
+    threads: int
+    k: int
+    matching_file_prefix: str
+    matcher_path: str
+    euler_mode: EulerMode = EulerMode.HostReferenceOrder
+    device_id: int = 0
+
+    def to_c(self) -> "_lib.MtgConfig":
+        c = GreedytigAlgorithmConfiguration(self.threads, self.k, euler_mode=self.euler_mode, device_ids=(self.device_id,)).to_c()
+        self._keep = (str(self.matching_file_prefix).encode(), str(self.matcher_path).encode())  # c_char_p fields borrow these
+        c.matching_file_prefix, c.matcher_path = self._keep
+        return c
+
+
 # ---- edge payload view (implementation/mod.rs:287-317; clib.rs:45-85) -------------------------
 @dataclass(frozen=True)
 class MatchtigEdgeData:
@@ -459,6 +478,81 @@ class EulertigAlgorithm(TigAlgorithm):
         return _take_walks_np(L, L.mtg_compute_eulertigs_cfg(graph.handle, C.byref(c)))
 
 
+class MatchingInstance:
+    """The minimum-perfect-matching instance of optimal matchtigs (matchtigs/mod.rs:150-719), built from the GPU's candidate
+    lists: ``write`` produces the matcher's input file, ``read_solution`` turns the matcher's output into matched pairs."""
+
+    def __init__(self, graph: Bigraph, k: int, device_id: int = 0, _handle=None):
+        self._L = _lib.load()
+        if _handle is not None:
+            self._m = _handle
+            return
+        c = GreedytigAlgorithmConfiguration(1, k, device_ids=(device_id,)).to_c()
+        self._m = self._L.mtg_matching_instance(graph.handle, C.byref(c))
+
+    @classmethod
+    def from_lists(cls, graph: Bigraph, k: int, out_nodes, multiplicity, cand_start, cand_count, pool) -> "MatchingInstance":
+        """The host stage alone over caller-held candidate lists (mtg_matching_instance_from_lists)."""
+        L = _lib.load()
+        on = np.ascontiguousarray(out_nodes, np.uint32)
+        mu = np.ascontiguousarray(multiplicity, np.int32)
+        cs = np.ascontiguousarray(cand_start, np.uint64)
+        cc = np.ascontiguousarray(cand_count, np.uint32)
+        po = np.ascontiguousarray(pool, np.uint64)
+        h = L.mtg_matching_instance_from_lists(graph.handle, k, len(on), _ptr(on) if len(on) else None, _ptr(mu),
+                                               _ptr(cs) if len(cs) else None, _ptr(cc) if len(cc) else None,
+                                               _ptr(po) if len(po) else None)
+        return cls(graph, k, _handle=h)
+
+    def stats(self) -> dict:
+        st = _lib.MtgMatchingStats()
+        self._L.mtg_matching_get_stats(self._m, C.byref(st))
+        return st.as_dict()
+
+    def write(self, path: str) -> int:
+        return int(self._L.mtg_matching_write(self._m, str(path).encode()))
+
+    def read_solution(self, path: str) -> np.ndarray:
+        pp = C.POINTER(_lib.MtgPair)()
+        n = self._L.mtg_matching_read_solution(self._m, str(path).encode(), C.byref(pp))
+        arr = np.zeros(n, np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)]))
+        if n:
+            C.memmove(arr.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
+        self._L.mtg_free(pp)
+        return arr
+
+    def close(self):
+        if self._m:
+            self._L.mtg_matching_free(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatchtigAlgorithm(TigAlgorithm):
+    """matchtigs/mod.rs:47-62: optimal matchtigs; the matching itself is solved by the external matcher the configuration names."""
+
+    Configuration = MatchtigAlgorithmConfiguration
+
+    @classmethod
+    def compute_tigs(cls, graph: Bigraph, configuration: MatchtigAlgorithmConfiguration):
+        L = _lib.load()
+        c = configuration.to_c()
+        return _take_walks(L, L.mtg_compute_matchtigs_cfg(graph.handle, C.byref(c)))
+
+    @staticmethod
+    def finish(graph: Bigraph, pairs: np.ndarray, k: int):
+        """matchtigs/mod.rs:797-935 on already matched pairs (mtg_finish_matchtigs_cfg)."""
+        L = _lib.load()
+        p = np.ascontiguousarray(pairs)
+        c = GreedytigAlgorithmConfiguration(1, k).to_c()
+        return _take_walks(L, L.mtg_finish_matchtigs_cfg(graph.handle, _ptr(p) if len(p) else None, len(p), C.byref(c)))
+
+
 def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
                          device_id: int = 0):
     """mtg_finish_greedytigs_cfg returning flat numpy walks (limits, edges) -- for large graphs."""
@@ -622,7 +716,8 @@ def last_phase_seconds() -> dict:
 
 
 # ---- the reference's C-ABI, driven from Python exactly like a C caller would (clib.rs) ----------
-def clib_compute_tigs(unitig_weights, links, tig_algorithm: int, threads: int, k: int):
+def clib_compute_tigs(unitig_weights, links, tig_algorithm: int, threads: int, k: int, matching_file_prefix: str = "",
+                      matcher_path: str = ""):
     """matchtigs_initialise_graph -> merge_nodes* -> build_graph -> compute_tigs. Returns
     (n_tigs, tigs_edge_out, tigs_insert_out, tigs_out_limits) trimmed to their used lengths."""
     L = _lib.load()
@@ -636,6 +731,7 @@ def clib_compute_tigs(unitig_weights, links, tig_algorithm: int, threads: int, k
     eo = np.zeros(max(2 * edge_count, 1), np.int64)
     io = np.zeros(max(2 * edge_count, 1), np.uint64)
     lo = np.zeros(max(edge_count, 1), np.uint64)
-    n = int(L.matchtigs_compute_tigs(data, tig_algorithm, threads, k, b"", b"", _ptr(eo), _ptr(io), _ptr(lo)))
+    n = int(L.matchtigs_compute_tigs(data, tig_algorithm, threads, k, str(matching_file_prefix).encode(),
+                                     str(matcher_path).encode(), _ptr(eo), _ptr(io), _ptr(lo)))
     total = int(lo[n - 1]) if n else 0
     return n, eo[:total].copy(), io[:total].copy(), lo[:n].copy()

@@ -2,7 +2,12 @@
 //
 // matchtigs_* are the drop-in replacements of /root/reference/src/clib.rs:87-410; mtg_* is the
 // engine layer underneath (see the header for which reference lines each stage replaces).
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdarg>
 #include <cstring>
@@ -16,6 +21,8 @@
 #include "host_graph.hpp"
 
 using namespace mtg;
+
+extern char **environ;
 
 struct mtg_graph { HostGraph g; };
 struct mtg_device { Device *d; };
@@ -374,6 +381,135 @@ uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint
     return n;
 }
 
+// ---- optimal matchtigs around the external matcher (matchtigs/mod.rs:150-940) ----
+struct mtg_matching {
+    MatchingInstance *m;
+};
+mtg_matching *mtg_matching_instance(const mtg_graph *g, const mtg_config *cfg) {
+    check_config(cfg, "mtg_matching_instance");
+    if (!g || !g->g.built) MTG_DIE("mtg_matching_instance: graph is not built");
+    const uint64_t k = cfg->k;
+    double t0 = now_s();
+    mtg_device *dev = mtg_device_create(g, k, cfg->device_ids[0]);
+    log_info("Collecting nodes with missing incoming or outgoing edges");
+    const uint64_t S = mtg_classify(dev, nullptr);
+    std::vector<uint32_t> out_nodes(S);
+    std::vector<int32_t> mult(g->g.node_count());
+    mtg_classify_download(dev, nullptr, out_nodes.data(), mult.data(), nullptr);
+    log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
+    log_info("Computing shortest paths between nodes with missing outgoing and nodes with missing incoming edges");
+    std::vector<uint64_t> cand_start, pool;
+    std::vector<uint32_t> cand_count;
+    device_candidates_to_host(dev->d, nullptr, cand_start, cand_count, pool);
+    mtg_device_free(dev);
+    double t1 = now_s();
+    log_info("Found %zu shortest paths", pool.size());
+    MatchingInstance *m = build_matching_instance(g->g, k, S, out_nodes.data(), mult.data(), cand_start.data(), cand_count.data(), pool.data());
+    log_info("Took %.6fs for computing paths and getting edges, of this %.6fs are from dijkstra", now_s() - t0, t1 - t0);
+    log_info("Found %llu nodes and %zu edges", (unsigned long long)m->transformed_node_count, m->edge_n2.size());
+    log_info("Matching problem contains %llu edges that originate from %llu mirror biedges", (unsigned long long)m->mirror_expanded_biedges,
+             (unsigned long long)m->mirror_biedges);
+    log_info("Found %llu relevant WCCs", (unsigned long long)m->wcc_amount);
+    return new mtg_matching{m};
+}
+mtg_matching *mtg_matching_instance_from_lists(const mtg_graph *g, uint64_t k, uint64_t n_sources, const uint32_t *out_nodes,
+                                               const int32_t *multiplicity, const uint64_t *cand_start, const uint32_t *cand_count,
+                                               const uint64_t *pool) {
+    if (!g || !g->g.built) MTG_DIE("mtg_matching_instance_from_lists: graph is not built");
+    if (k < 1) MTG_DIE("mtg_matching_instance_from_lists: k must be >= 1");
+    if (!multiplicity || (n_sources && (!out_nodes || !cand_start || !cand_count))) MTG_DIE("mtg_matching_instance_from_lists: null argument");
+    return new mtg_matching{build_matching_instance(g->g, k, n_sources, out_nodes, multiplicity, cand_start, cand_count, pool)};
+}
+void mtg_matching_get_stats(const mtg_matching *m, mtg_matching_stats *out) {
+    if (!m || !out) MTG_DIE("mtg_matching_get_stats: null argument");
+    out->transformed_node_count = m->m->transformed_node_count;
+    out->edge_count = m->m->edge_n2.size();
+    out->wcc_amount = m->m->wcc_amount;
+    out->matching_node_count = m->m->matching_node_count;
+    out->matching_edge_count = m->m->matching_edge_count;
+    out->mirror_biedges = m->m->mirror_biedges;
+    out->mirror_expanded_biedges = m->m->mirror_expanded_biedges;
+}
+uint64_t mtg_matching_write(const mtg_matching *m, const char *path) {
+    if (!m || !path) MTG_DIE("mtg_matching_write: null argument");
+    log_info("Outputting matching problem to \"%s\"", path);
+    return write_matching_instance(*m->m, path);
+}
+uint64_t mtg_matching_read_solution(const mtg_matching *m, const char *solution_path, mtg_pair **pairs_out) {
+    if (!m || !solution_path || !pairs_out) MTG_DIE("mtg_matching_read_solution: null argument");
+    std::vector<Pair> p = read_matching_solution(*m->m, solution_path);
+    mtg_pair *out = (mtg_pair *)std::malloc(std::max<size_t>(p.size(), 1) * sizeof(mtg_pair));
+    if (!out) MTG_DIE("out of memory");
+    if (!p.empty()) std::memcpy(out, p.data(), p.size() * sizeof(mtg_pair));
+    *pairs_out = out;
+    return p.size();
+}
+void mtg_matching_free(mtg_matching *m) {
+    if (!m) return;
+    delete m->m;
+    delete m;
+}
+mtg_walks *mtg_finish_matchtigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg) {
+    check_config(cfg, "mtg_finish_matchtigs_cfg");
+    if (!g || !g->g.built) MTG_DIE("mtg_finish_matchtigs_cfg: graph is not built");
+    const uint64_t k = cfg->k;
+    uint64_t bidirected = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) bidirected += pairs[i].out_node == g->g.mirror[pairs[i].in_node] ? 2 : 0;
+    const uint64_t dummy_edge_id = insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);  // :797-808
+    log_info("Inserted %llu matched edges", (unsigned long long)(2 * n_pairs));
+    if (bidirected) log_info("Inserted %llu bidirected loops", (unsigned long long)bidirected);
+    log_info("Making graph Eulerian by completing unmatched nodes");
+    make_eulerian(g->g, dummy_edge_id, k);  // :831
+    if (!is_eulerian(g->g)) MTG_DIE("Failed to make the graph Eulerian. (matchtigs/mod.rs:849)");
+    log_info("Finding Eulerian bicycle");
+    Walks cycles = euler_cycles_by_mode(g->g, *cfg);
+    log_info("Found %zu Eulerian bicycles", cycles.limits.size());
+    uint64_t begin = 0;
+    for (uint64_t c = 0; c < cycles.limits.size(); c++) {  // :870-886
+        uint64_t longest = 0;
+        for (uint64_t i = begin; i < cycles.limits[c]; i++)
+            if (g->g.is_dummy(cycles.edges[i])) longest = std::max<uint64_t>(longest, g->g.e_weight[cycles.edges[i]]);
+        if (longest > 0 && longest < k) MTG_DIE("Eulerian bicycle contains at least one dummy edge, but no breaking edge (matchtigs/mod.rs:883)");
+        begin = cycles.limits[c];
+    }
+    mtg_walks *tigs = new mtg_walks{cut_cycles(g->g, cycles, k)};
+    log_info("Found %zu matchtigs", tigs->w.limits.size());
+    return tigs;
+}
+mtg_walks *mtg_compute_matchtigs_cfg(mtg_graph *g, const mtg_config *cfg) {
+    check_config(cfg, "mtg_compute_matchtigs_cfg");
+    if (!cfg->matching_file_prefix) MTG_DIE("mtg_compute_matchtigs_cfg: matching_file_prefix is null");
+    if (!cfg->matcher_path) MTG_DIE("mtg_compute_matchtigs_cfg: matcher_path is null");
+    mtg_matching *m = mtg_matching_instance(g, cfg);
+    const std::string instance_path = std::string(cfg->matching_file_prefix) + ".minimalperfectmatching";  // :592-593
+    const std::string solution_path = instance_path + ".solution";                                          // :722
+    mtg_matching_write(m, instance_path.c_str());
+    if (m->m->transformed_node_count != 0) {  // :724-741
+        log_info("Running matcher at \"%s\"", cfg->matcher_path);
+        const char *argv[] = {cfg->matcher_path, "-e", instance_path.c_str(), "-w", solution_path.c_str(), nullptr};
+        pid_t pid = 0;
+        const int rc = posix_spawn(&pid, cfg->matcher_path, nullptr, nullptr, const_cast<char *const *>(argv), environ);
+        if (rc != 0) MTG_DIE("cannot start the matcher %s: %s", cfg->matcher_path, std::strerror(rc));
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0)
+            if (errno != EINTR) MTG_DIE("waitpid on the matcher failed: %s", std::strerror(errno));
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) MTG_DIE("Matcher was unsuccessful: wait status %d (matchtigs/mod.rs:735)", status);
+    } else {
+        log_info("Nothing to match, generating empty output file");  // :742-746
+        FILE *f = std::fopen(solution_path.c_str(), "w");
+        if (!f) MTG_DIE("cannot create %s", solution_path.c_str());
+        std::fputs("0 0\n", f);
+        std::fclose(f);
+    }
+    log_info("Applying matcher result to graph");
+    mtg_pair *pairs = nullptr;
+    const uint64_t n_pairs = mtg_matching_read_solution(m, solution_path.c_str(), &pairs);
+    mtg_matching_free(m);
+    mtg_walks *tigs = mtg_finish_matchtigs_cfg(g, pairs, n_pairs, cfg);
+    std::free(pairs);
+    return tigs;
+}
+
 mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg) {
     check_config(cfg, "mtg_compute_tigs_cfg");
     if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs: graph is not built");
@@ -442,9 +578,8 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
         }
         case 2:
             MTG_DIE("tig algorithm 2 (pathtigs) is outside the scope of the MI355X engine (SURVEY.md 2, row 11)");
-        case 4:
-            MTG_DIE("tig algorithm 4 (optimal matchtigs) needs the external blossom5 matcher and is outside the scope "
-                    "of the MI355X engine (SURVEY.md 2, row 10); use 5 for greedy matchtigs");
+        case 4:  // clib.rs:362-376: needs the external matcher the configuration names
+            return mtg_compute_matchtigs_cfg(g, cfg);
         default:
             MTG_DIE("Unknown tigs algorithm identifier %llu", (unsigned long long)tig_algorithm);  // clib.rs:390
     }
@@ -511,6 +646,8 @@ size_t matchtigs_compute_tigs(MatchtigsData *data, size_t tig_algorithm, size_t 
     mtg_config_init(&cfg, threads, k);
     cfg.resource_limit_factor = 1;
     cfg.node_weight_array_type = MTG_NODE_WEIGHT_EPOCH_ARRAY;
+    cfg.matching_file_prefix = matching_file_prefix;  // clib.rs:362-376
+    cfg.matcher_path = matcher_path;
     mtg_walks *tigs = mtg_compute_tigs_cfg(&data->graph, tig_algorithm, &cfg);
     const uint64_t n = flatten_clib(data->graph.g, tigs->w, reinterpret_cast<int64_t *>(tigs_edge_out),
                                     reinterpret_cast<uint64_t *>(tigs_insert_out),

@@ -107,6 +107,23 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k);
 bool is_eulerian(const HostGraph &g);
 Walks euler_cycles(const HostGraph &g);
 Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k);
+// matching_instance.cpp: optimal matchtigs around the external matcher (matchtigs/mod.rs:150-812)
+struct MatchingInstance {
+    uint64_t k = 0;
+    uint64_t transformed_node_count = 0;  // GraphMatchingNodeMap::node_count()
+    uint64_t wcc_amount = 0, matching_node_count = 0, matching_edge_count = 0;
+    uint64_t mirror_biedges = 0, mirror_expanded_biedges = 0;
+    std::vector<uint32_t> first_id, id_count;  // [V] node_id_map[n] = first_id[n] .. + id_count[n]
+    // the edge map, sorted by (n1, n2): edges of n1 are [edge_begin[n1], edge_begin[n1 + 1])
+    std::vector<uint64_t> edge_begin;                            // [transformed_node_count + 1]
+    PodVec<uint32_t> edge_n2, edge_weight, edge_out, edge_target;  // value = (weight, out_node, target_node) of the last insert
+    std::vector<uint64_t> extra_offset;                          // matching_node_extra_offset [transformed_node_count]
+};
+MatchingInstance *build_matching_instance(const HostGraph &g, uint64_t k, uint64_t n_sources, const uint32_t *out_nodes,
+                                          const int32_t *multiplicity, const uint64_t *cand_start, const uint32_t *cand_count,
+                                          const uint64_t *pool);
+uint64_t write_matching_instance(const MatchingInstance &m, const char *path);  // returns bytes written
+std::vector<Pair> read_matching_solution(const MatchingInstance &m, const char *path);
 // bcalm2.cpp: bin.rs:902-912 input route, FASTA file output
 struct UnitigStore {
     std::string data;           // concatenated ASCII sequences

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -25,6 +26,24 @@ void parallel_ranges(uint64_t n, F &&f, unsigned max_threads = 32) {
         const uint64_t lo = std::min<uint64_t>(n, i * chunk), hi = std::min<uint64_t>(n, lo + chunk);
         if (lo < hi) th.emplace_back([&f, lo, hi]() { f(lo, hi); });
     }
+    for (auto &x : th) x.join();
+}
+
+// Calls f(i) for every i in [0, n) from up to max_threads threads, tasks handed out dynamically (for few, large tasks).
+template <typename F>
+void parallel_tasks(uint64_t n, F &&f, unsigned max_threads = 32) {
+    unsigned t = std::thread::hardware_concurrency();
+    t = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)t, (uint64_t)max_threads, n}));
+    if (t == 1) {
+        for (uint64_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < t; i++)
+        th.emplace_back([&]() {
+            for (uint64_t j = next.fetch_add(1); j < n; j = next.fetch_add(1)) f(j);
+        });
     for (auto &x : th) x.join();
 }
 

@@ -1013,6 +1013,238 @@ uint64_t og_clib_compute_tigs(og_graph *g, uint64_t tig_algorithm, uint64_t k, i
 }
 
 /* ===================================================================================== */
+/* Optimal matchtigs: the minimum-perfect-matching instance handed to the external matcher, */
+/* and the application of its solution.  matchtigs/mod.rs:150-940, the `threads == 1`       */
+/* branch (:207-325): its order of (out_node, target) results is the deterministic one      */
+/* (sources ascending, targets in Dijkstra pop order); with threads > 1 the reference        */
+/* appends worker chunks in completion order (:330-458), which only permutes the matching    */
+/* node numbering.                                                                           */
+/* ===================================================================================== */
+struct og_matching {
+    uint64_t k;
+    uint32_t n_nodes;
+    /* GraphMatchingNodeMap (implementation/mod.rs:188-250): node_id_map[n] is the id range
+     * first_id[n] .. first_id[n] + id_count[n]; id_count 0 = the empty Vec */
+    uint32_t *first_id, *id_count;
+    uint64_t current_node_id;
+    /* edges: HashMap<(usize, usize), (weight, out_node, target_node)>, open addressing on n1 << 32 | n2 */
+    uint64_t *ekey, *eweight; uint32_t *eout, *etarget; uint64_t ecap, en;
+    uint64_t mirror_biedges, mirror_expanded_biedges;
+    uint64_t wcc_amount;
+    uint64_t *extra_offset; /* matching_node_extra_offset, [current_node_id] */
+    uint64_t matching_node_count, matching_edge_count;
+};
+#define OM_EMPTY UINT64_MAX
+static uint64_t om_slot(const og_matching *m, uint64_t key) {
+    uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 17;
+    h &= m->ecap - 1;
+    while (m->ekey[h] != OM_EMPTY && m->ekey[h] != key) h = (h + 1) & (m->ecap - 1);
+    return h;
+}
+static void om_grow(og_matching *m) {
+    uint64_t ocap = m->ecap, *ok = m->ekey, *ow = m->eweight; uint32_t *oo = m->eout, *ot = m->etarget;
+    m->ecap = ocap ? ocap * 2 : 1024;
+    m->ekey = xmalloc(m->ecap * 8); m->eweight = xmalloc(m->ecap * 8); m->eout = xmalloc(m->ecap * 4); m->etarget = xmalloc(m->ecap * 4);
+    memset(m->ekey, 0xFF, m->ecap * 8);
+    for (uint64_t i = 0; i < ocap; i++)
+        if (ok[i] != OM_EMPTY) { uint64_t h = om_slot(m, ok[i]); m->ekey[h] = ok[i]; m->eweight[h] = ow[i]; m->eout[h] = oo[i]; m->etarget[h] = ot[i]; }
+    free(ok); free(ow); free(oo); free(ot);
+}
+/* HashMap::insert: returns 1 if there was a previous value (which is overwritten) */
+static int om_insert(og_matching *m, uint64_t n1, uint64_t n2, uint64_t weight, uint32_t out, uint32_t target) {
+    if ((m->en + 1) * 2 > m->ecap) om_grow(m);
+    uint64_t key = n1 << 32 | n2, h = om_slot(m, key);
+    int previous = m->ekey[h] == key;
+    if (!previous) { m->ekey[h] = key; m->en++; }
+    m->eweight[h] = weight; m->eout[h] = out; m->etarget[h] = target;
+    return previous;
+}
+/* get_or_create_node_indexes, implementation/mod.rs:202-225 */
+static void om_get_or_create(og_matching *m, const og_graph *g, uint32_t n) {
+    if (m->id_count[n]) return;
+    int64_t d = og_superfluous_out_biedges(g, n);
+    if (d < 0) d = -d;
+    if (m->current_node_id + (uint64_t)d > 0xFFFFFFFFull) DIE("matching node ids exceed 32 bits");
+    m->first_id[n] = (uint32_t)m->current_node_id; m->id_count[n] = (uint32_t)d;
+    m->current_node_id += (uint64_t)d;
+    uint32_t mn = g->mirror[n];
+    m->first_id[mn] = m->first_id[n]; m->id_count[mn] = m->id_count[n];   /* :218 */
+}
+static uint32_t wcc_find(uint32_t *p, uint32_t x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+static int cmp_u64x3(const void *a, const void *b) {
+    const uint64_t *x = a, *y = b;
+    for (int i = 0; i < 3; i++) if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+    return 0;
+}
+
+og_matching *og_matching_instance(const og_graph *g, uint64_t k) {
+    og_matching *m = xcalloc(1, sizeof *m);
+    uint32_t nn = g->n_nodes;
+    m->k = k; m->n_nodes = nn;
+    m->first_id = xcalloc(nn, 4); m->id_count = xcalloc(nn, 4);
+    /* :167-199: out-nodes, in-nodes (the greedy path's classification; multiplicities are not used below) */
+    uint32_t *out_nodes = xmalloc((size_t)nn * 4);
+    uint8_t *in_node_map = xmalloc(nn);
+    int64_t *mult = xmalloc((size_t)nn * 8);
+    uint32_t in_count = 0;
+    uint32_t n_out = og_classify(g, out_nodes, in_node_map, mult, &in_count, NULL);
+    /* :207-300 */
+    dijkstra *dj = dijkstra_new(nn);
+    dist_vec distances = {0};
+    for (uint32_t i = 0; i < n_out; i++) {
+        uint32_t out_node = out_nodes[i];
+        shortest_path_lens(g, dj, out_node, in_node_map, in_count, k - 1, 1, &distances, NULL);   /* :235-246 */
+        for (size_t c = 0; c < distances.n; c++) {
+            uint32_t target_node = distances.v[c].node;
+            uint64_t weight = distances.v[c].dist;
+            if (out_node == target_node) DIE("Found shortest path with same start and end (:251)");
+            if (weight == 0) DIE("Found zero weight path from %u to %u (:257)", out_node, target_node);
+            int is_mirror_biedge = out_node == g->mirror[target_node] && out_node != target_node;   /* :267 */
+            if (is_mirror_biedge) m->mirror_biedges++;
+            om_get_or_create(m, g, out_node);
+            om_get_or_create(m, g, target_node);
+            for (uint32_t a = 0; a < m->id_count[out_node]; a++)
+                for (uint32_t b = 0; b < m->id_count[target_node]; b++) {
+                    uint64_t c1 = m->first_id[out_node] + a, c2 = m->first_id[target_node] + b;
+                    if (c1 == c2) { if (!is_mirror_biedge) DIE("Found self-loop not caused by a mirror biedge (:281)"); continue; }
+                    int previous = om_insert(m, c1 < c2 ? c1 : c2, c1 < c2 ? c2 : c1, weight, out_node, target_node);   /* :292 */
+                    if (!previous && is_mirror_biedge) m->mirror_expanded_biedges++;
+                }
+        }
+    }
+    dijkstra_free(dj); free(distances.v); free(out_nodes); free(in_node_map); free(mult);
+    uint64_t T = m->current_node_id;   /* transformed_node_count, :531 */
+    /* :545-565: WCCs of the graph (as a plain digraph: mirror nodes are not joined), those with a matching node numbered by first
+     * appearance in node order */
+    uint32_t *parent = xmalloc((size_t)nn * 4);
+    for (uint32_t n = 0; n < nn; n++) parent[n] = n;
+    for (uint32_t e = 0; e < g->n_edges; e++) {
+        uint32_t a = wcc_find(parent, g->from[e]), b = wcc_find(parent, g->to[e]);
+        if (a != b) parent[a > b ? a : b] = a > b ? b : a;
+    }
+    uint64_t *wcc_index = xmalloc((size_t)nn * 8);
+    for (uint32_t n = 0; n < nn; n++) wcc_index[n] = UINT64_MAX;
+    for (uint32_t n = 0; n < nn; n++)
+        if (m->id_count[n]) { uint32_t r = wcc_find(parent, n); if (wcc_index[r] == UINT64_MAX) wcc_index[r] = m->wcc_amount++; }
+    /* :569-587 */
+    m->extra_offset = xmalloc(T * 8);
+    for (uint64_t i = 0; i < T; i++) m->extra_offset[i] = UINT64_MAX;
+    for (uint32_t n = 0; n < nn; n++)
+        for (uint32_t a = 0; a < m->id_count[n]; a++) m->extra_offset[m->first_id[n] + a] = 2 * T + 4 * wcc_index[wcc_find(parent, n)];
+    free(parent); free(wcc_index);
+    m->matching_node_count = T * 2 + 4 * m->wcc_amount;   /* :598 */
+    m->matching_edge_count = m->en * 2 + T + 4 * T;       /* :600 */
+    return m;
+}
+void og_matching_counts(const og_matching *m, uint64_t out[7]) {
+    out[0] = m->current_node_id; out[1] = m->en; out[2] = m->wcc_amount; out[3] = m->matching_node_count;
+    out[4] = m->matching_edge_count; out[5] = m->mirror_biedges; out[6] = m->mirror_expanded_biedges;
+}
+void og_matching_free(og_matching *m) {
+    if (!m) return;
+    free(m->first_id); free(m->id_count); free(m->ekey); free(m->eweight); free(m->eout); free(m->etarget); free(m->extra_offset); free(m);
+}
+
+/* matchtigs/mod.rs:591-719 */
+void og_matching_write(const og_matching *m, const char *path) {
+    FILE *f = fopen(path, "w");
+    if (!f) DIE("cannot create %s", path);
+    uint64_t T = m->current_node_id, k = m->k;
+    fprintf(f, "%llu %llu\n", (unsigned long long)m->matching_node_count, (unsigned long long)m->matching_edge_count);
+    uint64_t (*sorted)[3] = xmalloc((m->en ? m->en : 1) * 24);   /* :603-607 */
+    uint64_t ns = 0;
+    for (uint64_t h = 0; h < m->ecap; h++)
+        if (m->ekey[h] != OM_EMPTY) { sorted[ns][0] = m->ekey[h] >> 32; sorted[ns][1] = m->ekey[h] & 0xFFFFFFFFull; sorted[ns][2] = m->eweight[h]; ns++; }
+    qsort(sorted, ns, 24, cmp_u64x3);
+#define OM_X(i) ((unsigned long long)m->extra_offset[i])
+    /* first copy, :610-655 */
+    int have_last = 0; uint64_t last_n1 = 0;
+    for (uint64_t i = 0; i < ns; i++) {
+        uint64_t n1 = sorted[i][0], n2 = sorted[i][1], weight = sorted[i][2];
+        if (have_last)
+            while (last_n1 < n1) {
+                fprintf(f, "%llu %llu %llu\n%llu %llu %d\n%llu %llu %d\n", (unsigned long long)last_n1, (unsigned long long)(last_n1 + T),
+                        (unsigned long long)(k - 1), (unsigned long long)last_n1, OM_X(last_n1), 0, (unsigned long long)last_n1, OM_X(last_n1) + 1, 0);
+                last_n1++;
+            }
+        fprintf(f, "%llu %llu %llu\n", (unsigned long long)n1, (unsigned long long)n2, (unsigned long long)weight);
+        last_n1 = n1; have_last = 1;
+    }
+    if (!have_last) last_n1 = 0;   /* unwrap_or(0), :638 */
+    while (last_n1 < T) {
+        fprintf(f, "%llu %llu %llu\n%llu %llu %d\n%llu %llu %d\n", (unsigned long long)last_n1, (unsigned long long)(last_n1 + T),
+                (unsigned long long)(k - 1), (unsigned long long)last_n1, OM_X(last_n1), 0, (unsigned long long)last_n1, OM_X(last_n1) + 1, 0);
+        last_n1++;
+    }
+    /* second copy, :657-714 */
+    have_last = 0; last_n1 = 0;
+    for (uint64_t i = 0; i < ns; i++) {
+        uint64_t n1 = sorted[i][0], n2 = sorted[i][1], weight = sorted[i][2];
+        if (have_last)
+            while (last_n1 < n1) {
+                fprintf(f, "%llu %llu %d\n%llu %llu %d\n", (unsigned long long)(last_n1 + T), OM_X(last_n1) + 2, 0,
+                        (unsigned long long)(last_n1 + T), OM_X(last_n1) + 3, 0);
+                last_n1++;
+            }
+        last_n1 = n1; have_last = 1;
+        if (n1 == n2) continue;
+        fprintf(f, "%llu %llu %llu\n", (unsigned long long)(n1 + T), (unsigned long long)(n2 + T), (unsigned long long)weight);
+    }
+    if (!have_last) last_n1 = 0;
+    while (last_n1 < T) {
+        fprintf(f, "%llu %llu %d\n%llu %llu %d\n", (unsigned long long)(last_n1 + T), OM_X(last_n1) + 2, 0,
+                (unsigned long long)(last_n1 + T), OM_X(last_n1) + 3, 0);
+        last_n1++;
+    }
+#undef OM_X
+    free(sorted);
+    if (fclose(f) != 0) DIE("write error on %s", path);
+}
+
+/* matchtigs/mod.rs:746-940: reads the matcher's solution, inserts the matched edges, Eulerises, walks and cuts. */
+og_walks *og_matching_apply(const og_matching *m, og_graph *g, const char *solution_path, uint64_t k) {
+    FILE *f = fopen(solution_path, "r");
+    if (!f) DIE("cannot open %s", solution_path);
+    uint64_t T = m->current_node_id;
+    char line[256];
+    if (!fgets(line, sizeof line, f)) DIE("matcher output is empty (:756)");   /* header, only debug-asserted */
+    uint64_t dummy_edge_id = 0;
+    while (fgets(line, sizeof line, f)) {
+        unsigned long long a, b;
+        if (sscanf(line, "%llu %llu", &a, &b) != 2) DIE("malformed matcher output line: %s", line);
+        uint64_t n1 = a, n2 = b;
+        if ((n1 >= T && n2 >= T) || n1 >= 2 * T || n2 >= 2 * T) continue;   /* :769-776 */
+        if (n1 >= T) n1 -= T;
+        if (n2 >= T) n2 -= T;
+        uint64_t key = n1 << 32 | n2;
+        uint64_t h = m->ecap ? om_slot(m, key) : 0;
+        if (!m->ecap || m->ekey[h] != key) {   /* :789-795 */
+            if (n1 == n2) continue;
+            DIE("Edge does not exist: (%llu, %llu)", (unsigned long long)n1, (unsigned long long)n2);
+        }
+        uint32_t o1 = m->eout[h], o2 = m->etarget[h];
+        dummy_edge_id += 1;   /* :800-808 */
+        og_add_edge(g, o1, o2, m->eweight[h], dummy_edge_id, 0, 1);
+        og_add_edge(g, g->mirror[o2], g->mirror[o1], m->eweight[h], dummy_edge_id, 0, 0);
+    }
+    fclose(f);
+    og_make_eulerian_with_breaking_edges(g, &dummy_edge_id, k);   /* :831 */
+    if (!og_decomposes_into_eulerian_bicycles(g)) DIE("Failed to make the graph Eulerian. (matchtigs :849)");
+    og_walks *cycles = og_euler_cycles(g);   /* :857 */
+    uint64_t begin = 0;
+    for (uint64_t c = 0; c < cycles->n_walks; c++) {   /* the one difference to the greedy cutter: :870-886 */
+        uint64_t longest = 0;
+        for (uint64_t i = begin; i < cycles->limits[c]; i++)
+            if (is_dummy(g, cycles->edges[i]) && g->weight[cycles->edges[i]] > longest) longest = g->weight[cycles->edges[i]];
+        if (longest > 0 && longest < k) DIE("Eulerian bicycle contains at least one dummy edge, but no breaking edge (:883)");
+        begin = cycles->limits[c];
+    }
+    og_walks *tigs = og_cut_cycles(g, cycles, k, NULL);   /* :865-935 == greedytigs/mod.rs:726-789 */
+    og_walks_free(cycles);
+    return tigs;
+}
+
+/* ===================================================================================== */
 /* Tig spelling, bin.rs:466-606.  Sequences are ASCII; reverse complement per character.   */
 /* ===================================================================================== */
 static char rc_char(char c) {

@@ -136,6 +136,18 @@ og_walks *og_cut_cycles(const og_graph *g, og_walks *cycles, uint64_t k, uint64_
 og_walks *og_compute_greedytigs(og_graph *g, uint64_t k, og_sssp_stats *stats);   /* greedytigs/mod.rs:201-801 */
 og_walks *og_compute_eulertigs(og_graph *g, uint64_t k);                          /* eulertigs/mod.rs:48-198 */
 
+/* ---- optimal matchtigs (matchtigs/mod.rs:150-940), everything but the external matcher itself ---- */
+typedef struct og_matching og_matching;
+/* :150-600, threads == 1: all (out-node, in-node) pairs within k-1, collapsed matching node ids, the edge map, WCC extra nodes */
+og_matching *og_matching_instance(const og_graph *g, uint64_t k);
+/* transformed_node_count, edges.len(), relevant WCCs, matching_node_count, matching_edge_count, mirror biedges, expanded mirror biedges */
+void og_matching_counts(const og_matching *m, uint64_t out[7]);
+/* :591-719: the `<prefix>.minimalperfectmatching` text */
+void og_matching_write(const og_matching *m, const char *path);
+/* :746-940: applies the matcher's `.solution` file to g (mutated), returns the matchtigs */
+og_walks *og_matching_apply(const og_matching *m, og_graph *g, const char *solution_path, uint64_t k);
+void og_matching_free(og_matching *m);
+
 /* clib.rs:393-407 flattening. Arrays caller-allocated as clib.rs:332-348 says. Returns #tigs. */
 uint64_t og_flatten_clib(const og_graph *g, const og_walks *tigs, int64_t *tigs_edge_out,
                          uint64_t *tigs_insert_out, uint64_t *tigs_out_limits);

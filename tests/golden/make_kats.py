@@ -84,10 +84,24 @@ KATS.append({
     "k": 5,
     "mirror": pairs_mirror(10),
     "unitigs": [[2, 0, 9], [4, 0, 9], [6, 0, 9], [0, 8, 2], [0, 10, 2], [8, 12, 9], [8, 14, 9], [10, 16, 9], [10, 18, 9]],
-    "expect": {"pairs": [[0, 8, 2]]},
+    "expect": {
+        "pairs": [[0, 8, 2]],
+        # optimal matchtigs' matching instance (matchtigs/mod.rs:150-719), derived by hand below
+        "matching_stats": {"transformed_node_count": 3, "edge_count": 2, "wcc_amount": 2, "matching_node_count": 14,
+                           "matching_edge_count": 19, "mirror_biedges": 0, "mirror_expanded_biedges": 0},
+        "matching_instance": "14 19\n0 1 2\n0 2 2\n0 3 4\n0 10 0\n0 11 0\n1 4 4\n1 10 0\n1 11 0\n2 5 4\n2 10 0\n2 11 0\n"
+                             "3 4 2\n3 5 2\n3 12 0\n3 13 0\n4 12 0\n4 13 0\n5 12 0\n5 13 0\n",
+    },
     "why": "node 0: in 3 / out 2 -> demand 1, T = 2; targets 8 and 10 (each out 2 / in 1) both at distance 2; "
            "D = [(8,2),(10,2)]; 8 is claimed, demand drops to 0 and the loop breaks at (10,2) (greedytigs/mod.rs:412-414). "
-           "Source 9 = mirror(8) is skipped later (mult[8] == 0), source 11 only reaches the dead node 1.",
+           "Source 9 = mirror(8) is skipped later (mult[8] == 0), source 11 only reaches the dead node 1. "
+           "Matching instance: the all-targets searches give (0,8,2), (0,10,2), (9,1,2), (11,1,2) (out-nodes 3,5,7,12,.. have no "
+           "out-edges). Matching ids in first-touch order: binode {0,1} -> 0, {8,9} -> 1, {10,11} -> 2; edge map (0,1) -> 2 and "
+           "(0,2) -> 2 (each inserted twice, once per strand). The two strands are separate WCCs; in node order node 0 puts the forward "
+           "one at index 0, node 1 the mirror one at index 1; the extra offset of an id is written per input node in ascending order "
+           "(matchtigs/mod.rs:569-587), so the odd (larger) node of every binode wins: 2*3 + 4*1 = 10 for all three ids. File: header "
+           "2*3 + 4*2 = 14 nodes, 2*2 + 3 + 4*3 = 19 edges; first copy = edges of id 0, then per id its copy edge (weight k-1 = 4) and "
+           "its two extra edges; second copy shifted by 3 with extras +2/+3.",
 })
 
 # --- KAT-3: bound is inclusive: distance k-1 accepted, k rejected ---------------------------------------
@@ -115,9 +129,17 @@ KATS.append({
     "k": 5,
     "mirror": pairs_mirror(5),
     "unitigs": [[0, 1, 2], [2, 0, 9], [4, 0, 9], [6, 0, 9], [8, 0, 9]],
-    "expect": {"pairs": [[0, 1, 2]]},
+    "expect": {
+        "pairs": [[0, 1, 2]],
+        "matching_stats": {"transformed_node_count": 2, "edge_count": 1, "wcc_amount": 1, "matching_node_count": 8,
+                           "matching_edge_count": 12, "mirror_biedges": 1, "mirror_expanded_biedges": 1},
+        "matching_instance": "8 12\n0 1 2\n0 2 4\n0 4 0\n0 5 0\n1 3 4\n1 4 0\n1 5 0\n2 3 2\n2 6 0\n2 7 0\n3 6 0\n3 7 0\n",
+    },
     "why": "node 0: in 4 / out 2 -> demand 2; candidate node 1 == mirror(0) with demand >= 2 -> is_self_mirror_edge, "
-           "multiplicity_reduction 2 (greedytigs/mod.rs:355-357, 399, 468-469).",
+           "multiplicity_reduction 2 (greedytigs/mod.rs:355-357, 399, 468-469). "
+           "Matching instance: the only result is (0,1,2), a mirror biedge; binode {0,1} gets the two ids 0,1 (|diff| = 2) and the "
+           "target shares them, so of the four id combinations (0,0) and (1,1) are skipped as self-loops and (0,1), (1,0) hit the "
+           "same key (0,1): one edge, one expanded mirror biedge. One WCC (the arc 0->1 joins the strands): all extra offsets 2*2 = 4.",
 })
 
 # --- KAT-5: a target claimed by an earlier source is skipped by a later one -----------------------------

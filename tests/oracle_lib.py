@@ -98,6 +98,11 @@ def lib():
         "og_flatten_clib": (u64, [vp, P(Walks), P(i64), P(u64), P(u64)]),
         "og_clib_compute_tigs": (u64, [vp, u64, u64, P(i64), P(u64), P(u64)]),
         "og_write_walks_fasta": (vp, [vp, P(Walks), C.c_char_p, P(u64), u64, P(u64)]),
+        "og_matching_instance": (vp, [vp, u64]),
+        "og_matching_counts": (None, [vp, P(u64)]),
+        "og_matching_write": (None, [vp, C.c_char_p]),
+        "og_matching_apply": (P(Walks), [vp, vp, C.c_char_p, u64]),
+        "og_matching_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -368,6 +373,9 @@ class OracleGraph:
         total = int(lo[n - 1]) if n else 0
         return n, eo[:total].copy(), io[:total].copy(), lo[:n].copy()
 
+    def matching_instance(self, k):
+        return OracleMatching(self, k)
+
     def fasta(self, tigs, seqs: list[str], k):
         """Spell tigs (list of edge-id lists into *this* graph) as FASTA text."""
         limits, edges = [], []
@@ -385,3 +393,39 @@ class OracleGraph:
         s = C.string_at(p, ln.value).decode()
         self.L.og_free(p)
         return s
+
+
+class OracleMatching:
+    """og_matching: the optimal-matchtigs matching instance (matchtigs/mod.rs:150-940 minus the matcher)."""
+
+    NAMES = ["transformed_node_count", "edge_count", "wcc_amount", "matching_node_count", "matching_edge_count", "mirror_biedges",
+             "mirror_expanded_biedges"]
+
+    def __init__(self, graph: OracleGraph, k):
+        self.L = lib()
+        self.g = graph
+        self.k = k
+        self.h = self.L.og_matching_instance(graph.h, k)
+
+    def stats(self) -> dict:
+        a = (C.c_uint64 * 7)()
+        self.L.og_matching_counts(self.h, a)
+        return {n: int(a[i]) for i, n in enumerate(self.NAMES)}
+
+    def write(self, path):
+        self.L.og_matching_write(self.h, str(path).encode())
+
+    def apply(self, solution_path):
+        """Mutates the graph the instance was built from; returns the matchtigs."""
+        w = self.L.og_matching_apply(self.h, self.g.h, str(solution_path).encode(), self.k)
+        out = _walks_to_lists(w)
+        self.L.og_walks_free(w)
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.og_matching_free(self.h)
+                self.h = None
+        except Exception:
+            pass

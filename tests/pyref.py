@@ -345,6 +345,120 @@ def compute_eulertigs(g: PyBigraph, k):
     return cut_cycles(g, euler_cycles(g), k)
 
 
+# ---- optimal matchtigs around the external matcher (matchtigs/mod.rs:150-940, threads == 1) ----
+class MatchingInstance:
+    """matchtigs/mod.rs:150-600: node map (implementation/mod.rs:188-250), edge map, WCC extra offsets."""
+
+    def __init__(self, g: PyBigraph, k):
+        self.k = k
+        out_nodes, live, _ = classify(g)  # :167-199 (same classification as the greedy path)
+        in_count = sum(live)
+        self.node_id_map = [[] for _ in range(g.n)]
+        self.current_node_id = 0
+        self.edges = {}
+        self.mirror_biedges = self.mirror_expanded = 0
+        for o in out_nodes:  # :225-300
+            for t, w in dijkstra(g, o, live, in_count, k - 1):
+                assert o != t and w != 0
+                is_mirror = o == g.mirror[t] and o != t
+                self.mirror_biedges += is_mirror
+                for n in (o, t):  # get_or_create_node_indexes
+                    if not self.node_id_map[n]:
+                        ids = list(range(self.current_node_id, self.current_node_id + abs(g.diff(n))))
+                        self.current_node_id += len(ids)
+                        self.node_id_map[n] = ids
+                        self.node_id_map[g.mirror[n]] = list(ids)
+                for c1 in self.node_id_map[o]:
+                    for c2 in self.node_id_map[t]:
+                        if c1 == c2:
+                            assert is_mirror
+                            continue
+                        key = (min(c1, c2), max(c1, c2))
+                        if key not in self.edges and is_mirror:
+                            self.mirror_expanded += 1
+                        assert key not in self.edges or self.edges[key][0] == w
+                        self.edges[key] = (w, o, t)
+        T = self.T = self.current_node_id
+        # :545-565 WCCs of the plain digraph; relevant ones numbered by first appearance in node order
+        comp = list(range(g.n))
+
+        def find(x):
+            while comp[x] != x:
+                comp[x] = comp[comp[x]]
+                x = comp[x]
+            return x
+
+        for e in g.edges:
+            a, b = find(e.frm), find(e.to)
+            if a != b:
+                comp[a] = b
+        wcc_map = {}
+        for n in range(g.n):
+            if self.node_id_map[n] and find(n) not in wcc_map:
+                wcc_map[find(n)] = len(wcc_map)
+        self.wcc_amount = len(wcc_map)
+        self.extra = [None] * T  # :569-587
+        for n in range(g.n):
+            for mnode in self.node_id_map[n]:
+                self.extra[mnode] = 2 * T + 4 * wcc_map[find(n)]
+        self.matching_node_count = 2 * T + 4 * self.wcc_amount
+        self.matching_edge_count = 2 * len(self.edges) + T + 4 * T
+
+    def text(self) -> str:
+        """:591-719"""
+        T, k, X = self.T, self.k, self.extra
+        out = [f"{self.matching_node_count} {self.matching_edge_count}"]
+        sorted_edges = sorted((n1, n2, v[0]) for (n1, n2), v in self.edges.items())
+        last = None
+        for n1, n2, w in sorted_edges:
+            if last is not None:
+                while last < n1:
+                    out += [f"{last} {last + T} {k - 1}", f"{last} {X[last]} 0", f"{last} {X[last] + 1} 0"]
+                    last += 1
+            out.append(f"{n1} {n2} {w}")
+            last = n1
+        last = last or 0
+        while last < T:
+            out += [f"{last} {last + T} {k - 1}", f"{last} {X[last]} 0", f"{last} {X[last] + 1} 0"]
+            last += 1
+        last = None
+        for n1, n2, w in sorted_edges:
+            if last is not None:
+                while last < n1:
+                    out += [f"{last + T} {X[last] + 2} 0", f"{last + T} {X[last] + 3} 0"]
+                    last += 1
+            last = n1
+            out.append(f"{n1 + T} {n2 + T} {w}")
+        last = last or 0
+        while last < T:
+            out += [f"{last + T} {X[last] + 2} 0", f"{last + T} {X[last] + 3} 0"]
+            last += 1
+        return "\n".join(out) + "\n"
+
+    def apply(self, g: PyBigraph, solution_text: str):
+        """:746-940 -> matchtigs (g is mutated)"""
+        T, k = self.T, self.k
+        did = 0
+        for line in solution_text.splitlines()[1:]:
+            n1, n2 = (int(x) for x in line.split(" ")[:2])
+            if (n1 >= T and n2 >= T) or n1 >= 2 * T or n2 >= 2 * T:
+                continue
+            n1, n2 = (n1 - T if n1 >= T else n1), (n2 - T if n2 >= T else n2)
+            if (n1, n2) not in self.edges:
+                assert n1 == n2, f"Edge does not exist: ({n1}, {n2})"
+                continue
+            w, o1, o2 = self.edges[(n1, n2)]
+            did += 1
+            g.add_edge(o1, o2, w, did, 0, True)
+            g.add_edge(g.mirror[o2], g.mirror[o1], w, did, 0, False)
+        make_eulerian(g, did, k)
+        cycles = euler_cycles(g)
+        for cyc in cycles:
+            longest = max([g.edges[e].weight for e in cyc if g.edges[e].is_dummy], default=0)
+            assert longest == 0 or longest >= k, "Eulerian bicycle contains at least one dummy edge, but no breaking edge"
+        return cut_cycles(g, cycles, k)
+
+
 def flatten_clib(g: PyBigraph, tigs):
     """clib.rs:393-407."""
     eo, io, lim = [], [], []

@@ -77,9 +77,20 @@ def test_abort_conventions_match_reference_panics(product_lib):
     r = _run_snippet("""
         import numpy as np
         from matchtigs_amd import api
-        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 4, 1, 5)
+        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 2, 1, 5)
     """)
-    assert r.returncode != 0 and "blossom5" in r.stderr
+    assert r.returncode != 0 and "pathtigs" in r.stderr and "outside the scope" in r.stderr
+    # optimal matchtigs without the configuration's paths (the C-ABI asserts them non-null, clib.rs:300,316; the engine
+    # configuration leaves them NULL unless set)
+    r = _run_snippet("""
+        import ctypes as C
+        import numpy as np
+        from matchtigs_amd import api, _lib
+        G = api.Bigraph.from_unitig_links(np.array([3, 3], dtype=np.uint64), [(0, True, 1, True)])
+        c = api.GreedytigAlgorithmConfiguration(1, 5).to_c()
+        _lib.load().mtg_compute_tigs_cfg(G.handle, 4, C.byref(c))
+    """)
+    assert r.returncode != 0 and "matching_file_prefix is null" in r.stderr
     # null weights -> assert at clib.rs:188
     r = _run_snippet("""
         from matchtigs_amd import _lib
@@ -106,6 +117,12 @@ def test_greedy_without_gpu_fails_loudly(product_lib):
         api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 5, 1, 5)
     """)
     assert r.returncode != 0 and "no CPU path" in r.stderr
+    r = _run_snippet("""
+        import numpy as np
+        from matchtigs_amd import api
+        api.clib_compute_tigs(np.array([3,3],dtype=np.uint64), [(0,True,1,True)], 4, 1, 5, "/tmp/mtg_nogpu", "/bin/true")
+    """)
+    assert r.returncode != 0 and "no CPU path" in r.stderr  # optimal matchtigs' searches are the same device stage
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         G = api.Bigraph.from_unitig_links(np.array([3, 3], dtype=np.uint64), [(0, True, 1, True)])
         api.DeviceGraph(G, 5)
