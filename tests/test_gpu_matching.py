@@ -120,6 +120,28 @@ def test_real_dbg_through_the_reference_cabi(gpu, oracle, tmp_path):
     assert n < ua.n_unitigs
 
 
+def test_cli_matchtigs_fasta_equals_oracle(gpu, oracle, tmp_path):
+    """bin.rs route: --bcalm-in + --matchtigs-fa-out + --blossom5-command, FASTA spelled on the GPU."""
+    from matchtigs_amd import synth
+
+    k = 31
+    ua = synth.g_seq_arrays(200_000, seed=5, k=k, haplotypes=4, sub_rate=0.02)
+    inp, out = tmp_path / "unitigs.fa", tmp_path / "matchtigs.fa"
+    inp.write_bytes(ua.bcalm2_text())
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "matchtigs_amd", "--bcalm-in", str(inp), "-k", str(k), "--matchtigs-fa-out", str(out),
+                        "--blossom5-command", MATCHER], capture_output=True, text=True, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    og = oracle.OracleGraph.from_unitig_links_arrays(ua.weights, ua.links)
+    om = og.matching_instance(k)
+    om.write(tmp_path / "o")
+    assert Path(str(out) + ".minimalperfectmatching").read_bytes() == (tmp_path / "o").read_bytes()  # bin.rs:1146-1149
+    tigs = om.apply(str(out) + ".minimalperfectmatching.solution")
+    want = og.fasta(tigs, ua.unitig_list(), k).encode()
+    fa = out.read_bytes()
+    assert len(fa) == len(want) and fa == want
+
+
 def test_matcher_failure_aborts_like_the_reference(gpu, tmp_path):
     """A matcher that exits non-zero: "Matcher was unsuccessful" (matchtigs/mod.rs:735), i.e. the process aborts."""
     kat = MATCHING_KATS[0]  # two-strand graph: its instance has no perfect matching, the stand-in matcher exits 1
