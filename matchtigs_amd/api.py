@@ -388,12 +388,7 @@ class DeviceGraph:
         """The claim loop on the GPU over device-resident candidate arrays of ALL sources -> pairs (host numpy)."""
         pp = C.POINTER(_lib.MtgPair)()
         n = self._L.mtg_replay_claims_device(self._d, stream, self.n_sources, d_cand_start, d_cand_count, d_pool, C.byref(pp))
-        dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
-        arr = np.zeros(n, dt)
-        if n:
-            C.memmove(arr.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
-        self._L.mtg_free(pp)
-        return arr
+        return _adopt_pairs(self._L, pp, n)
 
     def last_replay_rounds(self) -> int:
         return int(self._L.mtg_last_replay_rounds(self._d))
@@ -424,18 +419,29 @@ def compute_pairs(devices: Sequence[DeviceGraph]) -> np.ndarray:
     arr = (C.c_void_p * len(devices))(*[d.handle for d in devices])
     pp = C.POINTER(_lib.MtgPair)()
     n = L.mtg_compute_pairs(arr, len(devices), C.byref(pp))
-    dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
-    out = np.zeros(n, dt)
-    if n:
-        C.memmove(out.ctypes.data, pp, n * C.sizeof(_lib.MtgPair))
-    L.mtg_free(pp)
-    return out
+    return _adopt_pairs(L, pp, n)
 
 
 def partition_sources(device: DeviceGraph, parts: int) -> list[int]:
     cuts = (C.c_uint64 * (parts + 1))()
     _lib.load().mtg_partition_sources(device.handle, parts, cuts)
     return [int(x) for x in cuts]
+
+
+PAIR_DTYPE = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+
+
+def _adopt_pairs(L, pp, n: int) -> np.ndarray:
+    """A numpy view of the library's malloc'd mtg_pair array (no copy); mtg_free runs when the last view is gone."""
+    import weakref
+
+    if not n:
+        L.mtg_free(pp)
+        return np.zeros(0, PAIR_DTYPE)
+    addr = C.cast(pp, C.c_void_p).value
+    raw = (C.c_char * (n * C.sizeof(_lib.MtgPair))).from_address(addr)
+    weakref.finalize(raw, L.mtg_free, C.c_void_p(addr))
+    return np.frombuffer(raw, dtype=PAIR_DTYPE)
 
 
 class TigAlgorithm:

@@ -1079,6 +1079,8 @@ struct ReplayWork {
     unsigned long long *final_off = nullptr, *block_sums = nullptr;
     unsigned long long *ctl = nullptr, *h_ctl = nullptr;  // control block (device / pinned host copy)
     mtg_pair *out = nullptr;
+    mtg_pair *h_out = nullptr;                // pinned staging of the pair download (pageable D2H runs at a few GB/s)
+    uint64_t cap_h_out = 0;
     unsigned grid = 0;                        // co-resident workgroups of the cooperative launch
 };
 
@@ -1417,6 +1419,7 @@ void device_free(Device *d) {
                   w.final_off, w.block_sums, w.ctl, w.out};
     for (void *b : rb) (void)hipFree(b);
     (void)hipHostFree(w.h_ctl);
+    (void)hipHostFree(w.h_out);
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
@@ -1549,6 +1552,16 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (!d->classified || n_sources != d->n_sources) MTG_DIE("mtg_replay_claims_device: classify first; n_sources must be all sources");
     ReplayWork &w = d->replay;  // buffers are re-used across calls on this device
     const uint64_t V = d->V, S = n_sources;
+    struct {  // MTG_DEBUG=1: host-side wall clock of the call's segments
+        const bool on = std::getenv("MTG_DEBUG") != nullptr;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(const char *what) {
+            if (!on) return;
+            const auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mtg] replay: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+            t = n;
+        }
+    } rt;
     if (S == 0) {
         *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
         d->last_replay_rounds = 0;
@@ -1626,9 +1639,11 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(w.grid, (S + REPLAY_BLOCK - 1) / REPLAY_BLOCK));
     void *kargs[] = {&a};
+    rt.lap("buffers + launches");
     HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
     HIP_CHECK(hipMemcpyAsync(w.h_ctl, w.ctl, RC_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    rt.lap("state init + rounds kernel");
     if (w.h_ctl[RC_ABORT]) MTG_DIE("claim replay: a workgroup never reached the grid barrier (watchdog)");
     const int rounds = (int)w.h_ctl[RC_ROUNDS];
     w.tag_base += (uint32_t)rounds + 2;
@@ -1661,6 +1676,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     scan_u32(d, st, w, w.pair_count, S, w.final_off, cnt);
     read_counters(d, st);
     const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
+    rt.lap("tail + scan");
     mtg_pair *host = (mtg_pair *)std::malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
     if (!host) MTG_DIE("out of memory");
     if (n_pairs) {
@@ -1671,9 +1687,43 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         }
         hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(host, w.out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        if (n_pairs < (1u << 18)) {
+            HIP_CHECK(hipMemcpyAsync(host, w.out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            // through a pinned staging buffer kept with the device, in slices: while slice i+1 crosses PCIe, a few host threads
+            // copy slice i into the caller's (pageable, freshly allocated) array
+            if (n_pairs > w.cap_h_out) {
+                if (w.h_out) HIP_CHECK(hipHostFree(w.h_out));
+                w.cap_h_out = n_pairs + n_pairs / 4;
+                HIP_CHECK(hipHostMalloc(&w.h_out, w.cap_h_out * sizeof(mtg_pair), hipHostMallocNonCoherent));
+            }
+            const uint64_t n_slices = std::min<uint64_t>(8, (n_pairs + (1u << 18) - 1) >> 18);
+            const uint64_t slice = (n_pairs + n_slices - 1) / n_slices;
+            std::vector<hipEvent_t> ev(n_slices);
+            for (uint64_t i = 0; i < n_slices; i++) {
+                const uint64_t lo = i * slice, n = std::min(slice, n_pairs - lo);
+                HIP_CHECK(hipMemcpyAsync(w.h_out + lo, w.out + lo, n * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(ev[i], st));
+            }
+            const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8, (uint64_t)std::thread::hardware_concurrency(), n_pairs >> 18}));
+            auto worker = [&](unsigned t) {
+                for (uint64_t i = 0; i < n_slices; i++) {
+                    const uint64_t lo = i * slice, n = std::min(slice, n_pairs - lo);
+                    const uint64_t a0 = lo + n * t / T, a1 = lo + n * (t + 1) / T;
+                    HIP_CHECK(hipEventSynchronize(ev[i]));
+                    std::memcpy(host + a0, w.h_out + a0, (a1 - a0) * sizeof(mtg_pair));
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(worker, t);
+            worker(0);
+            for (auto &x : th) x.join();
+            for (uint64_t i = 0; i < n_slices; i++) HIP_CHECK(hipEventDestroy(ev[i]));
+        }
     }
+    rt.lap("compact + pair download");
     *pairs_out = host;
     return n_pairs;
 }

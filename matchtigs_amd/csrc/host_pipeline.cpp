@@ -108,9 +108,11 @@ std::vector<Pair> replay_claims(const HostGraph &g, uint64_t n_sources, const ui
 uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
     StageTimer tm;
     if (n_pairs && g.first_breaking_edge != UINT64_MAX) g.dummies_canonical = false;  // matched edges after breaking edges
-    std::vector<uint32_t> out(n_pairs), in(n_pairs);
-    std::vector<uint64_t> w(n_pairs);
-    for (uint64_t i = 0; i < n_pairs; i++) { out[i] = pairs[i].out_node; in[i] = pairs[i].in_node; w[i] = pairs[i].distance; }
+    PodVec<uint32_t> out(n_pairs), in(n_pairs);
+    PodVec<uint64_t> w(n_pairs);
+    parallel_ranges(n_pairs, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) { out[i] = pairs[i].out_node; in[i] = pairs[i].in_node; w[i] = pairs[i].distance; }
+    });
     tm.lap("insert_pairs: unpack");
     g.add_biedges_bulk(out.data(), in.data(), w.data(), 0, n_pairs);  // dummy ids 1..n_pairs, :681
     tm.lap("insert_pairs: bulk add");
