@@ -170,8 +170,10 @@ const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
 /* Which SSSP level plan runs: 0 = default (table-free path enumeration per lane + sorting post-pass, then the cooperative
- * cascade for the sources it hands on), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the
- * counting kernels use). Returns the plan in force. */
+ * cascade for the sources it hands on; the level gathers its 64-byte node blocks per lane, or four lanes per block once the
+ * blocks exceed 3 GB), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the counting kernels
+ * use), 2 / 3 = plan 0 with the four-lanes-per-block / per-lane form of the gathers regardless of the graph's size (same
+ * results; lets small graphs exercise both forms). Returns the plan in force. */
 int mtg_set_sssp_plan(mtg_device *d, int plan);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified

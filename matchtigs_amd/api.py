@@ -409,7 +409,8 @@ class DeviceGraph:
         return st.as_dict()
 
     def set_plan(self, plan: int) -> int:
-        """0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only."""
+        """0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only, 2 / 3 = plan 0 with
+        quad-cooperative / per-lane block gathers regardless of the graph size (mtg_engine.h)."""
         return int(self._L.mtg_set_sssp_plan(self._d, plan))
 
 

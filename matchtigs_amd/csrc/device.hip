@@ -35,6 +35,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "device.hpp"
@@ -58,18 +59,19 @@ enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
 // therefore spends ONE 64-byte gather on a node and its embedded children instead of one gather each: 1.8 visited nodes per gather
 // on the bench graph (35 fetched bytes per visited node instead of 64; a 32-byte record costs a 64-byte request anyway).
 // Everything in it is a function of the graph alone, so it is built once with the device graph (build kernels below).
+// The encoding is chosen so that the enumeration decodes a block without a single table lookup or slot -> parent search: an unused
+// weight slot holds 0xFFFF (never within a bound < 0x8000), and a grandchild slot holds the weight of the whole two-edge path.
 struct alignas(64) NodeBlock {
     uint32_t nbr[4];   // words 0-3: inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
-    uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path)
+    uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path); unused slots 0xFFFF
     uint8_t deg;       // word 6: inline degree 0..4 (0 if F_EXT)
     uint8_t flags;     //         F_TARGET (initial in-node, greedytigs/mod.rs:231-240) | F_EXT
-    uint16_t cmeta;    //         4 bits per child j: [2:0] = number of its out-edges embedded below (7 = child not embedded), [3] = child is an in-node
+    uint16_t cmeta;    //         bit j (0-3): child j is an in-node; bit 4+j: child j is NOT embedded below (it needs its own gather)
     uint32_t gnbr[6];  // words 7-12: out-neighbours of the embedded children, children in order, each child's edges in order
-    uint16_t gw[6];    // words 13-15: their weights
+    uint16_t gw[6];    // words 13-15: weight of the path node -> child -> that neighbour, saturated at 0xFFFF; unused slots 0xFFFF
 };
 static_assert(sizeof(NodeBlock) == 64, "NodeBlock must be 64 bytes");
 constexpr int GSLOTS = 6;
-constexpr uint32_t CHILD_NOT_EMBEDDED = 7;
 
 // compute_eulerian_superfluous_out_biedges (bigraph) and the classification rule of greedytigs/mod.rs:229-245
 struct NodeClass { int32_t diff; uint8_t cls; };
@@ -208,7 +210,9 @@ __global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const
 #pragma unroll
     for (int i = 0; i < 16; i++) bw[i] = 0;
     b.flags = c.cls & F_TARGET;
-    b.cmeta = 0x7777;  // no child embedded (build_children_kernel fills this in)
+    b.cmeta = 0x00F0;  // no child embedded (build_children_kernel fills this in)
+    for (int j = 0; j < 4; j++) b.w[j] = 0xFFFFu;
+    for (int t = 0; t < GSLOTS; t++) b.gw[t] = 0xFFFFu;
     if (dg <= 4) {
         uint32_t ids[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         for (uint32_t j = 0; j < dg; j++) ids[j] = blocks[n].nbr[j];
@@ -246,34 +250,35 @@ __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
     const uint32_t dg = meta & 0xFFu;
     uint32_t cmeta = 0, used = 0;
     uint32_t gn[GSLOTS];
-    uint16_t gwt[GSLOTS];
+    uint32_t gwt[GSLOTS];
 #pragma unroll
-    for (int i = 0; i < GSLOTS; i++) { gn[i] = 0; gwt[i] = 0; }
-    bool open = true;  // children are embedded in order while they fit (prefix rule: the decoder walks the slots in child order)
+    for (int i = 0; i < GSLOTS; i++) { gn[i] = 0; gwt[i] = 0xFFFFu; }
+    bool open = true;  // children are embedded in order while they fit
     for (uint32_t j = 0; j < 4; j++) {
-        uint32_t cm = CHILD_NOT_EMBEDDED;
-        if (j < dg) {
-            const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + me[j]);  // first half only: never written by this kernel
-            const uint32_t cmt = ch[6];
-            const uint32_t cflags = (cmt >> 8) & 0xFFu, cdeg = cmt & 0xFFu;
-            if (cflags & F_TARGET) cm |= 8u;
-            if (open && !(cflags & F_EXT) && used + cdeg <= (uint32_t)GSLOTS) {
-                for (uint32_t t = 0; t < cdeg; t++) {
-                    gn[used + t] = ch[t];
-                    gwt[used + t] = (uint16_t)((ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu);
-                }
-                used += cdeg;
-                cm = (cm & 8u) | cdeg;
-            } else open = false;
+        if (j >= dg) continue;
+        const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + me[j]);  // first half only: never written by this kernel
+        const uint32_t cmt = ch[6];
+        const uint32_t cflags = (cmt >> 8) & 0xFFu, cdeg = cmt & 0xFFu;
+        const uint32_t wj = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+        if (cflags & F_TARGET) cmeta |= 1u << j;
+        if (open && !(cflags & F_EXT) && used + cdeg <= (uint32_t)GSLOTS) {
+            for (uint32_t t = 0; t < cdeg; t++) {
+                gn[used + t] = ch[t];
+                const uint32_t sum = wj + ((ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu);
+                gwt[used + t] = sum < 0xFFFFu ? sum : 0xFFFFu;
+            }
+            used += cdeg;
+        } else {
+            open = false;
+            cmeta |= 16u << j;
         }
-        cmeta |= cm << (4 * j);
     }
     uint32_t *out = reinterpret_cast<uint32_t *>(blocks + n);
     out[6] = (meta & 0xFFFFu) | (cmeta << 16);
 #pragma unroll
     for (int i = 0; i < GSLOTS; i++) out[7 + i] = gn[i];
 #pragma unroll
-    for (int i = 0; i < GSLOTS / 2; i++) out[13 + i] = (uint32_t)gwt[2 * i] | ((uint32_t)gwt[2 * i + 1] << 16);
+    for (int i = 0; i < GSLOTS / 2; i++) out[13 + i] = gwt[2 * i] | (gwt[2 * i + 1] << 16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -687,335 +692,353 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 // ------------------------------------------------------------------------------------------------
 // Lane-per-source kernel WITHOUT a table (level 0 of the default plan)
 //
-// The calibration chase (tools/gather_bench.hip) says what limits a lane-per-source kernel: the integer work between a
-// gather's arrival and the next gather's issue (34 G gathers/s at the 368 VALU instructions per step of the register-table
-// kernel, 50 G/s at ~100). A (k-1)-ball of a unitig graph is almost a tree (bench graph: 1.0004 path enumerations per
-// settled node), so the search needs no visited set at all: every lane enumerates the bounded PATHS from its source
-// depth-first with a small private stack in LDS -- pop, gather the node's 64-byte family block (the node, its children's
-// in-node flags and the embedded children's out-edges), remember the in-nodes among the node and its children, push the
-// grandchildren (and not-embedded children) whose distance stays <= k-1. No select-min, no find, no insert. A node reached along two
-// paths is expanded twice (bounded: every edge weighs >= 1 and the path length is capped at k-1), its target hits are
-// de-duplicated (minimum distance) and sorted by (distance, node) by the post-pass below, which makes the output identical
-// to the Dijkstra order. A source whose enumeration exceeds the pop budget, the stack or the hit buffer is handed to the
-// cooperative cascade, which is exact for any ball.
+// A (k-1)-ball of a unitig graph is almost a tree (bench graph: 1.0004 path enumerations per settled node), so the search needs
+// no visited set at all: every lane enumerates the bounded PATHS from its source depth-first with a small private stack in LDS --
+// gather the node's 64-byte family block (the node, its children's in-node flags and the embedded children's out-edges), remember
+// the in-nodes among the node and its children, push the grandchildren (and not-embedded children) whose distance stays <= k-1,
+// pop the next one. No select-min, no find, no insert. A node reached along two paths is expanded twice (bounded: every edge
+// weighs >= 1 and the path length is capped at k-1), its target hits are de-duplicated (minimum distance) and sorted by
+// (distance, node) -- lists of up to four in registers when the source finishes, longer ones by the post-pass below --, which
+// makes the output identical to the Dijkstra order. A source whose enumeration exceeds the step budget or its LDS space is handed
+// to the cooperative cascade, which is exact for any ball.
+//
+// What bounds it (round 3 measurements): round 2's version was bound by instruction issue (460 VALU + 366 SALU per
+// wave step, 188 VGPRs, 8 waves per CU). Written branch-free -- every potential push / hit is an UNCONDITIONAL LDS store to the
+// lane's next free slot (a store that does not count leaves the counter where it was), the next node always comes off the stack,
+// sources are handed out by two cross-lane permutes from chunks held in registers -- a step is half the instructions and the
+// kernel becomes bound by the latency of the gathers, i.e. by the number of waves per CU, i.e. by LDS. Hence:
+//  * per lane only S1 stack and H1 hit slots; whatever a search needs beyond them lives in an EXTENSION BLOCK of 16 entries
+//    (stack from the bottom, hits from the top) taken from a per-wave pool. The pool's free mask is one wave-uniform 64-bit
+//    value: allocation and release are a few scalar instructions, no atomics;
+//  * nothing is staged: a finished source takes its pool space with one LDS atomic and writes its keys, (start, count) and, if
+//    needed, its post-pass work-list entry straight to memory.
+// 10 KB of LDS per wave -> 16 waves per CU.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ENUM_POP_BUDGET = 256;
-constexpr unsigned long long ENUM_POOL_CHUNK = 4096;  // keys per wave-local pool chunk (a burst needs ~250; fewer same-address atomics)
-constexpr unsigned long long ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
+constexpr uint32_t ENUM_POOL_CHUNK = 2048;  // keys per wave-local pool chunk (one global atomic per chunk)
+constexpr uint32_t ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
+constexpr int ENUM_BE = 16;                 // entries per extension block
+#ifndef MTG_ENUM_S1
+#define MTG_ENUM_S1 4
+#define MTG_ENUM_H1 3
+#define MTG_ENUM_NB 46
+#endif
 
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {  // value of the first lane, known uniform to the compiler
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 
-template <int WPB, int S, int H>
+template <int WPB, int S1, int H1, int NB, bool QUAD>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
-    // LDS: 6-byte stack and hit entries, hits of the CURRENT source only per lane, finished sources' keys compacted into one
-    // wave-shared buffer: 17 KB per wave, 2 workgroups (8 waves) per CU. Measured alternatives: 12 waves per CU with
-    // 9-10 stack / 8-12 hit slots run this level 10-20 % faster at 2^24 but hand 2-6 x more sources to the cascade, which costs more
-    // than it saves at 2^27, where the gathers are bound by address translation (tools/gather_bench64 with a 5.7-GB table).
-    constexpr int RQ = 128;       // staged results (finished sources) per wave
-    constexpr int OB = 512;       // staged candidate keys per wave (a step that would stage more hands its last sources to the cascade)
-    __shared__ uint32_t s_stk_node[WPB][S][64];   // slot-major / lane-minor: conflict free
-    __shared__ uint16_t s_stk_dist[WPB][S][64];   // distance | own-flag-done << 15
-    __shared__ uint32_t s_hit_node[WPB][H][64];   // in-node hits of the lane's current source, discovery order
-    __shared__ uint16_t s_hit_dist[WPB][H][64];
-    __shared__ unsigned long long s_out[WPB][OB]; // keys of finished sources, compact, until the wave's next burst
-    __shared__ uint32_t s_res_idx[WPB][RQ], s_res_misc[WPB][RQ];  // misc: offset in s_out:12 | count:8 | overflow:1 << 31
-    __shared__ uint32_t s_nfix[WPB];
-    __shared__ uint32_t s_fix[WPB][RQ];  // staged sources whose hits are not yet in Dijkstra order
+    static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
+    constexpr int BE = ENUM_BE;
+    constexpr uint32_t T1 = (uint32_t)(S1 + H1) * 64u;     // words of the per-lane tiers
+    constexpr uint32_t SCRATCH = T1 + (uint32_t)NB * BE;   // block that absorbs the stores of lanes without a block of their own
+    constexpr uint32_t IDLE_DIST = 0xFFFF0000u;            // distance of a lane without a source: nothing is within the bound from there
+    // stack entry: node | (distance | own-flag-done << 16) << 32; hit entry = candidate key: node | distance << 32
+    __shared__ unsigned long long s_mem[WPB][T1 + (NB + 1) * BE];
+    __shared__ uint32_t s_cnt[WPB];
     __shared__ WaveOvfBuf s_ovf[WPB];
-    __shared__ uint32_t s_src[WPB][64];  // source ids of the wave's current chunk
-    __shared__ uint32_t s_nkeys[WPB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
+    const uint32_t K1 = a.K1;
+    unsigned long long *const mem = s_mem[wv];
 
-    unsigned long long chunk_lo = 0, chunk_hi = 0, chunk_base = 0, pool_next = 0, pool_end = 0, fix_next = 0, fix_end = 0;  // wave-uniform
-    uint32_t n_res = 0, n_keys = 0;                                       // wave-uniform
-    bool exhausted = false;
-    bool active = false;
-    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, n_overflow = 0;
-    unsigned long long prev_key = 0;      // hits already in (distance, node) order and without a repeated node need no post-pass:
-    uint32_t bloom = 0;                   // 32-bit filter over node ids (a set bit seen twice = "maybe repeated")
-    bool unclean = false;
-    uint32_t cur_node = 0, cur_dist = 0;  // the step in progress; the stack holds the branches still to take
-    bool cur_chk = false;                 // the node's own in-node flag was already evaluated from its parent's block
-    unsigned long long item = 0;
-    if (lane == 0) { s_nfix[wv] = 0; s_nkeys[wv] = 0; }
+    unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
+    unsigned long long pool_base = 0, fix_next = 0, fix_end = 0;                     // wave-uniform
+    uint32_t n_overflow = 0;                                                         // wave-uniform
+    if (lane == 0) s_cnt[wv] = ENUM_POOL_CHUNK;  // position inside the wave's pool chunk (no chunk yet)
 
-    auto flush_results = [&]() {
-        const uint32_t n_fix = __shfl(lane == 0 ? s_nfix[wv] : 0u, 0);
-        // both cursors are taken by one lane back to back (one memory round trip, not two) and before this burst's stores
-        const bool need_pool = n_keys && pool_next + n_keys > pool_end;
-        const unsigned long long grab = n_keys > ENUM_POOL_CHUNK ? (unsigned long long)n_keys : ENUM_POOL_CHUNK;
-        const bool need_fix = n_fix && fix_next + n_fix > fix_end;
-        unsigned long long p0 = 0, f0 = 0;
-        if (lane == 0) {
-            if (need_pool) p0 = atomicAdd(&a.counters[C_POOL], grab);
-            if (need_fix) f0 = atomicAdd(&a.counters[C_FIX], ENUM_FIX_CHUNK);
-        }
-        p0 = __shfl(p0, 0);
-        f0 = __shfl(f0, 0);
-        if (need_pool) {
-            pool_next = p0;
-            pool_end = pool_next + grab;
-        }
-        if (need_fix) {  // (a burst stages at most RQ <= ENUM_FIX_CHUNK lists); the rest of the old chunk is marked unused
-            for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
-            fix_next = f0;
-            fix_end = f0 + ENUM_FIX_CHUNK;
-        }
-        for (uint32_t t = lane; t < n_fix; t += 64) a.fix_list[fix_next + t] = s_fix[wv][t];  // (almost) dense work list for the post-pass
-        fix_next += n_fix;
-        for (uint32_t t = lane; t < n_keys; t += 64)                                            // the keys: one coalesced copy
-            if (pool_next + t < a.pool_cap) a.pool[pool_next + t] = s_out[wv][t];
-        for (uint32_t t = lane; t < n_res; t += 64) {
-            const uint32_t i = s_res_idx[wv][t], misc = s_res_misc[wv][t];
-            if (misc >> 31) a.cand_count[i] = CAND_OVERFLOW;
-            else {
-                a.cand_start[i] = pool_next + (misc & 0xFFFu);
-                a.cand_count[i] = (misc >> 12) & 0xFFu;
-            }
-        }
-        pool_next += n_keys;
-        n_res = 0;
-        n_keys = 0;
-        if (lane == 0) s_nfix[wv] = 0;
+    // ---- sources: chunks of 64 in a STATIC stride (chunk c belongs to wave c mod n_waves), held in registers: `ids` is the chunk
+    // being handed out, `ahead` the wave's next one (loaded a whole chunk before it is needed). A lane that needs a source gets
+    // the next unused one by a cross-lane permute: no atomic, no memory round trip, no LDS. ----
+    const unsigned long long n_items = a.n_items;
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB;
+    unsigned long long next_chunk = (unsigned long long)blockIdx.x * WPB + wv;  // chunk that `ahead` holds (wave-uniform)
+    uint32_t cur_base = 0, cur_len = 0, cur_pos = 0, nxt_base = 0, nxt_len = 0;  // wave-uniform
+    uint32_t ids = 0, ahead = 0;
+    auto prefetch_chunk = [&]() {
+        const unsigned long long lo = next_chunk * 64;
+        nxt_base = (uint32_t)lo;
+        nxt_len = lo >= n_items ? 0u : (n_items - lo < 64 ? (uint32_t)(n_items - lo) : 64u);
+        ahead = (uint32_t)lane < nxt_len ? a.sources[a.src_begin + lo + lane] : 0u;
+        next_chunk += n_waves;
     };
-
-    // Software-pipelined main loop. An iteration (1) decodes the block that arrived for every active lane just far enough to
-    // know where the lane goes next -- a successor within the bound, else the top of its stack, else a NEW source --, (2) issues
-    // the gather of that next block straight away, and only then (3) records the in-node hits, pushes the other successors and
-    // stages finished sources.
-    uint4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;  // family block of cur_node (valid for active lanes)
-    auto load_block = [&](uint32_t node, uint4 &o0, uint4 &o1, uint4 &o2, uint4 &o3) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
-        o0 = rp[0]; o1 = rp[1]; o2 = rp[2]; o3 = rp[3];
-    };
-    // Hands out source indices to the lanes in `want`. Waves take chunks of 64 sources in a STATIC stride (chunk c belongs to wave
-    // c mod n_waves): no atomic, and the ids of the wave's NEXT chunk are loaded one chunk ahead (a register per lane), so a
-    // refill costs neither a same-address atomic nor a memory round trip (measured before: a quarter of the kernel's time went
-    // into the two dependent round trips of a dynamic chunk grab). The searches are short and the per-wave totals close, so the
-    // static split loses less at the tail than the dynamic one lost in queues.
-    const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB, my_wave = (unsigned long long)blockIdx.x * WPB + wv;
-    unsigned long long next_chunk = my_wave;  // chunk whose ids are in `ahead` (wave-uniform)
-    uint32_t ahead = 0;
-    auto prefetch_ids = [&]() {
-        const unsigned long long t = next_chunk * 64 + lane;
-        ahead = t < a.n_items ? a.sources[a.src_index ? a.src_index[t] : a.src_begin + t] : 0u;
-    };
-    prefetch_ids();
-    auto take_sources = [&](bool want, unsigned long long &new_item, uint32_t &new_src) -> bool {
-        bool got = false;
-        unsigned long long need = __ballot(want);
-        for (int pass = 0; pass < 2 && need && !exhausted; pass++) {
-            if (chunk_lo >= chunk_hi) {
-                const unsigned long long lo = next_chunk * 64;
-                if (lo >= a.n_items) { exhausted = true; break; }
-                chunk_lo = chunk_base = lo;
-                chunk_hi = (lo + 64) < a.n_items ? (lo + 64) : a.n_items;
-                s_src[wv][lane] = ahead;      // the ids loaded one chunk ago
-                next_chunk += n_waves;
-                prefetch_ids();               // in flight while this chunk is being consumed
-            }
-            const unsigned n_want = (unsigned)__popcll(need);
-            if (want && !got) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const unsigned long long it = chunk_lo + rank;
-                if (it < chunk_hi) {
-                    new_item = it;
-                    new_src = s_src[wv][it - chunk_base];
-                    got = true;
-                }
-            }
-            chunk_lo = (chunk_lo + n_want) < chunk_hi ? (chunk_lo + n_want) : chunk_hi;
-            need = __ballot(want && !got);
+    prefetch_chunk();
+    ids = ahead; cur_base = nxt_base; cur_len = nxt_len;
+    prefetch_chunk();
+    bool exhausted = cur_len == 0;
+    auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src) -> bool {
+        if (exhausted) return false;
+        const unsigned long long need = __ballot(want);
+        const uint32_t idx = cur_pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        const bool second = idx >= 64u;  // (only a full chunk has a successor: cur_len < 64 means nxt_len == 0)
+        const bool got = want && (second ? idx - 64u < nxt_len : idx < cur_len);
+        const int sel = (int)((idx & 63u) << 2);
+        const uint32_t from_cur = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ids), from_nxt = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ahead);
+        new_src = second ? from_nxt : from_cur;
+        new_item = second ? nxt_base + idx - 64u : cur_base + idx;
+        cur_pos += (uint32_t)__popcll(need);
+        if (cur_pos >= 64u) {
+            cur_pos -= 64u;
+            ids = ahead; cur_base = nxt_base; cur_len = nxt_len;
+            prefetch_chunk();  // in flight while the chunk that just became current is handed out
         }
+        exhausted = cur_pos >= cur_len;
         return got;
     };
 
-    {  // prologue: first sources and their blocks
-        unsigned long long ni = 0;
-        uint32_t ns = 0;
-        if (take_sources(true, ni, ns)) {
-            item = ni; src_node = ns; cur_node = ns; cur_dist = 0; cur_chk = false;
-            active = true;
-            load_block(cur_node, b0, b1, b2, b3);
-        }
-    }
-    for (;;) {
-        if (!__any(active)) {
-            if (exhausted) break;
-            unsigned long long ni = 0;  // (all lanes idle although sources remain: only after a wave-wide overflow)
-            uint32_t ns = 0;
-            if (take_sources(true, ni, ns)) {
-                item = ni; src_node = ns; cur_node = ns; cur_dist = 0; cur_chk = false;
-                sp = 0; nhit = 0; pops = 0; prev_key = 0; bloom = 0; unclean = false;
-                active = true;
-                load_block(cur_node, b0, b1, b2, b3);
+    // ---- per-lane search state ----
+    bool active = false;
+    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, item = 0;
+    uint32_t blk = SCRATCH;                       // word index of the lane's extension block
+    uint32_t cur_node = 0, cur_dist = IDLE_DIST;  // the node whose block is in b0..b3
+    bool cur_chk = false;                         // its own in-node flag was already evaluated from its parent's block
+    // The gather. QUAD = false: every lane loads the four quarters of its own block (four requests per lane to the same line).
+    // QUAD = true: the four lanes of a quad load one block together -- in load l lane q fetches quarter q of the block of quad
+    // lane l -- and transpose the quad's 4 x 4 quarters in registers (DPP) when the data is needed. An instruction then touches
+    // 16 lines instead of 64. Measured (tools/gather_bench_tlb.hip): with a 5.7-GB table (the 2^27 graph) dependent random
+    // 64-byte gathers run at 18.8 G/s with four requests per lane and at 44 G/s either way of making it one request per lane
+    // and line -- beyond ~4 GB every lane-request pays an address translation; below 3 GB both forms reach 51-55 G/s.
+    uint4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0}, g3 = {0, 0, 0, 0};  // as loaded
+    uint4 b0 = g0, b1 = g0, b2 = g0, b3 = g0;                                          // block of cur_node
+    constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+    auto quad_bcast = [](uint32_t v, auto sel) -> uint32_t {  // value of lane `sel` of the quad
+        constexpr int L = decltype(sel)::value;
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, L * 0x55, 0xF, 0xF, false);
+    };
+    auto load_block = [&](bool need, uint32_t node) {
+        if constexpr (!QUAD) {
+            if (need) {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
+                g0 = rp[0]; g1 = rp[1]; g2 = rp[2]; g3 = rp[3];
             }
-            continue;
+        } else {
+            const uint32_t want = need ? node : NO_NODE;
+            const uint32_t q = (uint32_t)lane & 3u;
+            const uint32_t n0 = quad_bcast(want, std::integral_constant<int, 0>{}), n1 = quad_bcast(want, std::integral_constant<int, 1>{});
+            const uint32_t n2 = quad_bcast(want, std::integral_constant<int, 2>{}), n3 = quad_bcast(want, std::integral_constant<int, 3>{});
+            if (n0 != NO_NODE) g0 = reinterpret_cast<const uint4 *>(a.recs + n0)[q];
+            if (n1 != NO_NODE) g1 = reinterpret_cast<const uint4 *>(a.recs + n1)[q];
+            if (n2 != NO_NODE) g2 = reinterpret_cast<const uint4 *>(a.recs + n2)[q];
+            if (n3 != NO_NODE) g3 = reinterpret_cast<const uint4 *>(a.recs + n3)[q];
         }
-        // room for the result records of every source that can finish in this step (key space is checked where they are staged)
-        if (n_res + 64 > (uint32_t)RQ) flush_results();
-
-        // ---- (1) where does every lane go next? ----
+    };
+    auto arrive_block = [&]() {  // g -> b (QUAD: transpose of the quad's quarters, two exchange stages)
+        if constexpr (!QUAD) {
+            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
+        } else {
+            const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
+            auto xchg = [](uint32_t &lo, uint32_t &hi, bool odd, auto ctrl) {  // even lanes: hi <- partner's lo; odd lanes: lo <- partner's hi
+                constexpr int C = decltype(ctrl)::value;
+                const uint32_t from_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, C, 0xF, 0xF, false);
+                const uint32_t from_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, C, 0xF, 0xF, false);
+                lo = odd ? from_hi : lo;
+                hi = odd ? hi : from_lo;
+            };
+            auto xchg4 = [&](uint4 &lo, uint4 &hi, bool odd, auto ctrl) {
+                xchg(lo.x, hi.x, odd, ctrl); xchg(lo.y, hi.y, odd, ctrl); xchg(lo.z, hi.z, odd, ctrl); xchg(lo.w, hi.w, odd, ctrl);
+            };
+            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
+            xchg4(b0, b1, odd1, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
+            xchg4(b2, b3, odd1, std::integral_constant<int, 0xB1>{});
+            xchg4(b0, b2, odd2, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+            xchg4(b1, b3, odd2, std::integral_constant<int, 0x4E>{});
+        }
+    };
+    // LDS word of stack / hit row `row` of this lane: first tier (slot-major / lane-minor: conflict free), then the extension block
+    // at `base` (stack from its bottom, hits from its top). Rows are in range by construction: a lane whose step would not fit
+    // is redirected to the scratch block BEFORE it stores anything.
+    auto stack_word = [&](uint32_t base, uint32_t row) -> uint32_t {
+        return row < (uint32_t)S1 ? row * 64u + (uint32_t)lane : base - (uint32_t)S1 + row;
+    };
+    auto hit_word = [&](uint32_t base, uint32_t row) -> uint32_t {
+        return row < (uint32_t)H1 ? (uint32_t)(S1 * 64) + row * 64u + (uint32_t)lane : base + (uint32_t)(BE - 1 + H1) - row;
+    };
+    {
+        uint32_t ni = 0, ns = 0;
+        if (take_source(true, ni, ns)) {
+            item = ni; src_node = ns; cur_node = ns; cur_dist = 0;
+            active = true;
+        }
+        load_block(active, cur_node);
+    }
+    while (__any(active)) {
+        arrive_block();
+        // ---- the block that arrived: which hits and successors count ----
         const uint32_t u = cur_node, d = cur_dist;
         const uint32_t meta = b1.z;
-        const uint32_t flags = (meta >> 8) & 0xFFu;
-        const bool ext = active && (flags & F_EXT);
-        const uint32_t deg = meta & 0xFFu, cmeta = meta >> 16;
         const uint32_t nb[4] = {b0.x, b0.y, b0.z, b0.w};
-        const uint32_t ww[4] = {b1.x & 0xFFFFu, b1.x >> 16, b1.y & 0xFFFFu, b1.y >> 16};
         const uint32_t gn[GSLOTS] = {b1.w, b2.x, b2.y, b2.z, b2.w, b3.x};
-        const uint32_t gwt[GSLOTS] = {b3.y & 0xFFFFu, b3.y >> 16, b3.z & 0xFFFFu, b3.z >> 16, b3.w & 0xFFFFu, b3.w >> 16};
-        uint32_t dc[4];            // distance of child j (0xFFFFFFFF = absent or beyond the bound)
-        uint32_t succ_d[4 + GSLOTS];  // successors that need their own block: not-embedded children [0,4), grandchildren [4,10)
-        uint32_t bound[4];
-        uint32_t acc = 0;
+        const uint32_t dc[4] = {d + (b1.x & 0xFFFFu), d + (b1.x >> 16), d + (b1.y & 0xFFFFu), d + (b1.y >> 16)};
+        const uint32_t dg[GSLOTS] = {d + (b3.y & 0xFFFFu), d + (b3.y >> 16), d + (b3.z & 0xFFFFu), d + (b3.z >> 16), d + (b3.w & 0xFFFFu), d + (b3.w >> 16)};
+        const bool is_ext = active && (meta & ((uint32_t)F_EXT << 8));
+        bool hv[5], pv[4 + GSLOTS];
+        hv[0] = active && !cur_chk && (meta & ((uint32_t)F_TARGET << 8)) && u != src_node;  // forbid_source_target, greedytigs/mod.rs:329
+        uint32_t nh_f = nhit + (hv[0] ? 1u : 0u), sp_f = sp;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t cg = (cmeta >> (4 * j)) & 7u;
-            const bool present = active && !ext && j < (int)deg;
-            const uint32_t dj = d + ww[j];
-            const bool within = present && dj <= a.K1;
-            dc[j] = within ? dj : 0xFFFFFFFFu;
-            succ_d[j] = (within && cg == CHILD_NOT_EMBEDDED) ? dj : 0xFFFFFFFFu;
-            acc += (present && cg != CHILD_NOT_EMBEDDED) ? cg : 0u;
-            bound[j] = acc;
+            hv[1 + j] = dc[j] <= K1 && (meta & (0x10000u << j)) && nb[j] != src_node;
+            pv[j] = dc[j] <= K1 && (meta & (0x100000u << j));
+            nh_f += hv[1 + j] ? 1u : 0u;
+            sp_f += pv[j] ? 1u : 0u;
         }
 #pragma unroll
         for (int t = 0; t < GSLOTS; t++) {
-            const uint32_t pd = (uint32_t)t < bound[0] ? dc[0] : (uint32_t)t < bound[1] ? dc[1] : (uint32_t)t < bound[2] ? dc[2] : dc[3];
-            const uint32_t nd = pd + gwt[t];
-            succ_d[4 + t] = ((uint32_t)t < acc && pd != 0xFFFFFFFFu && nd <= a.K1) ? nd : 0xFFFFFFFFu;
+            pv[4 + t] = dg[t] <= K1;
+            sp_f += pv[4 + t] ? 1u : 0u;
         }
-        bool have_next = false;
-        uint32_t nx_node = 0, nx_dist = 0;
-        bool nx_chk = false;
-        int nx_slot = -1;
-#pragma unroll
-        for (int t = 4 + GSLOTS - 1; t >= 0; t--) {  // lowest slot wins
-            if (succ_d[t] != 0xFFFFFFFFu) { have_next = true; nx_slot = t; nx_dist = succ_d[t]; nx_node = t < 4 ? nb[t] : gn[t - 4]; nx_chk = t < 4; }
-        }
-        uint64_t ext_begin = 0;
-        uint32_t ext_deg = 0;
-        if (ext) {  // spilled adjacency (more than 4 out-edges): the first successor within the bound
-            ext_begin = ((uint64_t)b0.y << 32) | b0.x;
-            ext_deg = b0.z;
-            for (uint32_t j = 0; j < ext_deg && !have_next; j++) {
-                const uint32_t nd = d + a.ext_w[ext_begin + j];
-                if (nd <= a.K1) { have_next = true; nx_slot = (int)j; nx_dist = nd; nx_node = a.ext_col[ext_begin + j]; nx_chk = false; }
+        if (__any(is_ext)) {  // spilled adjacency (more than 4 out-edges; never in a de Bruijn graph): count first
+            if (is_ext) {
+                const uint64_t ext_begin = ((uint64_t)b0.y << 32) | b0.x;
+                for (uint32_t j = 0; j < b0.z; j++) sp_f += d + a.ext_w[ext_begin + j] <= K1 ? 1u : 0u;
             }
         }
-        bool popped = false;
-        if (active && !have_next && sp > 0) {  // dead end: back to the most recent branch (nothing is pushed in such a step)
-            nx_node = s_stk_node[wv][sp - 1][lane];
-            const uint32_t dd = s_stk_dist[wv][sp - 1][lane];
-            nx_dist = dd & 0x7FFFu;
-            nx_chk = (dd >> 15) != 0;
-            popped = true;
+        // ---- extension blocks for the lanes that outgrow their first tier in this step ----
+        const bool need_blk = blk == SCRATCH && (sp_f > (uint32_t)S1 || nh_f > (uint32_t)H1);
+        unsigned long long nm = __ballot(need_blk);
+        while (nm && free_mask) {
+            const int l = __builtin_ctzll(nm);
+            const int bi = __builtin_ctzll(free_mask);
+            nm &= nm - 1;
+            free_mask &= free_mask - 1;
+            blk = lane == l ? T1 + (uint32_t)bi * BE : blk;
         }
-        const bool will_end = active && !have_next && !popped;  // the source finishes (or overflows) in this step
-        unsigned long long new_item = 0;
-        uint32_t new_src = 0;
-        const bool got_new = take_sources(!active || will_end, new_item, new_src);
-        if (got_new) { nx_node = new_src; nx_dist = 0; nx_chk = false; }
-        // ---- (2) the next gather leaves now ----
-        uint4 n0 = b0, n1 = b1, n2 = b2, n3 = b3;
-        if (have_next || popped || got_new) load_block(nx_node, n0, n1, n2, n3);
+        const uint32_t es = sp_f > (uint32_t)S1 ? sp_f - (uint32_t)S1 : 0u, eh = nh_f > (uint32_t)H1 ? nh_f - (uint32_t)H1 : 0u;
+        pops += active ? 1u : 0u;
+        // (a lane the pool had no block for, or whose block is full, hands its source to the cascade)
+        // (one word stays free: the store after the last one that counts must not land on the other side's newest entry)
+        const bool ovf = active && ((need_blk && blk == SCRATCH) || es + eh >= (uint32_t)BE || pops > ENUM_POP_BUDGET);
 
-        // ---- (3) the rest of this step, while that gather is in flight ----
-        bool fin = false, ovf = false;
-        if (active) {
-            auto hit = [&](uint32_t node, uint32_t dist) {
-                const unsigned long long key = ((unsigned long long)dist << 32) | node;
-                const uint32_t bit = 1u << (node & 31u);
-                unclean |= (key <= prev_key) | ((bloom & bit) != 0u);
-                prev_key = key;
-                bloom |= bit;
-                if (nhit < (uint32_t)H) {
-                    s_hit_node[wv][nhit][lane] = node;
-                    s_hit_dist[wv][nhit][lane] = (uint16_t)dist;
-                } else ovf = true;  // more in-nodes than a lane keeps: the cascade takes this source
-                nhit++;
-            };
-            auto push = [&](uint32_t nbn, uint32_t nd, bool chk) {
-                if (sp < (uint32_t)S) {
-                    s_stk_node[wv][sp][lane] = nbn;
-                    s_stk_dist[wv][sp][lane] = (uint16_t)(nd | (chk ? 0x8000u : 0u));
-                } else ovf = true;
-                sp++;
-            };
-            if (!cur_chk && (flags & F_TARGET) && u != src_node) hit(u, d);  // forbid_source_target, greedytigs/mod.rs:329
-            if (!ext) {
+        // ---- hits and successors, straight into LDS (an overflowing lane scribbles into the scratch block instead) ----
+        const uint32_t base = ovf ? SCRATCH : blk;
+        uint32_t wsp = ovf ? 0u : sp, wnh = ovf ? 0u : nhit;
+        mem[hit_word(base, wnh)] = ((unsigned long long)d << 32) | u;
+        wnh += hv[0] ? 1u : 0u;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (dc[j] != 0xFFFFFFFFu && ((cmeta >> (4 * j)) & 8u) && nb[j] != src_node) hit(nb[j], dc[j]);
-                    if (succ_d[j] != 0xFFFFFFFFu && nx_slot != j) push(nb[j], succ_d[j], true);  // its in-node flag is done
-                }
-#pragma unroll
-                for (int t = 0; t < GSLOTS; t++)
-                    if (succ_d[4 + t] != 0xFFFFFFFFu && nx_slot != 4 + t) push(gn[t], succ_d[4 + t], false);
-            } else {
-                for (uint32_t j = (uint32_t)(nx_slot + 1); have_next && j < ext_deg; j++) {
+        for (int j = 0; j < 4; j++) {
+            if (j < 2 || __any(hv[1 + j])) {
+                mem[hit_word(base, wnh)] = ((unsigned long long)dc[j] << 32) | nb[j];
+                wnh += hv[1 + j] ? 1u : 0u;
+            }
+        }
+        if (__any(is_ext)) {
+            if (is_ext && !ovf) {
+                const uint64_t ext_begin = ((uint64_t)b0.y << 32) | b0.x;
+                for (uint32_t j = 0; j < b0.z; j++) {
                     const uint32_t nd = d + a.ext_w[ext_begin + j];
-                    if (nd <= a.K1) push(a.ext_col[ext_begin + j], nd, false);
+                    if (nd <= K1) { mem[stack_word(base, wsp)] = ((unsigned long long)nd << 32) | a.ext_col[ext_begin + j]; wsp++; }
                 }
             }
-            if (popped) sp--;
-            if (++pops > ENUM_POP_BUDGET) ovf = true;
-            if (will_end && !ovf) fin = true;
         }
+#pragma unroll
+        for (int t = GSLOTS - 1; t >= 0; t--) {
+            if (t < 4 || __any(pv[4 + t])) {
+                mem[stack_word(base, wsp)] = ((unsigned long long)dg[t] << 32) | gn[t];
+                wsp += pv[4 + t] ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {  // (children come off the stack before grandchildren: nearer nodes first)
+            if (j < 2 || __any(pv[j])) {
+                mem[stack_word(base, wsp)] = ((unsigned long long)(dc[j] | 0x10000u) << 32) | nb[j];  // its in-node flag is done
+                wsp += pv[j] ? 1u : 0u;
+            }
+        }
+        sp = wsp; nhit = wnh;
+        const bool go_on = active && !ovf && sp > 0;  // the next node comes off the stack
+        const unsigned long long top = mem[stack_word(base, sp > 0 ? sp - 1u : 0u)];
+        sp -= go_on ? 1u : 0u;
+        const bool fin = active && !ovf && !go_on;  // the source is finished
 
-        // ---- finished / overflowed lanes stage their result: keys compacted into the wave's buffer (hits as they are: the
-        // post-pass de-duplicates and sorts) ----
+        // ---- lanes without a next node take a new source; every lane's next gather leaves now ----
+        uint32_t new_item = 0, new_src = 0;
+        const bool got_new = take_source(!go_on, new_item, new_src);
+        const uint32_t nx_node = go_on ? (uint32_t)top : new_src;
+        load_block(go_on || got_new, nx_node);
+
+        // ---- finished / overflowed sources write their result ----
         const unsigned long long donemask = __ballot(fin || ovf);
         if (donemask) {
             uint32_t c = fin ? nhit : 0u;
-            uint32_t total = 0;  // keys this step stages: sum over the wave, bit plane by bit plane (scalar work only)
-#pragma unroll
-            for (int bit = 0; bit < 5; bit++) total += (uint32_t)__popcll(__ballot((c >> bit) & 1u)) << bit;
-            if (n_keys && n_keys + total > (uint32_t)OB) flush_results();  // wave-uniform
-            if (lane == 0) s_nkeys[wv] = n_keys;
-            if (fin || ovf) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(donemask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donemask, 0u));
-                const uint64_t abs_idx = a.src_index ? a.src_index[item] : a.src_begin + item;
-                uint32_t off = c ? atomicAdd(&s_nkeys[wv], c) : 0u;  // any order: (start, count) index the content
-                if (off + c > (uint32_t)OB) { ovf = true; fin = false; c = 0; off = 0; }  // (only if ONE step stages more than OB keys)
-                unsigned long long keys[H];
-#pragma unroll
-                for (int r = 0; r < H; r++)  // all reads in flight, then all writes (a dependent read -> write pair per key would serialise)
-                    keys[r] = (uint32_t)r < c ? (((unsigned long long)s_hit_dist[wv][r][lane] << 32) | s_hit_node[wv][r][lane]) : 0ull;
-#pragma unroll
-                for (int r = 0; r < H; r++)
-                    if ((uint32_t)r < c) s_out[wv][off + r] = keys[r];
-                s_res_idx[wv][n_res + rank] = (uint32_t)(abs_idx - a.src_begin);
-                s_res_misc[wv][n_res + rank] = off | (c << 12) | (ovf ? 0x80000000u : 0u);
-                if (fin && unclean && c > 1) s_fix[wv][atomicAdd(&s_nfix[wv], 1u)] = (uint32_t)(abs_idx - a.src_begin);
+            // lists of up to four keys are put in Dijkstra order in registers; longer ones (and repeated nodes) go to the post-pass
+            unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
+            if (c > 0) k0 = mem[hit_word(blk, 0)];
+            if (c > 1) k1 = mem[hit_word(blk, 1)];
+            if (c > 2) k2 = mem[hit_word(blk, 2)];
+            if (c > 3) k3 = mem[hit_word(blk, 3)];
+            bool fix = c > 4;
+            if (__any(c >= 2 && c <= 4)) {
+                auto cswap = [](unsigned long long &x, unsigned long long &y) {
+                    const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+                    x = lo; y = hi;
+                };
+                cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // (longer lists are sorted again anyway)
+                const uint32_t n0 = (uint32_t)k0, n1 = (uint32_t)k1, n2 = (uint32_t)k2, n3 = (uint32_t)k3;
+                const bool dup = (c >= 2 && c <= 4) && (n0 == n1 || (c > 2 && (n0 == n2 || n1 == n2)) || (c > 3 && (n0 == n3 || n1 == n3 || n2 == n3)));
+                if (dup && c == 2) c = 1;  // the same node along two paths: the shorter distance stays
+                else fix |= dup;
             }
-            n_keys = __shfl(lane == 0 ? s_nkeys[wv] : 0u, 0);
-            if (n_keys > (uint32_t)OB) n_keys = (uint32_t)OB;
-            n_res += (uint32_t)__popcll(donemask);
-            uint32_t ovf_idx = 0;
-            if (ovf) ovf_idx = (uint32_t)(a.src_index ? a.src_index[item] : a.src_begin + item);
-            wave_ovf_push(s_ovf[wv], n_overflow, ovf, ovf_idx, a, lane);
+            uint32_t off = c ? atomicAdd(&s_cnt[wv], c) : 0u;  // any order: (start, count) index the content
+            if (__builtin_amdgcn_readfirstlane(s_cnt[wv]) > ENUM_POOL_CHUNK) {  // chunk used up: this step's lists go to a new one
+                unsigned long long p0 = 0;
+                if (lane == 0) {
+                    p0 = atomicAdd(&a.counters[C_POOL], (unsigned long long)ENUM_POOL_CHUNK);
+                    s_cnt[wv] = 0;
+                }
+                pool_base = uniform_u64(p0);
+                off = c ? atomicAdd(&s_cnt[wv], c) : 0u;
+            }
+            const unsigned long long pos = pool_base + off;
+            const bool room = pos + c <= a.pool_cap;  // (pool too small: the host retries with a larger one)
+            if (c > 0 && room) a.pool[pos] = k0;
+            if (c > 1 && room) a.pool[pos + 1] = k1;
+            if (c > 2 && room) a.pool[pos + 2] = k2;
+            if (c > 3 && room) a.pool[pos + 3] = k3;
+            for (uint32_t r = 4; __any(r < c); r++)
+                if (r < c && room) a.pool[pos + r] = mem[hit_word(blk, r)];
+            if (fin) {
+                a.cand_start[item] = pos;
+                a.cand_count[item] = c;
+            } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
+            const unsigned long long fm = __ballot(fix);
+            if (fm) {
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                if (fix_next + nf > fix_end) {  // the rest of the old chunk is marked unused
+                    for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
+                    unsigned long long f0 = 0;
+                    if (lane == 0) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
+                    fix_next = uniform_u64(f0);
+                    fix_end = fix_next + ENUM_FIX_CHUNK;
+                }
+                if (fix) a.fix_list[fix_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
+                fix_next += nf;
+            }
+            unsigned long long rel = __ballot((fin || ovf) && blk != SCRATCH);  // extension blocks go back to the pool
+            while (rel) {
+                const int l = __builtin_ctzll(rel);
+                rel &= rel - 1;
+                free_mask |= 1ull << ((((uint32_t)__builtin_amdgcn_readlane((int)blk, l) - T1) / (uint32_t)BE) & 63u);
+            }
+            wave_ovf_push(s_ovf[wv], n_overflow, ovf, (uint32_t)(a.src_begin + item), a, lane);
         }
 
         // ---- commit: every lane moves to its next block ----
-        if (fin || ovf || !active) {
-            if (got_new) {
-                item = new_item; src_node = new_src;
-                cur_node = new_src; cur_dist = 0; cur_chk = false;
-                sp = 0; nhit = 0; pops = 0; prev_key = 0; bloom = 0; unclean = false;
-                active = true;
-            } else {
-                nhit = 0;
-                active = false;
-            }
+        if (go_on) {
+            cur_node = nx_node;
+            cur_dist = (uint32_t)(top >> 32) & 0xFFFFu;
+            cur_chk = ((uint32_t)(top >> 32) & 0x10000u) != 0u;
         } else {
-            cur_node = nx_node; cur_dist = nx_dist; cur_chk = nx_chk;
+            sp = 0; nhit = 0; pops = 0;
+            blk = SCRATCH;
+            cur_chk = false;
+            active = got_new;
+            item = new_item; src_node = new_src; cur_node = new_src;
+            cur_dist = got_new ? 0u : IDLE_DIST;
         }
-        b0 = n0; b1 = n1; b2 = n2; b3 = n3;
     }
-    flush_results();
     for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
 }
@@ -1114,7 +1137,8 @@ struct Device {
     double last_level_ms[8] = {0};
     uint64_t last_level_sources[8] = {0};
     std::string last_level_name[8];
-    int plan = 0;  // 0 = table-free path enumeration per lane, then the cooperative cascade for the heaviest sources; 1 = cascade only
+    int plan = 0;  // 0 = table-free path enumeration per lane, then the cooperative cascade for the heaviest sources (the form of its gathers
+                   // chosen by the size of the graph); 1 = cascade only; 2 / 3 = plan 0 with quad-cooperative / per-lane gathers regardless of size
     int n_cu = 256;
     uint64_t graph_bytes = 0;
     ReplayWork replay;
@@ -1148,10 +1172,11 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-constexpr int ENUM_WPB = 4, ENUM_STACK = 12, ENUM_HITS = 16;  // 68 KB of LDS per workgroup: 2 workgroups = 8 waves per CU
-static std::string enum_level_name() {
+constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_NB = MTG_ENUM_NB;  // 40 KB of LDS per workgroup: 4 workgroups = 16 waves per CU
+constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
+static std::string enum_level_name(bool quad) {
     char b[96];
-    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d> + sort_candidates_kernel", ENUM_WPB, ENUM_STACK, ENUM_HITS);
+    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d,%d,%s> + sort_candidates_kernel", ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane");
     return b;
 }
 
@@ -1181,19 +1206,27 @@ static float elapsed_ms(Device *d) {
     return ms;
 }
 
+static bool enum_uses_quad_gathers(const Device *d) {
+    // beyond ~3 GB of family blocks every lane-request pays an address translation: quad-cooperative gathers (see the kernel)
+    return d->plan == 2 || (d->plan == 0 && d->V * sizeof(NodeBlock) > (3ull << 30));
+}
+
 static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     if (args.n_items == 0) return;
-    sssp_fn fn = sssp_enum_kernel<ENUM_WPB, ENUM_STACK, ENUM_HITS>;
+    const bool quad = enum_uses_quad_gathers(d);
+    sssp_fn fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false>;
     int occ = 1;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, ENUM_WPB * 64, 0));
     if (occ < 1) occ = 1;
+    static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
+    if (debug) std::fprintf(stderr, "[mtg] enumeration level: %d workgroups of %d waves per CU\n", occ, ENUM_WPB);
     const uint64_t waves_needed = (args.n_items + 63) / 64;
     uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + ENUM_WPB - 1) / ENUM_WPB);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(sort_candidates_kernel<ENUM_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
+    hipLaunchKernelGGL(sort_candidates_kernel<ENUM_MAX_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
                        dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start, args.cand_count, args.fix_list,
                        args.counters + C_FIX);
     HIP_CHECK(hipGetLastError());
@@ -1257,7 +1290,8 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
         if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
-        HIP_CHECK(hipMalloc(&d->d_fix, (std::max<uint64_t>(n, 1) + (uint64_t)d->n_cu * 8 * ENUM_WPB * ENUM_FIX_CHUNK) * sizeof(uint32_t)));  // + chunk slack per wave
+        // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/8 of every chunk) + one chunk per wave
+        HIP_CHECK(hipMalloc(&d->d_fix, (std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * ENUM_FIX_CHUNK) * sizeof(uint32_t)));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
@@ -1265,7 +1299,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
-    const bool use_enum = d->plan == 0 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
+    const bool use_enum = d->plan != 1 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
     if (use_enum) launch_enum(d, st, a);
     else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
@@ -1273,7 +1307,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     if (n) {
         total_ms += elapsed_ms(d);
         d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1;
-        d->last_level_name[0] = use_enum ? enum_level_name() : coop_level(first_coop, false).name();
+        d->last_level_name[0] = use_enum ? enum_level_name(enum_uses_quad_gathers(d)) : coop_level(first_coop, false).name();
     }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_enum ? "enum" : "coop level 0",
@@ -1729,7 +1763,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 }
 
 int device_set_plan(Device *d, int plan) {
-    if (plan == 0 || plan == 1) d->plan = plan;
+    if (plan >= 0 && plan <= 3) d->plan = plan;
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }

@@ -25,7 +25,7 @@ def gpu(product_lib):
     return torch
 
 
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 2])
 @pytest.mark.parametrize("kat", PAIR_KATS, ids=[k["name"] for k in PAIR_KATS])
 def test_kat_pairs_through_hip(kat, plan, gpu, oracle):
     from matchtigs_amd import api, torch_glue

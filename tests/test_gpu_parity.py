@@ -74,7 +74,8 @@ def test_classification_matches_oracle(gpu, oracle, idx):
     assert np.array_equal(li, o_live), name
 
 
-@pytest.mark.parametrize("plan", [0, 1])  # 0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only
+@pytest.mark.parametrize("plan", [0, 1, 2])  # 0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only,
+#                                               2 = plan 0 with the quad-cooperative gathers large graphs get (mtg_set_sssp_plan)
 @pytest.mark.parametrize("idx", range(5))
 def test_t1_candidate_lists(gpu, oracle, idx, plan):
     name, bg = graphs()[idx]
@@ -139,7 +140,7 @@ def test_t2_t3_t4_pairs_and_tigs(gpu, oracle, idx):
     assert (ex["edge_weight"][matched] >= 1).all()
 
 
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 2])
 def test_overflow_levels_big_balls(gpu, oracle, plan):
     """Unit weights + out-degree ~3 + k=31 make balls far larger than the level-0 budgets: the larger levels must agree."""
     from matchtigs_amd import synth
@@ -155,7 +156,7 @@ def test_overflow_levels_big_balls(gpu, oracle, plan):
     assert cnt["settled_nodes"] == st["settled_nodes"] and cnt["relaxed_edges"] == st["relaxed_edges"]
 
 
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 2])
 def test_deepest_levels_huge_balls(gpu, oracle, plan):
     """Balls above 16384 nodes only fit the last level (table in a global workspace): a unit-weight graph whose
     (k-1)-balls cover most of its 36000 nodes, on a slice of the sources (the oracle would need minutes for all)."""
@@ -174,7 +175,7 @@ def test_deepest_levels_huge_balls(gpu, oracle, plan):
     assert np.array_equal(got, keys)
 
 
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 2])
 def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, plan):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
     from matchtigs_amd import synth
