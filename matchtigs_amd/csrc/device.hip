@@ -304,6 +304,7 @@ enum Counter : int {
     C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
     C_MAX_ENT = 11,  // COUNT: most table entries of one batch
     C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
+    C_FIX_LONG = 13, // enumeration level: cursor of the post-pass work list of the long lists
     C_COUNT = 16
 };
 
@@ -324,7 +325,8 @@ struct SsspArgs {
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
-    uint32_t *fix_list;          // out (enumeration level): indices (relative to src_begin) of the lists to sort (cursor: C_FIX)
+    uint32_t *fix_list;          // out (enumeration level): indices (relative to src_begin) of the lists of 5..8 keys to sort (cursor: C_FIX)
+    uint32_t *fix_long;          //                          ... of the longer lists (cursor: C_FIX_LONG)
 };
 
 template <bool GLOBAL_WS>
@@ -717,13 +719,16 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr uint32_t ENUM_POOL_CHUNK = 2048;  // keys per wave-local pool chunk (one global atomic per chunk)
 constexpr uint32_t ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
+constexpr uint32_t ENUM_FIX_LONG_CHUNK = 512;
+constexpr uint32_t ENUM_SHORT_LIST = 8;     // the post-pass handles lists of up to / of more than this many keys in separate launches
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
-constexpr int ENUM_BE = 16;                 // entries per extension block
 #ifndef MTG_ENUM_S1
 #define MTG_ENUM_S1 4
-#define MTG_ENUM_H1 3
-#define MTG_ENUM_NB 46
+#define MTG_ENUM_H1 4
+#define MTG_ENUM_NB 40
+#define MTG_ENUM_BE 16
 #endif
+constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {  // value of the first lane, known uniform to the compiler
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -747,18 +752,23 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     unsigned long long *const mem = s_mem[wv];
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
-    unsigned long long pool_base = 0, fix_next = 0, fix_end = 0;                     // wave-uniform
+    unsigned long long pool_base = 0, fix_next = 0, fix_end = 0, fixl_next = 0, fixl_end = 0;  // wave-uniform
     uint32_t n_overflow = 0;                                                         // wave-uniform
     if (lane == 0) s_cnt[wv] = ENUM_POOL_CHUNK;  // position inside the wave's pool chunk (no chunk yet)
+#ifdef MTG_ENUM_STATS
+    uint32_t st_starved = 0, st_full = 0, st_budget = 0, st_steps = 0, st_lanes = 0;
+#endif
 
     // ---- sources: chunks of 64 in a STATIC stride (chunk c belongs to wave c mod n_waves), held in registers: `ids` is the chunk
     // being handed out, `ahead` the wave's next one (loaded a whole chunk before it is needed). A lane that needs a source gets
     // the next unused one by a cross-lane permute: no atomic, no memory round trip, no LDS. ----
     const unsigned long long n_items = a.n_items;
     const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB;
-    unsigned long long next_chunk = (unsigned long long)blockIdx.x * WPB + wv;  // chunk that `ahead` holds (wave-uniform)
+    unsigned long long next_chunk = (unsigned long long)blockIdx.x * WPB + wv;  // chunk that `ahead` will hold (wave-uniform)
     uint32_t cur_base = 0, cur_len = 0, cur_pos = 0, nxt_base = 0, nxt_len = 0;  // wave-uniform
     uint32_t ids = 0, ahead = 0;
+    // (measured and dropped: the last quarter of the chunks handed out by a global counter, requested two chunks ahead so that the
+    // atomic is never waited for -- 7 % slower at 2^27 and no better lane utilisation at 2^24)
     auto prefetch_chunk = [&]() {
         const unsigned long long lo = next_chunk * 64;
         nxt_base = (uint32_t)lo;
@@ -830,8 +840,12 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         if constexpr (!QUAD) {
             b0 = g0; b1 = g1; b2 = g2; b3 = g3;
         } else {
+            // two exchange stages (lane ^ 1, lane ^ 2); in a stage even lanes take hi <- partner's lo, odd lanes lo <- partner's hi.
+            // (v_cndmask_b32_dpp would do select and exchange in one instruction, but the compiler emits mov_dpp + cndmask for the
+            // builtin, and the inline-asm form measured 3 % slower: its wait states and early-clobber copies cost more than it saves.)
+            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
             const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
-            auto xchg = [](uint32_t &lo, uint32_t &hi, bool odd, auto ctrl) {  // even lanes: hi <- partner's lo; odd lanes: lo <- partner's hi
+            auto xchg = [](uint32_t &lo, uint32_t &hi, bool odd, auto ctrl) {
                 constexpr int C = decltype(ctrl)::value;
                 const uint32_t from_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, C, 0xF, 0xF, false);
                 const uint32_t from_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, C, 0xF, 0xF, false);
@@ -841,7 +855,6 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             auto xchg4 = [&](uint4 &lo, uint4 &hi, bool odd, auto ctrl) {
                 xchg(lo.x, hi.x, odd, ctrl); xchg(lo.y, hi.y, odd, ctrl); xchg(lo.z, hi.z, odd, ctrl); xchg(lo.w, hi.w, odd, ctrl);
             };
-            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
             xchg4(b0, b1, odd1, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
             xchg4(b2, b3, odd1, std::integral_constant<int, 0xB1>{});
             xchg4(b0, b2, odd2, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
@@ -911,6 +924,13 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         // (a lane the pool had no block for, or whose block is full, hands its source to the cascade)
         // (one word stays free: the store after the last one that counts must not land on the other side's newest entry)
         const bool ovf = active && ((need_blk && blk == SCRATCH) || es + eh >= (uint32_t)BE || pops > ENUM_POP_BUDGET);
+#ifdef MTG_ENUM_STATS  // development build: why sources leave this level, how many steps run, how full the lanes are
+        st_starved += (uint32_t)__popcll(__ballot(active && need_blk && blk == SCRATCH));
+        st_full += (uint32_t)__popcll(__ballot(active && !(need_blk && blk == SCRATCH) && es + eh >= (uint32_t)BE));
+        st_budget += (uint32_t)__popcll(__ballot(active && pops > ENUM_POP_BUDGET));
+        st_steps += 1;
+        st_lanes += (uint32_t)__popcll(__ballot(active));
+#endif
 
         // ---- hits and successors, straight into LDS (an overflowing lane scribbles into the scratch block instead) ----
         const uint32_t base = ovf ? SCRATCH : blk;
@@ -970,7 +990,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             if (c > 2) k2 = mem[hit_word(blk, 2)];
             if (c > 3) k3 = mem[hit_word(blk, 3)];
             bool fix = c > 4;
-            if (__any(c >= 2 && c <= 4)) {
+            if (__any(c >= 2)) {  // (the first four keys of a longer list are put in order as well: the post-pass starts behind them)
                 auto cswap = [](unsigned long long &x, unsigned long long &y) {
                     const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
                     x = lo; y = hi;
@@ -1003,19 +1023,24 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                 a.cand_start[item] = pos;
                 a.cand_count[item] = c;
             } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
-            const unsigned long long fm = __ballot(fix);
-            if (fm) {
+            // post-pass work lists: one of the lists of up to ENUM_SHORT_LIST keys, one of the longer ones (a wave of the
+            // post-pass then sorts lists of similar length)
+            auto append_fix = [&](bool f, uint32_t *list, unsigned long long &next, unsigned long long &end, int counter, uint32_t chunk) {
+                const unsigned long long fm = __ballot(f);
+                if (!fm) return;
                 const uint32_t nf = (uint32_t)__popcll(fm);
-                if (fix_next + nf > fix_end) {  // the rest of the old chunk is marked unused
-                    for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
+                if (next + nf > end) {  // the rest of the old chunk is marked unused
+                    for (unsigned long long t = next + lane; t < end; t += 64) list[t] = FIX_NONE;
                     unsigned long long f0 = 0;
-                    if (lane == 0) f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
-                    fix_next = uniform_u64(f0);
-                    fix_end = fix_next + ENUM_FIX_CHUNK;
+                    if (lane == 0) f0 = atomicAdd(&a.counters[counter], (unsigned long long)chunk);
+                    next = uniform_u64(f0);
+                    end = next + chunk;
                 }
-                if (fix) a.fix_list[fix_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
-                fix_next += nf;
-            }
+                if (f) list[next + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
+                next += nf;
+            };
+            append_fix(fix && c <= ENUM_SHORT_LIST, a.fix_list, fix_next, fix_end, C_FIX, ENUM_FIX_CHUNK);
+            append_fix(fix && c > ENUM_SHORT_LIST, a.fix_long, fixl_next, fixl_end, C_FIX_LONG, ENUM_FIX_LONG_CHUNK);
             unsigned long long rel = __ballot((fin || ovf) && blk != SCRATCH);  // extension blocks go back to the pool
             while (rel) {
                 const int l = __builtin_ctzll(rel);
@@ -1040,46 +1065,79 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         }
     }
     for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
+    for (unsigned long long t = fixl_next + lane; t < fixl_end; t += 64) a.fix_long[t] = FIX_NONE;
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
+#ifdef MTG_ENUM_STATS
+    if (lane == 0) {
+        atomicAdd(&a.counters[C_SETTLED], (unsigned long long)st_steps);
+        atomicAdd(&a.counters[C_RELAXED], (unsigned long long)st_lanes);
+        atomicAdd(&a.counters[C_EMITTED], (unsigned long long)st_starved);
+        atomicAdd(&a.counters[C_ATTEMPTS], (unsigned long long)st_full);
+        atomicAdd(&a.counters[C_PUSHES], (unsigned long long)st_budget);
+    }
+#endif
 }
 
 // Post-pass of the enumeration level: a source's hits arrive in discovery order and may name a node more than once (one
 // hit per path). Keep the smallest distance per node and order by (distance, node) -- what Dijkstra's pop order gives
-// (SURVEY App. A.1). Lists written by the cooperative levels are already in that form and pass through unchanged.
-template <int H>
-__global__ __launch_bounds__(256) void sort_candidates_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
-                                                              uint32_t *cand_count, const uint32_t *fix_list, const unsigned long long *n_fix) {
-    __shared__ unsigned long long s_k[H][256];
+// (SURVEY App. A.1). The level itself puts lists of up to four keys in order; what it leaves here are the longer lists and the
+// rare short list with a repeated node, in two work lists by length. One thread per list, the keys in REGISTERS: Batcher's
+// odd-even merge network over N slots (19 compare-exchanges for 8, 191 for 32; unused slots hold the largest key), then an
+// all-pairs test for repeated nodes. (Round 2's form -- insertion sort in LDS -- spent 25 000 instructions per wave on dependent
+// LDS round trips and divergent loop control: 0.6 ms at 2^27.)
+template <int N>
+struct OddEvenMergeNetwork {  // comparator list of Batcher's odd-even merge sort for N = 2^x inputs
+    int lo[N * 8], hi[N * 8], n = 0;
+    constexpr OddEvenMergeNetwork() : lo{}, hi{} {
+        for (int p = 1; p < N; p *= 2)
+            for (int k = p; k >= 1; k /= 2)
+                for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+                    for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { lo[n] = i + j; hi[n] = i + j + k; n++; }
+    }
+};
+
+template <int N, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sort_candidates_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
+                                                                uint32_t *cand_count, const uint32_t *fix_list, const unsigned long long *n_fix) {
+    constexpr OddEvenMergeNetwork<N> net{};
     const unsigned long long n = *n_fix;
-    for (unsigned long long p = (unsigned long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (unsigned long long)gridDim.x * 256) {
-    const uint32_t i = fix_list[p];
-    if (i == FIX_NONE) continue;
-    const uint32_t c = cand_count[i];
-    if (c < 2 || c > (uint32_t)H) continue;
-    const unsigned long long st = cand_start[i];
-    if (st + c > pool_cap) continue;  // pool too small: the host retries with a larger one
-    const int t = threadIdx.x;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; p < n; p += (unsigned long long)gridDim.x * BLOCK) {
+        const uint32_t i = fix_list[p];
+        if (i == FIX_NONE) continue;
+        const uint32_t c = cand_count[i];
+        if (c < 2 || c > (uint32_t)N) continue;
+        const unsigned long long st = cand_start[i];
+        if (st + c > pool_cap) continue;  // pool too small: the host retries with a larger one
+        unsigned long long k[N];
 #pragma unroll
-    for (uint32_t r = 0; r < (uint32_t)H; r++)  // all loads in flight at once (a load per sorting step would serialise their latencies)
-        if (r < c) s_k[r][t] = pool[st + r];
-    for (uint32_t r = 1; r < c; r++) {  // insertion sort by key = (distance, node)
-        const unsigned long long key = s_k[r][t];
-        uint32_t q = r;
-        while (q > 0 && s_k[q - 1][t] > key) {
-            s_k[q][t] = s_k[q - 1][t];
-            q--;
+        for (int r = 0; r < N; r++) k[r] = (uint32_t)r < c ? pool[st + r] : ~0ull;
+#pragma unroll
+        for (int x = 0; x < net.n; x++) {
+            const unsigned long long a = k[net.lo[x]], b = k[net.hi[x]];
+            k[net.lo[x]] = a < b ? a : b;
+            k[net.hi[x]] = a < b ? b : a;
         }
-        s_k[q][t] = key;
-    }
-    uint32_t m = 0;  // keep the first (= smallest distance) occurrence of every node
-    for (uint32_t r = 0; r < c; r++) {
-        const unsigned long long key = s_k[r][t];
-        bool dup = false;
-        for (uint32_t q = 0; q < m; q++) dup |= (uint32_t)s_k[q][t] == (uint32_t)key;
-        if (!dup) s_k[m++][t] = key;
-    }
-    for (uint32_t r = 0; r < m; r++) pool[st + r] = s_k[r][t];
-    if (m != c) cand_count[i] = m;
+        bool any_dup = false;  // a node named twice: only its first (= smallest distance) occurrence stays
+#pragma unroll
+        for (int r = 1; r < N; r++)
+#pragma unroll
+            for (int q = 0; q < r; q++) any_dup |= (uint32_t)r < c && (uint32_t)k[q] == (uint32_t)k[r];
+        if (!any_dup) {
+#pragma unroll
+            for (int r = 0; r < N; r++)
+                if ((uint32_t)r < c) pool[st + r] = k[r];
+        } else {
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 0; r < N; r++) {
+                bool dup = (uint32_t)r >= c;
+#pragma unroll
+                for (int q = 0; q < r; q++) dup |= (uint32_t)k[q] == (uint32_t)k[r];
+                if (!dup) { pool[st + m] = k[r]; m++; }
+            }
+            cand_count[i] = m;
+        }
     }
 }
 
@@ -1131,7 +1189,7 @@ struct Device {
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
-    uint32_t *d_fix = nullptr;                // enumeration level: candidate lists its post-pass has to put in order
+    uint32_t *d_fix = nullptr, *d_fix_long = nullptr;  // enumeration level: candidate lists its post-pass has to put in order
     uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
@@ -1226,9 +1284,13 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(sort_candidates_kernel<ENUM_MAX_HITS>, dim3((unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 8)),
-                       dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start, args.cand_count, args.fix_list,
-                       args.counters + C_FIX);
+    const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 16);
+    hipLaunchKernelGGL((sort_candidates_kernel<ENUM_SHORT_LIST, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
+                       args.cand_count, args.fix_list, args.counters + C_FIX);
+    HIP_CHECK(hipGetLastError());
+    static_assert(ENUM_MAX_HITS <= 32, "the long-list post-pass sorts up to 32 keys");
+    hipLaunchKernelGGL((sort_candidates_kernel<32, 128>), dim3(post_grid), dim3(128), 0, st, args.pool, args.pool_cap, args.cand_start,
+                       args.cand_count, args.fix_long, args.counters + C_FIX_LONG);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(d->ev1, st));
 }
@@ -1290,12 +1352,15 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
         if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
+        if (d->d_fix_long) HIP_CHECK(hipFree(d->d_fix_long));
+        HIP_CHECK(hipMalloc(&d->d_fix_long, (std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * ENUM_FIX_LONG_CHUNK) * sizeof(uint32_t)));
         // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/8 of every chunk) + one chunk per wave
         HIP_CHECK(hipMalloc(&d->d_fix, (std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * ENUM_FIX_CHUNK) * sizeof(uint32_t)));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
     a.fix_list = d->d_fix;
+    a.fix_long = d->d_fix_long;
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
@@ -1312,6 +1377,11 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_enum ? "enum" : "coop level 0",
                                  (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
+#ifdef MTG_ENUM_STATS
+    if (use_enum && n) std::fprintf(stderr, "[mtg] enum stats: wave steps %llu, lane steps %llu (%.1f of 64), starved %llu, block full %llu, step budget %llu, fix cursor %llu, pool cursor %llu\n",
+                                    d->h_counters[C_SETTLED], d->h_counters[C_RELAXED], (double)d->h_counters[C_RELAXED] / (double)std::max<unsigned long long>(d->h_counters[C_SETTLED], 1),
+                                    d->h_counters[C_EMITTED], d->h_counters[C_ATTEMPTS], d->h_counters[C_PUSHES], d->h_counters[C_FIX], d->h_counters[C_POOL]);
+#endif
     const uint64_t total_overflow = d->h_counters[C_OVERFLOW];
     // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
     // to the other of two ping-pong lists
@@ -1448,6 +1518,7 @@ void device_free(Device *d) {
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
+    (void)hipFree(d->d_fix_long);
     ReplayWork &w = d->replay;
     void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.big, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};

@@ -20,7 +20,7 @@ def short(name: str) -> str:
 
 def is_count_instantiation(name: str) -> bool:
     m = re.search(r"<(.*)>", name)
-    return bool(m and "true" in [x.strip() for x in m.group(1).split(",")][-2:] and "sssp" in name)
+    return bool(m and "true" in [x.strip() for x in m.group(1).split(",")][-2:] and "sssp_kernel" in name)
 
 
 def main():
