@@ -265,8 +265,9 @@ def main():
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic_bytes(args, world),
-            "gather_ceiling_note": "dependent random 32-B gathers saturate at ~54 G/s on MI355X (tools/gather_bench.hip): "
-                                   "floor for this stage = settled_nodes / 54e9",
+            "gather_ceiling_note": "dependent random 64-B block gathers saturate at ~54 G/s below 3 GB of blocks and at ~44 G/s (one request "
+                                   "per lane and line; 19 G/s with four) at 5.7 GB, tools/gather_bench_tlb.hip: floor for the enumeration "
+                                   "level = visited family blocks (~0.55 x settled_nodes) / that rate",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(local_kernel_ms, 4),
             "kernel_sssp_edges_per_s": round(stats["relaxed_edges"] / (local_kernel_ms * 1e-3), 1) if local_kernel_ms > 0 else 0.0,
             "work_efficiency_attempts_per_edge": round(stats["relax_attempts"] / max(stats["relaxed_edges"], 1), 4),

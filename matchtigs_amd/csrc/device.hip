@@ -16,8 +16,8 @@
 // SSSP stage (integer, gather/latency bound, no MFMA) = a cascade of levels; a source a
 // level cannot finish is appended to a device list by that kernel and re-run from scratch by the next:
 //   level 0   sssp_enum_kernel: one LANE per source enumerates the bounded paths depth-first with a private LDS stack (a
-//             (k-1)-ball of a unitig graph is almost a tree, so no visited table is needed); one 32-byte gather per step,
-//             self-refilling lanes, no barrier; results staged per wave and written in bursts; sort_candidates_kernel puts
+//             (k-1)-ball of a unitig graph is almost a tree, so no visited table is needed); one 64-byte block gather per step,
+//             self-refilling lanes, no barrier; results written straight to memory; fix_compact_kernel + sort_lists_kernel put
 //             the lists that are not yet in Dijkstra order in order. Sources beyond its budgets go to level 1+.
 //   level 1+  sssp_kernel: a workgroup takes a batch of BSRC sources and runs all their bounded searches
 //             together as ONE label-correcting wavefront over a shared LDS open-addressing table keyed by
@@ -304,8 +304,9 @@ enum Counter : int {
     C_MAX_LOG = 10,  // COUNT: longest frontier log of one batch
     C_MAX_ENT = 11,  // COUNT: most table entries of one batch
     C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
-    C_FIX_LONG = 13, // enumeration level: cursor of the post-pass work list of the long lists
-    C_COUNT = 16
+    C_FIX_CLASS0 = 13,  // enumeration level's post-pass: number of work-list entries per length class (13, 14, 15)
+    C_FIX_CURSOR0 = 16, // ... and the cursors of its compaction (16, 17, 18)
+    C_COUNT = 24
 };
 
 struct SsspArgs {
@@ -325,8 +326,8 @@ struct SsspArgs {
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
-    uint32_t *fix_list;          // out (enumeration level): indices (relative to src_begin) of the lists of 5..8 keys to sort (cursor: C_FIX)
-    uint32_t *fix_long;          //                          ... of the longer lists (cursor: C_FIX_LONG)
+    uint32_t *fix_list;          // out (enumeration level): post-pass work list in chunks of ENUM_FIX_CHUNK slots (cursor: C_FIX): slot 0 = the
+                                 // chunk's length class, then indices (relative to src_begin) of lists of that class, FIX_NONE = unused
 };
 
 template <bool GLOBAL_WS>
@@ -719,8 +720,7 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr uint32_t ENUM_POOL_CHUNK = 2048;  // keys per wave-local pool chunk (one global atomic per chunk)
 constexpr uint32_t ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
-constexpr uint32_t ENUM_FIX_LONG_CHUNK = 512;
-constexpr uint32_t ENUM_SHORT_LIST = 8;     // the post-pass handles lists of up to / of more than this many keys in separate launches
+constexpr uint32_t FIX_CLASS_TAG = 0xFFFFFF00u;  // slot 0 of a work-list chunk: FIX_CLASS_TAG | class (0: <= 8 keys, 1: <= 16, 2: <= 32)
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #ifndef MTG_ENUM_S1
 #define MTG_ENUM_S1 4
@@ -752,7 +752,9 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     unsigned long long *const mem = s_mem[wv];
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
-    unsigned long long pool_base = 0, fix_next = 0, fix_end = 0, fixl_next = 0, fixl_end = 0;  // wave-uniform
+    unsigned long long pool_base = 0;                                                // wave-uniform
+    unsigned long long fix_next[3] = {0, 0, 0}, fix_end[3] = {0, 0, 0};             // wave-uniform: the wave's open work-list chunk per length class
+    uint32_t fix_total[3] = {0, 0, 0};                                              // wave-uniform: entries appended per class
     uint32_t n_overflow = 0;                                                         // wave-uniform
     if (lane == 0) s_cnt[wv] = ENUM_POOL_CHUNK;  // position inside the wave's pool chunk (no chunk yet)
 #ifdef MTG_ENUM_STATS
@@ -1023,24 +1025,29 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
                 a.cand_start[item] = pos;
                 a.cand_count[item] = c;
             } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
-            // post-pass work lists: one of the lists of up to ENUM_SHORT_LIST keys, one of the longer ones (a wave of the
-            // post-pass then sorts lists of similar length)
-            auto append_fix = [&](bool f, uint32_t *list, unsigned long long &next, unsigned long long &end, int counter, uint32_t chunk) {
+            // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
+            // similar length with a network of that size)
+            auto append_fix = [&](bool f, int cls) {
                 const unsigned long long fm = __ballot(f);
                 if (!fm) return;
                 const uint32_t nf = (uint32_t)__popcll(fm);
-                if (next + nf > end) {  // the rest of the old chunk is marked unused
-                    for (unsigned long long t = next + lane; t < end; t += 64) list[t] = FIX_NONE;
+                if (fix_next[cls] + nf > fix_end[cls]) {  // the rest of the old chunk is marked unused
+                    for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
                     unsigned long long f0 = 0;
-                    if (lane == 0) f0 = atomicAdd(&a.counters[counter], (unsigned long long)chunk);
-                    next = uniform_u64(f0);
-                    end = next + chunk;
+                    if (lane == 0) {
+                        f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
+                        a.fix_list[f0] = FIX_CLASS_TAG | (uint32_t)cls;
+                    }
+                    fix_next[cls] = uniform_u64(f0) + 1;
+                    fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
                 }
-                if (f) list[next + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
-                next += nf;
+                if (f) a.fix_list[fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
+                fix_next[cls] += nf;
+                fix_total[cls] += nf;
             };
-            append_fix(fix && c <= ENUM_SHORT_LIST, a.fix_list, fix_next, fix_end, C_FIX, ENUM_FIX_CHUNK);
-            append_fix(fix && c > ENUM_SHORT_LIST, a.fix_long, fixl_next, fixl_end, C_FIX_LONG, ENUM_FIX_LONG_CHUNK);
+            append_fix(fix && c <= 8, 0);
+            append_fix(fix && c > 8 && c <= 16, 1);
+            append_fix(fix && c > 16, 2);
             unsigned long long rel = __ballot((fin || ovf) && blk != SCRATCH);  // extension blocks go back to the pool
             while (rel) {
                 const int l = __builtin_ctzll(rel);
@@ -1064,8 +1071,10 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             cur_dist = got_new ? 0u : IDLE_DIST;
         }
     }
-    for (unsigned long long t = fix_next + lane; t < fix_end; t += 64) a.fix_list[t] = FIX_NONE;
-    for (unsigned long long t = fixl_next + lane; t < fixl_end; t += 64) a.fix_long[t] = FIX_NONE;
+    for (int cls = 0; cls < 3; cls++) {
+        for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
+        if (lane == 0 && fix_total[cls]) atomicAdd(&a.counters[C_FIX_CLASS0 + cls], (unsigned long long)fix_total[cls]);
+    }
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
 #ifdef MTG_ENUM_STATS
     if (lane == 0) {
@@ -1080,64 +1089,92 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
 
 // Post-pass of the enumeration level: a source's hits arrive in discovery order and may name a node more than once (one
 // hit per path). Keep the smallest distance per node and order by (distance, node) -- what Dijkstra's pop order gives
-// (SURVEY App. A.1). The level itself puts lists of up to four keys in order; what it leaves here are the longer lists and the
-// rare short list with a repeated node, in two work lists by length. One thread per list, the keys in REGISTERS: Batcher's
-// odd-even merge network over N slots (19 compare-exchanges for 8, 191 for 32; unused slots hold the largest key), then an
-// all-pairs test for repeated nodes. (Round 2's form -- insertion sort in LDS -- spent 25 000 instructions per wave on dependent
-// LDS round trips and divergent loop control: 0.6 ms at 2^27.)
-template <int N>
-struct OddEvenMergeNetwork {  // comparator list of Batcher's odd-even merge sort for N = 2^x inputs
-    int lo[N * 8], hi[N * 8], n = 0;
-    constexpr OddEvenMergeNetwork() : lo{}, hi{} {
-        for (int p = 1; p < N; p *= 2)
-            for (int k = p; k >= 1; k /= 2)
-                for (int j = k % p; j <= N - 1 - k; j += 2 * k)
-                    for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); i++)
-                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { lo[n] = i + j; hi[n] = i + j + k; n++; }
+// (SURVEY App. A.1). The level itself puts lists of up to four keys in order; what it leaves here are the longer lists (5.8 % of
+// the bench graph's sources have 5-8 candidates, 2.8 % 9-16, 0.4 % more: together 58 % of all keys) and the rare short list with a
+// repeated node. What was measured on the way (2^27 bench graph): one thread per list with an insertion sort in LDS
+// (round 2) 0.61 ms -- dependent LDS round trips and divergent loop control; one thread per list with the keys in registers and a
+// sorting network 0.15 + 0.23 ms for the lists of <= 8 / <= 16 keys, bound by the number of memory requests (every lane reads and
+// writes its own list), and a 32-slot network is 40 KB of straight-line code whose first pass runs at the latency of
+// instruction-cache misses (0.26 ms for a handful of lists); the form below 0.13 + 0.12 + 0.03 ms.
+// The level's work list is chunked (slot 0 of a chunk names its length class, unused slots hold FIX_NONE); this pass makes it dense:
+// class 0 first, then class 1, then class 2 (the level counted the entries per class), so that the sorting kernels below run over
+// plain ranges.
+__global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_list, unsigned long long *counters, uint32_t *dense) {
+    __shared__ uint32_t s_cnt[3], s_off[3];
+    __shared__ unsigned long long s_base[3];
+    const unsigned long long n_slots = counters[C_FIX];
+    const unsigned long long off[3] = {0, counters[C_FIX_CLASS0], counters[C_FIX_CLASS0] + counters[C_FIX_CLASS0 + 1]};
+    // a workgroup takes a contiguous, chunk-aligned slice of the slots: it counts its entries per class, reserves its dense ranges with
+    // ONE global atomic per class (same-address atomics cost ~7 ns each: one per wave made this pass 0.64 ms at 2^27), then copies
+    const unsigned long long n_chunks = (n_slots + ENUM_FIX_CHUNK - 1) / ENUM_FIX_CHUNK;
+    const unsigned long long per_block = (n_chunks + gridDim.x - 1) / gridDim.x * ENUM_FIX_CHUNK;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * per_block, hi = lo + per_block < n_slots ? lo + per_block : n_slots;
+    if (threadIdx.x < 3) { s_cnt[threadIdx.x] = 0; s_off[threadIdx.x] = 0; }
+    __syncthreads();
+    for (unsigned long long s0 = lo; s0 < hi; s0 += 256) {  // (a wave stays inside one chunk: one class)
+        const unsigned long long sl = s0 + threadIdx.x;
+        const uint32_t e = sl < hi && (sl % ENUM_FIX_CHUNK) != 0 ? fix_list[sl] : FIX_NONE;
+        const unsigned long long m = __ballot(e != FIX_NONE);
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(&s_cnt[fix_list[sl / ENUM_FIX_CHUNK * ENUM_FIX_CHUNK] & 3u], (uint32_t)__popcll(m));
     }
-};
+    __syncthreads();
+    if (threadIdx.x < 3 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = off[threadIdx.x] + atomicAdd(&counters[C_FIX_CURSOR0 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+    for (unsigned long long s0 = lo; s0 < hi; s0 += 256) {
+        const unsigned long long sl = s0 + threadIdx.x;
+        const uint32_t e = sl < hi && (sl % ENUM_FIX_CHUNK) != 0 ? fix_list[sl] : FIX_NONE;
+        const unsigned long long m = __ballot(e != FIX_NONE);
+        if (!m) continue;
+        const uint32_t cls = fix_list[sl / ENUM_FIX_CHUNK * ENUM_FIX_CHUNK] & 3u;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&s_off[cls], (uint32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (e != FIX_NONE) dense[s_base[cls] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e;
+    }
+}
 
-template <int N, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sort_candidates_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
-                                                                uint32_t *cand_count, const uint32_t *fix_list, const unsigned long long *n_fix) {
-    constexpr OddEvenMergeNetwork<N> net{};
-    const unsigned long long n = *n_fix;
-    for (unsigned long long p = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; p < n; p += (unsigned long long)gridDim.x * BLOCK) {
-        const uint32_t i = fix_list[p];
-        if (i == FIX_NONE) continue;
-        const uint32_t c = cand_count[i];
-        if (c < 2 || c > (uint32_t)N) continue;
-        const unsigned long long st = cand_start[i];
-        if (st + c > pool_cap) continue;  // pool too small: the host retries with a larger one
-        unsigned long long k[N];
+// Lane-parallel form: G lanes per list, one key per lane -- coalesced reads and writes (a list is one or two memory requests instead
+// of one per key or key pair), bitonic sort across the lanes, then each key looks at the keys before it for its node.
+template <int G, int CLS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
+                                                           uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters) {
+    constexpr uint32_t LPB = BLOCK / G;  // lists per workgroup pass
+    unsigned long long begin = 0;
+    for (int k = 0; k < CLS; k++) begin += counters[C_FIX_CLASS0 + k];
+    const unsigned long long n = counters[C_FIX_CLASS0 + CLS];
+    const uint32_t g = threadIdx.x % G;
+    for (unsigned long long l0 = (unsigned long long)blockIdx.x * LPB; l0 < n; l0 += (unsigned long long)gridDim.x * LPB) {
+        const unsigned long long l = l0 + threadIdx.x / G;
+        const uint32_t i = l < n ? dense[begin + l] : FIX_NONE;
+        uint32_t c = i != FIX_NONE ? cand_count[i] : 0u;
+        const unsigned long long st = i != FIX_NONE ? cand_start[i] : 0ull;
+        if (c < 2 || c > (uint32_t)G || st + c > pool_cap) c = 0;  // (pool too small: the host retries with a larger one)
+        unsigned long long key = g < c ? pool[st + g] : ~0ull;
 #pragma unroll
-        for (int r = 0; r < N; r++) k[r] = (uint32_t)r < c ? pool[st + r] : ~0ull;
+        for (int k = 2; k <= G; k <<= 1) {
 #pragma unroll
-        for (int x = 0; x < net.n; x++) {
-            const unsigned long long a = k[net.lo[x]], b = k[net.hi[x]];
-            k[net.lo[x]] = a < b ? a : b;
-            k[net.hi[x]] = a < b ? b : a;
-        }
-        bool any_dup = false;  // a node named twice: only its first (= smallest distance) occurrence stays
-#pragma unroll
-        for (int r = 1; r < N; r++)
-#pragma unroll
-            for (int q = 0; q < r; q++) any_dup |= (uint32_t)r < c && (uint32_t)k[q] == (uint32_t)k[r];
-        if (!any_dup) {
-#pragma unroll
-            for (int r = 0; r < N; r++)
-                if ((uint32_t)r < c) pool[st + r] = k[r];
-        } else {
-            uint32_t m = 0;
-#pragma unroll
-            for (int r = 0; r < N; r++) {
-                bool dup = (uint32_t)r >= c;
-#pragma unroll
-                for (int q = 0; q < r; q++) dup |= (uint32_t)k[q] == (uint32_t)k[r];
-                if (!dup) { pool[st + m] = k[r]; m++; }
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j);
+                const bool take_min = ((g & (uint32_t)k) == 0) == ((g & (uint32_t)j) == 0);
+                const unsigned long long lo = key < other ? key : other, hi = key < other ? other : key;
+                key = take_min ? lo : hi;
             }
-            cand_count[i] = m;
         }
+        const uint32_t node = (uint32_t)key;
+        bool dup = false;  // a node named twice: only its first (= smallest distance) occurrence stays
+#pragma unroll
+        for (int dlt = 1; dlt < G; dlt++) {
+            const uint32_t before = __shfl_up(node, dlt, G);
+            dup |= g >= (uint32_t)dlt && g < c && before == node;
+        }
+        const unsigned long long dm = __ballot(dup);
+        if (dm) {  // (rare)
+            const uint32_t lane = threadIdx.x & 63u;
+            const unsigned long long group = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (lane - g);
+            const uint32_t before = (uint32_t)__popcll(dm & group & ((1ull << lane) - 1ull));
+            if (g < c && !dup) pool[st + g - before] = key;
+            if (g == 0 && (dm & group)) cand_count[i] = c - (uint32_t)__popcll(dm & group);
+        } else if (g < c) pool[st + g] = key;
     }
 }
 
@@ -1189,7 +1226,7 @@ struct Device {
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
-    uint32_t *d_fix = nullptr, *d_fix_long = nullptr;  // enumeration level: candidate lists its post-pass has to put in order
+    uint32_t *d_fix = nullptr, *d_fix_dense = nullptr;  // enumeration level: work list of its post-pass (chunked, as written / dense, by length class)
     uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level
     double last_level_ms[8] = {0};
@@ -1234,7 +1271,7 @@ constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_N
 constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
 static std::string enum_level_name(bool quad) {
     char b[96];
-    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d,%d,%s> + sort_candidates_kernel", ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane");
+    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d,%d,%s> + fix_compact_kernel + sort_lists_kernel", ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane");
     return b;
 }
 
@@ -1279,18 +1316,21 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug) std::fprintf(stderr, "[mtg] enumeration level: %d workgroups of %d waves per CU\n", occ, ENUM_WPB);
     const uint64_t waves_needed = (args.n_items + 63) / 64;
+    // (always the full grid: 8 waves per CU with twice the chunks per wave measured 20 % slower at 2^24, 65 % slower at 2^22)
     uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + ENUM_WPB - 1) / ENUM_WPB);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256, (uint64_t)d->n_cu * 16);
-    hipLaunchKernelGGL((sort_candidates_kernel<ENUM_SHORT_LIST, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
-                       args.cand_count, args.fix_list, args.counters + C_FIX);
-    HIP_CHECK(hipGetLastError());
-    static_assert(ENUM_MAX_HITS <= 32, "the long-list post-pass sorts up to 32 keys");
-    hipLaunchKernelGGL((sort_candidates_kernel<32, 128>), dim3(post_grid), dim3(128), 0, st, args.pool, args.pool_cap, args.cand_start,
-                       args.cand_count, args.fix_long, args.counters + C_FIX_LONG);
+    const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
+    static_assert(ENUM_MAX_HITS <= 32, "the post-pass sorts up to 32 keys");
+    hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.counters, d->d_fix_dense);
+    hipLaunchKernelGGL((sort_lists_kernel<8, 0, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
+                       args.cand_count, d->d_fix_dense, args.counters);
+    hipLaunchKernelGGL((sort_lists_kernel<16, 1, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
+                       args.cand_count, d->d_fix_dense, args.counters);
+    hipLaunchKernelGGL((sort_lists_kernel<32, 2, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
+                       args.cand_count, d->d_fix_dense, args.counters);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(d->ev1, st));
 }
@@ -1352,15 +1392,16 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
             HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         }
         if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
-        if (d->d_fix_long) HIP_CHECK(hipFree(d->d_fix_long));
-        HIP_CHECK(hipMalloc(&d->d_fix_long, (std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * ENUM_FIX_LONG_CHUNK) * sizeof(uint32_t)));
-        // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/8 of every chunk) + one chunk per wave
-        HIP_CHECK(hipMalloc(&d->d_fix, (std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * ENUM_FIX_CHUNK) * sizeof(uint32_t)));
+
+        // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/7 of every chunk incl. its tag) + three open chunks per wave
+        const uint64_t fix_slots = std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * 3 * ENUM_FIX_CHUNK;
+        HIP_CHECK(hipMalloc(&d->d_fix, fix_slots * sizeof(uint32_t)));
+        if (d->d_fix_dense) HIP_CHECK(hipFree(d->d_fix_dense));
+        HIP_CHECK(hipMalloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
     a.fix_list = d->d_fix;
-    a.fix_long = d->d_fix_long;
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
@@ -1423,7 +1464,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     // C_POOL is the pool cursor: keys plus the unused tails of block-local chunks (positions are launch-dependent,
     // (start,count) index the content). A retry may chunk differently, hence the slack.
     const bool too_small = !count && d->h_counters[C_POOL] > pool_cap;
-    if (pool_needed) *pool_needed = d->h_counters[C_POOL] + (too_small ? (uint64_t)d->n_cu * 8 * POOL_CHUNK : 0);
+    if (pool_needed) *pool_needed = d->h_counters[C_POOL] + (too_small ? (uint64_t)d->n_cu * 16 * POOL_CHUNK : 0);
     return too_small ? 1 : 0;
 }
 
@@ -1518,7 +1559,7 @@ void device_free(Device *d) {
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
-    (void)hipFree(d->d_fix_long);
+    (void)hipFree(d->d_fix_dense);
     ReplayWork &w = d->replay;
     void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.big, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};
