@@ -844,7 +844,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
         } else {
             // two exchange stages (lane ^ 1, lane ^ 2); in a stage even lanes take hi <- partner's lo, odd lanes lo <- partner's hi.
             // (v_cndmask_b32_dpp would do select and exchange in one instruction, but the compiler emits mov_dpp + cndmask for the
-            // builtin, and the inline-asm form measured 3 % slower: its wait states and early-clobber copies cost more than it saves.)
+            // builtin, and two inline-asm forms -- one block per word pair, one per stage and register quadruple, the latter with the
+            // block ADDRESS handed round the quad instead of the node id -- measured 3 % slower: fewer instructions, more stalls.)
             b0 = g0; b1 = g1; b2 = g2; b3 = g3;
             const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
             auto xchg = [](uint32_t &lo, uint32_t &hi, bool odd, auto ctrl) {

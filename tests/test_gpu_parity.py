@@ -94,6 +94,28 @@ def test_t1_candidate_lists(gpu, oracle, idx, plan):
     assert cnt["emitted"] == len(keys)
 
 
+@pytest.mark.parametrize("plan", [0, 2])
+def test_t1_long_lists_from_the_enumeration_level(gpu, oracle, plan):
+    """Short unitigs and many in-nodes: the enumeration level itself finishes sources with 5-8, 9-16 and more than 16 candidates
+    (its three post-pass length classes: work-list compaction + lane-parallel sort) and lists that name a node along two paths."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(40000, seed=7, k=31, mean_out_degree=1.25, mean_weight=3.0)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
+    levels = dev.last_sssp_levels()
+    handed_on = levels[1]["sources"] if len(levels) > 1 else 0
+    o_on, off, keys, _ = _oracle(oracle, bg).candidate_lists(bg.k)
+    lens = np.diff(off).astype(np.int64)
+    # (a source with more than 19 candidates cannot finish in the level; of the others the cascade took over fewer than there are
+    # lists in every class, so the level finished lists of every class)
+    others_handed_on = handed_on - int((lens > 19).sum())
+    for lo_, hi_ in ((5, 8), (9, 16), (17, 19)):
+        assert int(((lens >= lo_) & (lens <= hi_)).sum()) > others_handed_on >= 0, (lo_, hi_, handed_on, np.bincount(lens)[:24])
+    assert np.array_equal(count.astype(np.int64), lens)
+    idx_arr = np.concatenate([np.arange(s, s + c, dtype=np.int64) for s, c in zip(start, count)])
+    assert np.array_equal(pool[idx_arr], keys)
+
+
 def test_t1_source_subrange(gpu, oracle):
     name, bg = graphs()[2]
     o_on, off, keys, _ = _oracle(oracle, bg).candidate_lists(bg.k)

@@ -15,7 +15,21 @@ ap.add_argument("--k", type=int, default=31)
 ap.add_argument("--euler", choices=["host", "device"], default="device")
 ap.add_argument("--host-replay-check", action="store_true", help="also run the host claim loop on the same lists and compare")
 ap.add_argument("--out", default=None)
+ap.add_argument("--rss-limit-gb", type=float, default=260.0, help="watchdog: leave (exit code 3) before the box runs out of memory")
 a = ap.parse_args()
+import threading
+
+
+def _rss_watchdog():
+    while True:
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS:") and int(line.split()[1]) / 1e6 > a.rss_limit_gb:
+                print(f"RSS above {a.rss_limit_gb} GB: giving up", flush=True)
+                os._exit(3)
+        time.sleep(0.5)
+
+
+threading.Thread(target=_rss_watchdog, daemon=True).start()
 k = a.k
 res = {"log2_edges": a.log2_edges, "k": k, "euler_mode": a.euler}
 T0 = time.time()
