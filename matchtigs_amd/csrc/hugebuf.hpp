@@ -23,12 +23,15 @@ inline int current_numa_node() {
     return (int)node;
 }
 
-// Pins the calling thread to the CPUs of its current NUMA node for the lifetime of the guard (restores the old mask).
+// Pins the calling thread to the CPUs of its current NUMA node (never beyond its current mask) for the lifetime of the guard and
+// restores the old mask. A host program that manages affinities itself turns this off with MTG_NO_NUMA_PIN=1 (speed only: results
+// do not depend on it).
 struct NumaPin {
     cpu_set_t old_mask;
     bool active = false;
     int node = -1;
     NumaPin() {
+        if (std::getenv("MTG_NO_NUMA_PIN")) return;
         node = current_numa_node();
         if (node < 0 || sched_getaffinity(0, sizeof old_mask, &old_mask) != 0) return;
         char path[128];
