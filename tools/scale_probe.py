@@ -15,6 +15,7 @@ ap.add_argument("--k", type=int, default=31)
 ap.add_argument("--euler", choices=["host", "device"], default="device")
 ap.add_argument("--host-replay-check", action="store_true", help="also run the host claim loop on the same lists and compare")
 ap.add_argument("--out", default=None)
+ap.add_argument("--no-finish", action="store_true", help="stop after the GPU stages (2^31: the edge count with dummies exceeds the device Euler mode's 2^31 limit and the exact host walk's records exceed the box's memory)")
 ap.add_argument("--rss-limit-gb", type=float, default=260.0, help="watchdog: leave (exit code 3) before the box runs out of memory")
 a = ap.parse_args()
 import threading
@@ -98,6 +99,13 @@ if a.host_replay_check:
 del start, count, pool, bufs
 gc.collect()
 torch.cuda.empty_cache()
+if a.no_finish:
+    res["total_s"] = round(time.time() - T0, 1)
+    s = json.dumps(res)
+    print(s)
+    if a.out:
+        open(a.out, "w").write(s + "\n")
+    sys.exit(0)
 t = time.time()
 mode = api.EulerMode.Device if a.euler == "device" else api.EulerMode.HostReferenceOrder
 lim, edges = api.finish_greedytigs_np(G, pairs, k, mode)
