@@ -18,15 +18,22 @@ ap.add_argument("--out", default=None)
 ap.add_argument("--no-finish", action="store_true", help="stop after the GPU stages (2^31: the edge count with dummies exceeds the device Euler mode's 2^31 limit and the exact host walk's records exceed the box's memory)")
 ap.add_argument("--rss-limit-gb", type=float, default=260.0, help="watchdog: leave (exit code 3) before the box runs out of memory")
 a = ap.parse_args()
+T0 = time.time()
 import threading
 
 
 def _rss_watchdog():
+    beat = time.time()
     while True:
         for line in open("/proc/self/status"):
-            if line.startswith("VmRSS:") and int(line.split()[1]) / 1e6 > a.rss_limit_gb:
-                print(f"RSS above {a.rss_limit_gb} GB: giving up", flush=True)
-                os._exit(3)
+            if line.startswith("VmRSS:"):
+                rss = int(line.split()[1]) / 1e6
+                if rss > a.rss_limit_gb:
+                    print(f"RSS above {a.rss_limit_gb} GB: giving up", flush=True)
+                    os._exit(3)
+                if time.time() - beat > 60:  # (a silent run is taken to be hung)
+                    beat = time.time()
+                    print(f"[{time.time() - T0:7.1f}s] ... working, RSS {rss:.1f} GB", flush=True)
         time.sleep(0.5)
 
 
