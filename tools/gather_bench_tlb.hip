@@ -5,7 +5,7 @@
 //   quad64   four lanes load one block together (lane q of a quad loads quarter q of block i of the quad in load i):
 //            an instruction touches 16 lines / pages instead of 64
 //   window   lane64, but the random indices fall into a window of the table (footprint of the access, not of the allocation)
-// usage: gather_bench_tlb [n_blocks = 89523223]
+// usage: gather_bench_tlb [n_blocks = 89523223] [contiguous = 0]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -79,13 +79,16 @@ int main(int argc, char **argv) {
     const uint32_t n_blk = argc > 1 ? (uint32_t)atoll(argv[1]) : 89523223;
     printf("table: %u blocks of 64 bytes = %.2f GB\n", n_blk, n_blk * 64.0 / 1e9);
     uint4 *d; uint32_t *o;
-    CK(hipMalloc(&d, (size_t)n_blk * 64));
+    const int contiguous = argc > 2 ? atoi(argv[2]) : 0;  // 1: hipDeviceMallocContiguous (physically contiguous: larger translation fragments?)
+    if (contiguous) { CK(hipExtMallocWithFlags((void **)&d, (size_t)n_blk * 64, hipDeviceMallocContiguous)); printf("allocation: hipDeviceMallocContiguous\n"); }
+    else CK(hipMalloc(&d, (size_t)n_blk * 64));
     hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, d, (size_t)n_blk * 4);
     CK(hipDeviceSynchronize());
     CK(hipMalloc(&o, 256 * 32 * 64 * 4 * sizeof(uint32_t)));
     run<0>("lane64", d, n_blk, 0, o);
     run<1>("lane16", d, n_blk, 0, o);
     run<2>("quad64", d, n_blk, 0, o);
+    if (contiguous) return 0;
     run<0>("window/2", d, n_blk / 2, n_blk / 4, o);
     run<0>("window/4", d, n_blk / 4, n_blk / 3, o);
     run<0>("window/8", d, n_blk / 8, n_blk / 2, o);
