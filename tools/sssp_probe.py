@@ -14,6 +14,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--plan", type=int, default=0)
 ap.add_argument("--replay", action="store_true")
 ap.add_argument("--gap", type=float, default=-1.0, help=">= 0: like bench.py, run the claim replay after every SSSP pass and idle this many seconds")
+ap.add_argument("--between", choices=["both", "classify", "replay"], default="both", help="with --gap: what runs between two SSSP passes")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 from matchtigs_amd import _lib
@@ -35,12 +36,13 @@ def probe(tag, G):
     bufs = None
     runs = []
     for _ in range(a.reps):
-        if a.gap >= 0 and bufs is not None:
+        if a.gap >= 0 and bufs is not None and a.between in ("both", "classify"):
             dev.classify(stream)
         bufs = torch_glue.run_sssp(dev, 0, S, bufs)
         runs.append(dev.last_sssp_levels())
         if a.gap >= 0:
-            dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), stream)
+            if a.between in ("both", "replay"):
+                dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), stream)
             time.sleep(a.gap)
     best = min(runs, key=lambda lv: sum(x["ms"] for x in lv))
     res = {"workload": tag, "lib": a.lib or "default", "plan": a.plan, "V": G.node_count(), "E": G.edge_count(), "sources": S, "device_graph_s": round(t_dev, 3),
