@@ -67,7 +67,7 @@ Walks euler_cycles(const HostGraph &g) {
     NumaPin pin;  // the walk is one latency-bound thread: keep it next to the memory it chases through
 
     // ---- records ----
-    HugeBuf<EulerNode3> nodes(V);
+    HugeBuf<EulerNode3> nodes(V, &g.arena);
     std::vector<uint32_t> ext_begin(V + 1, 0);
     {
         uint64_t ext_total = 0;
@@ -172,7 +172,7 @@ Walks euler_cycles(const HostGraph &g) {
     };
 
     // entries: one per biedge plus one per splice; the FIFO sees every entry once plus one re-push per splice
-    HugeBuf<uint32_t> ent_edge(E + 1), ent_next(E + 1), ent_node(E + 1), fifo(E + E / 2 + 2);
+    HugeBuf<uint32_t> ent_edge(E + 1, &g.arena), ent_next(E + 1, &g.arena), ent_node(E + 1, &g.arena), fifo(E + E / 2 + 2, &g.arena);
     size_t n_ent = 0, fifo_tail = 0;
     Walks out;
     out.edges.reserve(E / 2);

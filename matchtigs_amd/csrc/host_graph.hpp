@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include "huge_arena.hpp"
+
 #define MTG_DIE(...)                                  \
     do {                                              \
         std::fprintf(stderr, "libmatchtigs: ");       \
@@ -73,6 +75,7 @@ struct HostGraph {
     uint64_t first_breaking_edge = UINT64_MAX;
     uint64_t breaking_weight = 0;
     bool dummies_canonical = true;
+    mutable HugeArena arena;  // large scratch mappings of the host stages, kept between calls on this graph (huge_arena.hpp)
 
     uint64_t node_count() const { return mirror.size(); }
     uint64_t edge_count() const { return e_from.size(); }

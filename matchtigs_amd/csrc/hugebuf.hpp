@@ -69,9 +69,18 @@ template <typename T>
 struct HugeBuf {
     T *p = nullptr;
     size_t n = 0, bytes = 0;
-    explicit HugeBuf(size_t count) : n(count) {
+    HugeArena *arena = nullptr;  // non-null: the mapping belongs to this arena (taken from it or adopted by it) and goes back there
+    // With an arena the content is NOT zero when the mapping is a reused one: callers write before they read.
+    explicit HugeBuf(size_t count, HugeArena *from = nullptr) : n(count) {
         bytes = ((count * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
         if (bytes == 0) bytes = 2u << 20;
+        if (from) {
+            if (void *m = from->take(bytes)) {
+                p = static_cast<T *>(m);
+                arena = from;
+                return;
+            }
+        }
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) MTG_DIE("out of memory (%zu bytes)", bytes);
         madvise(m, bytes, MADV_HUGEPAGE);
@@ -81,9 +90,12 @@ struct HugeBuf {
             (void)syscall(SYS_mbind, m, bytes, 1 /*MPOL_PREFERRED*/, &mask, sizeof(mask) * 8, 0);
         }
         p = static_cast<T *>(m);
+        if (from && from->adopt(m, bytes)) arena = from;
     }
     ~HugeBuf() {
-        if (p) munmap(p, bytes);
+        if (!p) return;
+        if (arena && arena->give_back(p)) return;
+        munmap(p, bytes);
     }
     HugeBuf(const HugeBuf &) = delete;
     HugeBuf &operator=(const HugeBuf &) = delete;
