@@ -94,6 +94,28 @@ def test_euler_cycles_linked_list_equals_literal_on_larger_graph(oracle, product
     assert og.euler_cycles() == G.euler_cycles()
 
 
+def test_euler_walk_scratch_is_reused_between_calls_on_one_graph(oracle, product_lib):
+    """The walk's large scratch mappings stay with the graph (huge_arena.hpp) and come back with whatever the last call left
+    in them: a second and third call on the same graph -- same size, then a different Eulerisation -- must not see any of it."""
+    k = 31
+    bg = synth.g_csr(20000, seed=78, k=k)
+    arrs = (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    og = helpers.oracle_graph(*arrs)
+    G = helpers.product_graph(*arrs)
+    og.make_eulerian(k, 0)
+    G.make_eulerian(0, k)
+    want = og.euler_cycles()
+    assert G.euler_cycles() == want   # fresh mappings
+    assert G.euler_cycles() == want   # reused mappings, identical graph
+    G.reset()
+    og2 = helpers.oracle_graph(*arrs)
+    pairs, _ = og2.greedy_pairs_np(k)
+    og2.insert_pair_edges([(int(a), int(b), int(c)) for a, b, c in pairs])
+    G.insert_pair_edges(pairs)
+    assert og2.make_eulerian(k, len(pairs)) == G.make_eulerian(len(pairs), k)
+    assert G.euler_cycles() == og2.euler_cycles()   # reused (or regrown) mappings, other edge set
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_clib_builder_matches_oracle_and_pyref(seed, oracle, product_lib):
     ug = synth.g_seq(1500, seed=seed, k=11, haplotypes=3, sub_rate=0.04)
