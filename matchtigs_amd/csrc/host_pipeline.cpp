@@ -509,16 +509,18 @@ Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
 // clib.rs:393-407
 uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, uint64_t *insert_out,
                       uint64_t *limits) {
-    uint64_t begin = 0;
-    for (size_t i = 0; i < tigs.limits.size(); i++) {
-        for (uint64_t j = begin; j < tigs.limits[i]; j++) {
+    // clib.rs:393-407, per walk edge; position j of the flat arrays only depends on edge j (host threads over ranges of j)
+    const uint64_t n_edges = tigs.limits.empty() ? 0 : tigs.limits.back();
+    parallel_ranges(n_edges, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t j = lo; j < hi; j++) {
             const uint32_t e = tigs.edges[j];
             edge_out[j] = (int64_t)g.e_unitig[e] * (g.e_fwd[e] ? 1 : -1);
             insert_out[j] = g.is_dummy(e) ? g.e_weight[e] : 0;
         }
-        begin = tigs.limits[i];
-        limits[i] = begin;
-    }
+    });
+    parallel_ranges(tigs.limits.size(), [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) limits[i] = tigs.limits[i];
+    });
     return tigs.limits.size();
 }
 
