@@ -137,6 +137,17 @@ def test_clib_builder_matches_oracle_and_pyref(seed, oracle, product_lib):
         assert n == n_o and np.array_equal(eo, eo_o) and np.array_equal(io, io_o) and np.array_equal(lo, lo_o)
 
 
+def test_clib_flattening_on_host_threads_equals_oracle(oracle, product_lib):
+    """clib.rs:393-407 at a size where the flattening runs on several host threads (> 2^16 walk edges): eulertigs of a real
+    de Bruijn graph through matchtigs_compute_tigs, all three output arrays against the oracle's."""
+    ua = synth.g_seq_arrays(1_200_000, seed=5, k=21)
+    links = [tuple(int(x) for x in l) for l in ua.links.tolist()] if hasattr(ua.links, "tolist") else ua.links
+    n, eo, io, lo = api.clib_compute_tigs(ua.weights, links, 3, 1, 21)
+    assert len(eo) > (1 << 16)
+    n_o, eo_o, io_o, lo_o = oracle.OracleGraph.from_unitig_links_arrays(ua.weights, ua.links).clib_compute_tigs(3, 21)
+    assert n == n_o and np.array_equal(eo, eo_o) and np.array_equal(io, io_o) and np.array_equal(lo, lo_o)
+
+
 def test_edge_cases_empty_and_balanced(oracle, product_lib):
     # empty graph
     G = api.Bigraph.from_edges(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint64))
