@@ -2,6 +2,8 @@
 // node-centric unitig-link interface (/root/reference/src/clib.rs:94-259).
 #include "host_graph.hpp"
 
+#include <chrono>
+
 #include <algorithm>
 
 #include "parallel.hpp"
@@ -123,11 +125,22 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
     if (n_edges % 2) MTG_DIE("mtg_graph_from_edges: edges must come in (forward, mirror) pairs");
     if (n_edges >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
     HostGraph *g = new HostGraph();
+    static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mtg] graph_from_edges: %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     g->init_nodes(n_nodes);
+    lap("init_nodes");
     parallel_ranges(n_nodes, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; i++) g->mirror[i] = mirror[i];
     });
+    lap("mirror");
     g->validate_pairing();
+    lap("validate_pairing");
     // bulk form of n_edges / 2 add_biedge calls: arrays filled by host threads, adjacency linked by node range. Room for the dummy
     // edges the algorithms append later (matched pairs + breaking edges: 43 % of the original edges on the bench graph) is reserved
     // now -- address space only, untouched pages cost nothing --, so that the first insertion does not copy 5 GB of edge arrays.
@@ -150,7 +163,9 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
             g->e_fwd[e] = 1; g->e_fwd[e + 1] = 0;
         }
     });
+    lap("edge arrays");
     link_adjacency(*g, n_edges);
+    lap("link_adjacency");
     g->n_original_edges = n_edges;
     g->built = true;
     return g;
