@@ -222,9 +222,24 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         }
     }
 
+    // (the loop is one thread chasing need[] / mirror[] of nodes it knows long in advance: both lists are walked monotonically,
+    // so the entries a few positions ahead are fetched early)
+    constexpr int64_t AHEAD = 12;
     for (;;) {  // :526
         while (out_cur >= 0 && need[out_list[out_cur]] >= 0) out_cur--;
         if (out_cur < 0) break;
+        if (out_cur >= AHEAD) {
+            const uint32_t po = out_list[out_cur - AHEAD];
+            __builtin_prefetch(&need[po]);
+            __builtin_prefetch(&g.mirror[po]);
+        }
+        if (out_cur >= AHEAD / 2) __builtin_prefetch(&need[g.mirror[out_list[out_cur - AHEAD / 2]]]);
+        if (in_cur + (uint64_t)AHEAD < NI) {
+            const uint32_t pi = in_list[in_cur + (uint64_t)AHEAD];
+            __builtin_prefetch(&need[pi]);
+            __builtin_prefetch(&g.mirror[pi]);
+        }
+        if (in_cur + (uint64_t)AHEAD / 2 < NI) __builtin_prefetch(&need[g.mirror[in_list[in_cur + (uint64_t)AHEAD / 2]]]);
         const uint32_t out_node = out_list[out_cur];
         const int32_t out_diff = need[out_node];
         // choose_in_node_from_iterator, :252-285
