@@ -705,8 +705,8 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 // makes the output identical to the Dijkstra order. A source whose enumeration exceeds the step budget or its LDS space is handed
 // to the cooperative cascade, which is exact for any ball.
 //
-// What bounds it (round 3 measurements): round 2's version was bound by instruction issue (460 VALU + 366 SALU per
-// wave step, 188 VGPRs, 8 waves per CU). Written branch-free -- every potential push / hit is an UNCONDITIONAL LDS store to the
+// What bounds it: the version at the end of round 2's first session was bound by instruction issue (460 VALU +
+// 366 SALU per wave step, 188 VGPRs, 8 waves per CU). Written branch-free -- every potential push / hit is an UNCONDITIONAL LDS store to the
 // lane's next free slot (a store that does not count leaves the counter where it was), the next node always comes off the stack,
 // sources are handed out by two cross-lane permutes from chunks held in registers -- a step is half the instructions and the
 // kernel becomes bound by the latency of the gathers, i.e. by the number of waves per CU, i.e. by LDS. Hence:
@@ -715,7 +715,8 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 //    value: allocation and release are a few scalar instructions, no atomics;
 //  * nothing is staged: a finished source takes its pool space with one LDS atomic and writes its keys, (start, count) and, if
 //    needed, its post-pass work-list entry straight to memory.
-// 10 KB of LDS per wave -> 16 waves per CU.
+// 10 KB of LDS per wave -> 16 waves per CU, where the SIMDs are busy again (4 waves x 27 % active each): the level now sits between
+// instruction issue and its gather ceiling (78 % of it at 2^27).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr uint32_t ENUM_POOL_CHUNK = 2048;  // keys per wave-local pool chunk (one global atomic per chunk)
