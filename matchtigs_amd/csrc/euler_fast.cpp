@@ -64,7 +64,8 @@ Walks euler_cycles(const HostGraph &g) {
 
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    NumaPin pin;  // the walk is one latency-bound thread: keep it next to the memory it chases through
+    // the walk is one latency-bound thread: keep it next to the memory it chases through (the graph's arena from an earlier call, if any)
+    NumaPin pin(g.arena.node);
 
     // ---- records ----
     HugeBuf<EulerNode3> nodes(V, &g.arena);

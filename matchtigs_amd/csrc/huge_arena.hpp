@@ -19,6 +19,7 @@ struct HugeArena {
     };
     std::vector<Slot> slots;
     std::mutex mu;
+    int node = -1;  // NUMA node the mappings were placed on (the first user's): later users run there, next to the memory
     static constexpr size_t MAX_SLOTS = 8;
 
     HugeArena() = default;

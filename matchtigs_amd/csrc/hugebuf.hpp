@@ -30,9 +30,10 @@ struct NumaPin {
     cpu_set_t old_mask;
     bool active = false;
     int node = -1;
-    NumaPin() {
+    // preferred >= 0: that node (where an arena's memory lives), else the node the thread is running on
+    explicit NumaPin(int preferred = -1) {
         if (std::getenv("MTG_NO_NUMA_PIN")) return;
-        node = current_numa_node();
+        node = preferred >= 0 ? preferred : current_numa_node();
         if (node < 0 || sched_getaffinity(0, sizeof old_mask, &old_mask) != 0) return;
         char path[128];
         std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
@@ -84,7 +85,8 @@ struct HugeBuf {
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) MTG_DIE("out of memory (%zu bytes)", bytes);
         madvise(m, bytes, MADV_HUGEPAGE);
-        const int node = current_numa_node();
+        const int node = (from && from->node >= 0) ? from->node : current_numa_node();  // (an arena keeps all its mappings on one node)
+        if (from && from->node < 0) from->node = node;
         if (node >= 0 && node < 64) {  // MPOL_PREFERRED = 1: allocate on this node whoever touches the page first
             unsigned long mask = 1ul << node;
             (void)syscall(SYS_mbind, m, bytes, 1 /*MPOL_PREFERRED*/, &mask, sizeof(mask) * 8, 0);
