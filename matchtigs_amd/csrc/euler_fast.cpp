@@ -53,20 +53,6 @@ struct alignas(256) EulerNode3 {
     bool sub2_more(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q) + 2)) & 1u; }
 };
 static_assert(sizeof(EulerNode3) == 256, "EulerNode3 must be 256 bytes");
-// What the record build gathers from OTHER nodes, in compact form: a head's own first three positions (one 32-byte entry instead of
-// the first line of its 256-byte record: two nodes per cache line, an eighth of the address range) and a head's heads' first two
-// positions (one 64-byte line instead of two lines of the record).
-struct alignas(32) EulerAdj1 {
-    uint32_t eid[3], to[3];
-    uint16_t deg, pad;
-    uint32_t pad2;
-};
-struct alignas(64) EulerAdj2 {
-    uint32_t eid[3][2], to[3][2];  // first two positions of the node's heads q = 0..2
-    uint32_t info;                 // 3 bits per q: copied positions of head q (0..3, as in sub_info) | more << 2
-    uint32_t pad[3];
-};
-static_assert(sizeof(EulerAdj1) == 32 && sizeof(EulerAdj2) == 64, "compact adjacency entries");
 }  // namespace
 
 Walks euler_cycles(const HostGraph &g) {
@@ -83,8 +69,6 @@ Walks euler_cycles(const HostGraph &g) {
 
     // ---- records ----
     HugeBuf<EulerNode3> nodes(V, &g.arena);
-    HugeBuf<EulerAdj1> adj1(V, &g.arena);
-    HugeBuf<EulerAdj2> adj2(V, &g.arena);
     std::vector<uint32_t> ext_begin(V + 1, 0);
     {
         uint64_t ext_total = 0;
@@ -112,9 +96,6 @@ Walks euler_cycles(const HostGraph &g) {
                 if (i < 3) { r.eid[i] = e; r.to[i] = g.e_to[e]; }
                 else { ext_eid[r.ext_begin + i - 3] = e; ext_to[r.ext_begin + i - 3] = g.e_to[e]; }
             }
-            EulerAdj1 &c1 = adj1[n];
-            for (uint32_t q = 0; q < 3; q++) { c1.eid[q] = r.eid[q]; c1.to[q] = r.to[q]; }
-            c1.deg = r.deg; c1.pad = 0; c1.pad2 = 0;
         }
     });
     const auto t_a = std::chrono::steady_clock::now();
@@ -122,23 +103,20 @@ Walks euler_cycles(const HostGraph &g) {
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: first 3 positions of each inline edge's head node
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 16 < hi) {
-                const EulerAdj1 &a = adj1[n + 16];
+                const EulerNode3 &a = nodes[n + 16];
                 for (uint32_t j = 0; j < 3; j++)
-                    if (a.to[j] != NONE) __builtin_prefetch(&adj1[a.to[j]]);
+                    if (a.to[j] != NONE) __builtin_prefetch(&nodes[a.to[j]]);
             }
             EulerNode3 &r = nodes[n];
-            EulerAdj2 &c2 = adj2[n];
             const uint32_t d = r.deg < 3 ? r.deg : 3;
             uint32_t info = 0;
             for (uint32_t j = 0; j < d; j++) {
-                const EulerAdj1 &w = adj1[r.to[j]];
+                const EulerNode3 &w = nodes[r.to[j]];
                 const uint32_t c = w.deg < 3 ? w.deg : 3;
                 for (uint32_t q = 0; q < c; q++) { r.sub_eid[j][q] = w.eid[q]; r.sub_to[j][q] = w.to[q]; }
-                for (uint32_t q = 0; q < 2; q++) { c2.eid[j][q] = q < c ? w.eid[q] : NONE; c2.to[j][q] = q < c ? w.to[q] : NONE; }
                 info |= (c | (w.deg > 3 ? 4u : 0u)) << (3 * j);
             }
             r.sub_info = (uint16_t)info;
-            c2.info = info;
         }
     }, BUILD_THREADS);
     const auto t_b = std::chrono::steady_clock::now();
@@ -147,21 +125,24 @@ Walks euler_cycles(const HostGraph &g) {
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 12 < hi) {
-                const EulerAdj1 &a = adj1[n + 12];
+                const EulerNode3 &a = nodes[n + 12];
                 for (uint32_t j = 0; j < 3; j++)
-                    if (a.to[j] != NONE) __builtin_prefetch(&adj2[a.to[j]]);
+                    if (a.to[j] != NONE) {
+                        const char *p = reinterpret_cast<const char *>(&nodes[a.to[j]]);
+                        __builtin_prefetch(p);
+                        __builtin_prefetch(p + 64);
+                    }
             }
             EulerNode3 &r = nodes[n];
             const uint32_t d = r.deg < 3 ? r.deg : 3;
             uint32_t info = 0;
             for (uint32_t j = 0; j < d; j++) {
-                const EulerAdj2 &w = adj2[r.to[j]];
+                const EulerNode3 &w = nodes[r.to[j]];
                 for (uint32_t q = 0; q < r.sub_cnt(j); q++) {
-                    const uint32_t wi = (w.info >> (3 * q)) & 7u;  // copied positions of x = w.to[q] (up to 3) | more << 2
-                    const uint32_t wc = wi & 3u;
+                    const uint32_t wc = w.sub_cnt(q);  // copied positions of x = w.to[q] (up to 3)
                     const uint32_t c = wc < 2 ? wc : 2;
-                    for (uint32_t t = 0; t < c; t++) { r.sub2_eid[j][q][t] = w.eid[q][t]; r.sub2_to[j][q][t] = w.to[q][t]; }
-                    info |= (c | ((wc > 2 || (wi & 4u)) ? 4u : 0u)) << (3 * (3 * j + q));
+                    for (uint32_t t = 0; t < c; t++) { r.sub2_eid[j][q][t] = w.sub_eid[q][t]; r.sub2_to[j][q][t] = w.sub_to[q][t]; }
+                    info |= (c | ((wc > 2 || w.sub_more(q)) ? 4u : 0u)) << (3 * (3 * j + q));
                 }
             }
             r.sub2_info = info;
