@@ -66,6 +66,11 @@ enum { MTG_NODE_WEIGHT_EPOCH_ARRAY = 0, MTG_NODE_WEIGHT_HASHBROWN_HASH_MAP = 1 }
 enum { MTG_HEAP_STD_BINARY_HEAP = 0 };                                            /* implementation/mod.rs:83-102 */
 enum { MTG_PERFORMANCE_DATA_NONE = 0, MTG_PERFORMANCE_DATA_COMPLETE = 1 };        /* implementation/mod.rs:104-126 */
 enum { MTG_EULER_HOST_REFERENCE_ORDER = 0, MTG_EULER_DEVICE = 1 };
+/* Where dummy insertion, the Euleriser and the cutter run: AUTO = on the GPU (device_ids[0]) whenever one is visible and the
+ * graph holds only its original edges, else the host stages; HOST / DEVICE force one (DEVICE aborts without a GPU). Both give
+ * the same edges and tigs: the GPU Euleriser reproduces the reference's sequence of breaking edges. With
+ * MTG_EULER_HOST_REFERENCE_ORDER the device stage builds the walk's node records and the host only walks. */
+enum { MTG_FINISH_AUTO = 0, MTG_FINISH_HOST = 1, MTG_FINISH_DEVICE = 2 };
 #define MTG_MAX_DEVICES 8
 typedef struct {
     uint64_t threads;                  /* greedytigs/mod.rs:42 */
@@ -79,6 +84,7 @@ typedef struct {
                                           #tigs / cumulative length, different order) */
     int32_t n_devices;                 /* GPUs to shard the SSSP sources over; >= 1 */
     int32_t device_ids[MTG_MAX_DEVICES];
+    int32_t finish_stage;              /* MTG_FINISH_AUTO / _HOST / _DEVICE */
     /* MatchtigAlgorithmConfiguration (matchtigs/mod.rs:33-45), tig algorithm 4 only; may be NULL otherwise */
     const char *matching_file_prefix; /* the instance goes to <prefix>.minimalperfectmatching, the matcher writes <that>.solution */
     const char *matcher_path;         /* blossom5-compatible executable: `<matcher> -e <instance> -w <solution>` */
@@ -133,7 +139,7 @@ void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from,
                       uint8_t *edge_forwards);
 
 /* ---- device stage ---------------------------------------------------------------------- */
-/* Builds the 32-byte node records for bound k-1 and uploads them to GPU `device_id`.
+/* Uploads the original edges to GPU `device_id` and builds the 64-byte family blocks for bound k-1 there.
  * Aborts if no GPU is present (there is no CPU path). Weights must be >= 1 for algorithm 5
  * (checked here; the reference's (distance, node) pop order needs it). */
 mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id);
@@ -260,7 +266,15 @@ mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t 
  * mode 0 (default) = host walk in the reference's order, mode 1 = this. Aborts without a GPU. */
 mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id);
 double mtg_last_euler_kernel_ms(void); /* of the last device decomposition on this thread */
-/* The two finishing paths with an explicit configuration (euler_mode, device_ids[0] for the device decomposition). */
+/* The whole finish on the GPU for a graph that holds only its original edges (finish_device.hip): matched-pair darts, the
+ * Euleriser in the reference's sequence (implementation/mod.rs:392-649), Euler bicycles per cfg->euler_mode (device
+ * decomposition, or the reference-order host walk over GPU-built records), rotate + cut (greedytigs/mod.rs:726-789). Appends the
+ * dummy edges to g like the host stages do (same ids, weights and dummy ids). n_pairs == 0 is the Eulertig finish. */
+mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
+/* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,
+ * [2] Euler bicycles, [3] rotate + cut + tig download; [4] kernel ms of the device decomposition; [5] breaking biedges added. */
+void mtg_last_finish_device_times(double out[6]);
+/* The two finishing paths with an explicit configuration (euler_mode, finish_stage, device_ids[0]). */
 mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
 mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg);
 
@@ -317,6 +331,14 @@ uint64_t mtg_last_spell_bytes(void);   /* HBM bytes it moved (text written + pac
 uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges,
                                          char **text_out);
 uint64_t mtg_write_tigs_duplication_bitvector_file(const mtg_graph *g, const mtg_walks *tigs, const char *path);
+
+/* ---- synthetic input on the GPU (bench / test infrastructure; numpy twin: matchtigs_amd/synth.py g_csr) ---------------- */
+/* G-csr(n_binodes mirror pairs + n_self_mirrors self-mirror nodes; n_unitigs candidate unitigs with uniform endpoints from the
+ * counter-based splitmix64 streams of `seed`; a unitig whose directed edges would exceed max_degree at their from-nodes is
+ * dropped; weight = 1 + #{j : x <= weight_thresholds[j]} with x the 53-bit uniform of stream 3 and the thresholds descending,
+ * i.e. a clipped geometric distribution in integer form). Returns the built graph. Aborts without a GPU. */
+mtg_graph *mtg_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t n_unitigs, uint64_t seed, uint64_t k,
+                           const uint64_t *weight_thresholds, uint64_t n_thresholds, int max_degree, int device_id);
 
 /* Whole path: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. matchtigs_compute_tigs builds the configuration from
  * clib.rs:378-389's constants and calls this. */

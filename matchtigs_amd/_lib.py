@@ -51,6 +51,7 @@ class MtgConfig(C.Structure):
         ("euler_mode", C.c_int32),
         ("n_devices", C.c_int32),
         ("device_ids", C.c_int32 * MTG_MAX_DEVICES),
+        ("finish_stage", C.c_int32),
         ("matching_file_prefix", C.c_char_p),
         ("matcher_path", C.c_char_p),
     ]
@@ -199,6 +200,9 @@ def load():
         "mtg_write_walks_gfa": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, C.c_char_p, P(vp)]),
         "mtg_write_tigs_gfa_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_char_p, C.c_int]),
         "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),
+        "mtg_finish_device": (vp, [vp, vp, u64, P(MtgConfig)]),
+        "mtg_last_finish_device_times": (None, [P(C.c_double)]),
+        "mtg_synth_g_csr": (vp, [u64, u64, u64, u64, u64, vp, u64, C.c_int, C.c_int]),
         "mtg_last_phase_seconds": (None, [P(C.c_double)]),
         "matchtigs_initialise": (None, []),
         "matchtigs_initialise_graph": (vp, [C.c_size_t]),

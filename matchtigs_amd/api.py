@@ -67,6 +67,15 @@ class EulerMode(enum.IntEnum):
     Device = 1
 
 
+class FinishStage(enum.IntEnum):
+    """Engine-only option (mtg_config.finish_stage): where dummy insertion, the Euleriser and the cutter run. Auto = on the GPU
+    whenever one is visible (same edges and tigs as the host stages)."""
+
+    Auto = 0
+    Host = 1
+    Device = 2
+
+
 @dataclass
 class GreedytigAlgorithmConfiguration:
     """greedytigs/mod.rs:40-73. heap / node-weight-array / staged-parallelism settings select CPU data
@@ -83,6 +92,7 @@ class GreedytigAlgorithmConfiguration:
     performance_data_type: PerformanceDataType = PerformanceDataType.None_
     euler_mode: EulerMode = EulerMode.HostReferenceOrder
     device_ids: Sequence[int] = (0,)
+    finish_stage: FinishStage = FinishStage.Auto
 
     @classmethod
     def new(cls, threads: int, k: int) -> "GreedytigAlgorithmConfiguration":
@@ -97,6 +107,7 @@ class GreedytigAlgorithmConfiguration:
         c.heap_type = list(HeapType).index(self.heap_type)
         c.performance_data_type = list(PerformanceDataType).index(self.performance_data_type)
         c.euler_mode = int(self.euler_mode)
+        c.finish_stage = int(self.finish_stage)
         c.n_devices = len(self.device_ids)
         for i, dv in enumerate(self.device_ids):
             c.device_ids[i] = int(dv)
@@ -110,9 +121,11 @@ class EulertigAlgorithmConfiguration:
     k: int
     euler_mode: EulerMode = EulerMode.HostReferenceOrder
     device_id: int = 0
+    finish_stage: FinishStage = FinishStage.Auto
 
     def to_c(self) -> "_lib.MtgConfig":
-        return GreedytigAlgorithmConfiguration(1, self.k, euler_mode=self.euler_mode, device_ids=(self.device_id,)).to_c()
+        return GreedytigAlgorithmConfiguration(1, self.k, euler_mode=self.euler_mode, device_ids=(self.device_id,),
+                                               finish_stage=self.finish_stage).to_c()
 
 
 @dataclass
@@ -561,12 +574,20 @@ class MatchtigAlgorithm(TigAlgorithm):
 
 
 def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
-                         device_id: int = 0):
+                         device_id: int = 0, finish_stage: FinishStage = FinishStage.Auto):
     """mtg_finish_greedytigs_cfg returning flat numpy walks (limits, edges) -- for large graphs."""
     L = _lib.load()
     p = np.ascontiguousarray(pairs)
-    c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,)).to_c()
-    return _take_walks_np(L, L.mtg_finish_greedytigs_cfg(graph.handle, _ptr(p), len(p), C.byref(c)))
+    c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,), finish_stage=finish_stage).to_c()
+    return _take_walks_np(L, L.mtg_finish_greedytigs_cfg(graph.handle, _ptr(p) if len(p) else None, len(p), C.byref(c)))
+
+
+def last_finish_device_times() -> dict:
+    """Segments of the last device finish on this thread (mtg_last_finish_device_times)."""
+    out = (C.c_double * 6)()
+    _lib.load().mtg_last_finish_device_times(out)
+    return {"insert_eulerise_s": out[0], "host_graph_s": out[1], "euler_s": out[2], "cut_s": out[3], "euler_kernel_ms": out[4],
+            "breaking_biedges": int(out[5])}
 
 
 def last_performance_data() -> dict:

@@ -37,6 +37,11 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
 std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int parts);
 // euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
 Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out);
+// finish_device.hip: insertion + Euleriser + Euler bicycles + cut on the GPU (see mtg_finish_device)
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6]);
+// synth_device.hip: the G-csr generator on the GPU
+HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t n_unitigs, uint64_t seed, uint64_t k,
+                              const uint64_t *thresholds, uint64_t n_thresholds, int max_degree, int device_id);
 // spell_device.hip: tig spelling on the GPU (bin.rs:466-606 / 667-818), byte-identical to spell.cpp for ACGT input
 uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
                                  const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, int device_id,

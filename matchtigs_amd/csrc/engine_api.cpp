@@ -35,12 +35,15 @@ static bool g_log_initialised = false;
 static thread_local double g_last_euler_kernel_ms = 0;
 static thread_local double g_last_gather_ms = 0;
 static thread_local mtg_dijkstra_performance_data g_last_perf = {};
+static thread_local double g_last_finish_times[6] = {0, 0, 0, 0, 0, 0};
 
 static void check_config(const mtg_config *cfg, const char *who) {
     if (!cfg) MTG_DIE("%s: null configuration", who);
     if (cfg->k < 1) MTG_DIE("%s: k must be >= 1", who);
     if (cfg->n_devices < 1 || cfg->n_devices > MTG_MAX_DEVICES) MTG_DIE("%s: n_devices = %d is out of range [1, %d]", who, cfg->n_devices, MTG_MAX_DEVICES);
     if (cfg->euler_mode != MTG_EULER_HOST_REFERENCE_ORDER && cfg->euler_mode != MTG_EULER_DEVICE) MTG_DIE("%s: unknown euler_mode %d", who, cfg->euler_mode);
+    if (cfg->finish_stage != MTG_FINISH_AUTO && cfg->finish_stage != MTG_FINISH_HOST && cfg->finish_stage != MTG_FINISH_DEVICE)
+        MTG_DIE("%s: unknown finish_stage %d", who, cfg->finish_stage);
     if (cfg->node_weight_array_type != MTG_NODE_WEIGHT_EPOCH_ARRAY && cfg->node_weight_array_type != MTG_NODE_WEIGHT_HASHBROWN_HASH_MAP)
         MTG_DIE("Unknown node weight array type: %d", cfg->node_weight_array_type);       // implementation/mod.rs:78
     if (cfg->heap_type != MTG_HEAP_STD_BINARY_HEAP) MTG_DIE("Unknown heap type: %d", cfg->heap_type);  // implementation/mod.rs:99
@@ -204,6 +207,32 @@ mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t 
     return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
 }
 
+// The device finish takes a graph that holds only its original edges and matched pairs shorter than k (what the claim loop
+// produces); anything else (a graph Eulerised before, pairs from elsewhere) goes through the generic host stages.
+static bool use_device_finish(const HostGraph &g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config &cfg) {
+    if (cfg.finish_stage == MTG_FINISH_HOST) return false;
+    const bool forced = cfg.finish_stage == MTG_FINISH_DEVICE;
+    if (device_count() <= cfg.device_ids[0]) {
+        if (forced) MTG_DIE("finish_stage = MTG_FINISH_DEVICE, but no MI355X/HIP device %d is visible", cfg.device_ids[0]);
+        return false;
+    }
+    bool ok = g.edge_count() == g.n_original_edges && g.first_breaking_edge == UINT64_MAX && cfg.k <= 0xFFFFFFFFull;
+    for (uint64_t i = 0; i < n_pairs && ok; i++) ok = pairs[i].distance < cfg.k && pairs[i].out_node < g.node_count() && pairs[i].in_node < g.node_count();
+    if (!ok && forced) MTG_DIE("finish_stage = MTG_FINISH_DEVICE needs a graph without dummy edges and matched pairs shorter than k");
+    return ok;
+}
+static mtg_walks *finish_on_device(HostGraph &g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config &cfg) {
+    log_info("Making graph Eulerian by adding breaking dummy edges");
+    log_info("Finding Eulerian bicycle");
+    double *t = g_last_finish_times;
+    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t)};
+    g_phase[5] = t[0] + t[1];
+    g_phase[6] = t[2];
+    g_phase[7] = t[3];
+    g_last_euler_kernel_ms = t[4];
+    return tigs;
+}
+
 static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, const mtg_config &cfg) {
     const uint64_t k = cfg.k;
     double t0 = now_s();
@@ -233,6 +262,7 @@ void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k) {  // Greedy
     cfg->heap_type = MTG_HEAP_STD_BINARY_HEAP;
     cfg->performance_data_type = MTG_PERFORMANCE_DATA_NONE;
     cfg->euler_mode = MTG_EULER_HOST_REFERENCE_ORDER;
+    cfg->finish_stage = MTG_FINISH_AUTO;
     cfg->n_devices = 1;
     cfg->device_ids[0] = 0;
 }
@@ -240,12 +270,38 @@ void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k) {  // Greedy
 mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg) {
     check_config(cfg, "mtg_finish_greedytigs_cfg");
     if (!g || !g->g.built) MTG_DIE("mtg_finish_greedytigs_cfg: graph is not built");
+    if (n_pairs && !pairs) MTG_DIE("mtg_finish_greedytigs_cfg: null pairs");
+    if (use_device_finish(g->g, pairs, n_pairs, *cfg)) {
+        mtg_walks *tigs = finish_on_device(g->g, pairs, n_pairs, *cfg);
+        log_info("Found %zu greedytigs", tigs->w.limits.size());
+        return tigs;
+    }
     double t0 = now_s();
     const uint64_t dummy_edge_id = insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);
     g_phase[5] = now_s() - t0;
     mtg_walks *tigs = eulerise_and_cut(g->g, dummy_edge_id, *cfg);
     log_info("Found %zu greedytigs", tigs->w.limits.size());
     return tigs;
+}
+mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg) {
+    check_config(cfg, "mtg_finish_device");
+    if (!g || !g->g.built) MTG_DIE("mtg_finish_device: graph is not built");
+    if (n_pairs && !pairs) MTG_DIE("mtg_finish_device: null pairs");
+    mtg_config forced = *cfg;
+    forced.finish_stage = MTG_FINISH_DEVICE;
+    (void)use_device_finish(g->g, pairs, n_pairs, forced);
+    return finish_on_device(g->g, pairs, n_pairs, forced);
+}
+void mtg_last_finish_device_times(double out[6]) {
+    for (int i = 0; i < 6; i++) out[i] = g_last_finish_times[i];
+}
+mtg_graph *mtg_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t n_unitigs, uint64_t seed, uint64_t k,
+                           const uint64_t *weight_thresholds, uint64_t n_thresholds, int max_degree, int device_id) {
+    if (n_thresholds && !weight_thresholds) MTG_DIE("mtg_synth_g_csr: null thresholds");
+    HostGraph *h = device_synth_g_csr(n_binodes, n_self_mirrors, n_unitigs, seed, k, weight_thresholds, n_thresholds, max_degree, device_id);
+    mtg_graph *g = new mtg_graph{std::move(*h)};
+    delete h;
+    return g;
 }
 mtg_walks *mtg_finish_greedytigs(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, uint64_t k) {
     mtg_config cfg;
@@ -256,7 +312,8 @@ mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg) {
     check_config(cfg, "mtg_compute_eulertigs_cfg");
     if (!g || !g->g.built) MTG_DIE("mtg_compute_eulertigs_cfg: graph is not built");
     g_phase[5] = 0;
-    mtg_walks *tigs = eulerise_and_cut(g->g, 0, *cfg);  // eulertigs/mod.rs:101-102
+    mtg_walks *tigs = use_device_finish(g->g, nullptr, 0, *cfg) ? finish_on_device(g->g, nullptr, 0, *cfg)
+                                                                : eulerise_and_cut(g->g, 0, *cfg);  // eulertigs/mod.rs:101-102
     log_info("Found %zu eulertigs", tigs->w.limits.size());
     return tigs;
 }
@@ -488,7 +545,7 @@ mtg_walks *mtg_compute_matchtigs_cfg(mtg_graph *g, const mtg_config *cfg) {
         log_info("Running matcher at \"%s\"", cfg->matcher_path);
         const char *argv[] = {cfg->matcher_path, "-e", instance_path.c_str(), "-w", solution_path.c_str(), nullptr};
         pid_t pid = 0;
-        const int rc = posix_spawn(&pid, cfg->matcher_path, nullptr, nullptr, const_cast<char *const *>(argv), environ);
+        const int rc = posix_spawnp(&pid, cfg->matcher_path, nullptr, nullptr, const_cast<char *const *>(argv), environ);  // searches PATH like Command::new (matchtigs/mod.rs:727)
         if (rc != 0) MTG_DIE("cannot start the matcher %s: %s", cfg->matcher_path, std::strerror(rc));
         int status = 0;
         while (waitpid(pid, &status, 0) < 0)

@@ -36,84 +36,14 @@
 #include <vector>
 
 #include "device.hpp"
+#include "finish_device.hpp"
+#include "hip_util.hpp"
 
 namespace mtg {
 
-#define HIP_CHECK(expr)                                                                          \
-    do {                                                                                         \
-        hipError_t _e = (expr);                                                                  \
-        if (_e != hipSuccess) MTG_DIE("HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
-    } while (0)
+using namespace hu;
 
 namespace {
-
-constexpr int EB = 256;  // threads per block for the element-wise kernels
-constexpr uint32_t SPLIT_FLAG = 0x80000000u;
-
-inline unsigned grid_for(uint64_t n, int block = EB) { return (unsigned)((n + block - 1) / block); }
-
-// ---- exclusive scan u32 -> u32, three phases, 2048 items per block -----------------------------------------
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_CHUNK = EB * SCAN_ITEMS;
-
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total) {
-    __shared__ uint32_t wave_sum[EB / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wave_sum[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, all = 0;
-    for (int w = 0; w < EB / 64; w++) {
-        if (w < wave) base += wave_sum[w];
-        all += wave_sum[w];
-    }
-    __syncthreads();
-    *total = all;
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(EB) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint32_t *block_sums) {
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) s += in[base + i];
-    uint32_t total;
-    block_exclusive_scan(s, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(EB) void scan_block_sums_kernel(uint32_t *block_sums, uint32_t n_blocks, uint32_t *total_out) {
-    uint32_t carry = 0;
-    for (uint32_t start = 0; start < n_blocks; start += EB) {
-        const uint32_t i = start + threadIdx.x;
-        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, &total);
-        if (i < n_blocks) block_sums[i] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
-
-__global__ __launch_bounds__(EB) void scan_apply_kernel(const uint32_t *in, uint64_t n, const uint32_t *block_offsets, uint32_t *out) {
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
-    }
-    uint32_t total;
-    uint32_t run = block_offsets[blockIdx.x] + block_exclusive_scan(s, &total);
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-}
 
 // ---- lock-free union-find (links always point to a smaller id, so a root is the smallest id of its set) -----
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
@@ -147,24 +77,24 @@ __device__ __forceinline__ bool uf_union(uint32_t *parent, uint32_t a, uint32_t 
 }
 
 // ---- step 1: bucket darts by from-node ------------------------------------------------------------------------
-__global__ __launch_bounds__(EB) void degree_kernel(const uint32_t *from, uint32_t n_darts, uint32_t *deg) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
+// (dart ids are 32-bit and may use all 32 bits: element indices are computed in 64 bits, hu::gid())
+__global__ __launch_bounds__(EB) void degree_kernel(const uint32_t *from, uint64_t n_darts, uint32_t *deg) {
+    const uint64_t e = gid();
     if (e < n_darts) atomicAdd(&deg[from[e]], 1u);
 }
-__global__ __launch_bounds__(EB) void fill_kernel(const uint32_t *from, uint32_t n_darts, const uint32_t *row, uint32_t *cursor,
-                                                 uint32_t *adj, uint32_t *pos) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
+__global__ __launch_bounds__(EB) void fill_kernel(const uint32_t *from, uint64_t n_darts, const uint32_t *row, uint32_t *cursor,
+                                                 uint32_t *adj) {
+    const uint64_t e = gid();
     if (e >= n_darts) return;
     const uint32_t u = from[e];
     const uint32_t p = atomicAdd(&cursor[u], 1u);
-    adj[row[u] + p] = e;
-    pos[e] = p;
+    adj[row[u] + p] = (uint32_t)e;
 }
 
 // buckets are filled in atomic order; sorting each node's few out-darts by id makes slots (and with them the whole
 // decomposition) independent of thread timing
-__global__ __launch_bounds__(EB) void sort_buckets_kernel(uint32_t n_nodes, const uint32_t *row, uint32_t *adj, uint32_t *pos) {
-    const uint32_t v = blockIdx.x * EB + threadIdx.x;
+__global__ __launch_bounds__(EB) void sort_buckets_kernel(uint64_t n_nodes, const uint32_t *row, uint32_t *adj, uint32_t *pos) {
+    const uint64_t v = gid();
     if (v >= n_nodes) return;
     const uint32_t lo = row[v], hi = row[v + 1];
     for (uint32_t i = lo + 1; i < hi; i++) {  // insertion sort (degrees are tiny in a de Bruijn graph)
@@ -176,15 +106,17 @@ __global__ __launch_bounds__(EB) void sort_buckets_kernel(uint32_t n_nodes, cons
         }
         adj[j] = x;
     }
-    for (uint32_t i = lo; i < hi; i++) pos[adj[i]] = i - lo;
+    if (pos)
+        for (uint32_t i = lo; i < hi; i++) pos[adj[i]] = i - lo;
 }
 
 // ---- step 2: mirror-symmetric pairing --------------------------------------------------------------------------
-__global__ __launch_bounds__(EB) void succ_kernel(const uint32_t *from, const uint32_t *mirror, uint32_t n_darts, const uint32_t *row,
+__global__ __launch_bounds__(EB) void succ_kernel(const uint32_t *from, const uint32_t *mirror, uint64_t n_darts, const uint32_t *row,
                                                  const uint32_t *adj, const uint32_t *pos, uint32_t *succ, uint32_t *parent,
                                                  uint32_t *error) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e >= n_darts) return;
+    const uint64_t i = gid();
+    if (i >= n_darts) return;
+    const uint32_t e = (uint32_t)i;
     const uint32_t vm = from[e ^ 1];  // e = (u -> v)  <=>  e^1 = (mirror v -> mirror u)
     const uint32_t v = mirror[vm];
     const uint32_t dv = row[v + 1] - row[v];
@@ -204,21 +136,32 @@ __global__ __launch_bounds__(EB) void succ_kernel(const uint32_t *from, const ui
 }
 
 // ---- step 3: trail labels ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EB) void union_succ_kernel(const uint32_t *succ, uint32_t n_darts, uint32_t *parent) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e < n_darts) uf_union(parent, e, succ[e]);
+__global__ __launch_bounds__(EB) void union_succ_kernel(const uint32_t *succ, uint64_t n_darts, uint32_t *parent) {
+    const uint64_t e = gid();
+    if (e < n_darts) uf_union(parent, (uint32_t)e, succ[e]);
 }
-__global__ __launch_bounds__(EB) void flatten_kernel(uint32_t *parent, uint32_t n, uint32_t *label) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e < n) label[e] = uf_find(parent, e);
+// In place: parent[e] = root of e for EVERY e when the kernel ends. The find must not compress here: a path-halving store of
+// another thread (parent[e] = some ancestor it read earlier) could land after this thread's parent[e] = root and leave a
+// non-root behind -- harmless for a union-find that is only ever read through uf_find, wrong for an array read as labels.
+// Every slot is written by its own thread only; readers passing through see the old parent or the root, both ancestors.
+__global__ __launch_bounds__(EB) void flatten_kernel(uint32_t *parent, uint64_t n) {
+    const uint64_t e = gid();
+    if (e >= n) return;
+    uint32_t cur = (uint32_t)e, next;
+    while ((next = __hip_atomic_load(&parent[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != cur) cur = next;
+    __hip_atomic_store(&parent[e], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// comp[e] = smaller trail label of the pair {trail of e, trail of e^1}; second union-find starts as identity
-__global__ __launch_bounds__(EB) void comp_kernel(const uint32_t *label, uint32_t n_darts, uint32_t *comp, uint32_t *parent2) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e >= n_darts) return;
-    const uint32_t a = label[e], b = label[e ^ 1];
-    comp[e] = a < b ? a : b;
-    parent2[e] = e;
+// one thread per biedge, in place over the flattened trail labels: comp[e] = comp[e^1] = smaller trail label of the pair
+// {trail of e, trail of e^1}; the second union-find starts as identity
+__global__ __launch_bounds__(EB) void comp_kernel(uint32_t *label_to_comp, uint64_t n_biedges, uint32_t *parent2) {
+    const uint64_t b = gid();
+    if (b >= n_biedges) return;
+    const uint32_t a = label_to_comp[2 * b], c = label_to_comp[2 * b + 1];
+    const uint32_t m = a < c ? a : c;
+    label_to_comp[2 * b] = m;
+    label_to_comp[2 * b + 1] = m;
+    parent2[2 * b] = (uint32_t)(2 * b);
+    parent2[2 * b + 1] = (uint32_t)(2 * b + 1);
 }
 
 // ---- step 4: spanning forest (deterministic hooking rounds) + successor rotation ------------------------------
@@ -240,10 +183,11 @@ __device__ __forceinline__ void for_each_passage(const uint32_t *mirror, const u
         f(i, a, b);
     }
 }
-__global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uint32_t n_nodes, const uint32_t *row, const uint32_t *adj,
+__global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
                                                     const uint32_t *comp, uint32_t *parent2, unsigned long long *best) {
-    const uint32_t v = blockIdx.x * EB + threadIdx.x;
-    if (v >= n_nodes) return;
+    const uint64_t vi = gid();
+    if (vi >= n_nodes) return;
+    const uint32_t v = (uint32_t)vi;
     uint32_t r0 = 0;
     for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t, uint32_t b) {
         const uint32_t r = uf_find(parent2, comp[b]);
@@ -258,23 +202,26 @@ __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uin
         if (key < __hip_atomic_load(&best[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[hi], key);
     });
 }
-__global__ __launch_bounds__(EB) void hook_kernel(uint32_t n_darts, uint32_t *parent2, const unsigned long long *best, uint32_t *selected,
+// `best` holds ~0 everywhere except at the roots that received a proposal this round; the kernel resets what it consumes,
+// so the array is cleared once per call and not once per round
+__global__ __launch_bounds__(EB) void hook_kernel(uint64_t n_darts, uint32_t *parent2, unsigned long long *best, uint32_t *selected,
                                                  uint32_t *changed) {
-    const uint32_t r = blockIdx.x * EB + threadIdx.x;
+    const uint64_t r = gid();
     if (r >= n_darts) return;
     const unsigned long long p = best[r];
     if (p == ~0ull) return;
+    best[r] = ~0ull;
     parent2[r] = (uint32_t)(p >> 32);  // r was a root when it was proposed for, and only this thread writes it
     selected[(uint32_t)p] = 1u;        // the passage whose out-dart this is joins its node's rotation
     *changed = 1u;
 }
-__global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint32_t n_nodes, const uint32_t *row, const uint32_t *adj,
+__global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
                                                    const uint32_t *selected, uint32_t *succ) {
-    const uint32_t v = blockIdx.x * EB + threadIdx.x;
-    if (v >= n_nodes) return;
+    const uint64_t vi = gid();
+    if (vi >= n_nodes) return;
     uint32_t a_prev = 0, b0 = 0;
     bool any = false;
-    for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t a, uint32_t b) {
+    for_each_passage(mirror, row, adj, (uint32_t)vi, [&](uint32_t i, uint32_t a, uint32_t b) {
         if (i == 0) {
             a_prev = a;
             b0 = b;
@@ -294,64 +241,70 @@ __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint
 
 // ---- step 5: ranking ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool hash_splitter(uint32_t e) { return ((e * 0x9E3779B1u) >> 26) == 0; }
+__device__ __forceinline__ bool bit_of(const uint32_t *bits, uint32_t e) { return (bits[e >> 5] >> (e & 31)) & 1u; }
 
-// flag[e] = 1 for splitters; rootflag packed in bit 1
-__global__ __launch_bounds__(EB) void splitter_flag_kernel(const uint32_t *comp, uint32_t *parent2, uint32_t n_darts, uint32_t *flag,
-                                                          uint8_t *is_root) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e >= n_darts) return;
-    const bool root = uf_find(parent2, comp[e]) == e;  // smallest dart of its connected component
-    is_root[e] = root;
-    flag[e] = (root || hash_splitter(e)) ? 1u : 0u;
+// flag[e] = 1 for splitters (1/64 of the darts by hash + the smallest dart of every connected component); the same flags as
+// a bitmap (one word per 32 darts, written whole by one thread) for the walks, and the roots as a second bitmap
+__global__ __launch_bounds__(EB) void splitter_flag_kernel(const uint32_t *comp, uint32_t *parent2, uint64_t n_darts, uint32_t *flag,
+                                                          uint32_t *split_bits, uint32_t *root_bits) {
+    const uint64_t i = gid();
+    const bool in = i < n_darts;
+    bool root = false, split = false;
+    if (in) {
+        const uint32_t e = (uint32_t)i;
+        root = uf_find(parent2, comp[e]) == e;  // smallest dart of its connected component
+        split = root || hash_splitter(e);
+        flag[e] = split ? 1u : 0u;
+    }
+    const unsigned long long ms = __ballot(split), mr = __ballot(root);
+    const int lane = threadIdx.x & 63;
+    if (in && (lane & 31) == 0) {
+        split_bits[i >> 5] = (uint32_t)(ms >> lane);
+        root_bits[i >> 5] = (uint32_t)(mr >> lane);
+    }
 }
-__global__ __launch_bounds__(EB) void splitter_compact_kernel(const uint32_t *flag, const uint32_t *sidx, uint32_t n_darts, uint32_t *splitters) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e < n_darts && flag[e]) splitters[sidx[e]] = e;
-}
-// succ gets bit 31 set where the successor is a splitter (n_darts < 2^31 is checked on the host)
-__global__ __launch_bounds__(EB) void succ_mark_kernel(uint32_t *succ, const uint32_t *flag, uint32_t n_darts) {
-    const uint32_t e = blockIdx.x * EB + threadIdx.x;
-    if (e >= n_darts) return;
-    const uint32_t s = succ[e];
-    if (flag[s]) succ[e] = s | SPLIT_FLAG;
+__global__ __launch_bounds__(EB) void splitter_compact_kernel(const uint32_t *flag, const uint32_t *sidx, uint64_t n_darts, uint32_t *splitters) {
+    const uint64_t e = gid();
+    if (e < n_darts && flag[e]) splitters[sidx[e]] = (uint32_t)e;
 }
 __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, const uint32_t *splitters, const uint32_t *sidx,
-                                                         const uint8_t *is_root, uint32_t n_split, uint32_t n_darts, uint32_t *seg_len,
-                                                         uint32_t *next_split, uint32_t *jump, uint32_t *dist, uint32_t *error) {
-    const uint32_t i = blockIdx.x * EB + threadIdx.x;
+                                                         const uint32_t *split_bits, const uint32_t *root_bits, uint32_t n_split,
+                                                         uint64_t n_darts, uint32_t *seg_len, uint32_t *next_split, uint32_t *jump,
+                                                         uint32_t *dist, uint32_t *error) {
+    const uint64_t i = gid();
     if (i >= n_split) return;
     const uint32_t s = splitters[i];
     uint32_t x = succ[s], len = 1;
-    while (!(x & SPLIT_FLAG)) {
+    while (!bit_of(split_bits, x)) {
         x = succ[x];
-        if (++len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
+        if (++len == 0 || len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
             atomicOr(error, 2u);
             break;
         }
     }
-    const uint32_t nxt = sidx[x & ~SPLIT_FLAG];
+    const uint32_t nxt = sidx[x];
     seg_len[i] = len;
     next_split[i] = nxt;
-    const bool root = is_root[s];
-    jump[i] = root ? i : nxt;  // roots are the terminals of the reduced lists
+    const bool root = bit_of(root_bits, s);
+    jump[i] = root ? (uint32_t)i : nxt;  // roots are the terminals of the reduced lists
     dist[i] = root ? 0u : len;
 }
 __global__ __launch_bounds__(EB) void wyllie_kernel(const uint32_t *jump_in, const uint32_t *dist_in, uint32_t n, uint32_t *jump_out,
                                                    uint32_t *dist_out) {
-    const uint32_t i = blockIdx.x * EB + threadIdx.x;
+    const uint64_t i = gid();
     if (i >= n) return;
     const uint32_t j = jump_in[i];
     jump_out[i] = jump_in[j];
     dist_out[i] = dist_in[i] + dist_in[j];
 }
 // per root splitter (ascending dart id): length of its trail
-__global__ __launch_bounds__(EB) void root_flag_kernel(const uint32_t *splitters, const uint8_t *is_root, uint32_t n_split, uint32_t *rflag) {
-    const uint32_t i = blockIdx.x * EB + threadIdx.x;
-    if (i < n_split) rflag[i] = is_root[splitters[i]];
+__global__ __launch_bounds__(EB) void root_flag_kernel(const uint32_t *splitters, const uint32_t *root_bits, uint32_t n_split, uint32_t *rflag) {
+    const uint64_t i = gid();
+    if (i < n_split) rflag[i] = bit_of(root_bits, splitters[i]) ? 1u : 0u;
 }
 __global__ __launch_bounds__(EB) void root_len_kernel(const uint32_t *rflag, const uint32_t *ridx, const uint32_t *seg_len,
                                                      const uint32_t *next_split, const uint32_t *dist, uint32_t n_split, uint32_t *cyc_len) {
-    const uint32_t i = blockIdx.x * EB + threadIdx.x;
+    const uint64_t i = gid();
     if (i >= n_split || !rflag[i]) return;
     cyc_len[ridx[i]] = seg_len[i] + dist[next_split[i]];  // next == i (single splitter): dist 0
 }
@@ -359,7 +312,7 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
                                                        const uint32_t *ridx, const uint32_t *jump, const uint32_t *dist,
                                                        const uint32_t *seg_len, const uint32_t *cyc_len, const uint32_t *cyc_base,
                                                        uint32_t n_split, uint32_t *out) {
-    const uint32_t i = blockIdx.x * EB + threadIdx.x;
+    const uint64_t i = gid();
     if (i >= n_split) return;
     const uint32_t t = jump[i];
     if (!rflag[t]) return;  // mirror trail (no root on it): not emitted
@@ -369,176 +322,133 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
     const uint32_t len = seg_len[i];
     for (uint32_t j = 0; j < len; j++) {
         out[p++] = x;
-        x = succ[x] & ~SPLIT_FLAG;
+        x = succ[x];
     }
-}
-
-// Stream-ordered allocations from the device's default memory pool, which is told to keep freed memory: the ~25
-// work arrays of a call cost milliseconds to map afresh, and a driver that Eulerises graph after graph reuses them.
-thread_local hipStream_t g_alloc_stream = nullptr;
-struct Buf {
-    void *p = nullptr;
-    ~Buf() {
-        if (p) (void)hipFreeAsync(p, g_alloc_stream);
-    }
-    template <typename T>
-    T *alloc(uint64_t n) {
-        HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), g_alloc_stream));
-        return (T *)p;
-    }
-};
-
-// out may alias in
-void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *block_sums, uint32_t *d_total) {
-    const uint32_t nb = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    if (nb == 0) {
-        HIP_CHECK(hipMemsetAsync(d_total, 0, 4, st));
-        return;
-    }
-    scan_reduce_kernel<<<nb, EB, 0, st>>>(in, n, block_sums);
-    scan_block_sums_kernel<<<1, EB, 0, st>>>(block_sums, nb, d_total);
-    scan_apply_kernel<<<nb, EB, 0, st>>>(in, n, block_sums, out);
 }
 
 }  // namespace
 
-Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out) {
-    const uint64_t E64 = g.edge_count(), V64 = g.node_count();
-    Walks result;
-    if (E64 == 0) return result;
-    if (E64 >= 0x7FFFFFFFull || (E64 & 1)) MTG_DIE("device_euler_cycles: %llu directed edges do not fit the 31-bit dart ids", (unsigned long long)E64);
-    const uint32_t E = (uint32_t)E64, V = (uint32_t)V64;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device_id)
-        MTG_DIE("device_euler_cycles: no MI355X device %d visible (there is no CPU fallback for this mode)", device_id);
-    HIP_CHECK(hipSetDevice(device_id));
-    static hipStream_t streams[64] = {nullptr};
-    if (device_id >= 64) MTG_DIE("device_euler_cycles: device id %d out of range", device_id);
-    if (!streams[device_id]) {
-        HIP_CHECK(hipStreamCreate(&streams[device_id]));
-        hipMemPool_t pool;
-        HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
-        uint64_t keep = UINT64_MAX;
-        HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    }
-    hipStream_t st = streams[device_id];
-    g_alloc_stream = st;
+// adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
+void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos) {
+    Buf b_cursor, b_bsum, b_tot;
+    uint32_t *d_cursor = b_cursor.alloc<uint32_t>(st, V);
+    uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(V + 1) + 1);
+    uint32_t *d_tot = b_tot.alloc<uint32_t>(st, 1);
+    HIP_CHECK(hipMemsetAsync(d_row, 0, (V + 1) * 4, st));
+    HIP_CHECK(hipMemsetAsync(d_cursor, 0, V * 4, st));
+    degree_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row);
+    scan_u32<uint32_t>(st, d_row, V + 1, d_row, d_bsum, d_tot);
+    fill_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_cursor, d_adj);
+    sort_buckets_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_pos);
+    HIP_CHECK(hipGetLastError());
+}
+
+// The decomposition over device arrays: from[E] (dart e leaves from[e]; its mirror is e ^ 1) and mirror[V]. Results: the closed
+// walks back to back in b_out (u32[E / 2], dart ids), their lengths in b_clen and start offsets in b_cbase (u32[*n_cycles]).
+void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E, uint64_t V, Buf &b_out, Buf &b_clen,
+                            Buf &b_cbase, uint32_t *n_cycles, double *kernel_ms_out) {
+    if (E == 0 || (E & 1) || E >= 0xFFFFFFFFull) MTG_DIE("device_euler_decompose: %llu darts (must be even and fit 32-bit ids)", (unsigned long long)E);
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));
     HIP_CHECK(hipEventCreate(&ev1));
-
-    Buf b_best, b_from, b_mirror, b_row, b_cursor, b_adj, b_pos, b_succ, b_parent, b_label, b_comp, b_parent2, b_flag, b_sidx, b_isroot,
-        b_bsum, b_small;
-    uint32_t *d_from = b_from.alloc<uint32_t>(E);
-    uint32_t *d_mirror = b_mirror.alloc<uint32_t>(V);
-    uint32_t *d_row = b_row.alloc<uint32_t>((uint64_t)V + 1);
-    uint32_t *d_cursor = b_cursor.alloc<uint32_t>(V);
-    uint32_t *d_adj = b_adj.alloc<uint32_t>(E);
-    uint32_t *d_pos = b_pos.alloc<uint32_t>(E);
-    uint32_t *d_succ = b_succ.alloc<uint32_t>(E);
-    uint32_t *d_parent = b_parent.alloc<uint32_t>(E);
-    uint32_t *d_label = b_label.alloc<uint32_t>(E);
-    uint32_t *d_comp = b_comp.alloc<uint32_t>(E);
-    uint32_t *d_parent2 = b_parent2.alloc<uint32_t>(E);
-    uint32_t *d_flag = b_flag.alloc<uint32_t>(E);
-    uint32_t *d_sidx = b_sidx.alloc<uint32_t>(E);
-    uint8_t *d_isroot = b_isroot.alloc<uint8_t>(E);
-    unsigned long long *d_best = b_best.alloc<unsigned long long>(E);
-    const uint64_t max_scan = std::max<uint64_t>(E, (uint64_t)V + 1);
-    uint32_t *d_bsum = b_bsum.alloc<uint32_t>(max_scan / SCAN_CHUNK + 2);
-    uint32_t *d_small = b_small.alloc<uint32_t>(8);  // [0] error, [1..] scan totals
-    uint32_t *d_error = d_small, *d_total = d_small + 1;
-
-    HIP_CHECK(hipMemcpyAsync(d_from, g.e_from.data(), (uint64_t)E * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_mirror, g.mirror.data(), (uint64_t)V * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(d_small, 0, 32, st));
     HIP_CHECK(hipEventRecord(ev0, st));
 
+    Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small;
+    uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1);
+    uint32_t *d_adj = b_adj.alloc<uint32_t>(st, E);
+    uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, E);  // bucket slots until the pairing is done, then the second union-find
+    uint32_t *d_succ = b_succ.alloc<uint32_t>(st, E);
+    uint32_t *d_comp = b_comp.alloc<uint32_t>(st, E);  // trail union-find -> trail labels -> component labels, in place
+    uint32_t *d_flag = b_flag.alloc<uint32_t>(st, E);
+    uint32_t *d_sidx = b_sidx.alloc<uint32_t>(st, E);
+    const uint64_t n_words = (E + 31) / 32;
+    uint32_t *d_sbits = b_sbits.alloc<uint32_t>(st, n_words);
+    uint32_t *d_rbits = b_rbits.alloc<uint32_t>(st, n_words);
+    unsigned long long *d_best = b_best.alloc<unsigned long long>(st, E);
+    uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(E) + 2);
+    uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] changed
+    uint32_t *d_error = d_small, *d_total = d_small + 1;
+    HIP_CHECK(hipMemsetAsync(d_small, 0, 32, st));
+
     // 1. buckets
-    HIP_CHECK(hipMemsetAsync(d_row, 0, ((uint64_t)V + 1) * 4, st));
-    HIP_CHECK(hipMemsetAsync(d_cursor, 0, (uint64_t)V * 4, st));
-    degree_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row);
-    scan_u32(st, d_row, (uint64_t)V + 1, d_row, d_bsum, d_total);
-    fill_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_cursor, d_adj, d_pos);
-    sort_buckets_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_pos);
+    device_build_buckets(st, d_from, E, V, d_row, d_adj, d_pos2);
     // 2. pairing, 3. trail labels
-    succ_kernel<<<grid_for(E), EB, 0, st>>>(d_from, d_mirror, E, d_row, d_adj, d_pos, d_succ, d_parent, d_error);
+    succ_kernel<<<grid_for(E), EB, 0, st>>>(d_from, d_mirror, E, d_row, d_adj, d_pos2, d_succ, d_comp, d_error);
     uint32_t h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: the graph is not Eulerian (greedytigs/mod.rs:708)");
-    union_succ_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, E, d_parent);
-    flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent, E, d_label);
-    comp_kernel<<<grid_for(E), EB, 0, st>>>(d_label, E, d_comp, d_parent2);
+    union_succ_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, E, d_comp);
+    flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, E);
+    uint32_t *d_parent2 = d_pos2;
+    comp_kernel<<<grid_for(E / 2), EB, 0, st>>>(d_comp, E / 2, d_parent2);
     // 4. merge the trails of every connected component
-    HIP_CHECK(hipMemsetAsync(d_flag, 0, (uint64_t)E * 4, st));  // `selected`, reused as the splitter flags afterwards
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`, reused as the splitter flags afterwards
+    HIP_CHECK(hipMemsetAsync(d_best, 0xFF, E * 8, st));
     int hook_rounds = 0;
     for (;; hook_rounds++) {
         if (hook_rounds > 64) MTG_DIE("device_euler_cycles: internal error (component hooking does not converge)");
-        HIP_CHECK(hipMemsetAsync(d_best, 0xFF, (uint64_t)E * 8, st));
         HIP_CHECK(hipMemsetAsync(d_small + 4, 0, 4, st));
         propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best);
         hook_kernel<<<grid_for(E), EB, 0, st>>>(E, d_parent2, d_best, d_flag, d_small + 4);
-        flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent2, E, d_parent2);
+        flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent2, E);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (!h_small[4]) break;
     }
+    b_best.release();
     rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_flag, d_succ);
     // 5. ranking
-    splitter_flag_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, d_parent2, E, d_flag, d_isroot);
-    scan_u32(st, d_flag, E, d_sidx, d_bsum, d_total);
+    splitter_flag_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, d_parent2, E, d_flag, d_sbits, d_rbits);
+    scan_u32<uint32_t>(st, d_flag, E, d_sidx, d_bsum, d_total);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const uint32_t M = h_small[1];  // splitters
     if (M == 0) MTG_DIE("device_euler_cycles: internal error (no splitters)");
+    b_row.release();
+    b_adj.release();
+    b_comp.release();
+    b_pos2.release();
 
-    Buf b_split, b_seglen, b_next, b_jump0, b_dist0, b_jump1, b_dist1, b_rflag, b_ridx, b_clen, b_cbase, b_out;
-    uint32_t *d_split = b_split.alloc<uint32_t>(M);
-    uint32_t *d_seglen = b_seglen.alloc<uint32_t>(M);
-    uint32_t *d_next = b_next.alloc<uint32_t>(M);
-    uint32_t *d_jump[2] = {b_jump0.alloc<uint32_t>(M), b_jump1.alloc<uint32_t>(M)};
-    uint32_t *d_dist[2] = {b_dist0.alloc<uint32_t>(M), b_dist1.alloc<uint32_t>(M)};
-    uint32_t *d_rflag = b_rflag.alloc<uint32_t>(M);
-    uint32_t *d_ridx = b_ridx.alloc<uint32_t>(M);
+    Buf b_split, b_seglen, b_next, b_jump0, b_dist0, b_jump1, b_dist1, b_rflag, b_ridx;
+    uint32_t *d_split = b_split.alloc<uint32_t>(st, M);
+    uint32_t *d_seglen = b_seglen.alloc<uint32_t>(st, M);
+    uint32_t *d_next = b_next.alloc<uint32_t>(st, M);
+    uint32_t *d_jump[2] = {b_jump0.alloc<uint32_t>(st, M), b_jump1.alloc<uint32_t>(st, M)};
+    uint32_t *d_dist[2] = {b_dist0.alloc<uint32_t>(st, M), b_dist1.alloc<uint32_t>(st, M)};
+    uint32_t *d_rflag = b_rflag.alloc<uint32_t>(st, M);
+    uint32_t *d_ridx = b_ridx.alloc<uint32_t>(st, M);
     splitter_compact_kernel<<<grid_for(E), EB, 0, st>>>(d_flag, d_sidx, E, d_split);
-    succ_mark_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, d_flag, E);
-    walk_measure_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_isroot, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
+    walk_measure_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
     int cur = 0;
     for (uint64_t span = 1; span < (uint64_t)M * 2; span <<= 1) {  // after r rounds a pointer spans 2^r reduced elements
         wyllie_kernel<<<grid_for(M), EB, 0, st>>>(d_jump[cur], d_dist[cur], M, d_jump[cur ^ 1], d_dist[cur ^ 1]);
         cur ^= 1;
     }
-    root_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_split, d_isroot, M, d_rflag);
-    scan_u32(st, d_rflag, M, d_ridx, d_bsum, d_total + 1);
+    root_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_split, d_rbits, M, d_rflag);
+    scan_u32<uint32_t>(st, d_rflag, M, d_ridx, d_bsum, d_total + 1);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: internal error (successor array is not a permutation)");
     const uint32_t R = h_small[2];  // connected components = closed walks
-    uint32_t *d_clen = b_clen.alloc<uint32_t>(R);
-    uint32_t *d_cbase = b_cbase.alloc<uint32_t>(R);
-    uint32_t *d_out = b_out.alloc<uint32_t>(E / 2);
+    if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] euler decompose: E %llu V %llu hook rounds %d splitters %u components %u\n", (unsigned long long)E, (unsigned long long)V, hook_rounds, M, R);
+    b_flag.release();
+    b_sidx.release();
+    uint32_t *d_clen = b_clen.alloc<uint32_t>(st, R);
+    uint32_t *d_cbase = b_cbase.alloc<uint32_t>(st, R);
+    uint32_t *d_out = b_out.alloc<uint32_t>(st, E / 2);
     root_len_kernel<<<grid_for(M), EB, 0, st>>>(d_rflag, d_ridx, d_seglen, d_next, d_dist[cur], M, d_clen);
-    scan_u32(st, d_clen, R, d_cbase, d_bsum, d_total + 2);
+    scan_u32<uint32_t>(st, d_clen, R, d_cbase, d_bsum, d_total + 2);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[3] != E / 2)
-        MTG_DIE("device_euler_cycles: internal error (closed walks cover %u of %u biedges)", h_small[3], E / 2);
+        MTG_DIE("device_euler_cycles: internal error (closed walks cover %u of %llu biedges)", h_small[3], (unsigned long long)(E / 2));
     walk_write_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M,
                                                    d_out);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev1, st));
-
-    result.edges.resize(E / 2);
-    std::vector<uint32_t> clen(R);
-    HIP_CHECK(hipMemcpyAsync(result.edges.data(), d_out, (uint64_t)(E / 2) * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(clen.data(), d_clen, (uint64_t)R * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    result.limits.resize(R);
-    uint64_t run = 0;
-    for (uint32_t r = 0; r < R; r++) {
-        run += clen[r];
-        result.limits[r] = run;
-    }
+    *n_cycles = R;
     if (kernel_ms_out) {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -546,6 +456,39 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     }
     HIP_CHECK(hipEventDestroy(ev0));
     HIP_CHECK(hipEventDestroy(ev1));
+}
+
+// Host-graph form (mtg_euler_cycles_device): uploads from / mirror of the graph as it stands, downloads the closed walks.
+Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out) {
+    const uint64_t E = g.edge_count(), V = g.node_count();
+    Walks result;
+    if (E == 0) return result;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device_id)
+        MTG_DIE("device_euler_cycles: no MI355X device %d visible (there is no CPU fallback for this mode)", device_id);
+    HIP_CHECK(hipSetDevice(device_id));
+    hipStream_t st = finish_stream(device_id);
+    Buf b_from, b_mirror, b_out, b_clen, b_cbase;
+    uint32_t *d_from = b_from.alloc<uint32_t>(st, E);
+    uint32_t *d_mirror = b_mirror.alloc<uint32_t>(st, V);
+    HIP_CHECK(hipMemcpyAsync(d_from, g.e_from.data(), E * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
+    uint32_t R = 0;
+    device_euler_decompose(st, d_from, d_mirror, E, V, b_out, b_clen, b_cbase, &R, kernel_ms_out);
+    result.edges.resize(E / 2);
+    std::vector<uint32_t> clen(R);
+    HIP_CHECK(hipMemcpyAsync(result.edges.data(), b_out.as<uint32_t>(), (E / 2) * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(clen.data(), b_clen.as<uint32_t>(), (uint64_t)R * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    result.limits.resize(R);
+    uint64_t run = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        run += clen[r];
+        result.limits[r] = run;
+    }
+    b_from.release(); b_mirror.release(); b_out.release(); b_clen.release(); b_cbase.release();
+    HIP_CHECK(hipStreamSynchronize(st));
+    finish_trim(device_id, E * 40);
     return result;
 }
 

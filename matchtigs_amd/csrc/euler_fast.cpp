@@ -59,6 +59,7 @@ Walks euler_cycles(const HostGraph &g) {
     const uint64_t E = g.edge_count();
     const uint64_t V = g.node_count();
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    g.ensure_linked();
     for (uint64_t n = 0; n < V; n++)
         if (g.out_deg[n] > 65535) return euler_cycles_generic(g);  // not a de Bruijn graph: simple formulation
 

@@ -1,0 +1,583 @@
+// finish_device.hip -- everything after the claim loop on the MI355X: dummy biedge insertion, the Euleriser, the Euler
+// bicycles (or the records of the reference-order host walk) and the cutter, over flat dart arrays in HBM.
+//
+//   stage                         reference lines (all under /root/reference/src/implementation/)
+//   matched-pair darts            greedytigs/mod.rs:678-689
+//   Euleriser                     mod.rs:392-649 (+ choose_in_node_from_iterator :252-285): the SAME sequence of breaking edges
+//   Euler bicycles                call greedytigs/mod.rs:722 / eulertigs/mod.rs:119 -> euler_device.hip (parallel, own order) or
+//                                 the host walk in the reference's order over records built here (euler_lean.cpp)
+//   rotate + cut                  greedytigs/mod.rs:726-789 == eulertigs/mod.rs:123-186
+//
+// A dart is a directed edge; dart e leaves from[e], its mirror dart is e ^ 1, its head is mirror[from[e ^ 1]]. Darts
+// [0, E0) are the original edges, [E0, E0 + 2P) the matched pairs in claim order, the breaking edges follow in the order the
+// reference adds them -- so "dummy" and "breaking" are id comparisons (like the host cutter, host_pipeline.cpp).
+//
+// The Euleriser in parallel. After the self-mirror phase the reference repeats: o = LARGEST node that still misses out-edges,
+// t = SMALLEST node that still misses in-edges (with one exception rule), add o -> t and its mirror, and decrement the four
+// counters of o, t, mirror(t), mirror(o). Every missing edge of an out-node o is also a missing edge of the in-node mirror(o), so
+// the state is one list of "units" (binode, copy) seen in two orders: order A = by out-node descending, order B = by in-node
+// ascending (copies of one binode in opposite order). A step removes the first live unit of A and the first live unit of B, and
+// the live set is always {A-rank >= a, B-rank >= b}: the whole state is two cursors. While neither cursor has to skip, step s
+// simply pairs A[s] with B[s + d] (d = 1 if the odd self-mirror took B[0]), and "no skip up to step s" is the per-unit test
+// B-rank(A[s]) > s + d and A-rank(B[s + d]) > s -- a parallel map plus a min-reduction for the first irregular step s*. In
+// graphs whose mirror nodes have neighbouring ids (every de Bruijn graph builder, and the generator here) order B is order A
+// reversed, the cursors meet in the middle and s* is the last step; otherwise the steps from s* on are replayed sequentially on
+// the host over the residual counters, which is the reference's loop itself. Either way the edges and their order are the
+// reference's (tests: against make_eulerian and the oracle's ordered-map form, including scrambled mirror numberings).
+//
+// Everything is integer streaming / gather work on arrays over darts and nodes; HBM-bound, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "device.hpp"
+#include "finish_device.hpp"
+#include "hugebuf.hpp"
+#include "parallel.hpp"
+
+namespace mtg {
+
+using namespace hu;
+
+Walks euler_cycles_generic(const HostGraph &g);
+
+namespace {
+
+// ---- degrees and imbalance ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EB) void degree_kernel(const uint32_t *from, uint64_t n, uint32_t *deg) {
+    const uint64_t e = gid();
+    if (e < n) atomicAdd(&deg[from[e]], 1u);
+}
+__global__ __launch_bounds__(EB) void pair_degree_kernel(const mtg_pair *pairs, uint64_t n, const uint32_t *mirror, uint32_t *deg) {
+    const uint64_t i = gid();
+    if (i >= n) return;
+    atomicAdd(&deg[pairs[i].out_node], 1u);
+    atomicAdd(&deg[mirror[pairs[i].in_node]], 1u);
+}
+__global__ __launch_bounds__(EB) void pair_darts_kernel(const mtg_pair *pairs, uint64_t n, const uint32_t *mirror, uint32_t *from_pairs,
+                                                       uint32_t *pair_w) {
+    const uint64_t i = gid();
+    if (i >= n) return;
+    from_pairs[2 * i] = pairs[i].out_node;           // out -> in
+    from_pairs[2 * i + 1] = mirror[pairs[i].in_node];  // mirror(in) -> mirror(out)
+    pair_w[i] = (uint32_t)pairs[i].distance;
+}
+// find_non_eulerian_binodes_with_differences (mod.rs:408-427): cin = missing in-edges (diff > 0), cout = missing out-edges
+// (diff < 0), smf = self-mirror node with odd degree (difference-0 entry)
+__global__ __launch_bounds__(EB) void need_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, uint32_t *cin, uint32_t *cout,
+                                                 uint32_t *smf) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const uint32_t mv = mirror[v], d = deg[v];
+    uint32_t ci = 0, co = 0, sm = 0;
+    if (mv == v) sm = d & 1u;
+    else {
+        const uint32_t dm = deg[mv];
+        if (d > dm) ci = d - dm;
+        else co = dm - d;
+    }
+    cin[v] = ci;
+    cout[v] = co;
+    smf[v] = sm;
+}
+__global__ __launch_bounds__(EB) void sm_compact_kernel(uint64_t n_nodes, const uint32_t *smf, const uint32_t *p_sm, uint32_t *sm_list) {
+    const uint64_t v = gid();
+    if (v < n_nodes && smf[v]) sm_list[p_sm[v]] = (uint32_t)v;
+}
+// order A: out-nodes descending (A-offset of o = N - p_out[o] - cout[o]); order B: in-nodes ascending (B-offset of t = p_in[t])
+__global__ __launch_bounds__(EB) void expand_kernel(uint64_t n_nodes, const uint32_t *cin, const uint32_t *cout, const uint32_t *p_in,
+                                                   const uint32_t *p_out, uint32_t n_units, uint32_t *a_node, uint32_t *b_node) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const uint32_t ci = cin[v], co = cout[v];
+    for (uint32_t j = 0; j < ci; j++) b_node[p_in[v] + j] = (uint32_t)v;
+    if (co) {
+        const uint32_t base = n_units - p_out[v] - co;
+        for (uint32_t j = 0; j < co; j++) a_node[base + j] = (uint32_t)v;
+    }
+}
+// first irregular step (see the header): min over s of "a cursor would have to skip at step s"
+__global__ __launch_bounds__(EB) void zip_check_kernel(uint32_t n_steps, uint32_t delta, uint32_t n_units, const uint32_t *mirror,
+                                                      const uint32_t *cin, const uint32_t *cout, const uint32_t *p_in, const uint32_t *p_out,
+                                                      const uint32_t *a_node, const uint32_t *b_node, uint32_t *s_star) {
+    const uint64_t s = gid();
+    if (s >= n_steps) return;
+    bool bad = false;
+    {
+        const uint32_t o = a_node[s], c = cout[o];
+        const uint64_t a_off = (uint64_t)n_units - p_out[o] - c;
+        const uint64_t j = s - a_off;                                     // copy of o at A-rank s
+        const uint64_t b_rank = (uint64_t)p_in[mirror[o]] + (c - 1 - j);  // copies sit in B in the opposite order
+        bad |= b_rank <= s + delta;
+    }
+    {
+        const uint32_t t = b_node[s + delta], c = cin[t];
+        const uint64_t jb = (s + delta) - p_in[t];
+        const uint64_t j = c - 1 - jb;
+        const uint32_t o = mirror[t];
+        const uint64_t a_rank = ((uint64_t)n_units - p_out[o] - c) + j;
+        bad |= a_rank <= s;
+    }
+    if (bad) atomicMin(s_star, (uint32_t)s);
+}
+// breaking biedge b = b0 + s: from[2b] = out-node, from[2b + 1] = mirror(in-node)   (mod.rs:572-577)
+__global__ __launch_bounds__(EB) void zip_emit_kernel(uint32_t n_steps, uint32_t delta, const uint32_t *mirror, const uint32_t *a_node,
+                                                     const uint32_t *b_node, uint32_t *from_brk) {
+    const uint64_t s = gid();
+    if (s >= n_steps) return;
+    from_brk[2 * s] = a_node[s];
+    from_brk[2 * s + 1] = mirror[b_node[s + delta]];
+}
+// self-mirror phase (mod.rs:481-524): pairs (sm[2p] -> sm[2p+1]); the odd one out takes the first in-node
+__global__ __launch_bounds__(EB) void sm_emit_kernel(uint32_t n_sm, const uint32_t *sm_list, const uint32_t *b_node, const uint32_t *mirror,
+                                                    uint32_t *from_brk) {
+    const uint64_t p = gid();
+    if (2 * p + 1 < n_sm) {
+        from_brk[2 * p] = sm_list[2 * p];
+        from_brk[2 * p + 1] = sm_list[2 * p + 1];  // mirror(in) with in a self-mirror node
+    } else if (2 * p + 1 == n_sm) {
+        from_brk[2 * p] = sm_list[2 * p];
+        from_brk[2 * p + 1] = mirror[b_node[0]];
+    }
+}
+// units of every out-node that the parallel prefix [0, s*) left alive
+__global__ __launch_bounds__(EB) void residual_kernel(uint64_t n_nodes, uint32_t s_star, uint32_t delta, uint32_t n_units, const uint32_t *mirror,
+                                                     const uint32_t *cout, const uint32_t *p_in, const uint32_t *p_out, uint32_t *resid,
+                                                     uint32_t *rflag, uint32_t *error) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const uint32_t c = cout[v];
+    uint32_t r = 0;
+    if (c) {
+        const int64_t a_off = (int64_t)n_units - p_out[v] - c, b_off = p_in[mirror[v]];
+        const int64_t ka = std::min<int64_t>(c, std::max<int64_t>(0, (int64_t)s_star - a_off));
+        const int64_t kb = std::min<int64_t>(c, std::max<int64_t>(0, (int64_t)s_star + delta - b_off));
+        if (ka + kb > c) atomicOr(error, 4u);
+        else r = (uint32_t)(c - ka - kb);
+    }
+    resid[v] = r;
+    rflag[v] = r ? 1u : 0u;
+}
+__global__ __launch_bounds__(EB) void residual_compact_kernel(uint64_t n_nodes, const uint32_t *resid, const uint32_t *rpos, uint32_t *r_node,
+                                                             uint32_t *r_cnt) {
+    const uint64_t v = gid();
+    if (v >= n_nodes || !resid[v]) return;
+    r_node[rpos[v]] = (uint32_t)v;
+    r_cnt[rpos[v]] = resid[v];
+}
+__global__ __launch_bounds__(EB) void head_kernel(const uint32_t *from, const uint32_t *mirror, uint64_t lo, uint64_t hi, uint32_t *to_out) {
+    const uint64_t e = lo + gid();
+    if (e < hi) to_out[e - lo] = mirror[from[e ^ 1]];
+}
+
+// ---- records of the reference-order host walk (euler_lean.cpp) ---------------------------------------------------
+__global__ __launch_bounds__(EB) void lean_ext_kernel(uint64_t n_nodes, const uint32_t *row, uint32_t *ext_need, uint32_t *error) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const uint32_t d = row[v + 1] - row[v];
+    ext_need[v] = d > 3 ? d - 3 : 0;
+    if (d > 65535) atomicOr(error, 8u);
+}
+__global__ __launch_bounds__(EB) void lean_build_kernel(uint64_t n_nodes, const uint32_t *row, const uint32_t *adj, const uint32_t *from,
+                                                       const uint32_t *mirror, const uint32_t *ext_off, LeanNode *nodes, uint32_t *ext_eid,
+                                                       uint32_t *ext_to) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const uint32_t lo = row[v], d = row[v + 1] - lo;
+    LeanNode r;
+    r.deg = (uint16_t)(d > 65535 ? 65535 : d);
+    r.pos = 0;
+    r.ext_begin = ext_off[v];
+    for (uint32_t p = 0; p < 3; p++) {
+        r.eid[p] = NONE;
+        r.to[p] = NONE;
+    }
+    for (uint32_t p = 0; p < d; p++) {  // position p = p-th NEWEST out-dart (petgraph order): buckets are ascending
+        const uint32_t e = adj[lo + d - 1 - p];
+        const uint32_t t = mirror[from[e ^ 1]];
+        if (p < 3) {
+            r.eid[p] = e;
+            r.to[p] = t;
+        } else {
+            ext_eid[r.ext_begin + p - 3] = e;
+            ext_to[r.ext_begin + p - 3] = t;
+        }
+    }
+    nodes[v] = r;
+}
+
+// ---- rotate + cut (greedytigs/mod.rs:726-789) ----------------------------------------------------------------------
+struct CutIds {
+    uint32_t n_orig;     // darts >= n_orig are dummies
+    uint32_t first_brk;  // darts >= first_brk are breaking edges (weight k); matched dummies in between have pair_w
+};
+__global__ __launch_bounds__(EB) void cycle_heads_kernel(uint32_t n_cycles, const uint32_t *cbase, uint32_t *head) {
+    const uint64_t r = gid();
+    if (r < n_cycles) head[cbase[r]] = 1u;
+}
+// rotation point (:737-748): the first dummy that is strictly longer than every dummy before it = the first occurrence of the
+// largest dummy weight = max over dummies of (weight, -position). One 64-bit atomicMax per cycle; a wave that lies inside one
+// cycle reduces first, and a key that cannot win is filtered by a plain load (a giant cycle's 10^7 breaking edges would
+// otherwise queue up on one word).
+__global__ __launch_bounds__(EB) void rotation_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *head, const uint32_t *hscan,
+                                                     const uint32_t *cbase, CutIds ids, uint32_t k, const uint32_t *pair_w,
+                                                     unsigned long long *rotkey) {
+    const uint64_t p = gid();
+    unsigned long long key = 0;
+    uint32_t c = 0xFFFFFFFFu;
+    if (p < n) {
+        c = hscan[p] + head[p] - 1;
+        const uint32_t e = cyc[p];
+        if (e >= ids.n_orig) {
+            const uint32_t w = e >= ids.first_brk ? k : pair_w[(e - ids.n_orig) >> 1];
+            if (w > 0) key = ((unsigned long long)w << 32) | (0xFFFFFFFFu - (uint32_t)(p - cbase[c]));
+        }
+    }
+    const uint32_t c0 = __shfl(c, 0, 64);
+    if (__all(c == c0 || p >= n)) {  // the whole wave is in one cycle
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if ((threadIdx.x & 63) != 0) key = 0;
+        c = c0;
+    }
+    if (key && key > __hip_atomic_load(&rotkey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&rotkey[c], key);
+}
+// rot[q] = the cycle rotated to its rotation point (:746-748), still back to back
+__global__ __launch_bounds__(EB) void rotate_cycles_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *head, const uint32_t *hscan,
+                                                          const uint32_t *cbase, const uint32_t *clen, const unsigned long long *rotkey,
+                                                          uint32_t *rot) {
+    const uint64_t p = gid();
+    if (p >= n) return;
+    const uint32_t c = hscan[p] + head[p] - 1;
+    const uint32_t base = cbase[c], len = clen[c];
+    const unsigned long long key = rotkey[c];
+    const uint32_t r = key ? 0xFFFFFFFFu - (uint32_t)key : 0u;
+    const uint32_t j = (uint32_t)(p - base);
+    const uint32_t jr = j >= r ? j - r : j + len - r;
+    rot[base + jr] = cyc[p];
+}
+// cut(j) = breaking edge, or any dummy at rotated index 0 (:767-769) or at the last index (the tail rule :779-788 drops a
+// trailing dummy, which is the same as cutting there). keep = !cut; a kept edge ends a tig if it is the cycle's last edge or its
+// successor is cut.
+__device__ __forceinline__ bool is_cut(uint32_t e, uint32_t j, uint32_t len, const CutIds &ids) {
+    return e >= ids.first_brk || (e >= ids.n_orig && (j == 0 || j + 1 == len));
+}
+__global__ __launch_bounds__(EB) void cut_flags_kernel(const uint32_t *rot, uint64_t n, const uint32_t *head, const uint32_t *hscan,
+                                                      const uint32_t *cbase, const uint32_t *clen, CutIds ids, uint32_t *keep, uint32_t *end) {
+    const uint64_t q = gid();
+    if (q >= n) return;
+    const uint32_t c = hscan[q] + head[q] - 1;
+    const uint32_t j = (uint32_t)(q - cbase[c]), len = clen[c];
+    const bool kp = !is_cut(rot[q], j, len, ids);
+    keep[q] = kp ? 1u : 0u;
+    end[q] = (kp && (j + 1 == len || is_cut(rot[q + 1], j + 1, len, ids))) ? 1u : 0u;
+}
+__global__ __launch_bounds__(EB) void cut_write_kernel(const uint32_t *rot, uint64_t n, const uint32_t *keep, const uint32_t *end,
+                                                      const uint32_t *kpos, const uint32_t *tpos, uint32_t *tig_edges,
+                                                      unsigned long long *tig_limits) {
+    const uint64_t q = gid();
+    if (q >= n || !keep[q]) return;
+    tig_edges[kpos[q]] = rot[q];
+    if (end[q]) tig_limits[tpos[q]] = (unsigned long long)kpos[q] + 1;
+}
+
+struct Lap {
+    const bool on = std::getenv("MTG_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double lap(const char *what) {
+        const auto n = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(n - t).count();
+        if (on) std::fprintf(stderr, "[mtg] device_finish: %-34s %8.3f ms\n", what, s * 1e3);
+        t = n;
+        return s;
+    }
+};
+
+// The steps from s* on, sequentially, over the residual units (= the reference's loop, mod.rs:526-645, on compact arrays):
+// r_node ascending out-nodes with r_cnt live units each; the in-entry of unit i is mirror(r_node[i]).
+void eulerise_tail(const HostGraph &g, const std::vector<uint32_t> &r_node, std::vector<uint32_t> &cnt, std::vector<uint32_t> &brk_out,
+                   std::vector<uint32_t> &brk_in) {
+    const size_t n = r_node.size();
+    std::vector<uint32_t> in_ord(n);  // indices by in-node ascending
+    std::iota(in_ord.begin(), in_ord.end(), 0u);
+    std::sort(in_ord.begin(), in_ord.end(), [&](uint32_t a, uint32_t b) { return g.mirror[r_node[a]] < g.mirror[r_node[b]]; });
+    int64_t out_cur = (int64_t)n - 1;
+    size_t in_cur = 0;
+    auto first_in = [&](size_t from) {
+        while (from < n && cnt[in_ord[from]] == 0) from++;
+        return from;
+    };
+    for (;;) {
+        while (out_cur >= 0 && cnt[(size_t)out_cur] == 0) out_cur--;
+        if (out_cur < 0) break;
+        const uint32_t oi = (uint32_t)out_cur;
+        in_cur = first_in(in_cur);
+        if (in_cur >= n) MTG_DIE("in_node_iterator.next().unwrap() on an empty map (implementation/mod.rs:262)");
+        size_t pick = in_cur;
+        if (in_ord[pick] == oi && cnt[oi] < 2) {  // t == mirror(o) and OUT[o] > -2 (:263): take the second key
+            pick = first_in(pick + 1);
+            if (pick >= n) MTG_DIE("No further in_nodes left (implementation/mod.rs:553)");
+        }
+        const uint32_t ti = in_ord[pick];
+        brk_out.push_back(r_node[oi]);
+        brk_in.push_back(g.mirror[r_node[ti]]);
+        cnt[oi]--;  // OUT[o] += 1 and IN[mirror o] -= 1 (:582, :628-644)
+        if (cnt[ti] == 0) MTG_DIE("internal error: Euleriser tail picked an exhausted in-node");
+        cnt[ti]--;  // IN[t] -= 1 and OUT[mirror t] += 1 (:583, :609-627)
+    }
+    if (first_in(in_cur) < n) MTG_DIE("in_node_differences not empty after Eulerisation (implementation/mod.rs:648)");
+}
+
+}  // namespace
+
+// Whole finish on device `device_id` for a graph that holds only its original edges: inserts the matched pairs (may be none:
+// eulertigs), Eulerises, decomposes (euler_mode MTG_EULER_DEVICE: on the GPU; MTG_EULER_HOST_REFERENCE_ORDER: host walk over
+// GPU-built records, the reference's order) and cuts. Appends the dummy edges to g's edge arrays (unlinked). times_out[0..5] =
+// seconds of {upload + insertion + Euleriser, host-graph materialisation, Euler decomposition, cut + download}, [4] = kernel ms
+// of the device decomposition, [5] = number of breaking biedges.
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6]) {
+    const uint64_t V = g.node_count(), E0 = g.n_original_edges;
+    if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
+    if (k < 1 || k > 0xFFFFFFFFull) MTG_DIE("device_finish: k out of range");
+    Walks tigs;
+    for (int i = 0; i < 6 && times_out; i++) times_out[i] = 0;
+    if (E0 == 0 && n_pairs == 0) return tigs;
+    if (device_count() <= device_id) MTG_DIE("device_finish: no MI355X/HIP device %d (there is no CPU fallback for this path)", device_id);
+    HIP_CHECK(hipSetDevice(device_id));
+    hipStream_t st = finish_stream(device_id);
+    Lap lap;
+    static_assert(sizeof(Pair) == sizeof(mtg_pair), "pair layout");
+
+    // ---- upload: original darts, mirror, pairs ----
+    Buf b_from0, b_mirror, b_pairs, b_deg, b_cin, b_cout, b_smf, b_pin, b_pout, b_psm, b_bsum, b_small;
+    uint32_t *d_from0 = b_from0.alloc<uint32_t>(st, E0);
+    uint32_t *d_mirror = b_mirror.alloc<uint32_t>(st, V);
+    mtg_pair *d_pairs = b_pairs.alloc<mtg_pair>(st, n_pairs);
+    uint32_t *d_deg = b_deg.alloc<uint32_t>(st, V);
+    if (E0) HIP_CHECK(hipMemcpyAsync(d_from0, g.e_from.data(), E0 * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
+    if (n_pairs) HIP_CHECK(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(mtg_pair), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(d_deg, 0, V * 4, st));
+    if (E0) degree_kernel<<<grid_for(E0), EB, 0, st>>>(d_from0, E0, d_deg);
+    if (n_pairs) pair_degree_kernel<<<grid_for(n_pairs), EB, 0, st>>>(d_pairs, n_pairs, d_mirror, d_deg);
+
+    // ---- imbalance, unit orders ----
+    uint32_t *d_cin = b_cin.alloc<uint32_t>(st, V), *d_cout = b_cout.alloc<uint32_t>(st, V), *d_smf = b_smf.alloc<uint32_t>(st, V);
+    uint32_t *d_pin = b_pin.alloc<uint32_t>(st, V), *d_pout = b_pout.alloc<uint32_t>(st, V), *d_psm = b_psm.alloc<uint32_t>(st, V);
+    uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(std::max<uint64_t>(V, (E0 + 2 * n_pairs) / 2 + 1) * 2) + 2);
+    uint32_t *d_small = b_small.alloc<uint32_t>(st, 16);  // [0] error, [1] N_in, [2] N_out, [3] n_sm, [4] s*, [5] residual nodes, [6..] cut totals
+    HIP_CHECK(hipMemsetAsync(d_small, 0, 64, st));
+    need_kernel<<<grid_for(V), EB, 0, st>>>(V, d_mirror, d_deg, d_cin, d_cout, d_smf);
+    scan_u32<uint32_t>(st, d_cin, V, d_pin, d_bsum, d_small + 1);
+    scan_u32<uint32_t>(st, d_cout, V, d_pout, d_bsum, d_small + 2);
+    scan_u32<uint32_t>(st, d_smf, V, d_psm, d_bsum, d_small + 3);
+    uint32_t h_small[16];
+    HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    b_deg.release();
+    const uint32_t N = h_small[1], n_sm = h_small[3];
+    if (h_small[2] != N) MTG_DIE("device_finish: internal error (missing in-edges %u != missing out-edges %u)", N, h_small[2]);
+    const uint32_t delta = n_sm & 1u, n_sm_edges = (n_sm + 1) / 2;
+    if (delta && N == 0)
+        MTG_DIE("Have an uneven number of self-mirrors, but no other nodes with missing in edges. (implementation/mod.rs:496-498)");
+    // every step removes two units; an odd rest cannot be paired: the reference's iterator runs dry (mod.rs:262)
+    const uint32_t n_steps = (N - delta) / 2;
+    const uint64_t brk_cap = (uint64_t)n_sm_edges + n_steps + ((N - delta) & 1u) + 2;
+    const uint64_t E_cap = E0 + 2 * n_pairs + 2 * brk_cap;
+    if (E_cap >= 0xFFFFFFFEull) MTG_DIE("device_finish: %llu darts do not fit 32-bit ids", (unsigned long long)E_cap);
+
+    Buf b_from, b_pw, b_sm, b_anode, b_bnode;
+    uint32_t *d_from = b_from.alloc<uint32_t>(st, E_cap);
+    uint32_t *d_pw = b_pw.alloc<uint32_t>(st, n_pairs);
+    if (E0) HIP_CHECK(hipMemcpyAsync(d_from, d_from0, E0 * 4, hipMemcpyDeviceToDevice, st));
+    b_from0.release();
+    if (n_pairs) pair_darts_kernel<<<grid_for(n_pairs), EB, 0, st>>>(d_pairs, n_pairs, d_mirror, d_from + E0, d_pw);
+    const uint64_t first_brk = E0 + 2 * n_pairs;
+    uint32_t *d_sm = b_sm.alloc<uint32_t>(st, n_sm);
+    uint32_t *d_anode = b_anode.alloc<uint32_t>(st, N), *d_bnode = b_bnode.alloc<uint32_t>(st, N);
+    if (n_sm) sm_compact_kernel<<<grid_for(V), EB, 0, st>>>(V, d_smf, d_psm, d_sm);
+    if (N) expand_kernel<<<grid_for(V), EB, 0, st>>>(V, d_cin, d_cout, d_pin, d_pout, N, d_anode, d_bnode);
+    if (n_sm) sm_emit_kernel<<<grid_for(n_sm_edges), EB, 0, st>>>(n_sm, d_sm, d_bnode, d_mirror, d_from + first_brk);
+    uint32_t s_star = n_steps;
+    if (n_steps) {
+        HIP_CHECK(hipMemcpyAsync(d_small + 4, &s_star, 4, hipMemcpyHostToDevice, st));
+        zip_check_kernel<<<grid_for(n_steps), EB, 0, st>>>(n_steps, delta, N, d_mirror, d_cin, d_cout, d_pin, d_pout, d_anode, d_bnode, d_small + 4);
+        HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        s_star = h_small[4];
+        if (s_star) zip_emit_kernel<<<grid_for(s_star), EB, 0, st>>>(s_star, delta, d_mirror, d_anode, d_bnode, d_from + first_brk + 2 * (uint64_t)n_sm_edges);
+    }
+    HIP_CHECK(hipGetLastError());
+    uint64_t n_brk = (uint64_t)n_sm_edges + s_star;
+    if ((uint64_t)N - delta - 2 * (uint64_t)s_star > 0) {  // irregular rest: the reference's loop over the residual counters
+        Buf b_resid, b_rflag, b_rpos, b_rnode, b_rcnt;
+        uint32_t *d_resid = b_resid.alloc<uint32_t>(st, V), *d_rflag = b_rflag.alloc<uint32_t>(st, V), *d_rpos = b_rpos.alloc<uint32_t>(st, V);
+        residual_kernel<<<grid_for(V), EB, 0, st>>>(V, s_star, delta, N, d_mirror, d_cout, d_pin, d_pout, d_resid, d_rflag, d_small);
+        scan_u32<uint32_t>(st, d_rflag, V, d_rpos, d_bsum, d_small + 5);
+        HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (h_small[0]) MTG_DIE("device_finish: internal error (Euleriser prefix removed a unit twice)");
+        const uint32_t n_res = h_small[5];
+        uint32_t *d_rnode = b_rnode.alloc<uint32_t>(st, n_res), *d_rcnt = b_rcnt.alloc<uint32_t>(st, n_res);
+        residual_compact_kernel<<<grid_for(V), EB, 0, st>>>(V, d_resid, d_rpos, d_rnode, d_rcnt);
+        std::vector<uint32_t> r_node(n_res), r_cnt(n_res), t_out, t_in;
+        HIP_CHECK(hipMemcpyAsync(r_node.data(), d_rnode, (uint64_t)n_res * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(r_cnt.data(), d_rcnt, (uint64_t)n_res * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        eulerise_tail(g, r_node, r_cnt, t_out, t_in);
+        if (n_brk + t_out.size() > brk_cap) MTG_DIE("device_finish: internal error (more breaking edges than units)");
+        std::vector<uint32_t> t_from(2 * t_out.size());
+        for (size_t i = 0; i < t_out.size(); i++) {
+            t_from[2 * i] = t_out[i];
+            t_from[2 * i + 1] = g.mirror[t_in[i]];
+        }
+        if (!t_from.empty()) HIP_CHECK(hipMemcpyAsync(d_from + first_brk + 2 * n_brk, t_from.data(), t_from.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        n_brk += t_out.size();
+    }
+    const uint64_t E = first_brk + 2 * n_brk, n_dummy = E - E0;
+    b_cin.release(); b_cout.release(); b_smf.release(); b_pin.release(); b_pout.release(); b_psm.release();
+    b_sm.release(); b_anode.release(); b_bnode.release(); b_pairs.release();
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (times_out) { times_out[0] = lap.lap("upload + insertion + Euleriser"); times_out[5] = (double)n_brk; }
+
+    // ---- the dummy edges join the host graph's edge arrays (unlinked: a host stage that walks adjacency links them first) ----
+    {
+        bool long_pair = false;
+        for (uint64_t i = 0; i < n_pairs && !long_pair; i++) long_pair = pairs[i].distance >= k;
+        Buf b_to;
+        uint32_t *d_to = b_to.alloc<uint32_t>(st, n_dummy);
+        if (n_dummy) head_kernel<<<grid_for(n_dummy), EB, 0, st>>>(d_from, d_mirror, E0, E, d_to);
+        HIP_CHECK(hipGetLastError());
+        g.append_unlinked(n_dummy);
+        if (n_dummy) {
+            HIP_CHECK(hipMemcpyAsync(g.e_from.data() + E0, d_from + E0, n_dummy * 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(g.e_to.data() + E0, d_to, n_dummy * 4, hipMemcpyDeviceToHost, st));
+        }
+        parallel_ranges(n_dummy / 2, [&](uint64_t lo, uint64_t hi) {  // meanwhile: weights, dummy ids (1-based, :681 / mod.rs:573)
+            for (uint64_t i = lo; i < hi; i++) {
+                const uint64_t e = E0 + 2 * i;
+                const uint64_t w = i < n_pairs ? pairs[i].distance : k;
+                g.e_weight[e] = g.e_weight[e + 1] = w;
+                g.e_dummy[e] = g.e_dummy[e + 1] = i + 1;
+                g.e_unitig[e] = g.e_unitig[e + 1] = 0;
+                g.e_fwd[e] = 1;
+                g.e_fwd[e + 1] = 0;
+            }
+        });
+        HIP_CHECK(hipStreamSynchronize(st));
+        g.first_breaking_edge = first_brk;
+        g.breaking_weight = k;
+        g.dummies_canonical = !long_pair;
+    }
+    if (times_out) times_out[1] = lap.lap("host graph: dummy edges");
+    if (E == 0) return tigs;
+
+    // ---- Euler bicycles ----
+    Buf b_cyc, b_clen, b_cbase;
+    uint32_t n_cycles = 0;
+    double kernel_ms = 0;
+    if (euler_mode == MTG_EULER_DEVICE) {
+        device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms);
+    } else {
+        Walks cycles;
+        {
+            Buf b_row, b_adj, b_need, b_off, b_tot, b_nodes, b_xe, b_xt;
+            uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1), *d_adj = b_adj.alloc<uint32_t>(st, E);
+            device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr);
+            uint32_t *d_need = b_need.alloc<uint32_t>(st, V), *d_off = b_off.alloc<uint32_t>(st, V), *d_tot = b_tot.alloc<uint32_t>(st, 1);
+            lean_ext_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_need, d_small);
+            scan_u32<uint32_t>(st, d_need, V, d_off, d_bsum, d_tot);
+            uint32_t ext_total = 0;
+            HIP_CHECK(hipMemcpyAsync(&ext_total, d_tot, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (h_small[0] & 8u) {  // a node with more than 65535 out-edges: the simple host formulation (never a de Bruijn graph)
+                b_row.release(); b_adj.release(); b_need.release(); b_off.release();
+                cycles = euler_cycles_generic(g);
+            } else {
+                LeanNode *d_nodes = b_nodes.alloc<LeanNode>(st, V);
+                uint32_t *d_xe = b_xe.alloc<uint32_t>(st, ext_total), *d_xt = b_xt.alloc<uint32_t>(st, ext_total);
+                lean_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_from, d_mirror, d_off, d_nodes, d_xe, d_xt);
+                HIP_CHECK(hipGetLastError());
+                HugeBuf<LeanNode> nodes(V, &g.arena);
+                std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
+                HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
+                if (ext_total) {
+                    HIP_CHECK(hipMemcpyAsync(ext_eid.data(), d_xe, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipMemcpyAsync(ext_to.data(), d_xt, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
+                }
+                HIP_CHECK(hipStreamSynchronize(st));
+                b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
+                lap.lap("walk records (GPU) + download");
+                cycles = euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+            }
+        }
+        n_cycles = (uint32_t)cycles.limits.size();
+        if (cycles.limits.size() >= 0xFFFFFFFFull) MTG_DIE("device_finish: too many cycles");
+        uint32_t *d_cyc = b_cyc.alloc<uint32_t>(st, E / 2);
+        uint32_t *d_clen = b_clen.alloc<uint32_t>(st, n_cycles), *d_cbase = b_cbase.alloc<uint32_t>(st, n_cycles);
+        std::vector<uint32_t> clen(n_cycles), cbase(n_cycles);
+        for (uint32_t c = 0; c < n_cycles; c++) {
+            const uint64_t lo = c ? cycles.limits[c - 1] : 0;
+            cbase[c] = (uint32_t)lo;
+            clen[c] = (uint32_t)(cycles.limits[c] - lo);
+        }
+        if (cycles.edges.size() != E / 2) MTG_DIE("device_finish: internal error (closed walks cover %zu of %llu biedges)", cycles.edges.size(), (unsigned long long)(E / 2));
+        HIP_CHECK(hipMemcpyAsync(d_cyc, cycles.edges.data(), (E / 2) * 4, hipMemcpyHostToDevice, st));
+        if (n_cycles) {
+            HIP_CHECK(hipMemcpyAsync(d_clen, clen.data(), (uint64_t)n_cycles * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(d_cbase, cbase.data(), (uint64_t)n_cycles * 4, hipMemcpyHostToDevice, st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (times_out) { times_out[2] = lap.lap("Euler bicycles"); times_out[4] = kernel_ms; }
+
+    // ---- rotate + cut ----
+    {
+        const uint64_t n = E / 2;
+        const uint32_t *d_cyc = b_cyc.as<uint32_t>(), *d_clen = b_clen.as<uint32_t>(), *d_cbase = b_cbase.as<uint32_t>();
+        Buf b_head, b_hscan, b_rotkey, b_rot, b_keep, b_end, b_kpos, b_tpos, b_te, b_tl;
+        uint32_t *d_head = b_head.alloc<uint32_t>(st, n), *d_hscan = b_hscan.alloc<uint32_t>(st, n);
+        unsigned long long *d_rotkey = b_rotkey.alloc<unsigned long long>(st, n_cycles);
+        uint32_t *d_rot = b_rot.alloc<uint32_t>(st, n);
+        HIP_CHECK(hipMemsetAsync(d_head, 0, n * 4, st));
+        HIP_CHECK(hipMemsetAsync(d_rotkey, 0, (uint64_t)std::max<uint32_t>(n_cycles, 1) * 8, st));
+        cycle_heads_kernel<<<grid_for(n_cycles), EB, 0, st>>>(n_cycles, d_cbase, d_head);
+        scan_u32<uint32_t>(st, d_head, n, d_hscan, d_bsum, d_small + 6);
+        CutIds ids{(uint32_t)E0, (uint32_t)first_brk};
+        rotation_kernel<<<grid_for(n), EB, 0, st>>>(d_cyc, n, d_head, d_hscan, d_cbase, ids, (uint32_t)k, d_pw, d_rotkey);
+        rotate_cycles_kernel<<<grid_for(n), EB, 0, st>>>(d_cyc, n, d_head, d_hscan, d_cbase, d_clen, d_rotkey, d_rot);
+        b_cyc.release();
+        uint32_t *d_keep = b_keep.alloc<uint32_t>(st, n), *d_end = b_end.alloc<uint32_t>(st, n);
+        uint32_t *d_kpos = b_kpos.alloc<uint32_t>(st, n), *d_tpos = b_tpos.alloc<uint32_t>(st, n);
+        cut_flags_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_head, d_hscan, d_cbase, d_clen, ids, d_keep, d_end);
+        scan_u32<uint32_t>(st, d_keep, n, d_kpos, d_bsum, d_small + 7);
+        scan_u32<uint32_t>(st, d_end, n, d_tpos, d_bsum, d_small + 8);
+        HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint64_t n_kept = h_small[7], n_tigs = h_small[8];
+        uint32_t *d_te = b_te.alloc<uint32_t>(st, n_kept);
+        unsigned long long *d_tl = b_tl.alloc<unsigned long long>(st, n_tigs);
+        cut_write_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_keep, d_end, d_kpos, d_tpos, d_te, d_tl);
+        HIP_CHECK(hipGetLastError());
+        tigs.edges.resize(n_kept);
+        tigs.limits.resize(n_tigs);
+        if (n_kept) HIP_CHECK(hipMemcpyAsync(tigs.edges.data(), d_te, n_kept * 4, hipMemcpyDeviceToHost, st));
+        if (n_tigs) HIP_CHECK(hipMemcpyAsync(tigs.limits.data(), d_tl, n_tigs * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (times_out) times_out[3] = lap.lap("rotate + cut + download");
+    b_from.release(); b_mirror.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
+    HIP_CHECK(hipStreamSynchronize(st));
+    finish_trim(device_id, E * 40 + V * 28);
+    return tigs;
+}
+
+}  // namespace mtg

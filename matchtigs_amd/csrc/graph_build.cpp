@@ -5,6 +5,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <thread>
 
 #include "parallel.hpp"
 
@@ -34,24 +35,76 @@ static inline void push_edge(HostGraph &g, uint32_t from, uint32_t to, uint64_t 
 }
 
 uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig) {
+    ensure_linked();
     uint32_t e = (uint32_t)e_from.size();
     push_edge(*this, from, to, weight, dummy_id, unitig, true);
     push_edge(*this, mirror[to], mirror[from], weight, dummy_id, unitig, false);
+    linked_edges = e_from.size();
     return e;
 }
 
-// Appends n dummy biedges (out[i] -> in[i] with weight[i] and dummy id first_dummy_id + 1 + i, each followed by its
-// mirror) exactly as n add_biedge calls would: the edge arrays are filled sequentially, the per-node adjacency lists
-// are then linked by node range in parallel (every node's new edges are prepended in ascending edge id by one thread,
-// so the newest-first iteration order is the same as with one-by-one insertion).
-void HostGraph::add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id,
-                                 uint64_t n) {
+// Links the edges [lo, hi) into the per-node adjacency lists in ascending id, i.e. exactly as one-by-one insertion would
+// (newest first, like petgraph's per-node edge list). One pass partitions the edge ids by node range (a thread per edge range,
+// one bucket per node range), then every node range prepends its edges, edge ranges in ascending order: O(E) reads instead of
+// the O(threads x E) of letting every node-range thread scan all edges.
+static void link_range(const HostGraph &g, uint64_t lo, uint64_t hi) {
+    const uint64_t n = hi - lo, V = g.node_count();
     if (!n) return;
-    const uint64_t base = e_from.size();
-    if (base + 2 * n >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
-    const uint64_t total = base + 2 * n;
+    unsigned T = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (n < (1u << 16) || V < 1024) T = 1;
+    if (T == 1) {
+        for (uint64_t e = lo; e < hi; e++) {
+            const uint32_t f = g.e_from[e];
+            g.e_next_out[e] = g.head_out[f];
+            g.head_out[f] = (uint32_t)e;
+            g.out_deg[f]++;
+        }
+        return;
+    }
+    unsigned shift = 0;
+    while ((((V - 1) >> shift) + 1) > T) shift++;
+    const unsigned NB = (unsigned)(((V - 1) >> shift) + 1);  // node ranges of 2^shift nodes
+    const uint64_t chunk = (n + T - 1) / T;
+    std::vector<std::vector<PodVec<uint32_t>>> bucket(T, std::vector<PodVec<uint32_t>>(NB));
+    parallel_tasks(T, [&](uint64_t i) {
+        const uint64_t a = std::min(hi, lo + i * chunk), b = std::min(hi, a + chunk);
+        auto &mine = bucket[i];
+        for (unsigned j = 0; j < NB; j++) mine[j].reserve((b - a) / NB + ((b - a) / NB) / 4 + 16);
+        for (uint64_t e = a; e < b; e++) mine[g.e_from[e] >> shift].push_back((uint32_t)e);
+    }, T);
+    parallel_tasks(NB, [&](uint64_t j) {
+        for (unsigned i = 0; i < T; i++)
+            for (const uint32_t e : bucket[i][j]) {
+                const uint32_t f = g.e_from[e];
+                g.e_next_out[e] = g.head_out[f];
+                g.head_out[f] = e;
+                g.out_deg[f]++;
+            }
+    }, T);
+}
+
+void HostGraph::ensure_linked() const {
+    const uint64_t total = e_from.size();
+    if (linked_edges >= total) return;
+    link_range(*this, linked_edges, total);
+    linked_edges = total;
+}
+
+void HostGraph::append_unlinked(uint64_t n_new) {
+    const uint64_t total = e_from.size() + n_new;
+    if (total >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
     e_from.resize(total); e_to.resize(total); e_next_out.resize(total);
     e_weight.resize(total); e_dummy.resize(total); e_unitig.resize(total); e_fwd.resize(total);
+}
+
+// Appends n dummy biedges (out[i] -> in[i] with weight[i] and dummy id first_dummy_id + 1 + i, each followed by its
+// mirror) exactly as n add_biedge calls would: the edge arrays are filled by host threads, the per-node adjacency lists
+// are then linked in ascending edge id (link_range), so the newest-first iteration order is the same as with one-by-one insertion.
+void HostGraph::add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id,
+                                 uint64_t n, bool link) {
+    if (!n) return;
+    const uint64_t base = e_from.size();
+    append_unlinked(2 * n);
     parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; i++) {
             const uint64_t e = base + 2 * i;
@@ -63,15 +116,7 @@ void HostGraph::add_biedges_bulk(const uint32_t *out, const uint32_t *in, const 
             e_fwd[e] = 1; e_fwd[e + 1] = 0;
         }
     });
-    parallel_ranges(node_count(), [&](uint64_t nlo, uint64_t nhi) {
-        for (uint64_t e = base; e < total; e++) {
-            const uint32_t f = e_from[e];
-            if (f < nlo || f >= nhi) continue;
-            e_next_out[e] = head_out[f];  // newest first, like petgraph's per-node edge list
-            head_out[f] = (uint32_t)e;
-            out_deg[f]++;
-        }
-    });
+    if (link) ensure_linked();
 }
 
 void HostGraph::reset_to_original() {
@@ -80,15 +125,24 @@ void HostGraph::reset_to_original() {
     dummies_canonical = true;
     const uint64_t total = e_from.size(), keep = n_original_edges;
     if (total == keep) return;
-    parallel_ranges(node_count(), [&](uint64_t nlo, uint64_t nhi) {  // pop per node, newest edge first
-        for (uint64_t e = total; e-- > keep;) {
-            const uint32_t f = e_from[e];
-            if (f < nlo || f >= nhi) continue;
-            if (head_out[f] != e) MTG_DIE("reset_to_original: adjacency list is not in insertion order");
-            head_out[f] = e_next_out[e];
-            out_deg[f]--;
-        }
-    });
+    // pop the linked dummy edges: the newest edge of a node unwinds the node's list down to its newest original edge
+    // (exactly one edge per touched node is the head, so every node is handled by one thread)
+    const uint64_t linked = std::min(linked_edges, total);
+    if (linked > keep)
+        parallel_ranges(linked - keep, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t e = keep + lo; e < keep + hi; e++) {
+                const uint32_t f = e_from[e];
+                if (__atomic_load_n(&head_out[f], __ATOMIC_RELAXED) != e) continue;
+                uint32_t x = (uint32_t)e, c = 0;
+                while (x != NONE && x >= keep) {
+                    x = e_next_out[x];
+                    c++;
+                }
+                __atomic_store_n(&head_out[f], x, __ATOMIC_RELAXED);
+                out_deg[f] -= c;
+            }
+        });
+    linked_edges = std::min(linked_edges, keep);
     e_from.resize(keep); e_to.resize(keep); e_next_out.resize(keep);
     e_weight.resize(keep); e_dummy.resize(keep); e_unitig.resize(keep); e_fwd.resize(keep);
 }
@@ -105,18 +159,11 @@ void HostGraph::validate_pairing() const {
     });
 }
 
-// per-node adjacency lists over edges [0, n_edges) in insertion order (newest first, like petgraph's per-node edge list), linked by
-// node range from host threads: every node's edges are prepended in ascending edge id by exactly one thread
+// per-node adjacency lists over edges [0, n_edges) in insertion order (newest first, like petgraph's per-node edge list)
 static void link_adjacency(HostGraph &g, uint64_t n_edges) {
-    parallel_ranges(g.node_count(), [&](uint64_t nlo, uint64_t nhi) {
-        for (uint64_t e = 0; e < n_edges; e++) {
-            const uint32_t f = g.e_from[e];
-            if (f < nlo || f >= nhi) continue;
-            g.e_next_out[e] = g.head_out[f];
-            g.head_out[f] = (uint32_t)e;
-            g.out_deg[f]++;
-        }
-    });
+    g.linked_edges = 0;
+    g.ensure_linked();
+    (void)n_edges;
 }
 
 HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *from,

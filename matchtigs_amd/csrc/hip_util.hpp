@@ -1,0 +1,156 @@
+// hip_util.hpp -- small device-side building blocks shared by the streaming HIP stages (finish_device.hip,
+// euler_device.hip, synth_device.hip): error check, stream-ordered buffers, a three-phase exclusive scan.
+// Every kernel here is `static`: each translation unit that includes the header gets its own copy.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "host_graph.hpp"
+
+#ifndef HIP_CHECK
+#define HIP_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) MTG_DIE("HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
+    } while (0)
+#endif
+
+namespace mtg {
+namespace hu {
+
+constexpr int EB = 256;  // threads per block of the element-wise kernels
+inline unsigned grid_for(uint64_t n, int block = EB) { return (unsigned)((n + (uint64_t)block - 1) / (uint64_t)block); }
+// global element index of a thread; 64-bit because the dart arrays pass 2^32 - 256 elements at the largest sizes
+__device__ __forceinline__ uint64_t gid() { return (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; }
+
+// ---- exclusive scan u32 -> T (u32 or u64), three phases, 2048 items per block ----
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = EB * SCAN_ITEMS;
+
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *total) {
+    __shared__ T wave_sum[EB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    T base = 0, all = 0;
+    for (int w = 0; w < EB / 64; w++) {
+        if (w < wave) base += wave_sum[w];
+        all += wave_sum[w];
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+template <typename T>
+static __global__ __launch_bounds__(EB) void scan_reduce_kernel(const uint32_t *in, uint64_t n, T *block_sums) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    T s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) s += in[base + i];
+    T total;
+    block_exclusive_scan<T>(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+template <typename T>
+static __global__ __launch_bounds__(EB) void scan_block_sums_kernel(T *block_sums, uint64_t n_blocks, T *total_out) {
+    T carry = 0;
+    for (uint64_t start = 0; start < n_blocks; start += EB) {
+        const uint64_t i = start + threadIdx.x;
+        const T v = i < n_blocks ? block_sums[i] : 0;
+        T total;
+        const T ex = block_exclusive_scan<T>(v, &total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+template <typename T>
+static __global__ __launch_bounds__(EB) void scan_apply_kernel(const uint32_t *in, uint64_t n, const T *block_offsets, T *out) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    T s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    T total;
+    T run = block_offsets[blockIdx.x] + block_exclusive_scan<T>(s, &total);
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+}
+inline uint64_t scan_blocks(uint64_t n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+// out[i] = sum of in[0..i), *d_total = sum of all; `out` may alias `in` when T is uint32_t. block_sums: scan_blocks(n) + 1 elements of T.
+template <typename T>
+static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *block_sums, T *d_total) {
+    const uint64_t nb = scan_blocks(n);
+    if (nb == 0) {
+        HIP_CHECK(hipMemsetAsync(d_total, 0, sizeof(T), st));
+        return;
+    }
+    scan_reduce_kernel<T><<<(unsigned)nb, EB, 0, st>>>(in, n, block_sums);
+    scan_block_sums_kernel<T><<<1, EB, 0, st>>>(block_sums, nb, d_total);
+    scan_apply_kernel<T><<<(unsigned)nb, EB, 0, st>>>(in, n, block_sums, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// Stream-ordered allocation from the device's default memory pool (which the callers tell to keep freed memory: the work
+// arrays of a call cost milliseconds to map afresh, and a driver that finishes graph after graph reuses them).
+struct Buf {
+    void *p = nullptr;
+    hipStream_t st = nullptr;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    ~Buf() { release(); }
+    void release() {
+        if (p) (void)hipFreeAsync(p, st);
+        p = nullptr;
+    }
+    template <typename T>
+    T *alloc(hipStream_t stream, uint64_t n) {
+        release();
+        st = stream;
+        HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), st));
+        return (T *)p;
+    }
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+// One stream per device for the finishing stages, created on first use; the device's default pool keeps freed memory.
+inline hipStream_t finish_stream(int device_id) {
+    static hipStream_t streams[64] = {nullptr};
+    if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
+    if (!streams[device_id]) {
+        HIP_CHECK(hipSetDevice(device_id));
+        HIP_CHECK(hipStreamCreate(&streams[device_id]));
+        hipMemPool_t pool;
+        HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
+        uint64_t keep = UINT64_MAX;
+        HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    }
+    return streams[device_id];
+}
+
+// Hands the pool's cached memory back to the driver when a call worked on more than `threshold` bytes (the next stage's plain
+// hipMalloc cannot use memory the stream-ordered pool is sitting on; small calls keep their arrays mapped for the next one).
+inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 8ull << 30) {
+    if (bytes_used < threshold) return;
+    hipMemPool_t pool;
+    HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
+    HIP_CHECK(hipMemPoolTrimTo(pool, 0));
+}
+
+}  // namespace hu
+}  // namespace mtg

@@ -63,9 +63,13 @@ struct HostGraph {
 
     // ---- graph ----
     std::vector<uint32_t> mirror;    // [V]
-    std::vector<uint32_t> head_out;  // [V] newest outgoing edge (petgraph iteration order: newest first)
-    std::vector<uint32_t> out_deg;   // [V]; in_deg(n) == out_deg(mirror(n)) by the mirror property
-    PodVec<uint32_t> e_from, e_to, e_next_out;  // [E]
+    // Per-node adjacency lists (newest edge first, the petgraph iteration order) cover the edges [0, linked_edges): the device
+    // finish appends its dummy edges to the edge arrays only, and a host stage that walks adjacency calls ensure_linked() first.
+    mutable std::vector<uint32_t> head_out;  // [V] newest outgoing edge among the linked ones
+    mutable std::vector<uint32_t> out_deg;   // [V] over the linked edges; in_deg(n) == out_deg(mirror(n)) by the mirror property
+    PodVec<uint32_t> e_from, e_to;              // [E]
+    mutable PodVec<uint32_t> e_next_out;        // [E]
+    mutable uint64_t linked_edges = 0;
     PodVec<uint64_t> e_weight;                  // [E]
     PodVec<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)
     PodVec<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
@@ -86,8 +90,13 @@ struct HostGraph {
     void reserve_edges(uint64_t n);
     // Appends edge `from -> to` and its mirror `mirror(to) -> mirror(from)` (ids e, e+1).
     uint32_t add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig);
-    // n dummy biedges at once (same result as n add_biedge calls; adjacency linked in parallel by node range)
-    void add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id, uint64_t n);
+    // n dummy biedges at once (same result as n add_biedge calls; adjacency linked in parallel by node range unless !link)
+    void add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id, uint64_t n,
+                          bool link = true);
+    // Grows the edge arrays by n_new (uninitialised) entries WITHOUT linking them; the caller fills e_from .. e_fwd.
+    void append_unlinked(uint64_t n_new);
+    // Links the edges [linked_edges, E) into the adjacency lists, in ascending id (== one-by-one insertion order).
+    void ensure_linked() const;
     void init_nodes(uint64_t n);
     void validate_pairing() const;
     // Pops all edges beyond the original ones (newest first), restoring head_out / out_deg.

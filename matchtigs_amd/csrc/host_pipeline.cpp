@@ -120,6 +120,7 @@ uint64_t insert_pair_edges(HostGraph &g, const Pair *pairs, uint64_t n_pairs) {
 }
 
 bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicycles (call :708)
+    g.ensure_linked();
     std::atomic<bool> ok{true};
     parallel_ranges(g.node_count(), [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++) {
@@ -142,6 +143,7 @@ bool is_eulerian(const HostGraph &g) {  // bigraph decomposes_into_eulerian_bicy
 // ---------------------------------------------------------------------------------------------
 uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
     StageTimer tm;
+    g.ensure_linked();
     const uint64_t V = g.node_count();
     PodVec<int32_t> need(V);
     // find_non_eulerian_binodes_with_differences, :408: per node range, then concatenated in node order
@@ -282,6 +284,7 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
 // The latency-optimised formulation lives in euler_fast.cpp (euler_cycles); this is the simple O(E) one it falls
 // back to for graphs whose node degrees do not fit its records.
 Walks euler_cycles_generic(const HostGraph &g) {
+    g.ensure_linked();
     const uint64_t E = g.edge_count();
     const uint64_t V = g.node_count();
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");

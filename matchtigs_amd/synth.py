@@ -102,6 +102,50 @@ def g_csr(n_binodes: int, seed: int = 1, k: int = 31, mean_out_degree: float = 1
     return Bigraph(mirror, frm[keep].copy(), to[keep].copy(), np.repeat(w[keep_u], 2), k)
 
 
+def g_csr_weight_thresholds(k: int, mean_weight: float) -> np.ndarray:
+    """Integer form of g_csr's weight rule: w = 1 + #{j : x <= T[j]}, x = (bits >> 11) + 1 in [1, 2^53], T descending, len k-1.
+    T[j-1] = the largest x whose numpy weight is still >= j + 1 (found by bisection on the very expression g_csr evaluates, which
+    is monotone in x), so the device generator reproduces numpy's floating-point result exactly."""
+    p = 1.0 / float(mean_weight)
+    if p >= 1.0 or k <= 1:
+        return np.zeros(0, dtype=np.uint64)
+    log1mp = np.log1p(-p)
+
+    def weight_of(x: int) -> int:
+        uni = (np.float64(x - 1) + 1.0) * (1.0 / 9007199254740992.0)
+        return int(min(max(1 + int(np.floor(np.log(uni) / log1mp)), 1), k))
+
+    out = []
+    for j in range(1, k):
+        lo, hi = 0, 1 << 53  # weight_of(lo) >= j + 1 (lo = 0: "none"), weight_of(hi) = 1 < j + 1
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if weight_of(mid) >= j + 1:
+                lo = mid
+            else:
+                hi = mid
+        out.append(lo)
+    return np.array(out, dtype=np.uint64)
+
+
+def g_csr_device(n_binodes: int, seed: int = 1, k: int = 31, mean_out_degree: float = 1.5, mean_weight: float = 8.0,
+                 self_mirror_frac: float = 0.001, max_degree: int = 4, device_id: int = 0):
+    """The same graph as ``g_csr`` generated on the GPU (csrc/synth_device.hip), returned as an ``api.Bigraph`` handle: seconds
+    instead of minutes at the 2^30 / 2^31 sizes. Needs a GPU; the numpy form above is its twin for CPU tests."""
+    import ctypes as C
+
+    from . import _lib, api
+
+    n_sm = int(round(self_mirror_frac * n_binodes))
+    v = 2 * n_binodes + n_sm
+    u = int(round(mean_out_degree * v / 2.0))
+    thr = g_csr_weight_thresholds(k, mean_weight)
+    L = _lib.load()
+    h = L.mtg_synth_g_csr(n_binodes, n_sm, u, seed & 0xFFFFFFFFFFFFFFFF, k, thr.ctypes.data_as(C.c_void_p) if len(thr) else None,
+                          len(thr), max_degree, device_id)
+    return api.Bigraph(h)
+
+
 # --------------------------------------------------------------------------------------
 # G-seq: tiny real de Bruijn graphs (unitigs + links), for spelling / k-mer-set tests
 # --------------------------------------------------------------------------------------
