@@ -138,6 +138,11 @@ void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from,
                       uint64_t *edge_weight, uint64_t *edge_dummy_id, uint64_t *edge_unitig,
                       uint8_t *edge_forwards);
 
+/* The same for the edges [first_edge, first_edge + n_edges) only (large graphs: checks that stream over the edge arrays). */
+void mtg_graph_export_range(const mtg_graph *g, uint64_t first_edge, uint64_t n_edges, uint32_t *edge_from, uint32_t *edge_to,
+                            uint64_t *edge_weight, uint64_t *edge_dummy_id, uint64_t *edge_unitig, uint8_t *edge_forwards);
+uint64_t mtg_graph_original_edge_count(const mtg_graph *g); /* edges before any dummy edge (2 x unitigs) */
+
 /* ---- device stage ---------------------------------------------------------------------- */
 /* Uploads the original edges to GPU `device_id` and builds the 64-byte family blocks for bound k-1 there.
  * Aborts if no GPU is present (there is no CPU path). Weights must be >= 1 for algorithm 5

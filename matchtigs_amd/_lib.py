@@ -138,6 +138,8 @@ def load():
         "mtg_graph_node_count": (u64, [vp]),
         "mtg_graph_edge_count": (u64, [vp]),
         "mtg_graph_export": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "mtg_graph_export_range": (None, [vp, u64, u64, vp, vp, vp, vp, vp, vp]),
+        "mtg_graph_original_edge_count": (u64, [vp]),
         "mtg_device_create": (vp, [vp, u64, C.c_int]),
         "mtg_device_free": (None, [vp]),
         "mtg_device_graph_bytes": (u64, [vp]),

@@ -259,6 +259,23 @@ class Bigraph:
                                              "edge_unitig", "edge_forwards")])
         return out
 
+    _EXPORT_FIELDS = (("edge_from", np.uint32), ("edge_to", np.uint32), ("edge_weight", np.uint64), ("edge_dummy_id", np.uint64),
+                      ("edge_unitig", np.uint64), ("edge_forwards", np.uint8))
+
+    def export_mirror(self) -> np.ndarray:
+        m = np.empty(self.node_count(), np.uint32)
+        self._L.mtg_graph_export(self._h, _ptr(m), None, None, None, None, None, None)
+        return m
+
+    def original_edge_count(self) -> int:
+        return int(self._L.mtg_graph_original_edge_count(self._h))
+
+    def export_range(self, first_edge: int, n_edges: int, fields: Sequence[str]) -> dict:
+        """Selected edge arrays of the edges [first_edge, first_edge + n_edges) (mtg_graph_export_range)."""
+        out = {name: np.empty(n_edges, dt) for name, dt in self._EXPORT_FIELDS if name in fields}
+        self._L.mtg_graph_export_range(self._h, first_edge, n_edges, *[_ptr(out.get(name)) for name, _ in self._EXPORT_FIELDS])
+        return out
+
     def edge_data(self, e: int, _cache={}) -> MatchtigEdgeData:
         ex = self.export()
         return MatchtigEdgeData(int(ex["edge_unitig"][e]), bool(ex["edge_forwards"][e]), int(ex["edge_weight"][e]),

@@ -124,6 +124,21 @@ void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from,
     if (edge_forwards && E) std::memcpy(edge_forwards, h.e_fwd.data(), E);
 }
 
+void mtg_graph_export_range(const mtg_graph *g, uint64_t first_edge, uint64_t n_edges, uint32_t *edge_from, uint32_t *edge_to,
+                            uint64_t *edge_weight, uint64_t *edge_dummy_id, uint64_t *edge_unitig, uint8_t *edge_forwards) {
+    const HostGraph &h = g->g;
+    if (first_edge > h.edge_count() || n_edges > h.edge_count() - first_edge) MTG_DIE("mtg_graph_export_range: range exceeds the %llu edges", (unsigned long long)h.edge_count());
+    if (!n_edges) return;
+    const size_t o = first_edge, n = n_edges;
+    if (edge_from) std::memcpy(edge_from, h.e_from.data() + o, n * 4);
+    if (edge_to) std::memcpy(edge_to, h.e_to.data() + o, n * 4);
+    if (edge_weight) std::memcpy(edge_weight, h.e_weight.data() + o, n * 8);
+    if (edge_dummy_id) std::memcpy(edge_dummy_id, h.e_dummy.data() + o, n * 8);
+    if (edge_unitig) std::memcpy(edge_unitig, h.e_unitig.data() + o, n * 8);
+    if (edge_forwards) std::memcpy(edge_forwards, h.e_fwd.data() + o, n);
+}
+uint64_t mtg_graph_original_edge_count(const mtg_graph *g) { return g->g.n_original_edges; }
+
 // ---- device stage ----
 mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id) {
     if (!g || !g->g.built) MTG_DIE("mtg_device_create: graph is not built");
