@@ -11,29 +11,34 @@ import numpy as np
 CHUNK = 1 << 28
 
 
-def check_candidates(torch, bufs, out_nodes, is_in_node, k):
-    """bufs: torch_glue.CandidateBuffers (device tensors); out_nodes / is_in_node: numpy classification. Returns #candidates."""
+def check_candidates(torch, bufs, out_nodes, is_in_node, k, chunk_sources=1 << 26):
+    """bufs: torch_glue.CandidateBuffers (device tensors); out_nodes / is_in_node: numpy classification. Returns #candidates.
+    Sources are taken in chunks so that the check's own tensors stay small next to a 110-GB device graph."""
     dev = bufs.pool.device
-    n = bufs.n
-    cnt = bufs.count[:n].to(torch.int64)
-    tot = int(cnt.sum())
-    if tot == 0:
-        return 0
-    seg_begin = torch.cumsum(cnt, 0) - cnt
-    src = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
-    idx = bufs.start[:n][src] + (torch.arange(tot, device=dev) - seg_begin[src])
-    keys = bufs.pool[idx]
-    del idx
-    same = src[1:] == src[:-1]
-    assert bool((keys[1:][same] > keys[:-1][same]).all()), "candidate keys not strictly ascending per source"
-    del same
-    nodes, dist = keys & 0xFFFFFFFF, keys >> 32
     live = torch.from_numpy(np.ascontiguousarray(is_in_node)).to(dev)
-    assert bool(live[nodes].bool().all()), "a candidate is not an initial in-node"
-    assert int(dist.min()) >= 1 and int(dist.max()) <= k - 1
-    on = torch.from_numpy(out_nodes.astype(np.int64)).to(dev)
-    assert bool((nodes != on[src]).all()), "a source lists itself"
-    return tot
+    total = 0
+    for lo in range(0, bufs.n, chunk_sources):
+        hi = min(bufs.n, lo + chunk_sources)
+        cnt = bufs.count[lo:hi].to(torch.int64)
+        tot = int(cnt.sum())
+        if tot == 0:
+            continue
+        total += tot
+        seg_begin = torch.cumsum(cnt, 0) - cnt
+        src = torch.repeat_interleave(torch.arange(hi - lo, device=dev), cnt)
+        idx = bufs.start[lo:hi][src] + (torch.arange(tot, device=dev) - seg_begin[src])
+        keys = bufs.pool[idx]
+        del idx, seg_begin, cnt
+        same = src[1:] == src[:-1]
+        assert bool((keys[1:][same] > keys[:-1][same]).all()), "candidate keys not strictly ascending per source"
+        del same
+        nodes, dist = keys & 0xFFFFFFFF, keys >> 32
+        assert bool(live[nodes].bool().all()), "a candidate is not an initial in-node"
+        assert int(dist.min()) >= 1 and int(dist.max()) <= k - 1
+        on = torch.from_numpy(out_nodes[lo:hi].astype(np.int64)).to(dev)
+        assert bool((nodes != on[src]).all()), "a source lists itself"
+        del keys, nodes, dist, on, src
+    return total
 
 
 def check_tigs(torch, G, lim, edges, k, device="cuda"):

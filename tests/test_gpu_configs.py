@@ -2,9 +2,10 @@
 
 configs[0]  E. coli K-12 BCALM2 unitigs k=31, --greedytigs-fa-out : SURVEY 8d stand-in G-seq(L = 4.6e6, H = 4, p = 0.02, k = 31),
             end to end through the BCALM2 file route; FASTA bytes == oracle, k-mer set preserved.
-configs[3]  human whole genome k=31 : G-csr stand-in at |E| = 2^27 (the bench.py default; 2^30 does not fit a test run's time
-            budget), through the size-independent properties of test_full_bench_size_properties + GPU/host claim-loop parity.
-configs[4]  661k-bacteria pangenome (|E| = 2^31, node ids at the u32 edge): not run -- the device graph alone is 128-256 GB.
+configs[3]  human whole genome k=31 : G-csr stand-in at |E| = 2^27 (the bench.py default, reference-order finish) AND at SURVEY 8d's
+            nominal 2^30, through the size-independent properties of tests/gpu_props.py + GPU/host claim-loop parity.
+configs[4]  661k-bacteria pangenome : G-csr stand-in at |E| = 2^31 (node ids at the u32 edge, 2.98 G darts after the finish), GPU
+            stages + device finish + properties. The 2^30 / 2^31 cases skip on a box without the HBM / host memory they need.
 configs[1] / configs[2] are covered at their sizes by test_gpu_parity.py::test_full_bench_size_properties,
 test_gpu_replay.py::test_gpu_replay_full_bench_size and test_gpu_euler.py::test_device_euler_full_bench_size."""
 import gc
@@ -66,57 +67,88 @@ def test_config0_ecoli_like_bcalm2_to_greedytigs_fasta(gpu, oracle, tmp_path):
           f"{int(ua.off[-1])} -> {int(off[-1])} characters; oracle queries {st['queries']}")
 
 
-def test_config3_human_like_2pow27_properties(gpu):
+def _free_memory_gb(torch):
+    """(free HBM, host memory this process may still use) in GB; the host side honours a cgroup limit if there is one."""
+    gc.collect()
+    torch.cuda.empty_cache()
+    free_hbm = torch.cuda.mem_get_info()[0] / 1e9
+    avail = None
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            avail = int(line.split()[1]) * 1024 / 1e9
+    try:
+        limit = Path("/sys/fs/cgroup/memory.max").read_text().strip()
+        stat = dict(line.split() for line in Path("/sys/fs/cgroup/memory.stat").read_text().splitlines())
+        used = int(stat.get("anon", 0)) + int(stat.get("shmem", 0))  # (page cache is reclaimable and does not count)
+        if limit != "max":
+            avail = min(avail, (int(limit) - used) / 1e9)
+    except (OSError, ValueError):
+        pass
+    return free_hbm, avail
+
+
+def _stand_in(gpu, log2_edges, hbm_gb, host_gb, host_replay_check, euler_mode):
+    """One G-csr stand-in through the whole HIP path: generated on the GPU, device graph, classification, SSSP, GPU claim replay,
+    finish (insertion + Euleriser + Euler bicycles + cut on the GPU), every stage checked by tests/gpu_props.py."""
+    import gpu_props
     from matchtigs_amd import api, synth, torch_glue
 
+    torch = gpu
+    free_hbm, free_host = _free_memory_gb(torch)
+    if free_hbm < hbm_gb or free_host < host_gb:
+        pytest.skip(f"2^{log2_edges} stand-in needs {hbm_gb} GB of free HBM and {host_gb} GB of host memory; this box has {free_hbm:.0f} / {free_host:.0f}")
     k = 31
-    bg = synth.g_csr(int((1 << 27) / 1.5 / 2), seed=1, k=k)
-    n_orig, V = bg.n_edges, bg.n_nodes
-    unitig_kmers = int(bg.edge_weight[0::2].sum())
-    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
-    del bg
-    gc.collect()
+    G = synth.g_csr_device(int((1 << log2_edges) / 1.5 / 2), seed=1, k=k)
+    n_orig, V = G.edge_count(), G.node_count()
     dev = api.DeviceGraph(G, k)
     stream = torch_glue.current_stream_ptr()
     S = dev.classify(stream)
     bufs = torch_glue.run_sssp(dev, 0, S)
+    levels = dev.last_sssp_levels()
     gpu_pairs = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), stream)
-    start, count, pool = torch_glue.candidates_to_numpy(bufs)
+    rounds = dev.last_replay_rounds()
     on, mu, li = dev.classify_download()
-    # candidate lists: strictly ascending keys per source, targets only, bound respected, source excluded
-    cnt64 = count.astype(np.int64)
-    tot = int(cnt64.sum())
-    seg_begin = np.cumsum(cnt64) - cnt64
-    idx = np.repeat(start.astype(np.int64), cnt64) + (np.arange(tot, dtype=np.int64) - np.repeat(seg_begin, cnt64))
-    keys = pool[idx]
-    del idx
-    seg_first = np.zeros(tot, bool)
-    seg_first[seg_begin[cnt64 > 0]] = True
-    assert (np.diff(keys.astype(np.int64))[~seg_first[1:]] > 0).all()
-    nodes, dist = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64), (keys >> np.uint64(32)).astype(np.int64)
-    assert li[nodes].all() and dist.min() >= 1 and dist.max() <= k - 1
-    assert (nodes != np.repeat(on.astype(np.int64), cnt64)).all()
-    del keys, nodes, dist, seg_first
-    # T2 at this size: the GPU claim loop equals the host claim loop on the same lists
-    host_pairs = G.replay_claims(on, mu, li, start, count, pool)
-    assert len(gpu_pairs) == len(host_pairs) and all(np.array_equal(gpu_pairs[f], host_pairs[f]) for f in ("out", "in", "dist"))
-    del host_pairs, start, count, pool, bufs
+    n_cand = gpu_props.check_candidates(torch, bufs, on, li, k)
+    if host_replay_check:  # T2 at this size: the GPU claim loop equals the host claim loop on the same lists
+        start, count, pool = torch_glue.candidates_to_numpy(bufs)
+        host_pairs = G.replay_claims(on, mu, li, start, count, pool)
+        assert len(gpu_pairs) == len(host_pairs) and all(np.array_equal(gpu_pairs[f], host_pairs[f]) for f in ("out", "in", "dist"))
+        del host_pairs, start, count, pool
+    del bufs, on, mu, li, dev
     gc.collect()
-    lim, edges = api.finish_greedytigs_np(G, gpu_pairs, k)
-    ex = G.export()
-    orig = edges[edges < n_orig]
-    assert len(orig) == n_orig // 2
-    seen = np.zeros(n_orig // 2, np.uint8)
-    seen[orig >> 1] = 1
-    assert seen.all()                                                    # every unitig exactly once, in one orientation
-    starts = np.r_[0, lim[:-1]].astype(np.int64)
-    assert (edges[starts] < n_orig).all() and (edges[lim.astype(np.int64) - 1] < n_orig).all()
-    w = ex["edge_weight"][edges[edges >= n_orig]]
-    assert (w >= 1).all() and (w <= k - 1).all()                         # only matched dummies survive inside tigs
-    outd = np.bincount(ex["edge_from"], minlength=V)
-    ind = np.bincount(ex["edge_to"], minlength=V)
-    sm = ex["mirror"] == np.arange(V)
-    assert (outd[~sm] == ind[~sm]).all() and (outd[sm] % 2 == 0).all()   # Eulerian after Eulerisation
-    cum = int(ex["edge_weight"][edges].sum()) + (k - 1) * len(lim)
-    assert cum == unitig_kmers + int(w.sum()) + (k - 1) * len(lim)       # cumulative-length identity
-    print(f"config3 stand-in: V={V} E={n_orig} S={S} pairs={len(gpu_pairs)} tigs={len(lim)} replay rounds={dev.last_replay_rounds()}")
+    torch.cuda.empty_cache()
+    lim, edges = api.finish_greedytigs_np(G, gpu_pairs, k, euler_mode)
+    E_total = G.edge_count()
+    cum, dummy_kmers = gpu_props.check_tigs(torch, G, lim, edges, k)
+    print(f"2^{log2_edges} stand-in: V={V} E={n_orig} S={S} candidates={n_cand} pairs={len(gpu_pairs)} replay rounds={rounds} "
+          f"darts after the finish={E_total} tigs={len(lim)} cumulative length={cum}; SSSP levels {[(l['sources'], round(l['ms'], 2)) for l in levels]}")
+    return dict(V=V, E=n_orig, tigs=len(lim), cum=cum, E_total=E_total, pairs=len(gpu_pairs))
+
+
+def test_config3_human_like_2pow27_properties(gpu):
+    """configs[3] at the bench's size, finish in the reference's walk order (the default)."""
+    from matchtigs_amd import api
+
+    r = _stand_in(gpu, 27, 40, 40, True, api.EulerMode.HostReferenceOrder)
+    assert r["E"] == 130045206 and r["tigs"] == 23687715 and r["cum"] == 1294322592
+
+
+def test_config3_human_like_2pow30_full_size(gpu):
+    """BASELINE configs[3] (human whole genome, k = 31) at SURVEY 8d's nominal size: |V| = 716 M, |E| = 1.04 G, 270 M sources on
+    ONE GPU; GPU-vs-host claim parity at that size; the finish in device Euler mode (the reference-order walk at this size takes
+    150 s: tools/scale_probe.py --euler host, profiles/r03_scale_probe_2p30_exact.json -- same tig count and cumulative length)."""
+    from matchtigs_amd import api
+
+    r = _stand_in(gpu, 30, 170, 140, True, api.EulerMode.Device)
+    assert r["E"] == 1040327706 and r["tigs"] == 189468154 and r["cum"] == 10353599420
+
+
+def test_config4_pangenome_like_2pow31(gpu):
+    """BASELINE configs[4] (661k-bacteria pangenome, ~10^9 unitigs) as its G-csr stand-in: |V| = 1.43 G, |E| = 2.08 G, 539 M
+    sources, node ids up to 1.43e9 and 2.98 G darts after the finish (beyond 2^31: the dart ids use all 32 bits) on ONE GPU."""
+    from matchtigs_amd import api
+
+    r = _stand_in(gpu, 31, 262, 190, False, api.EulerMode.Device)
+    assert r["E"] == 2080660578 and r["E_total"] == 2984426052 and r["tigs"] == 378964208
+
+
