@@ -41,15 +41,21 @@ def workload_key(args, world: int) -> str:
     return f"g_csr:log2_edges={args.log2_edges}:k={args.k}:seed={args.seed}:plan={args.plan}:gpus={world}"
 
 
-def traffic_bytes(args, world: int):
-    """HBM bytes per SSSP stage: --traffic-bytes, else the committed PMC measurement (separate rocprofv3 --pmc passes of this
-    very command, profiles/traffic.json) for exactly this workload, else null."""
+def traffic_bytes(args, world: int, level_names: list):
+    """(HBM bytes per SSSP stage, note): --traffic-bytes, else the committed PMC measurement (separate rocprofv3 --pmc passes of
+    this very command, profiles/traffic.json) for exactly this workload -- but only while the kernels it was measured on are
+    the kernels that ran (the entry's `levels` = mtg_last_sssp_level_name of the profiled run); a stale entry gives null."""
     if args.traffic_bytes is not None:
-        return args.traffic_bytes
+        return args.traffic_bytes, "--traffic-bytes"
     try:
-        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(workload_key(args, world), {}).get("traffic_bytes")
+        entry = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(workload_key(args, world))
     except (OSError, ValueError):
-        return None
+        return None, "profiles/traffic.json unreadable"
+    if not entry:
+        return None, "no PMC pass committed for this workload"
+    if entry.get("levels") != level_names:
+        return None, f"stale: PMC pass was taken on {entry.get('levels')}, this run used {level_names}"
+    return entry.get("traffic_bytes"), entry.get("source")
 
 
 def size_label(log2_edges: int) -> str:
@@ -61,6 +67,22 @@ def size_label(log2_edges: int) -> str:
     if log2_edges <= 29:
         return "human-like"
     return "human-like (full) / pangenome-like"
+
+
+def host_cores() -> int:
+    """CPU cores this process may really use: the cgroup quota if there is one (16 on a 1-GPU box of the pool), else the count."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return n
 
 
 def main():
@@ -75,13 +97,16 @@ def main():
     ap.add_argument("--genome-length", type=int, default=4_600_000, help="G-seq: genome length (4 haplotypes, 2 %% substitutions)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--extra-seeds", default="2,3", help="G-csr, N = 1: further seeds whose SSSP stage is timed after the main run (SURVEY 8d: seeds {1,2,3})")
     ap.add_argument("--plan", type=int, default=0, help="SSSP level plan: 0 = default (enumeration level + cascade), 1 = cascade only")
-    ap.add_argument("--euler-device-steps", type=int, default=1,
-                    help="untimed extra steps in device Euler mode after the timed region, reported as euler_device_ms_per_step")
+    ap.add_argument("--device-mode-steps", type=int, default=None,
+                    help="timed steps of the second mode (device Euler decomposition) after the headline region, reported as "
+                         "the device_mode block (default: as many as --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
     ap.add_argument("--host-replay", action="store_true", help="run the claim loop on the host instead of the GPU (A/B)")
+    ap.add_argument("--host-finish", action="store_true", help="run insertion / Euleriser / cut on the host instead of the GPU (A/B)")
     ap.add_argument("--euler", choices=["host", "device"], default="host",
                     help="host = Euler walk in the reference's order (default, bit-exact tigs); device = parallel Euler "
                          "bicycles on the GPU (SURVEY 8 f-3: valid walks, same #tigs/cumulative length, different order)")
@@ -108,32 +133,32 @@ def main():
     from matchtigs_amd import distributed as mdist
 
     k = args.k
-    # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned
+    # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned.
+    # G-csr is generated ON each rank's GPU (csrc/synth_device.hip, the twin of synth.g_csr): seconds, no numpy argsort.
     t_gen = time.perf_counter()
     if args.workload == "g_seq":
         ua = synth.g_seq_arrays(args.genome_length, seed=args.seed, k=k, haplotypes=4, sub_rate=0.02)
         graph = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
-        ex = graph.export()
-        bg = synth.Bigraph(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"], k)
         workload = (f"G-seq REAL compacted de Bruijn graph: random genome L={args.genome_length}, 4 haplotypes, 2% substitutions, "
                     f"k={k}, {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers (clib.rs graph construction), seed={args.seed}")
-        del ua, ex
+        del ua
     else:
-        bg = synth.g_csr(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k)
-        graph = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        graph = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k, device_id=local_rank)
         workload = (f"G-csr random bidirected de Bruijn-like unitig graph ({size_label(args.log2_edges)}, 2^{args.log2_edges} nominal "
-                    f"edges), k={k}, seed={args.seed}")
+                    f"edges), k={k}, seed={args.seed}, generated on the GPU")
+    n_nodes, n_edges = graph.node_count(), graph.edge_count()
     t_graph = time.perf_counter() - t_gen
     dev = api.DeviceGraph(graph, k, local_rank)  # H2D: inputs resident in HBM before any timed region
     dev.set_plan(args.plan)
+    if rank != 0:  # only rank 0 finishes: the other ranks keep the device copy and give the host graph back
+        dev.graph = None
+        graph = None
     euler_mode = api.EulerMode.Device if args.euler == "device" else api.EulerMode.HostReferenceOrder
+    finish_stage = api.FinishStage.Host if args.host_finish else api.FinishStage.Auto
     t_gen = time.perf_counter() - t_gen
     stream = torch_glue.current_stream_ptr()
 
     bufs = None
-    kernel_ms: list[float] = []
-    level_ms: list[list[dict]] = []
-    phases_acc: dict[str, float] = {}
     result_info: dict = {}
 
     def sync_barrier():
@@ -141,18 +166,16 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # static source partition: contiguous blocks of equal estimated work (1 + out-degree of the source node);
-    # classification is a function of the graph, so the split is computed once, before the timed region
+    # static source partition: contiguous blocks of equal estimated work (1 + out-degree of the source node),
+    # computed on the GPU (mtg_partition_sources); classification is a function of the graph, so the split is computed once,
+    # before the timed region, and every rank gets the same cuts
     ranges_by_work = None
     if world > 1:
-        S0 = dev.classify(stream)
-        on0, _, _ = dev.classify_download(stream)
-        outdeg = np.bincount(bg.edge_from, minlength=bg.n_nodes)
-        ranges_by_work = mdist.partition_sources_by_work(1 + outdeg[on0[:S0]], world)
+        dev.classify(stream)
+        cuts = api.partition_sources(dev, world)
+        ranges_by_work = [(cuts[r], cuts[r + 1]) for r in range(world)]
 
-    euler_mode_now = [euler_mode]
-
-    def step(record: bool):
+    def step(mode, acc, kernel_ms=None, level_ms=None):
         nonlocal bufs
         ph = {}
         t0 = time.perf_counter()
@@ -167,7 +190,7 @@ def main():
         bufs = torch_glue.run_sssp(dev, lo, hi, bufs)
         t2 = time.perf_counter()
         ph["sssp"] = t2 - t1
-        if record:
+        if kernel_ms is not None:
             kernel_ms.append(dev.last_sssp_kernel_ms())
             level_ms.append(dev.last_sssp_levels())
         if world > 1:
@@ -193,47 +216,55 @@ def main():
                 result_info["replay_visits"] = dev.last_replay_visits()
             t5 = time.perf_counter()
             ph["replay"] = t5 - t4
-            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, euler_mode_now[0], local_rank)
+            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, mode, local_rank, finish_stage)
             t6 = time.perf_counter()
-            ph["eulerise_euler_cut"] = t6 - t5
+            ph["finish"] = t6 - t5
             hp = api.last_phase_seconds()
-            ph["host_eulerise"], ph["host_euler"], ph["host_cut"] = hp["eulerise"], hp["euler"], hp["cut"]
-            if euler_mode_now[0] == api.EulerMode.Device:
+            # insertion + Euleriser (on the GPU unless --host-finish), Euler bicycles (reference-order host walk over GPU-built
+            # records, or the device decomposition), rotate + cut (GPU) + tig download
+            ph["insert_eulerise"], ph["euler"], ph["cut"] = hp["eulerise"], hp["euler"], hp["cut"]
+            if mode == api.EulerMode.Device:
                 ph["euler_device_kernels"] = api.last_euler_kernel_ms() * 1e-3
             result_info.update(S=int(S), pairs=int(len(pairs)), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
                                candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
+            del tigs_lim, tigs_edges
             graph.reset()
             ph["reset"] = time.perf_counter() - t6
-        if record:
-            for kk, v in ph.items():
-                phases_acc[kk] = phases_acc.get(kk, 0.0) + v
+        for kk, v in ph.items():
+            acc[kk] = acc.get(kk, 0.0) + v
 
-    for _ in range(args.warmup):
-        step(False)
-    sync_barrier()
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync_barrier()
-    elapsed = time.perf_counter() - t_begin
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    def timed_region(mode, n_warm, n_steps, kernel_ms=None, level_ms=None):
+        acc: dict[str, float] = {}
+        for _ in range(n_warm):
+            step(mode, {})
+        sync_barrier()
+        t_begin = time.perf_counter()
+        for _ in range(n_steps):
+            step(mode, acc, kernel_ms, level_ms)
+        sync_barrier()
+        elapsed = time.perf_counter() - t_begin
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed / max(n_steps, 1) * 1e3, acc
 
-    # ---- secondary figure: the same step with the parallel Euler decomposition on the GPU (untimed region) ----
-    euler_device_ms = None
-    if args.euler == "host" and args.euler_device_steps > 0:
-        euler_mode_now[0] = api.EulerMode.Device
-        step(False)
-        sync_barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.euler_device_steps):
-            step(False)
-        sync_barrier()
-        euler_device_ms = (time.perf_counter() - t0) / args.euler_device_steps * 1e3
-        euler_mode_now[0] = euler_mode
+    # ---- second mode, first class: the same step with the parallel Euler decomposition on the GPU, in its own timed region.
+    # It runs BEFORE the headline region: the two modes use different sets of device work arrays, and the runtime's stream-ordered
+    # pool serves a mode best right after that mode's own warm-up step. ----
+    device_mode = None
+    dm_steps = args.steps if args.device_mode_steps is None else args.device_mode_steps
+    if args.euler == "host" and dm_steps > 0:
+        dm_ms, dm_acc = timed_region(api.EulerMode.Device, 1, dm_steps)
+        device_mode = {"steps": dm_steps, "ms_per_step": round(dm_ms, 3),
+                       "phases_ms": {kk: round(v / dm_steps * 1e3, 3) for kk, v in dm_acc.items()},
+                       "tigs": result_info.get("tigs"),
+                       "note": "every stage of the step on the GPU; tig order differs from the reference's, tig count and cumulative length are equal (DESIGN 3.6)"}
+
+    # ---- the headline: K timed steps in the selected mode (default: the reference's walk order, bit-exact tigs) ----
+    kernel_ms: list[float] = []
+    level_ms: list[list[dict]] = []
+    ms_per_step, phases_acc = timed_region(euler_mode, args.warmup, args.steps, kernel_ms, level_ms)
 
     # ---- units of work (untimed counting kernel over this rank's block) ----
     S = dev.n_sources
@@ -242,15 +273,18 @@ def main():
     local_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
     tot = torch.tensor([stats["relaxed_edges"], stats["settled_nodes"], stats["emitted"], stats["relax_attempts"],
                         stats["overflow_sources"]], dtype=torch.int64, device="cuda")
-    kmax = torch.tensor([local_kernel_ms], dtype=torch.float64, device="cuda")
+    # per-N scaling figures of the stages that DO shard (the whole step is bound by rank 0's finish): max over ranks
+    kmax = torch.tensor([local_kernel_ms, phases_acc.get("sssp", 0.0) / max(args.steps, 1) * 1e3,
+                         phases_acc.get("allgather", 0.0) / max(args.steps, 1) * 1e3], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     tot = [int(x) for x in tot.tolist()]
+    kmax = [float(x) for x in kmax.tolist()]
     total_stats = dict(relaxed_edges=tot[0], settled_nodes=tot[1], emitted=tot[2], relax_attempts=tot[3], overflow_sources=tot[4])
 
     if rank == 0:
-        # roofline of the dominant kernel (sssp_kernel, level 0) on THIS rank's launch
+        # roofline of the dominant GPU stage (the SSSP stage = its level kernels) on THIS rank's launch
         alg_bytes = algorithmic_bytes(stats)
         achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
         kernels = []
@@ -260,11 +294,12 @@ def main():
                 kernels.append({"kernel": vals[0].get("kernel", f"level{li}"),
                                 "avg_launch_ms": round(float(np.mean([v["ms"] for v in vals])), 4),
                                 "sources": int(vals[0]["sources"])})
+        traffic, traffic_note = traffic_bytes(args, world, [kk["kernel"] for kk in kernels])
         roofline = {
             "bound": "hbm", "kernel": "SSSP stage = sum of its level kernels (see 'kernels')", "kernels": kernels,
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": traffic_bytes(args, world),
+            "traffic": traffic, "traffic_note": traffic_note,
             "gather_ceiling_note": "dependent random 64-B block gathers saturate at ~54 G/s below 3 GB of blocks and at ~44 G/s (one request "
                                    "per lane and line; 19 G/s with four) at 5.7 GB, tools/gather_bench_tlb.hip: floor for the enumeration "
                                    "level = visited family blocks (~0.55 x settled_nodes) / that rate",
@@ -274,23 +309,33 @@ def main():
         }
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
+            ex = graph.export()
+            bg = synth.Bigraph(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"], k)
+            del ex
             cpu_baseline = run_cpu_baseline(bg, k, args.cpu_baseline_seconds, dev, stream, total_stats["relaxed_edges"])
+            del bg
             gpu_stage_s = sum(phases_acc.get(kk, 0.0) for kk in ("classify", "sssp", "allgather", "download", "replay")) / max(args.steps, 1)
             cpu_baseline["gpu_same_stage_edges_per_s"] = round(total_stats["relaxed_edges"] / max(gpu_stage_s, 1e-9), 1)
+        extra_seeds = None
+        if world == 1 and args.workload == "g_csr" and args.extra_seeds:
+            extra_seeds = sssp_stage_of_seeds(args, [int(x) for x in args.extra_seeds.split(",") if x.strip()], local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {
             "metric": "greedy-matchtigs SSSP edges/s (whole hot-path step: classify+SSSP+claim+Euler+cut)",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "wall_clock_s": round(ms_per_step / 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
-            "config": {"workload": f"{workload}; |V|={bg.n_nodes}, |E|={bg.n_edges}; sources block-partitioned over ranks",
-                       "V": bg.n_nodes, "E": bg.n_edges, "k": k, "sources": result_info.get("S"),
+            "config": {"workload": f"{workload}; |V|={n_nodes}, |E|={n_edges}; sources block-partitioned over ranks",
+                       "V": n_nodes, "E": n_edges, "k": k, "sources": result_info.get("S"),
                        "pairs": result_info.get("pairs"), "tigs": result_info.get("tigs"),
                        "candidates": result_info.get("candidates"), "parallelism": f"sources/{world}"},
             "units_per_step": total_stats,
             "phases_ms": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in phases_acc.items()},
             "euler_mode": args.euler,
-            "euler_device_ms_per_step": None if euler_device_ms is None else round(euler_device_ms, 3),
+            "device_mode": device_mode,
+            "euler_device_ms_per_step": None if device_mode is None else device_mode["ms_per_step"],
+            # the stages that shard over ranks, max over ranks (the whole-step curve is flat by design: rank 0 finishes alone)
+            "scaling_stages_ms": {"sssp_kernels": round(kmax[0], 4), "sssp_stage": round(kmax[1], 4), "allgather": round(kmax[2], 4)},
             "level0_finish_rate": (round(1.0 - kernels[1]["sources"] / max(kernels[0]["sources"], 1), 6) if len(kernels) > 1 else 1.0) if kernels else None,
             "setup_s": round(t_gen, 2), "setup_graph_s": round(t_graph, 2),
             "device_graph_bytes": dev.graph_bytes(),
@@ -301,11 +346,38 @@ def main():
                        "model_bytes": None if result_info.get("replay_visits") is None else int(result_info["replay_visits"] * (32 + 16 + 1.2 * 16)),
                        "ms": round(phases_acc.get("replay", 0.0) / max(args.steps, 1) * 1e3, 3)},
             "cpu_baseline": cpu_baseline,
+            "vs_cpu_baseline_same_stage": None if not cpu_baseline else round(cpu_baseline["gpu_same_stage_edges_per_s"] / max(cpu_baseline["value"], 1e-9), 2),
+            "seeds": extra_seeds,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sssp_stage_of_seeds(args, seeds, device_id) -> dict:
+    """SURVEY 8d names seeds {1, 2, 3}: the SSSP stage (HIP events, sum of the level kernels) on the same workload from other seeds."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    out = {}
+    for seed in seeds:
+        if seed == args.seed:
+            continue
+        g = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=seed, k=args.k, device_id=device_id)
+        d = api.DeviceGraph(g, args.k, device_id)
+        d.set_plan(args.plan)
+        S = d.classify(torch_glue.current_stream_ptr())
+        b = torch_glue.run_sssp(d, 0, S)
+        ms = []
+        for _ in range(3):
+            b = torch_glue.run_sssp(d, 0, S, b)
+            ms.append(d.last_sssp_kernel_ms())
+        st = d.sssp_count(0, S, torch_glue.current_stream_ptr())
+        out[str(seed)] = {"V": g.node_count(), "E": g.edge_count(), "sources": int(S), "sssp_stage_ms": round(float(np.mean(ms)), 4),
+                          "frac": round(algorithmic_bytes(st) / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+        del b, d, g
+        torch.cuda.empty_cache()
+    return out
 
 
 def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_all: int) -> dict:
@@ -342,11 +414,19 @@ def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_a
     t0 = time.perf_counter()
     og.greedy_pairs_np(k, n1)
     rate = n1 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(n_sources, max(50000, rate * budget_s)))
+    n = int(min(n_sources, max(50000, rate * budget_s * 0.5)))  # half of the budget for 1 core, half for all cores
     t0 = time.perf_counter()
     _, st = og.greedy_pairs_np(k, n)
     dt = time.perf_counter() - t0
     full_ball_prefix = dev.sssp_count(0, n, stream)["relaxed_edges"]
+    # the reference's multi-threaded path (greedytigs/mod.rs:528-644: worker threads over chunks of out_nodes, per-node locks) on
+    # the cores this box gives the process, over a prefix sized to the other half of the budget
+    cores = host_cores()
+    n_mt = int(min(n_sources, max(50000, rate * budget_s * 0.5 * min(cores, 16) * 0.5)))
+    t0 = time.perf_counter()
+    pairs_mt, st_mt = og.greedy_pairs_np(k, n_mt, threads=cores)
+    dt_mt = time.perf_counter() - t0
+    full_ball_mt = dev.sssp_count(0, n_mt, stream)["relaxed_edges"]
     return {
         "value": round(full_ball_prefix / dt, 1), "unit": "edges/s", "cores": 1, "kind": "port",
         "sample": f"Dijkstra + claim stage only (greedytigs/mod.rs:276-526, oracle og_greedy_pairs_prefix) on the first {n} of "
@@ -357,6 +437,15 @@ def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_a
         "whole_stage_seconds_estimate": round(dt * n_sources / n, 1),
         "cpu_examined_edges": st["relaxed_edges"], "cpu_examined_edges_per_s": round(st["relaxed_edges"] / dt, 1),
         "settled_nodes": st["settled_nodes"], "queries": st["queries"],
+        "multi_thread": {
+            "value": round(full_ball_mt / dt_mt, 1), "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"the same stage with the reference's worker-thread scheme (oracle og_greedy_pairs_mt) on {cores} threads = the "
+                      f"cores this box gives the process, first {n_mt} of {n_sources} sources, {dt_mt:.1f} s; value = their {full_ball_mt} "
+                      f"full-ball SSSP edges / those seconds",
+            "sources": n_mt, "seconds": round(dt_mt, 2), "sources_per_s": round(n_mt / dt_mt, 1),
+            "whole_stage_seconds_estimate": round(dt_mt * n_sources / n_mt, 1),
+            "cpu_examined_edges_per_s": round(st_mt["relaxed_edges"] / dt_mt, 1), "pairs": int(len(pairs_mt)),
+        },
     }
 
 
@@ -366,7 +455,7 @@ def run_cpu_baseline_mt(bg, k: int, stages_1core: dict) -> dict:
     whole-path estimate reuses their 1-core times."""
     import oracle_lib
 
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = host_cores()
     og = oracle_lib.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     t0 = time.perf_counter()
     pairs, st = og.greedy_pairs_np(k, threads=cores)

@@ -287,6 +287,8 @@ uint64_t mtg_walks_count(const mtg_walks *w);
 uint64_t mtg_walks_total_edges(const mtg_walks *w);
 /* limits[i] = exclusive end of walk i in edges[] (edge ids into the mutated graph). */
 void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges);
+/* The walks' own arrays (no copy): valid until mtg_walks_free. */
+void mtg_walks_data(const mtg_walks *w, const uint64_t **limits, const uint32_t **edges);
 void mtg_walks_free(mtg_walks *w);
 /* Walks from caller arrays (copied), e.g. externally computed Euler cycles for mtg_cut_cycles. */
 mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const uint32_t *edges);

@@ -185,6 +185,7 @@ def load():
         "mtg_walks_total_edges": (u64, [vp]),
         "mtg_walks_export": (None, [vp, vp, vp]),
         "mtg_walks_free": (None, [vp]),
+        "mtg_walks_data": (None, [vp, P(vp), P(vp)]),
         "mtg_walks_from_arrays": (vp, [u64, vp, vp]),
         "mtg_flatten_clib": (u64, [vp, vp, vp, vp, vp]),
         "mtg_write_walks_fasta": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, P(vp)]),

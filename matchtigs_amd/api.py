@@ -358,7 +358,26 @@ def _take_walks(L, wp) -> list[list[int]]:
 
 
 def _take_walks_np(L, wp):
+    """(limits, edges) as numpy VIEWS of the library's walk arrays (no copy: 0.5 GB at the bench size); the walks are freed when
+    both views are gone."""
+    import weakref
+
     n, tot = int(L.mtg_walks_count(wp)), int(L.mtg_walks_total_edges(wp))
+    if n and tot:
+        lp, ep = C.c_void_p(), C.c_void_p()
+        L.mtg_walks_data(wp, C.byref(lp), C.byref(ep))
+        left = [2]
+
+        def done():
+            left[0] -= 1
+            if left[0] == 0:
+                L.mtg_walks_free(C.c_void_p(wp))
+
+        raw_l = (C.c_char * (n * 8)).from_address(lp.value)
+        raw_e = (C.c_char * (tot * 4)).from_address(ep.value)
+        weakref.finalize(raw_l, done)
+        weakref.finalize(raw_e, done)
+        return np.frombuffer(raw_l, dtype=np.uint64), np.frombuffer(raw_e, dtype=np.uint32)
     lim = np.zeros(n, np.uint64)
     ed = np.zeros(tot, np.uint32)
     L.mtg_walks_export(wp, _ptr(lim) if n else None, _ptr(ed) if tot else None)

@@ -39,15 +39,18 @@
 #include <vector>
 
 #include "device.hpp"
+#include "hip_util.hpp"
 #include "parallel.hpp"
 
 namespace mtg {
 
+#ifndef HIP_CHECK
 #define HIP_CHECK(expr)                                                                          \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \
         if (_e != hipSuccess) MTG_DIE("HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__, #expr); \
     } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Node records
@@ -1552,8 +1555,13 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         hipLaunchKernelGGL(build_children_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs);
         HIP_CHECK(hipGetLastError());
     }
+    // the finishing stages on this GPU start from the same two arrays: leave them with the graph instead of uploading them again
+    uint32_t *d_mirror_copy = nullptr;
+    HIP_CHECK(hipMalloc(&d_mirror_copy, std::max<uint64_t>(V, 1) * 4));
+    if (V) HIP_CHECK(hipMemcpyAsync(d_mirror_copy, d->d_mirror, V * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    for (void *p : {(void *)d_from, (void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
+    hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
+    for (void *p : {(void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
     d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13;
     return d;
 }

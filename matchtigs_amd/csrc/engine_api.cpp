@@ -344,6 +344,10 @@ void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges) {
     if (limits && !w->w.limits.empty()) std::memcpy(limits, w->w.limits.data(), w->w.limits.size() * 8);
     if (edges && !w->w.edges.empty()) std::memcpy(edges, w->w.edges.data(), w->w.edges.size() * 4);
 }
+void mtg_walks_data(const mtg_walks *w, const uint64_t **limits, const uint32_t **edges) {
+    if (limits) *limits = w->w.limits.data();
+    if (edges) *edges = w->w.edges.data();
+}
 void mtg_walks_free(mtg_walks *w) { delete w; }
 mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const uint32_t *edges) {
     if (n_walks && (!limits || !edges)) MTG_DIE("mtg_walks_from_arrays: null argument");

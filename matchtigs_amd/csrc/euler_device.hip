@@ -369,19 +369,32 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] changed
     uint32_t *d_error = d_small, *d_total = d_small + 1;
     HIP_CHECK(hipMemsetAsync(d_small, 0, 32, st));
+    static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        HIP_CHECK(hipStreamSynchronize(st));
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mtg] euler decompose:   %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t_lap).count());
+        t_lap = n;
+    };
+    lap("allocations");
 
     // 1. buckets
     device_build_buckets(st, d_from, E, V, d_row, d_adj, d_pos2);
+    lap("buckets");
     // 2. pairing, 3. trail labels
     succ_kernel<<<grid_for(E), EB, 0, st>>>(d_from, d_mirror, E, d_row, d_adj, d_pos2, d_succ, d_comp, d_error);
     uint32_t h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: the graph is not Eulerian (greedytigs/mod.rs:708)");
+    lap("pairing");
     union_succ_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, E, d_comp);
     flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, E);
     uint32_t *d_parent2 = d_pos2;
     comp_kernel<<<grid_for(E / 2), EB, 0, st>>>(d_comp, E / 2, d_parent2);
+    lap("trail labels");
     // 4. merge the trails of every connected component
     HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`, reused as the splitter flags afterwards
     HIP_CHECK(hipMemsetAsync(d_best, 0xFF, E * 8, st));
@@ -396,6 +409,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
         HIP_CHECK(hipStreamSynchronize(st));
         if (!h_small[4]) break;
     }
+    lap("hooking rounds");
     b_best.release();
     rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_flag, d_succ);
     // 5. ranking
@@ -403,6 +417,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     scan_u32<uint32_t>(st, d_flag, E, d_sidx, d_bsum, d_total);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    lap("rotate + splitter flags");
     const uint32_t M = h_small[1];  // splitters
     if (M == 0) MTG_DIE("device_euler_cycles: internal error (no splitters)");
     b_row.release();
@@ -430,6 +445,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: internal error (successor array is not a permutation)");
+    lap("segment walks + ranking");
     const uint32_t R = h_small[2];  // connected components = closed walks
     if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] euler decompose: E %llu V %llu hook rounds %d splitters %u components %u\n", (unsigned long long)E, (unsigned long long)V, hook_rounds, M, R);
     b_flag.release();
@@ -448,6 +464,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev1, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    lap("write walks");
     *n_cycles = R;
     if (kernel_ms_out) {
         float ms = 0;

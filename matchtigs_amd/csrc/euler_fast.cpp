@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include "euler_lean.hpp"
 #include "host_graph.hpp"
 #include "hugebuf.hpp"
 #include "parallel.hpp"
@@ -55,6 +56,11 @@ struct alignas(256) EulerNode3 {
 static_assert(sizeof(EulerNode3) == 256, "EulerNode3 must be 256 bytes");
 }  // namespace
 
+// Everything after the records' own adjacency (phase A) is filled: copies of the heads' adjacency (phases B, C), the walk.
+static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+                                const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
+                                std::chrono::steady_clock::time_point t_begin);
+
 Walks euler_cycles(const HostGraph &g) {
     const uint64_t E = g.edge_count();
     const uint64_t V = g.node_count();
@@ -63,7 +69,6 @@ Walks euler_cycles(const HostGraph &g) {
     for (uint64_t n = 0; n < V; n++)
         if (g.out_deg[n] > 65535) return euler_cycles_generic(g);  // not a de Bruijn graph: simple formulation
 
-    static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     // the walk is one latency-bound thread: keep it next to the memory it chases through (the graph's arena from an earlier call, if any)
     NumaPin pin(g.arena.node);
@@ -99,6 +104,37 @@ Walks euler_cycles(const HostGraph &g) {
             }
         }
     });
+    return euler_walk_records(nodes, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena, t_begin);
+}
+
+// The same walk from the 32-byte records the GPU builds out of the Eulerised dart arrays (finish_device.hip): a LeanNode IS
+// phase A of a record (own adjacency, newest first), so the host graph's adjacency lists are never linked or walked.
+Walks euler_cycles_from_lean(const LeanNode *lean, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
+                             const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    HugeBuf<EulerNode3> nodes(V, arena);
+    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++) {
+            EulerNode3 &r = nodes[n];
+            const LeanNode &l = lean[n];
+            for (int i = 0; i < 3; i++) { r.eid[i] = l.eid[i]; r.to[i] = l.to[i]; }
+            r.deg = l.deg;
+            r.pos = 0;
+            r.pad = 0;
+            r.sub_info = 0;
+            r.sub2_info = 0;
+            r.ext_begin = l.ext_begin;
+        }
+    });
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin);
+}
+
+static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+                                const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
+                                std::chrono::steady_clock::time_point t_begin) {
+    static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
     constexpr unsigned BUILD_THREADS = 128;  // phases B and C are random gathers: latency bound, so more threads than cores pay
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: first 3 positions of each inline edge's head node
@@ -174,7 +210,7 @@ Walks euler_cycles(const HostGraph &g) {
     };
 
     // entries: one per biedge plus one per splice; the FIFO sees every entry once plus one re-push per splice
-    HugeBuf<uint32_t> ent_edge(E + 1, &g.arena), ent_next(E + 1, &g.arena), ent_node(E + 1, &g.arena), fifo(E + E / 2 + 2, &g.arena);
+    HugeBuf<uint32_t> ent_edge(E + 1, arena_ptr), ent_next(E + 1, arena_ptr), ent_node(E + 1, arena_ptr), fifo(E + E / 2 + 2, arena_ptr);
     size_t n_ent = 0, fifo_tail = 0;
     Walks out;
     out.edges.reserve(E / 2);
@@ -190,7 +226,7 @@ Walks euler_cycles(const HostGraph &g) {
         n_ent = 0; fifo_tail = 0;
         size_t fifo_head = 0;
         uint32_t head = NONE;
-        uint32_t start_edge = (uint32_t)e0, start_to = g.e_to[e0], start_node = g.e_from[e0];
+        uint32_t start_edge = (uint32_t)e0, start_to = e_to[e0], start_node = e_from[e0];
         uint32_t splice_at = NONE;
 
         while (start_edge != NONE) {

@@ -21,4 +21,9 @@ static_assert(sizeof(LeanNode) == 32, "LeanNode must be 32 bytes");
 Walks euler_cycles_lean(LeanNode *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
                         const uint32_t *e_to, uint64_t E, HugeArena *arena);
 
+// The latency-optimised walk of euler_fast.cpp (256-byte records with two levels of copied adjacency) seeded from the same
+// GPU-built records: faster than euler_cycles_lean while 256 bytes per node fit the host.
+Walks euler_cycles_from_lean(const LeanNode *lean, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
+                             const uint32_t *e_to, uint64_t E, HugeArena *arena);
+
 }  // namespace mtg

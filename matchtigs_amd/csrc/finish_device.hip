@@ -354,14 +354,39 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     Lap lap;
     static_assert(sizeof(Pair) == sizeof(mtg_pair), "pair layout");
 
-    // ---- upload: original darts, mirror, pairs ----
-    Buf b_from0, b_mirror, b_pairs, b_deg, b_cin, b_cout, b_smf, b_pin, b_pout, b_psm, b_bsum, b_small;
-    uint32_t *d_from0 = b_from0.alloc<uint32_t>(st, E0);
-    uint32_t *d_mirror = b_mirror.alloc<uint32_t>(st, V);
+    // ---- original darts + mirror: left on this GPU by an earlier stage of the graph (HostGraph::device_cache), else uploaded
+    // now and left there for the next call; the pairs ----
+    Buf b_pairs, b_deg, b_cin, b_cout, b_smf, b_pin, b_pout, b_psm, b_bsum, b_small;
+    Buf b_from0_tmp, b_mirror_tmp;  // only when the graph's cache lives on another GPU
+    const uint32_t *d_from0 = nullptr, *d_mirror = nullptr;
+    if (const DeviceEdgeCache *cache = edge_cache_get(g, device_id)) {
+        d_from0 = (const uint32_t *)cache->d_from;
+        d_mirror = (const uint32_t *)cache->d_mirror;
+    } else {
+        const bool keep = !g.device_cache;
+        uint32_t *up_from = nullptr, *up_mirror = nullptr;
+        if (keep) {
+            HIP_CHECK(hipMalloc(&up_from, std::max<uint64_t>(E0, 1) * 4));
+            HIP_CHECK(hipMalloc(&up_mirror, std::max<uint64_t>(V, 1) * 4));
+        } else {
+            up_from = b_from0_tmp.alloc<uint32_t>(st, E0);
+            up_mirror = b_mirror_tmp.alloc<uint32_t>(st, V);
+        }
+        if (E0) HIP_CHECK(hipMemcpyAsync(up_from, g.e_from.data(), E0 * 4, hipMemcpyHostToDevice, st));
+        if (V) HIP_CHECK(hipMemcpyAsync(up_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (keep) edge_cache_put(g, device_id, up_from, up_mirror);  // (if another thread got there first, ours are freed: read again)
+        if (const DeviceEdgeCache *cache = keep ? edge_cache_get(g, device_id) : nullptr) {
+            d_from0 = (const uint32_t *)cache->d_from;
+            d_mirror = (const uint32_t *)cache->d_mirror;
+        } else if (keep) MTG_DIE("device_finish: the graph's device cache changed hands during the call");
+        else {
+            d_from0 = up_from;
+            d_mirror = up_mirror;
+        }
+    }
     mtg_pair *d_pairs = b_pairs.alloc<mtg_pair>(st, n_pairs);
     uint32_t *d_deg = b_deg.alloc<uint32_t>(st, V);
-    if (E0) HIP_CHECK(hipMemcpyAsync(d_from0, g.e_from.data(), E0 * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
     if (n_pairs) HIP_CHECK(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(mtg_pair), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(d_deg, 0, V * 4, st));
     if (E0) degree_kernel<<<grid_for(E0), EB, 0, st>>>(d_from0, E0, d_deg);
@@ -398,7 +423,6 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     uint32_t *d_from = b_from.alloc<uint32_t>(st, E_cap);
     uint32_t *d_pw = b_pw.alloc<uint32_t>(st, n_pairs);
     if (E0) HIP_CHECK(hipMemcpyAsync(d_from, d_from0, E0 * 4, hipMemcpyDeviceToDevice, st));
-    b_from0.release();
     if (n_pairs) pair_darts_kernel<<<grid_for(n_pairs), EB, 0, st>>>(d_pairs, n_pairs, d_mirror, d_from + E0, d_pw);
     const uint64_t first_brk = E0 + 2 * n_pairs;
     uint32_t *d_sm = b_sm.alloc<uint32_t>(st, n_sm);
@@ -520,7 +544,13 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 HIP_CHECK(hipStreamSynchronize(st));
                 b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
                 lap.lap("walk records (GPU) + download");
-                cycles = euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                // 256-byte records (two levels of copied adjacency: 2.6 steps per DRAM miss) while they fit comfortably, the
+                // 32-byte records themselves beyond (one miss per step, an eighth of the memory). Same walk either way;
+                // MTG_EULER_RECORDS=lean|wide overrides the choice (speed / memory only).
+                const char *rec = std::getenv("MTG_EULER_RECORDS");
+                const bool wide = rec ? std::strcmp(rec, "wide") == 0 : V * 256 <= (48ull << 30);
+                cycles = wide ? euler_cycles_from_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena)
+                              : euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
             }
         }
         n_cycles = (uint32_t)cycles.limits.size();
@@ -578,7 +608,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipStreamSynchronize(st));
     }
     if (times_out) times_out[3] = lap.lap("rotate + cut + download");
-    b_from.release(); b_mirror.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
+    b_from.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
     HIP_CHECK(hipStreamSynchronize(st));
     finish_trim(device_id, E * 40 + V * 28);
     return tigs;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 
 #include "host_graph.hpp"
 
@@ -143,9 +144,47 @@ inline hipStream_t finish_stream(int device_id) {
     return streams[device_id];
 }
 
+// ---- device-resident original edges of a host graph (HostGraph::device_cache) ----
+inline void edge_cache_free(DeviceEdgeCache *c) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_from);
+    (void)hipFree(c->d_mirror);
+    (void)hipSetDevice(cur);
+}
+// the cache of g on `device`, or null (another device, or a graph whose sizes changed: never the case after build)
+inline std::mutex &edge_cache_mutex() {  // (mtg_compute_tigs_cfg builds its device copies from concurrent host threads)
+    static std::mutex m;
+    return m;
+}
+inline const DeviceEdgeCache *edge_cache_get(const HostGraph &g, int device) {
+    std::lock_guard<std::mutex> l(edge_cache_mutex());
+    const DeviceEdgeCache *c = g.device_cache.get();
+    return (c && c->device == device && c->n_edges == g.n_original_edges && c->n_nodes == g.node_count()) ? c : nullptr;
+}
+// Takes ownership of two plain hipMalloc'd arrays on `device` (from-nodes of the original edges, mirror); keeps an existing
+// cache of the same device and frees the offered arrays instead.
+inline void edge_cache_put(const HostGraph &g, int device, uint32_t *d_from, uint32_t *d_mirror) {
+    std::lock_guard<std::mutex> l(edge_cache_mutex());
+    if (g.device_cache) {  // first come, first kept (one cache per graph)
+        (void)hipFree(d_from);
+        (void)hipFree(d_mirror);
+        return;
+    }
+    auto *c = new DeviceEdgeCache();
+    c->device = device;
+    c->n_edges = g.n_original_edges;
+    c->n_nodes = g.node_count();
+    c->d_from = d_from;
+    c->d_mirror = d_mirror;
+    c->free_fn = edge_cache_free;
+    g.device_cache.reset(c);
+}
+
 // Hands the pool's cached memory back to the driver when a call worked on more than `threshold` bytes (the next stage's plain
 // hipMalloc cannot use memory the stream-ordered pool is sitting on; small calls keep their arrays mapped for the next one).
-inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 8ull << 30) {
+inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 32ull << 30) {
     if (bytes_used < threshold) return;
     hipMemPool_t pool;
     HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));

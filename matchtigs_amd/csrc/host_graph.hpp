@@ -53,6 +53,22 @@ struct Walks {
     PodVec<uint32_t> edges;   // edge ids
 };
 
+// Device-resident copy of what never changes after the graph is built -- the from-node of every ORIGINAL edge and the mirror
+// array -- left behind by the first stage that uploaded them (device.hip / finish_device.hip) for the stages and steps that
+// follow on the same GPU. Owned by the graph, freed with it (free_fn is set by the HIP translation unit that made it).
+struct DeviceEdgeCache {
+    int device = -1;
+    uint64_t n_edges = 0, n_nodes = 0;
+    void *d_from = nullptr, *d_mirror = nullptr;
+    void (*free_fn)(DeviceEdgeCache *) = nullptr;
+};
+struct DeviceEdgeCacheDeleter {
+    void operator()(DeviceEdgeCache *c) const {
+        if (c && c->free_fn) c->free_fn(c);
+        delete c;
+    }
+};
+
 struct HostGraph {
     // ---- clib.rs builder state (src/clib.rs:97-170) ----
     bool has_builder = false;
@@ -80,6 +96,7 @@ struct HostGraph {
     uint64_t breaking_weight = 0;
     bool dummies_canonical = true;
     mutable HugeArena arena;  // large scratch mappings of the host stages, kept between calls on this graph (huge_arena.hpp)
+    mutable std::unique_ptr<DeviceEdgeCache, DeviceEdgeCacheDeleter> device_cache;
 
     uint64_t node_count() const { return mirror.size(); }
     uint64_t edge_count() const { return e_from.size(); }

@@ -45,39 +45,39 @@ def allgather_candidates(start: torch.Tensor, count: torch.Tensor, pool: torch.T
                          ranges: list[tuple[int, int]], group=None):
     """All ranks contribute (start[int64 n_r], count[int32 n_r], pool[int64 >= pool_used]) for their source block.
 
-    Returns (start_all, count_all, pool_all) on the same device, indexed by absolute source index, with
-    ``start`` rebased into the concatenated pool. Message shape: per rank one padded int64 buffer
-    [n_max + n_max/2(+1) + pool_max] (starts | counts packed 2 per word | keys) -> a single all_gather.
+    Returns (start_all, count_all, pool_all) on the same device, indexed by absolute source index, with ``start`` rebased
+    into the concatenated pool. The all-gather is variable-length, so it is issued as one broadcast per (rank, array) at the
+    EXACT sizes, straight into the slices of the concatenated result (grouped broadcasts; on GPUs RCCL runs them
+    back to back over xGMI): no padding to the largest rank and no per-rank staging copies -- the receive buffers ARE the
+    result. One tiny all-gather of the pool sizes precedes it.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = pool.device
-    n_local = ranges[rank][1] - ranges[rank][0]
     sizes = torch.tensor([pool_used], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    pool_sizes = [int(t.item()) for t in all_sizes]
-    n_max = max(hi - lo for lo, hi in ranges)
-    p_max = max(pool_sizes)
-    cnt_words = (n_max + 1) // 2
-    msg = torch.zeros(n_max + cnt_words + p_max, dtype=torch.int64, device=dev)
-    msg[:n_local] = start[:n_local]
-    cnt_pad = torch.zeros(cnt_words * 2, dtype=torch.int32, device=dev)
-    cnt_pad[:n_local] = count[:n_local]
-    msg[n_max:n_max + cnt_words] = cnt_pad.view(torch.int64)
-    msg[n_max + cnt_words:n_max + cnt_words + pool_used] = pool[:pool_used]
-    gathered = [torch.empty_like(msg) for _ in range(world)]
-    dist.all_gather(gathered, msg, group=group)
-    starts, counts, pools = [], [], []
-    offset = 0
+    all_sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    pool_sizes = [int(x) for x in all_sizes.tolist()]
+    n_total = ranges[-1][1]
+    start_all = torch.empty(n_total, dtype=torch.int64, device=dev)
+    count_all = torch.empty(n_total, dtype=torch.int32, device=dev)
+    pool_all = torch.empty(sum(pool_sizes), dtype=torch.int64, device=dev)
+    lo, hi = ranges[rank]
+    off = sum(pool_sizes[:rank])
+    start_all[lo:hi] = start[: hi - lo] + off  # own block: rebased before it travels
+    count_all[lo:hi] = count[: hi - lo]
+    pool_all[off:off + pool_used] = pool[:pool_used]
+    pending = []
+    off = 0
     for r, (lo, hi) in enumerate(ranges):
-        n_r = hi - lo
-        g = gathered[r]
-        starts.append(g[:n_r] + offset)
-        counts.append(g[n_max:n_max + cnt_words].view(torch.int32)[:n_r])
-        pools.append(g[n_max + cnt_words:n_max + cnt_words + pool_sizes[r]])
-        offset += pool_sizes[r]
-    return torch.cat(starts), torch.cat(counts), torch.cat(pools)
+        src = dist.get_global_rank(group, r) if group is not None else r
+        for view in (start_all[lo:hi], count_all[lo:hi], pool_all[off:off + pool_sizes[r]]):
+            if view.numel():
+                pending.append(dist.broadcast(view, src=src, group=group, async_op=True))
+        off += pool_sizes[r]
+    for w in pending:
+        w.wait()
+    return start_all, count_all, pool_all
 
 
 def to_numpy_u(start_all: torch.Tensor, count_all: torch.Tensor, pool_all: torch.Tensor):

@@ -643,6 +643,12 @@ static void *mt_worker_main(void *arg) {
 }
 
 uint64_t og_greedy_pairs_mt(const og_graph *g, uint64_t k, uint32_t threads, og_pair **pairs, og_sssp_stats *stats) {
+    return og_greedy_pairs_mt_prefix(g, k, threads, UINT64_MAX, pairs, stats);
+}
+
+/* The same over the first max_sources out-nodes only (bench.py: a bounded sample of a workload whose whole CPU run takes minutes). */
+uint64_t og_greedy_pairs_mt_prefix(const og_graph *g, uint64_t k, uint32_t threads, uint64_t max_sources, og_pair **pairs,
+                                   og_sssp_stats *stats) {
     uint32_t nn = g->n_nodes;
     if (threads < 1) threads = 1;
     uint32_t *out_nodes = xmalloc((size_t)nn * 4);
@@ -651,6 +657,7 @@ uint64_t og_greedy_pairs_mt(const og_graph *g, uint64_t k, uint32_t threads, og_
     uint8_t *locks = xmalloc(nn ? nn : 1);
     memset(locks, 0, nn);
     uint32_t n_out = og_classify(g, out_nodes, live, mult, NULL, NULL);
+    if ((uint64_t)n_out > max_sources) n_out = (uint32_t)max_sources;
     uint64_t cursor = 0;
     mt_worker *ws = xmalloc(sizeof(mt_worker) * threads);
     pthread_t *th = xmalloc(sizeof(pthread_t) * threads);

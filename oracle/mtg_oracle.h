@@ -96,6 +96,8 @@ uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sour
 /* The same claim loop run by `threads` workers with the reference's locking scheme (greedytigs/mod.rs:528-644).
  * Thread-timing dependent like the reference with threads > 1: for the bench's multi-core timing only. */
 uint64_t og_greedy_pairs_mt(const og_graph *g, uint64_t k, uint32_t threads, og_pair **pairs, og_sssp_stats *stats);
+uint64_t og_greedy_pairs_mt_prefix(const og_graph *g, uint64_t k, uint32_t threads, uint64_t max_sources, og_pair **pairs,
+                                   og_sssp_stats *stats);
 
 /* Full candidate lists L(s): every initial in-node within k-1 of s (s excluded), in (dist,node)
  * order; CSR-style output: offsets[n_out+1] (malloc'd), keys = dist<<32|node (malloc'd). */

@@ -84,6 +84,7 @@ def lib():
         "og_greedy_pairs_prefix": (u64, [vp, u64, u64, P(P(Pair)), P(Stats)]),
         "og_candidate_lists": (u32, [vp, u64, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
         "og_greedy_pairs_mt": (u64, [vp, u64, u32, P(P(Pair)), P(Stats)]),
+        "og_greedy_pairs_mt_prefix": (u64, [vp, u64, u32, u64, P(P(Pair)), P(Stats)]),
         "og_candidate_lists_range": (u32, [vp, u64, u32, u32, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
         "og_free": (None, [vp]),
         "og_insert_pair_edges": (u64, [vp, P(Pair), u64]),
@@ -257,7 +258,7 @@ class OracleGraph:
         st = Stats()
         ms = (1 << 64) - 1 if max_sources is None else int(max_sources)
         if threads > 1:   # reference-style worker threads: timing-dependent result, like the reference with -t > 1
-            n = self.L.og_greedy_pairs_mt(self.h, k, int(threads), C.byref(pp), C.byref(st))
+            n = self.L.og_greedy_pairs_mt_prefix(self.h, k, int(threads), ms, C.byref(pp), C.byref(st))
         else:
             n = self.L.og_greedy_pairs_prefix(self.h, k, ms, C.byref(pp), C.byref(st))
         dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])

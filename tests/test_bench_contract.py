@@ -20,7 +20,7 @@ def test_bench_json_line(product_lib):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "device_mode", "scaling_stages_ms", "seeds"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
@@ -28,6 +28,10 @@ def test_bench_json_line(product_lib):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and rf["kernels"][0]["kernel"].startswith("sssp_enum_kernel")
+    assert "traffic" in rf and "traffic_note" in rf
+    dm = d["device_mode"]
+    assert dm["ms_per_step"] > 0 and dm["tigs"] == d["config"]["tigs"] and "finish" in dm["phases_ms"]   # T3 across the two modes
+    assert set(d["seeds"]) == {"2", "3"} and all(v["sssp_stage_ms"] > 0 for v in d["seeds"].values())
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
     assert cb["pairs"] == d["config"]["pairs"] and cb["tigs"] == d["config"]["tigs"]   # the CPU port and the GPU path agree

@@ -87,7 +87,7 @@ def _same_graph(a, b):
 
 
 @pytest.mark.parametrize("idx", range(N_CASES))
-def test_device_finish_equals_host_finish_reference_order(gpu, idx):
+def test_device_finish_equals_host_finish_reference_order(gpu, idx, monkeypatch):
     """Greedy finish: same graph afterwards (every dummy edge: id, endpoints, weight, dummy id) and the same tigs."""
     from matchtigs_amd import api
 
@@ -96,10 +96,15 @@ def test_device_finish_equals_host_finish_reference_order(gpu, idx):
     pairs = _pairs_of(bg, k)
     H, D = _graphs(bg)
     lim_h, ed_h = api.finish_greedytigs_np(H, pairs, k, finish_stage=api.FinishStage.Host)
-    lim_d, ed_d = api.finish_greedytigs_np(D, pairs, k, finish_stage=api.FinishStage.Device)
-    _same_graph(H, D)
-    assert np.array_equal(lim_h, lim_d), name
-    assert np.array_equal(ed_h, ed_d), name
+    for records in ("lean", "wide"):  # both record formats of the reference-order walk (a speed / memory choice only)
+        monkeypatch.setenv("MTG_EULER_RECORDS", records)
+        lim_d, ed_d = api.finish_greedytigs_np(D, pairs, k, finish_stage=api.FinishStage.Device)
+        _same_graph(H, D)
+        assert np.array_equal(lim_h, lim_d), (name, records)
+        assert np.array_equal(ed_h, ed_d), (name, records)
+        if records == "lean":
+            D.reset()
+    monkeypatch.delenv("MTG_EULER_RECORDS")
     t = api.last_finish_device_times()
     assert t["breaking_biedges"] == (D.edge_count() - bg.n_edges) // 2 - len(pairs)
     # and the graph can be reset and finished again (the dummy edges were appended unlinked)
