@@ -733,6 +733,14 @@ constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #define MTG_ENUM_BE 16
 #endif
 constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
+// LDS words between the starts of two extension blocks: one more than a block holds. With a stride of 16 eight-byte entries
+// (128 bytes = all 32 banks once) the same row of every block falls on the same bank pair, and lanes that work in different
+// blocks -- the common case -- collide on every access (3.6 conflict cycles per LDS instruction in the round-2 PMC pass); an odd
+// stride walks the rows of consecutive blocks through the banks.
+#ifndef MTG_ENUM_BS
+#define MTG_ENUM_BS (MTG_ENUM_BE + 1)
+#endif
+constexpr int ENUM_BS = MTG_ENUM_BS;
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {  // value of the first lane, known uniform to the compiler
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -742,12 +750,13 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 template <int WPB, int S1, int H1, int NB, bool QUAD>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
-    constexpr int BE = ENUM_BE;
+    constexpr int BE = ENUM_BE, BS = ENUM_BS;
+    static_assert(BS >= BE, "block stride below the block size");
     constexpr uint32_t T1 = (uint32_t)(S1 + H1) * 64u;     // words of the per-lane tiers
-    constexpr uint32_t SCRATCH = T1 + (uint32_t)NB * BE;   // block that absorbs the stores of lanes without a block of their own
+    constexpr uint32_t SCRATCH = T1 + (uint32_t)NB * BS;   // block that absorbs the stores of lanes without a block of their own
     constexpr uint32_t IDLE_DIST = 0xFFFF0000u;            // distance of a lane without a source: nothing is within the bound from there
     // stack entry: node | (distance | own-flag-done << 16) << 32; hit entry = candidate key: node | distance << 32
-    __shared__ unsigned long long s_mem[WPB][T1 + (NB + 1) * BE];
+    __shared__ unsigned long long s_mem[WPB][T1 + (NB + 1) * BS];
     __shared__ uint32_t s_cnt[WPB];
     __shared__ WaveOvfBuf s_ovf[WPB];
     const int lane = threadIdx.x & 63;
@@ -927,7 +936,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             const int bi = __builtin_ctzll(free_mask);
             nm &= nm - 1;
             free_mask &= free_mask - 1;
-            blk = lane == l ? T1 + (uint32_t)bi * BE : blk;
+            blk = lane == l ? T1 + (uint32_t)bi * BS : blk;
         }
         const uint32_t es = sp_f > (uint32_t)S1 ? sp_f - (uint32_t)S1 : 0u, eh = nh_f > (uint32_t)H1 ? nh_f - (uint32_t)H1 : 0u;
         pops += active ? 1u : 0u;
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             while (rel) {
                 const int l = __builtin_ctzll(rel);
                 rel &= rel - 1;
-                free_mask |= 1ull << ((((uint32_t)__builtin_amdgcn_readlane((int)blk, l) - T1) / (uint32_t)BE) & 63u);
+                free_mask |= 1ull << ((((uint32_t)__builtin_amdgcn_readlane((int)blk, l) - T1) / (uint32_t)BS) & 63u);
             }
             wave_ovf_push(s_ovf[wv], n_overflow, ovf, (uint32_t)(a.src_begin + item), a, lane);
         }

@@ -31,35 +31,11 @@ namespace mtg {
 
 Walks euler_cycles_generic(const HostGraph &g);
 
-namespace {
-// Copied adjacency is in the owner's iteration order (newest edge first). A copy holds the first `cnt` positions of its
-// node and a `more` bit (the node has further positions): if none of the copied edges is unused and `more` is clear the
-// node is exhausted, with `more` set the walk falls back to the node's own record.
-struct alignas(256) EulerNode3 {
-    uint32_t eid[3];             // own adjacency positions 0..2
-    uint32_t to[3];
-    uint16_t deg;
-    uint16_t pos;                // positions < pos are known to be used
-    uint16_t sub_info;           // 3 bits per inline edge j: cnt (0..3) | more << 2
-    uint16_t pad;
-    uint32_t sub2_info;          // 3 bits per (j, q): cnt (0..2) | more << 2
-    uint32_t ext_begin;          // spill entries for own positions 3..deg-1
-    uint32_t sub_eid[3][3];      // adjacency of to[j]
-    uint32_t sub_to[3][3];
-    uint32_t sub2_eid[3][3][2];  // adjacency of sub_to[j][q]
-    uint32_t sub2_to[3][3][2];
-    uint32_t sub_cnt(uint32_t j) const { return (sub_info >> (3 * j)) & 3u; }
-    bool sub_more(uint32_t j) const { return (sub_info >> (3 * j + 2)) & 1u; }
-    uint32_t sub2_cnt(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q))) & 3u; }
-    bool sub2_more(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q) + 2)) & 1u; }
-};
-static_assert(sizeof(EulerNode3) == 256, "EulerNode3 must be 256 bytes");
-}  // namespace
 
 // Everything after the records' own adjacency (phase A) is filled: copies of the heads' adjacency (phases B, C), the walk.
-static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
-                                std::chrono::steady_clock::time_point t_begin);
+                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels);
 
 Walks euler_cycles(const HostGraph &g) {
     const uint64_t E = g.edge_count();
@@ -104,17 +80,16 @@ Walks euler_cycles(const HostGraph &g) {
             }
         }
     });
-    return euler_walk_records(nodes, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena, t_begin);
+    return euler_walk_records(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena, t_begin, false);
 }
 
 // The same walk from the 32-byte records the GPU builds out of the Eulerised dart arrays (finish_device.hip): a LeanNode IS
 // phase A of a record (own adjacency, newest first), so the host graph's adjacency lists are never linked or walked.
-Walks euler_cycles_from_lean(const LeanNode *lean, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
-                             const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+Walks euler_cycles_from_lean(const LeanNode *lean, EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+                             const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena) {
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
     const auto t_begin = std::chrono::steady_clock::now();
     NumaPin pin(arena ? arena->node : -1);
-    HugeBuf<EulerNode3> nodes(V, arena);
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++) {
             EulerNode3 &r = nodes[n];
@@ -128,15 +103,24 @@ Walks euler_cycles_from_lean(const LeanNode *lean, uint64_t V, const uint32_t *e
             r.ext_begin = l.ext_begin;
         }
     });
-    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, false);
 }
 
-static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
+                             const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true);
+}
+
+static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
-                                std::chrono::steady_clock::time_point t_begin) {
+                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels) {
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
     constexpr unsigned BUILD_THREADS = 128;  // phases B and C are random gathers: latency bound, so more threads than cores pay
+    if (!have_sub_levels)
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: first 3 positions of each inline edge's head node
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 16 < hi) {
@@ -159,6 +143,7 @@ static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, co
     const auto t_b = std::chrono::steady_clock::now();
     // phase C: first 2 positions of each head's heads. The head w = to[j] already holds copies of ITS heads' adjacency
     // (phase B), so one gather of w's record serves all three (j, q) slots.
+    if (!have_sub_levels)
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 12 < hi) {
@@ -186,6 +171,18 @@ static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, co
         }
     }, BUILD_THREADS);
     const auto t_built = std::chrono::steady_clock::now();
+    if (dbg_t) {  // how much of the process's anonymous memory sits on huge pages (the records are most of it)
+        if (FILE *f = std::fopen("/proc/self/smaps_rollup", "r")) {
+            char line[256];
+            unsigned long anon = 0, huge = 0;
+            while (std::fgets(line, sizeof line, f)) {
+                std::sscanf(line, "Anonymous: %lu kB", &anon);
+                std::sscanf(line, "AnonHugePages: %lu kB", &huge);
+            }
+            std::fclose(f);
+            std::fprintf(stderr, "[mtg] euler_cycles: anonymous memory %.1f GB, of it on transparent huge pages %.1f GB\n", anon / 1e6, huge / 1e6);
+        }
+    }
     if (dbg_t)
         std::fprintf(stderr, "[mtg] euler_cycles: records: alloc + own adjacency %.3f s, heads %.3f s, heads of heads %.3f s\n",
                      std::chrono::duration<double>(t_a - t_begin).count(), std::chrono::duration<double>(t_b - t_a).count(),
@@ -272,6 +269,37 @@ static Walks euler_walk_records(HugeBuf<EulerNode3> &nodes, const uint64_t V, co
                     level = 0;
                     n_full++;
                     n_pred_hit += (from == last_pf);
+                    {
+                        // The record has just arrived (the one DRAM miss of this step; measured floor on the bench host:
+                        // 130-140 ns per dependent miss, tools/host_latency.c). Everything that follows up to the prefetch of
+                        // the next record is a chain of used-bit lookups (an 11-MB bitmap at the bench size: L3 hits, 4-5 of
+                        // them in sequence), which used to delay that prefetch by ~60 ns per record. So, before looking at
+                        // any bit: (a) start the fetch of the record the walk needs next IF every first-listed edge on the way
+                        // is still unused (right about half of the time, and a wrong guess costs nothing but a line fill);
+                        // (b) start the fetches of all bitmap words the exact computation below can touch, so that its lookups
+                        // overlap instead of queueing up.
+                        const EulerNode3 &r0 = nodes[from];
+                        const uint32_t j0 = r0.pos;
+                        if (j0 < 3 && j0 < r0.deg) {
+                            const uint32_t c1 = r0.sub_cnt(j0);
+                            auto touch_bit = [&](uint32_t eid) { __builtin_prefetch(&used[(eid >> 1) >> 6]); };
+                            // every record the walk can need three steps from here if it leaves by position j0 (at most 3 x 2:
+                            // the first-listed edges are taken on a first visit, the second-listed ones on a second): wrong
+                            // guesses cost line fills, a few GB/s in all, and nothing on the dependent chain
+                            if (!c1) prefetch_record(r0.to[j0]);
+                            for (uint32_t q = 0; q < c1; q++) {
+                                const uint32_t c2 = r0.sub2_cnt(j0, q);
+                                if (!c2) prefetch_record(r0.sub_to[j0][q]);
+                                for (uint32_t t = 0; t < c2; t++) prefetch_record(r0.sub2_to[j0][q][t]);
+                            }
+                            for (uint32_t p = j0; p < 3 && p < r0.deg; p++) touch_bit(r0.eid[p]);
+                            for (uint32_t q = 0; q < c1; q++) {
+                                touch_bit(r0.sub_eid[j0][q]);
+                                const uint32_t c2 = r0.sub2_cnt(j0, q);
+                                for (uint32_t t = 0; t < c2; t++) touch_bit(r0.sub2_eid[j0][q][t]);
+                            }
+                        }
+                    }
                     uint32_t j = 0;
                     e = next_unused(from, to, j);
                     if (e != NONE) {

@@ -21,9 +21,37 @@ static_assert(sizeof(LeanNode) == 32, "LeanNode must be 32 bytes");
 Walks euler_cycles_lean(LeanNode *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
                         const uint32_t *e_to, uint64_t E, HugeArena *arena);
 
+// Copied adjacency is in the owner's iteration order (newest edge first). A copy holds the first `cnt` positions of its
+// node and a `more` bit (the node has further positions): if none of the copied edges is unused and `more` is clear the
+// node is exhausted, with `more` set the walk falls back to the node's own record.
+struct alignas(256) EulerNode3 {
+    uint32_t eid[3];             // own adjacency positions 0..2
+    uint32_t to[3];
+    uint16_t deg;
+    uint16_t pos;                // positions < pos are known to be used
+    uint16_t sub_info;           // 3 bits per inline edge j: cnt (0..3) | more << 2
+    uint16_t pad;
+    uint32_t sub2_info;          // 3 bits per (j, q): cnt (0..2) | more << 2
+    uint32_t ext_begin;          // spill entries for own positions 3..deg-1
+    uint32_t sub_eid[3][3];      // adjacency of to[j]
+    uint32_t sub_to[3][3];
+    uint32_t sub2_eid[3][3][2];  // adjacency of sub_to[j][q]
+    uint32_t sub2_to[3][3][2];
+    uint32_t sub_cnt(uint32_t j) const { return (sub_info >> (3 * j)) & 3u; }
+    bool sub_more(uint32_t j) const { return (sub_info >> (3 * j + 2)) & 1u; }
+    uint32_t sub2_cnt(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q))) & 3u; }
+    bool sub2_more(uint32_t j, uint32_t q) const { return (sub2_info >> (3 * (3 * j + q) + 2)) & 1u; }
+};
+static_assert(sizeof(EulerNode3) == 256, "EulerNode3 must be 256 bytes");
+
 // The latency-optimised walk of euler_fast.cpp (256-byte records with two levels of copied adjacency) seeded from the same
 // GPU-built records: faster than euler_cycles_lean while 256 bytes per node fit the host.
-Walks euler_cycles_from_lean(const LeanNode *lean, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
+// (nodes[V]: the caller's buffer for the 256-byte records, filled here by host threads)
+Walks euler_cycles_from_lean(const LeanNode *lean, EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+                             const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);
+
+// The same walk over complete 256-byte records (all three levels filled, e.g. by the GPU: finish_device.hip); nodes[V] is consumed.
+Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
                              const uint32_t *e_to, uint64_t E, HugeArena *arena);
 
 }  // namespace mtg

@@ -210,6 +210,45 @@ __global__ __launch_bounds__(EB) void lean_build_kernel(uint64_t n_nodes, const 
     nodes[v] = r;
 }
 
+// The 256-byte records of the latency-optimised walk (euler_fast.cpp: own adjacency + the first three positions of every head +
+// the first two positions of every head's heads) from the 32-byte ones: per node up to 3 + 9 gathers of 32-byte records, which
+// the GPU does ~100 x faster than the host's threads (phases B and C there: 1.4 s at the bench size).
+__global__ __launch_bounds__(EB) void wide_build_kernel(uint64_t n_nodes, const LeanNode *lean, EulerNode3 *wide) {
+    const uint64_t v = gid();
+    if (v >= n_nodes) return;
+    const LeanNode l = lean[v];
+    EulerNode3 r;
+    for (int i = 0; i < 3; i++) {
+        r.eid[i] = l.eid[i];
+        r.to[i] = l.to[i];
+    }
+    r.deg = l.deg;
+    r.pos = 0;
+    r.pad = 0;
+    r.ext_begin = l.ext_begin;
+    const uint32_t d = l.deg < 3 ? l.deg : 3;
+    uint32_t info = 0, info2 = 0;
+    for (uint32_t j = 0; j < d; j++) {
+        const LeanNode w = lean[l.to[j]];
+        const uint32_t c = w.deg < 3 ? w.deg : 3;
+        info |= (c | (w.deg > 3 ? 4u : 0u)) << (3 * j);
+        for (uint32_t q = 0; q < c; q++) {
+            r.sub_eid[j][q] = w.eid[q];
+            r.sub_to[j][q] = w.to[q];
+            const LeanNode x = lean[w.to[q]];
+            const uint32_t c2 = x.deg < 2 ? x.deg : 2;
+            info2 |= (c2 | (x.deg > 2 ? 4u : 0u)) << (3 * (3 * j + q));
+            for (uint32_t t = 0; t < c2; t++) {
+                r.sub2_eid[j][q][t] = x.eid[t];
+                r.sub2_to[j][q][t] = x.to[t];
+            }
+        }
+    }
+    r.sub_info = (uint16_t)info;
+    r.sub2_info = info2;
+    wide[v] = r;
+}
+
 // ---- rotate + cut (greedytigs/mod.rs:726-789) ----------------------------------------------------------------------
 struct CutIds {
     uint32_t n_orig;     // darts >= n_orig are dummies
@@ -510,7 +549,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     // ---- Euler bicycles ----
     Buf b_cyc, b_clen, b_cbase;
     uint32_t n_cycles = 0;
-    double kernel_ms = 0;
+    double kernel_ms = 0, acc2 = 0;
     if (euler_mode == MTG_EULER_DEVICE) {
         device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms);
     } else {
@@ -534,23 +573,59 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 uint32_t *d_xe = b_xe.alloc<uint32_t>(st, ext_total), *d_xt = b_xt.alloc<uint32_t>(st, ext_total);
                 lean_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_from, d_mirror, d_off, d_nodes, d_xe, d_xt);
                 HIP_CHECK(hipGetLastError());
-                HugeBuf<LeanNode> nodes(V, &g.arena);
                 std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
-                HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
                 if (ext_total) {
                     HIP_CHECK(hipMemcpyAsync(ext_eid.data(), d_xe, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
                     HIP_CHECK(hipMemcpyAsync(ext_to.data(), d_xt, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
                 }
-                HIP_CHECK(hipStreamSynchronize(st));
-                b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
-                lap.lap("walk records (GPU) + download");
                 // 256-byte records (two levels of copied adjacency: 2.6 steps per DRAM miss) while they fit comfortably, the
                 // 32-byte records themselves beyond (one miss per step, an eighth of the memory). Same walk either way;
                 // MTG_EULER_RECORDS=lean|wide overrides the choice (speed / memory only).
                 const char *rec = std::getenv("MTG_EULER_RECORDS");
                 const bool wide = rec ? std::strcmp(rec, "wide") == 0 : V * 256 <= (48ull << 30);
-                cycles = wide ? euler_cycles_from_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena)
-                              : euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                if (!wide) {
+                    HugeBuf<LeanNode> nodes(V, &g.arena);
+                    HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
+                    acc2 += lap.lap("walk records (GPU) + download");
+                    cycles = euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                } else {
+                    // The wide records live in the graph's arena. A mapping that comes back for its second call belongs to a
+                    // caller that iterates: it is page-locked once (hipHostRegister), and from then on the GPU builds all three
+                    // levels and the records come down at PCIe speed. A first (or only) call fills levels two and three with
+                    // host threads instead: pinning 23 GB of fresh memory costs more than it saves a one-shot caller.
+                    HugeBuf<EulerNode3> wbuf(V, &g.arena);
+                    bool pinned = false;
+                    const unsigned uses = g.arena.uses_of(wbuf.p, &pinned);
+                    static const bool pin_ok = std::getenv("MTG_NO_PIN") == nullptr;
+                    if (!pinned && uses >= 2 && pin_ok) {
+                        HugeArena::unpin_hook() = [](void *p) { (void)hipHostUnregister(p); };
+                        if (hipHostRegister(wbuf.p, wbuf.bytes, hipHostRegisterDefault) == hipSuccess) {
+                            g.arena.set_pinned(wbuf.p);
+                            pinned = true;
+                        } else (void)hipGetLastError();
+                    }
+                    if (pinned) {
+                        Buf b_wide;
+                        EulerNode3 *d_wide = b_wide.alloc<EulerNode3>(st, V);
+                        wide_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_nodes, d_wide);
+                        HIP_CHECK(hipGetLastError());
+                        HIP_CHECK(hipMemcpyAsync(wbuf.p, d_wide, V * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
+                        HIP_CHECK(hipStreamSynchronize(st));
+                        b_wide.release();
+                        b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
+                        acc2 += lap.lap("walk records, all levels (GPU) + download");
+                        cycles = euler_cycles_from_wide(wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                    } else {
+                        HugeBuf<LeanNode> nodes(V, &g.arena);
+                        HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
+                        HIP_CHECK(hipStreamSynchronize(st));
+                        b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
+                        acc2 += lap.lap("walk records (GPU) + download");
+                        cycles = euler_cycles_from_lean(nodes.p, wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                    }
+                }
             }
         }
         n_cycles = (uint32_t)cycles.limits.size();
@@ -571,7 +646,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         }
         HIP_CHECK(hipStreamSynchronize(st));
     }
-    if (times_out) { times_out[2] = lap.lap("Euler bicycles"); times_out[4] = kernel_ms; }
+    acc2 += lap.lap("Euler bicycles");
+    if (times_out) { times_out[2] = acc2; times_out[4] = kernel_ms; }
 
     // ---- rotate + cut ----
     {

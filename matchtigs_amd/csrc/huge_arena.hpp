@@ -16,7 +16,18 @@ struct HugeArena {
         void *p;
         size_t bytes;
         bool busy;
+        bool pinned = false;  // registered with the HIP runtime (page-locked) by the device finish: unregistered before it is unmapped
+        unsigned uses = 0;    // times the mapping was handed out
     };
+    // set by the HIP translation unit that pins mappings (hipHostUnregister); host-only builds never pin
+    static void (*&unpin_hook())(void *) {
+        static void (*hook)(void *) = nullptr;
+        return hook;
+    }
+    static void unmap_slot(const Slot &s) {
+        if (s.pinned && unpin_hook()) unpin_hook()(s.p);
+        munmap(s.p, s.bytes);
+    }
     std::vector<Slot> slots;
     std::mutex mu;
     int node = -1;  // NUMA node the mappings were placed on (the first user's): later users run there, next to the memory
@@ -33,6 +44,7 @@ struct HugeArena {
         for (Slot &s : slots)
             if (!s.busy && s.bytes >= bytes && s.bytes <= bytes + bytes / 4) {
                 s.busy = true;
+                s.uses++;
                 return s.p;
             }
         return nullptr;
@@ -44,14 +56,29 @@ struct HugeArena {
             bool dropped = false;
             for (size_t i = 0; i < slots.size() && !dropped; i++)
                 if (!slots[i].busy) {
-                    munmap(slots[i].p, slots[i].bytes);
+                    unmap_slot(slots[i]);
                     slots.erase(slots.begin() + (long)i);
                     dropped = true;
                 }
             if (!dropped) return false;
         }
-        slots.push_back(Slot{p, bytes, true});
+        slots.push_back(Slot{p, bytes, true, false, 1});
         return true;
+    }
+    // (uses, pinned) of the mapping at p; uses == 0: not an arena mapping
+    unsigned uses_of(void *p, bool *pinned = nullptr) {
+        std::lock_guard<std::mutex> l(mu);
+        for (Slot &s : slots)
+            if (s.p == p) {
+                if (pinned) *pinned = s.pinned;
+                return s.uses;
+            }
+        return 0;
+    }
+    void set_pinned(void *p) {
+        std::lock_guard<std::mutex> l(mu);
+        for (Slot &s : slots)
+            if (s.p == p) s.pinned = true;
     }
     bool give_back(void *p) {
         std::lock_guard<std::mutex> l(mu);
@@ -64,7 +91,7 @@ struct HugeArena {
     }
     void release() {
         std::lock_guard<std::mutex> l(mu);
-        for (Slot &s : slots) munmap(s.p, s.bytes);
+        for (Slot &s : slots) unmap_slot(s);
         slots.clear();
     }
 };
