@@ -324,6 +324,10 @@ uint64_t mtg_write_walks_gfa(const mtg_graph *g, uint64_t n_walks, const uint64_
                              const char *unitig_seqs, const uint64_t *seq_offsets, const char *header, char **gfa_out);
 uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
                                  const char *header, const char *path, int compression_level);
+/* Both file writers with the GPU to spell on named explicitly (mtg_config.device_ids[0] of the run that made the tigs): gfa == 0
+ * writes FASTA, else GFA with `gfa_header` or "H\tKL:Z:{k}". The two functions above spell on GPU 0. */
+uint64_t mtg_write_tigs_text_file_device(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs, int gfa,
+                                         const char *gfa_header, const char *path, int compression_level, int device_id);
 /* The same text (FASTA when gfa == 0, else GFA with `gfa_header` or "H\tKL:Z:{k}") spelled ON THE GPU `device_id`: the unitig
  * store is packed to 2 bits per base on the device and one kernel writes the characters at prefix-summed offsets. Byte-identical to
  * mtg_write_walks_fasta / _gfa for upper-case ACGT input (lower case is accepted and written upper case; any other character

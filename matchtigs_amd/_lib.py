@@ -195,6 +195,7 @@ def load():
         "mtg_unitigs_offsets": (vp, [vp]),
         "mtg_unitigs_free": (None, [vp]),
         "mtg_write_tigs_fasta_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_int]),
+        "mtg_write_tigs_text_file_device": (u64, [vp, vp, u64, vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
         "mtg_write_walks_text_device": (u64, [vp, u64, vp, vp, u64, C.c_char_p, vp, C.c_int, C.c_char_p, C.c_int, P(vp)]),
         "mtg_last_spell_kernel_ms": (C.c_double, []),
         "mtg_last_spell_bytes": (u64, []),

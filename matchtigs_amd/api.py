@@ -681,11 +681,12 @@ def compute_tigs_to_fasta_file(graph: Bigraph, store: UnitigStore, algorithm: in
     t1 = time.perf_counter()
     n_tigs = int(L.mtg_walks_count(w))
     nbytes = gbytes = 0
+    spell_dev = int(c.device_ids[0])  # spell where the tigs were computed (--device / cfg.device_ids)
     if path:
-        nbytes = int(L.mtg_write_tigs_fasta_file(graph.handle, w, k, store.handle, str(path).encode(), compression_level))
+        nbytes = int(L.mtg_write_tigs_text_file_device(graph.handle, w, k, store.handle, 0, None, str(path).encode(), compression_level, spell_dev))
     if gfa_path:
-        gbytes = int(L.mtg_write_tigs_gfa_file(graph.handle, w, k, store.handle, gfa_header.encode() if gfa_header else None,
-                                               str(gfa_path).encode(), compression_level))
+        gbytes = int(L.mtg_write_tigs_text_file_device(graph.handle, w, k, store.handle, 1, gfa_header.encode() if gfa_header else None,
+                                                       str(gfa_path).encode(), compression_level, spell_dev))
     if duplication_bitvector_path:
         L.mtg_write_tigs_duplication_bitvector_file(graph.handle, w, str(duplication_bitvector_path).encode())
     t2 = time.perf_counter()

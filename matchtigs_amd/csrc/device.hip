@@ -1865,7 +1865,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             if (n_pairs > w.cap_h_out) {
                 if (w.h_out) HIP_CHECK(hipHostFree(w.h_out));
                 w.cap_h_out = n_pairs + n_pairs / 4;
-                HIP_CHECK(hipHostMalloc(&w.h_out, w.cap_h_out * sizeof(mtg_pair), hipHostMallocNonCoherent));
+                // (coherent, the default: host threads read each slice right after hipEventSynchronize on an event recorded behind
+                // its copy; non-coherent host memory is only guaranteed visible after a stream / device synchronize)
+                HIP_CHECK(hipHostMalloc(&w.h_out, w.cap_h_out * sizeof(mtg_pair), hipHostMallocDefault));
             }
             const uint64_t n_slices = std::min<uint64_t>(8, (n_pairs + (1u << 18) - 1) >> 18);
             const uint64_t slice = (n_pairs + n_slices - 1) / n_slices;
@@ -1873,7 +1875,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             for (uint64_t i = 0; i < n_slices; i++) {
                 const uint64_t lo = i * slice, n = std::min(slice, n_pairs - lo);
                 HIP_CHECK(hipMemcpyAsync(w.h_out + lo, w.out + lo, n * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | hipEventReleaseToSystem));
                 HIP_CHECK(hipEventRecord(ev[i], st));
             }
             const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8, (uint64_t)std::thread::hardware_concurrency(), n_pairs >> 18}));

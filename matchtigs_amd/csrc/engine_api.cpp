@@ -429,32 +429,26 @@ void mtg_unitigs_free(mtg_unitigs *u) {
     delete u->s;
     delete u;
 }
-uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
-                                   const char *path, int compression_level) {
-    if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_fasta_file: null argument");
+uint64_t mtg_write_tigs_text_file_device(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs, int gfa,
+                                         const char *gfa_header, const char *path, int compression_level, int device_id) {
+    if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_text_file_device: null argument");
     char *buf = nullptr;
-    const uint64_t n = device_count() > 0
+    const uint64_t n = device_count() > device_id && device_id >= 0
                            ? device_write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k, unitigs->s->data.data(),
-                                                     unitigs->s->off.data(), false, nullptr, 0, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
-                           : write_walks_fasta(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
-                                               unitigs->s->data.data(), unitigs->s->off.data(), &buf);
+                                                     unitigs->s->off.data(), gfa != 0, gfa_header, device_id, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
+                           : write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                                              unitigs->s->data.data(), unitigs->s->off.data(), gfa != 0, gfa_header, &buf);
     write_file(path, buf, n, compression_level);
     std::free(buf);
     return n;
 }
-
+uint64_t mtg_write_tigs_fasta_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
+                                   const char *path, int compression_level) {
+    return mtg_write_tigs_text_file_device(g, tigs, k, unitigs, 0, nullptr, path, compression_level, 0);
+}
 uint64_t mtg_write_tigs_gfa_file(const mtg_graph *g, const mtg_walks *tigs, uint64_t k, const mtg_unitigs *unitigs,
                                  const char *header, const char *path, int compression_level) {
-    if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_gfa_file: null argument");
-    char *buf = nullptr;
-    const uint64_t n = device_count() > 0
-                           ? device_write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k, unitigs->s->data.data(),
-                                                     unitigs->s->off.data(), true, header, 0, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
-                           : write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
-                                              unitigs->s->data.data(), unitigs->s->off.data(), true, header, &buf);
-    write_file(path, buf, n, compression_level);
-    std::free(buf);
-    return n;
+    return mtg_write_tigs_text_file_device(g, tigs, k, unitigs, 1, header, path, compression_level, 0);
 }
 
 // ---- optimal matchtigs around the external matcher (matchtigs/mod.rs:150-940) ----
@@ -479,7 +473,6 @@ mtg_matching *mtg_matching_instance(const mtg_graph *g, const mtg_config *cfg) {
     device_candidates_to_host(dev->d, nullptr, cand_start, cand_count, pool);
     mtg_device_free(dev);
     double t1 = now_s();
-    log_info("Found %zu shortest paths", pool.size());
     MatchingInstance *m = build_matching_instance(g->g, k, S, out_nodes.data(), mult.data(), cand_start.data(), cand_count.data(), pool.data());
     log_info("Took %.6fs for computing paths and getting edges, of this %.6fs are from dijkstra", now_s() - t0, t1 - t0);
     log_info("Found %llu nodes and %zu edges", (unsigned long long)m->transformed_node_count, m->edge_n2.size());

@@ -55,9 +55,9 @@ def allgather_candidates(start: torch.Tensor, count: torch.Tensor, pool: torch.T
     rank = dist.get_rank(group)
     dev = pool.device
     sizes = torch.tensor([pool_used], dtype=torch.int64, device=dev)
-    all_sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
-    pool_sizes = [int(x) for x in all_sizes.tolist()]
+    all_sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    pool_sizes = [int(t.item()) for t in all_sizes]
     n_total = ranges[-1][1]
     start_all = torch.empty(n_total, dtype=torch.int64, device=dev)
     count_all = torch.empty(n_total, dtype=torch.int32, device=dev)

@@ -156,3 +156,25 @@ def test_matcher_failure_aborts_like_the_reference(gpu, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "Matcher was unsuccessful" in r.stderr
     assert os.path.exists(str(tmp_path / "f") + ".minimalperfectmatching")
+
+
+def test_bare_matcher_name_is_found_through_path(gpu, oracle, tmp_path, monkeypatch):
+    """The reference starts the matcher with Command::new(matcher_path) (matchtigs/mod.rs:727), which resolves a bare name such as
+    "blossom5" through PATH; so does the library (posix_spawnp), here through the reference's own C-ABI with algorithm 4."""
+    from matchtigs_amd import api, synth
+
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    exe = bindir / "blossom5-stand-in"
+    exe.write_text(f"#!/bin/sh\nexec {sys.executable} {MATCHER} \"$@\"\n")
+    exe.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{bindir}{os.pathsep}{os.environ.get('PATH', '')}")
+    k = 31
+    ua = synth.g_seq_arrays(60_000, seed=5, k=k, haplotypes=4, sub_rate=0.02)
+    links = [(int(a), bool(b), int(c), bool(d)) for a, b, c, d in ua.links]
+    prefix = tmp_path / "bare"
+    n, eo, io, lo = api.clib_compute_tigs(ua.weights, links, 4, 1, k, matching_file_prefix=str(prefix), matcher_path="blossom5-stand-in")
+    og = oracle.OracleGraph.from_unitig_links_arrays(ua.weights, ua.links)
+    om = og.matching_instance(k)
+    tigs = om.apply(str(prefix) + ".minimalperfectmatching.solution")
+    assert n == len(tigs) and int(lo[-1]) == sum(len(t) for t in tigs)
