@@ -11,9 +11,11 @@
  * on null pointers, an unknown algorithm id, a broken node pairing / mirror property, a graph that
  * cannot be made Eulerian, a missing GPU, or any HIP error. There is NO CPU fallback.
  *
- * Algorithms served on the MI355X path: 1 (unitigs), 3 (eulertigs), 5 (greedy matchtigs).
- * Ids 2 (pathtigs) and 4 (optimal matchtigs, needs the external blossom5 binary) are outside this
- * engine's scope and abort with a message saying so.
+ * Algorithms served on the MI355X path: 1 (unitigs), 3 (eulertigs), 5 (greedy matchtigs) and 4
+ * (optimal matchtigs: the matching instance is built from the GPU's candidate lists and the matcher named by
+ * `matcher_path` -- blossom5 or compatible, found through PATH like the reference's Command::new -- runs as a
+ * child process, exactly as in the reference). Id 2 (pathtigs) is outside this engine's scope and aborts with
+ * a message saying so.
  */
 #ifndef MATCHTIGS_H
 #define MATCHTIGS_H

@@ -165,7 +165,9 @@ const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d);
  * (distance << 32 | node), ascending, into d_pool[d_cand_start[i-src_begin] ..+ d_cand_count[..]].
  * Returns 0 on success; 1 if pool_capacity was too small (*pool_needed tells the size to retry
  * with; outputs are then invalid). Sources whose ball does not fit the fast kernel's LDS tables
- * are re-run by larger kernel levels internally; a ball that fits no level aborts.
+ * are re-run by larger kernel levels internally, down to a dense level without any limit on the ball
+ * (no legal input aborts: the reference's search has no size limit either, greedytigs/mod.rs:548-551).
+ * k may exceed 65535 as long as every unitig weight stays below 65535 (weights are 16-bit in HBM).
  * Synchronises `stream` before returning. */
 int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end,
                         uint64_t *d_pool, uint64_t pool_capacity, uint64_t *d_cand_start,

@@ -1384,6 +1384,111 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Last level: no limit on the ball. One source at a time over DENSE arrays in HBM (a 32-bit tentative distance and a round
+// stamp per node): frontier rounds of label-correcting relaxations (atomicMin; a node joins the next frontier once per
+// round), until the frontier is empty; then one pass over the nodes collects the in-nodes within the bound. O(V) per source
+// on top of the ball: only sources that overflowed the 2^22-entry global-workspace level land here (none on any genome graph;
+// the reference's search has no such limit either, greedytigs/mod.rs:548-551), and the price buys "no abort on legal input".
+// ------------------------------------------------------------------------------------------------
+__global__ void dense_relax_kernel(const NodeBlock *recs, const uint32_t *ext_col, const uint16_t *ext_w, uint32_t K1, const uint32_t *frontier,
+                                   uint64_t n_front, uint32_t round, uint32_t *dist, uint32_t *stamp, uint32_t *next, unsigned long long *n_next) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_front) return;
+    const uint32_t u = frontier[i];
+    const uint32_t du = __hip_atomic_load(&dist[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const NodeBlock &r = recs[u];
+    auto relax = [&](uint32_t v, uint32_t w) {
+        const uint64_t nd = (uint64_t)du + w;
+        if (nd > K1) return;
+        const uint32_t old = atomicMin(&dist[v], (uint32_t)nd);
+        if ((uint32_t)nd < old && atomicExch(&stamp[v], round) != round) next[atomicAdd(n_next, 1ull)] = v;
+    };
+    if (r.flags & F_EXT) {
+        const uint64_t b = (uint64_t)r.nbr[0] | ((uint64_t)r.nbr[1] << 32);
+        for (uint32_t e = 0; e < r.nbr[2]; e++) relax(ext_col[b + e], ext_w[b + e]);
+    } else {
+        for (uint32_t e = 0; e < r.deg; e++) relax(r.nbr[e], r.w[e]);
+    }
+}
+__global__ void dense_collect_kernel(const NodeBlock *recs, uint64_t n_nodes, uint32_t source, uint32_t K1, const uint32_t *dist,
+                                     unsigned long long *keys, unsigned long long *n_keys) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes || v == source) return;  // forbid_source_target
+    const uint32_t d = dist[v];
+    if (d <= K1 && (recs[v].flags & F_TARGET)) keys[atomicAdd(n_keys, 1ull)] = ((unsigned long long)d << 32) | v;
+}
+__global__ void dense_set_kernel(uint32_t *dist, uint32_t *frontier, uint32_t source) {
+    dist[source] = 0;
+    frontier[0] = source;
+}
+__global__ void dense_result_kernel(unsigned long long *cand_start, uint32_t *cand_count, uint64_t slot, unsigned long long start, uint32_t count) {
+    cand_start[slot] = start;
+    cand_count[slot] = count;
+}
+
+// Sources [0, n_src) of `list` (absolute source indices). Keys go to the pool at the cursor C_POOL like every other level's;
+// their order (distance, node) -- all distinct -- is established by a sort of the collected keys on the host.
+static void run_dense_level(Device *d, hipStream_t st, const SsspArgs &a, const uint32_t *d_list, uint64_t n_src) {
+    const uint64_t V = d->V;
+    std::vector<uint32_t> list(n_src);
+    HIP_CHECK(hipMemcpyAsync(list.data(), d_list, n_src * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::sort(list.begin(), list.end());
+    uint32_t *d_dist = nullptr, *d_stamp = nullptr, *d_front[2] = {nullptr, nullptr};
+    unsigned long long *d_keys = nullptr, *d_n = nullptr;
+    HIP_CHECK(hipMalloc(&d_dist, V * 4));
+    HIP_CHECK(hipMalloc(&d_stamp, V * 4));
+    HIP_CHECK(hipMalloc(&d_front[0], V * 4));
+    HIP_CHECK(hipMalloc(&d_front[1], V * 4));
+    HIP_CHECK(hipMalloc(&d_keys, V * 8));
+    HIP_CHECK(hipMalloc(&d_n, 16));
+    std::vector<unsigned long long> keys;
+    std::vector<uint32_t> sources(1);
+    for (const uint32_t idx : list) {
+        HIP_CHECK(hipMemcpyAsync(sources.data(), d->d_out_nodes + idx, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t s = sources[0];
+        HIP_CHECK(hipMemsetAsync(d_dist, 0xFF, V * 4, st));
+        HIP_CHECK(hipMemsetAsync(d_stamp, 0xFF, V * 4, st));
+        hipLaunchKernelGGL(dense_set_kernel, dim3(1), dim3(1), 0, st, d_dist, d_front[0], s);
+        uint64_t n_front = 1;
+        int cur = 0;
+        for (uint32_t round = 0; n_front; round++) {
+            if (round == 0xFFFFFFFEu) MTG_DIE("dense search level: round counter exhausted");
+            HIP_CHECK(hipMemsetAsync(d_n, 0, 8, st));
+            hipLaunchKernelGGL(dense_relax_kernel, dim3((unsigned)((n_front + 255) / 256)), dim3(256), 0, st, a.recs, a.ext_col, a.ext_w, a.K1,
+                               d_front[cur], n_front, round, d_dist, d_stamp, d_front[cur ^ 1], d_n);
+            HIP_CHECK(hipGetLastError());
+            unsigned long long h = 0;
+            HIP_CHECK(hipMemcpyAsync(&h, d_n, 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            n_front = h;
+            cur ^= 1;
+        }
+        HIP_CHECK(hipMemsetAsync(d_n, 0, 8, st));
+        hipLaunchKernelGGL(dense_collect_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, a.recs, V, s, a.K1, d_dist, d_keys, d_n);
+        HIP_CHECK(hipGetLastError());
+        unsigned long long n_keys = 0;
+        HIP_CHECK(hipMemcpyAsync(&n_keys, d_n, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (n_keys > 0xFFFFFFFFull) MTG_DIE("dense search level: a candidate list beyond 2^32 entries");
+        keys.resize(n_keys);
+        if (n_keys) HIP_CHECK(hipMemcpyAsync(keys.data(), d_keys, n_keys * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::sort(keys.begin(), keys.end());
+        const unsigned long long start = d->h_counters[C_POOL];  // host mirror of the pool cursor (read_counters ran after the last level)
+        d->h_counters[C_POOL] += n_keys;
+        if (start + n_keys <= a.pool_cap && n_keys) HIP_CHECK(hipMemcpyAsync(a.pool + start, keys.data(), n_keys * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(dense_result_kernel, dim3(1), dim3(1), 0, st, a.cand_start, a.cand_count, (uint64_t)idx - a.src_begin, start, (uint32_t)n_keys);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    HIP_CHECK(hipMemcpyAsync(&d->d_counters[C_POOL], &d->h_counters[C_POOL], 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (void *p : {(void *)d_dist, (void *)d_stamp, (void *)d_front[0], (void *)d_front[1], (void *)d_keys, (void *)d_n}) HIP_CHECK(hipFree(p));
+}
+
 static void read_counters(Device *d, hipStream_t st) {
     HIP_CHECK(hipMemcpyAsync(d->h_counters, d->d_counters, C_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -1424,6 +1529,25 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
     const bool use_enum = d->plan != 1 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
+    const bool dense_only = d->K1 >= (1u << 21);  // (the cooperative levels keep 21-bit distances in their table entries)
+    if (dense_only) {  // every source straight to the dense level: correct for any bound, O(V) per source
+        if (count) MTG_DIE("the counting kernels need k - 1 < 2^21");
+        std::vector<uint32_t> all(n);
+        for (uint64_t i = 0; i < n; i++) all[i] = (uint32_t)(src_begin + i);
+        if (n) HIP_CHECK(hipMemcpyAsync(d->d_ovf[0], all.data(), n * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        d->h_counters[C_POOL] = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (n) run_dense_level(d, st, a, d->d_ovf[0], n);
+        d->last_kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        d->last_n_levels = 1;
+        d->last_level_ms[0] = d->last_kernel_ms;
+        d->last_level_sources[0] = n;
+        d->last_level_name[0] = "dense_relax_kernel rounds + dense_collect_kernel (one source at a time)";
+        const bool small = d->h_counters[C_POOL] > pool_cap;
+        if (pool_needed) *pool_needed = d->h_counters[C_POOL];
+        return small ? 1 : 0;
+    }
     if (use_enum) launch_enum(d, st, a);
     else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
@@ -1467,10 +1591,23 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
         if (debug) std::fprintf(stderr, "[mtg] level %d (coop, %d src/block): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", li,
                                 next.bsrc, (unsigned long long)n_ovf, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
     }
+    if (d->h_counters[C_OVERFLOW] > 0) {  // balls beyond the 2^22 entries of the global-workspace level: the dense level has no limit
+        const uint64_t n_ovf = d->h_counters[C_OVERFLOW];
+        if (count) MTG_DIE("the counting kernels cannot follow %llu source(s) beyond the last cooperative level", (unsigned long long)n_ovf);
+        const auto t0 = std::chrono::steady_clock::now();
+        run_dense_level(d, st, a, d->d_ovf[cur_list], n_ovf);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        total_ms += ms;
+        if (d->last_n_levels < 8) {
+            d->last_level_ms[d->last_n_levels] = ms;
+            d->last_level_sources[d->last_n_levels] = n_ovf;
+            d->last_level_name[d->last_n_levels] = "dense_relax_kernel rounds + dense_collect_kernel (one source at a time)";
+            d->last_n_levels++;
+        }
+        if (debug) std::fprintf(stderr, "[mtg] dense level: %llu sources, %.3f ms\n", (unsigned long long)n_ovf, ms);
+        d->h_counters[C_OVERFLOW] = 0;
+    }
     if (!count) d->last_kernel_ms = total_ms;
-    if (d->h_counters[C_OVERFLOW] > 0)
-        MTG_DIE("bounded search from %llu source(s) exceeds every kernel level (ball larger than 2^22 table entries)",
-                (unsigned long long)d->h_counters[C_OVERFLOW]);
     if (stats) {
         stats->sources = n;
         stats->settled_nodes = d->h_counters[C_SETTLED];
@@ -1495,7 +1632,16 @@ int device_count() {
 
 Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     if (k < 1) MTG_DIE("k must be >= 1");
-    if (k > 65535) MTG_DIE("k = %llu is not supported by the device stage (weights are clamped into 16 bits)", (unsigned long long)k);
+    if (k > 0xFFFFFFFFull) MTG_DIE("k = %llu is not supported by the device stage (32-bit distances)", (unsigned long long)k);
+    if (k > 65535) {
+        // Edge weights live in 16 bits, clamped to min(w, k) (an edge of weight >= k can never lie on a path within k - 1). With
+        // k beyond 16 bits the clamp no longer fits, so every weight itself has to: true for any unitig set (a weight is a
+        // number of k-mers of a unitig). Distances beyond 15 / 21 bits skip the enumeration / cooperative levels (run_levels).
+        for (uint64_t e = 0; e < g.n_original_edges; e++)
+            if (g.e_weight[e] > 65534)
+                MTG_DIE("k = %llu with a unitig of %llu k-mers: beyond k = 65535 the device stage needs every weight below 65535",
+                        (unsigned long long)k, (unsigned long long)g.e_weight[e]);
+    }
     if (device_count() <= device_id) MTG_DIE("no MI355X/HIP device %d available; libmatchtigs has no CPU path", device_id);
     HIP_CHECK(hipSetDevice(device_id));
     Device *d = new Device();

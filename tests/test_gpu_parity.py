@@ -197,6 +197,42 @@ def test_deepest_levels_huge_balls(gpu, oracle, plan):
     assert np.array_equal(got, keys)
 
 
+def test_ball_beyond_every_table_level(gpu, oracle):
+    """No abort on legal input (the reference's search has no size limit, greedytigs/mod.rs:548-551): a unit-weight graph whose
+    (k-1)-balls hold more than the 2^22 entries of the last cooperative level's table; the dense level finishes such sources, and
+    the lists equal the oracle's Dijkstra lists. Two sources (every source of this graph has such a ball)."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(5_000_000, seed=2, k=120, mean_out_degree=1.7, mean_weight=1.0, self_mirror_frac=0.0)
+    lo, hi = 1000, 1002
+    G, dev, S, start, count, pool = _gpu_candidates(bg, 0, lo, hi)
+    levels = dev.last_sssp_levels()
+    assert levels[-1]["kernel"].startswith("dense_relax_kernel") and levels[-1]["sources"] >= 1, levels
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k, lo, hi)
+    assert st["settled_nodes"] > (1 << 22)   # the balls really are that large
+    assert np.array_equal(count.astype(np.uint64), np.diff(off)[lo:hi])
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])
+    assert np.array_equal(got, keys)
+
+
+@pytest.mark.parametrize("k", [70_000, 3_000_000])
+def test_k_beyond_16_bits(gpu, oracle, k):
+    """k above 65535 (weights still fit 16 bits): distances beyond 15 bits skip the enumeration level, beyond 21 bits every
+    source takes the dense level. Candidate lists and tigs equal the oracle's."""
+    from matchtigs_amd import api, synth
+
+    bg = synth.g_csr(150, seed=6, k=31, mean_out_degree=1.4, mean_weight=6.0, self_mirror_frac=0.02)
+    bg.k = k
+    G, dev, S, start, count, pool = _gpu_candidates(bg, 0)
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(k)
+    assert np.array_equal(count.astype(np.uint64), np.diff(off))
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)]) if len(start) else np.zeros(0, np.uint64)
+    assert np.array_equal(got, keys)
+    want, _ = _oracle(oracle, bg).compute_greedytigs(k)
+    H = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    assert api.GreedytigAlgorithm.compute_tigs(H, api.GreedytigAlgorithmConfiguration(1, k)) == want
+
+
 @pytest.mark.parametrize("plan", [0, 1, 2])
 def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, plan):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
