@@ -167,7 +167,7 @@ inline const DeviceEdgeCache *edge_cache_get(const HostGraph &g, int device) {
 // cache of the same device and frees the offered arrays instead.
 inline void edge_cache_put(const HostGraph &g, int device, uint32_t *d_from, uint32_t *d_mirror) {
     std::lock_guard<std::mutex> l(edge_cache_mutex());
-    if (g.device_cache) {  // first come, first kept (one cache per graph)
+    if (g.device_cache || std::getenv("MTG_NO_EDGE_CACHE")) {  // first come, first kept (one cache per graph)
         (void)hipFree(d_from);
         (void)hipFree(d_mirror);
         return;

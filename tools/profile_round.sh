@@ -7,8 +7,8 @@ set -u
 OUT=${1:-gpurun_out/prof}
 SIZE=${SIZE:-""}
 export TMPDIR=/tmp
-BENCH=${BENCH:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --euler-device-steps 0 $SIZE"}
-PMCBENCH=${PMCBENCH:-"python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --euler-device-steps 0 $SIZE"}
+BENCH=${BENCH:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --device-mode-steps 0 --extra-seeds= $SIZE"}
+PMCBENCH=${PMCBENCH:-"python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --device-mode-steps 0 --extra-seeds= $SIZE"}
 T="timeout -k 10 420"
 mkdir -p "$OUT"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err"; echo "stats rc=$?"
