@@ -1209,7 +1209,7 @@ struct ReplayWork {
     unsigned long long *resv[2] = {nullptr, nullptr};
     uint32_t tag_base = 0xFFFFFFFFu;          // reservation tags used so far (the arrays are never cleared between calls)
     Touch *touch = nullptr;
-    uint8_t *big = nullptr;
+    uint32_t *meta = nullptr, *src_mirror = nullptr;
     unsigned long long *claims = nullptr;
     uint32_t *pair_count = nullptr, *pending[2] = {nullptr, nullptr}, *spill = nullptr;
     unsigned long long *final_off = nullptr, *block_sums = nullptr;
@@ -1730,7 +1730,7 @@ void device_free(Device *d) {
     (void)hipFree(d->d_fix);
     (void)hipFree(d->d_fix_dense);
     ReplayWork &w = d->replay;
-    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.big, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
+    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.meta, w.src_mirror, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};
     for (void *b : rb) (void)hipFree(b);
     (void)hipHostFree(w.h_ctl);
@@ -1893,11 +1893,12 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     if (S > w.cap_s) {
         if (w.touch) {
-            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.big)); HIP_CHECK(hipFree(w.claims)); HIP_CHECK(hipFree(w.pair_count));
+            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.meta)); HIP_CHECK(hipFree(w.src_mirror)); HIP_CHECK(hipFree(w.claims)); HIP_CHECK(hipFree(w.pair_count));
             HIP_CHECK(hipFree(w.pending[0])); HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.final_off));
         }
         HIP_CHECK(hipMalloc(&w.touch, S * sizeof(Touch)));
-        HIP_CHECK(hipMalloc(&w.big, S));
+        HIP_CHECK(hipMalloc(&w.meta, S * 4));
+        HIP_CHECK(hipMalloc(&w.src_mirror, S * 4));
         HIP_CHECK(hipMalloc(&w.claims, S * 8));
         HIP_CHECK(hipMalloc(&w.pair_count, S * 4));
         HIP_CHECK(hipMalloc(&w.pending[0], S * 4));
@@ -1925,13 +1926,15 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // working copy of the classification state; per-source outputs start at "nothing claimed"
     hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
     HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(replay_src_mirror_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, d->d_out_nodes, d_cand_count, d->d_mirror, S, w.src_mirror);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(w.pair_count, 0, S * 4, st));
     HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
 
     ReplayArgs a{};
     a.out_nodes = d->d_out_nodes; a.state = w.state;
     a.cand_start = (const unsigned long long *)d_cand_start; a.cand_count = d_cand_count; a.pool = (const unsigned long long *)d_pool;
-    a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.big = w.big; a.claims = w.claims; a.pair_count = w.pair_count;
+    a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.meta = w.meta; a.src_mirror = w.src_mirror; a.claims = w.claims; a.pair_count = w.pair_count;
     a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
     a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
     // index-ordered admission windows: ~256 K sources each, between 4 and 64 of them (a round costs a grid barrier plus one
