@@ -265,6 +265,10 @@ mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k);
 uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs); /* returns last dummy id */
 uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k);          /* returns last dummy id */
 mtg_walks *mtg_euler_cycles(const mtg_graph *g);
+/* The same walk over the record formats the device finish feeds it, with the records built on the host from the
+ * graph's adjacency lists: 1 = 32-byte records (euler_lean.cpp), 2 = 256-byte records seeded from 32-byte ones. Same sequences as
+ * mtg_euler_cycles (format 0); exported for the CPU test suite and the sanitizer builds. */
+mtg_walks *mtg_euler_cycles_records(const mtg_graph *g, int record_format);
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k);
 /* the Euler bicycles computed on the GPU by a parallel algorithm (trail pairing, union-find merge,
  * list ranking). Same guarantees as the reference's decomposition (greedytigs/mod.rs:722: one closed biwalk per

@@ -165,6 +165,7 @@ def load():
         "mtg_insert_pair_edges": (u64, [vp, vp, u64]),
         "mtg_make_eulerian": (u64, [vp, u64, u64]),
         "mtg_euler_cycles": (vp, [vp]),
+        "mtg_euler_cycles_records": (vp, [vp, C.c_int]),
         "mtg_cut_cycles": (vp, [vp, vp, u64]),
         "mtg_euler_cycles_device": (vp, [vp, C.c_int]),
         "mtg_config_init": (None, [P(MtgConfig), u64, u64]),

@@ -1937,10 +1937,13 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.meta = w.meta; a.src_mirror = w.src_mirror; a.claims = w.claims; a.pair_count = w.pair_count;
     a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
     a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
-    // index-ordered admission windows: ~256 K sources each, between 4 and 64 of them (a round costs a grid barrier plus one
+    // index-ordered admission windows: ~128 K sources each, between 4 and 48 of them (measured on the round-3 kernel, 2^27: 32 / 48 /
+    // 64 / 96 windows = 8.2 / 7.7 / 8.4 / 8.9 ms; 2^24: 8 / 16 / 24 windows = 3.8 / 3.15 / 2.7 ms, the conflict chains alone need 33
+    // rounds there) (a round costs a grid barrier plus one
     // dependent-access chain, ~30-50 us, so tiny windows are latency bound; huge ones bring the waiting visits back)
     {
-        const uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(64, (S + (1u << 18) - 1) >> 18));
+        uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (S + (1u << 17) - 1) >> 17));
+        if (const char *e = std::getenv("MTG_REPLAY_WINDOWS")) n_win = std::max<uint64_t>(1, (uint64_t)std::atoll(e));  // (tuning only: the pair list does not depend on it)
         a.window = std::max<uint64_t>((S + n_win - 1) / n_win, REPLAY_BLOCK);
     }
 

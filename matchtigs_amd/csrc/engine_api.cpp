@@ -18,7 +18,9 @@
 #include "../../include/matchtigs.h"
 #include "../../include/mtg_engine.h"
 #include "device.hpp"
+#include "euler_lean.hpp"
 #include "host_graph.hpp"
+#include "hugebuf.hpp"
 
 using namespace mtg;
 
@@ -214,6 +216,32 @@ uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_p
 }
 uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k) { return make_eulerian(g->g, dummy_edge_id, k); }
 mtg_walks *mtg_euler_cycles(const mtg_graph *g) { return new mtg_walks{euler_cycles(g->g)}; }
+mtg_walks *mtg_euler_cycles_records(const mtg_graph *g, int record_format) {
+    const HostGraph &h = g->g;
+    if (record_format == 0) return new mtg_walks{euler_cycles(h)};
+    if (record_format != 1 && record_format != 2) MTG_DIE("mtg_euler_cycles_records: unknown record format %d", record_format);
+    h.ensure_linked();
+    const uint64_t V = h.node_count(), E = h.edge_count();
+    std::vector<LeanNode> lean(V);
+    std::vector<uint32_t> ext_eid, ext_to;
+    for (uint64_t n = 0; n < V; n++) {  // what lean_build_kernel writes (finish_device.hip): own adjacency, newest edge first
+        LeanNode &r = lean[n];
+        if (h.out_deg[n] > 65535) MTG_DIE("mtg_euler_cycles_records: out-degree beyond 65535");
+        r.deg = (uint16_t)h.out_deg[n];
+        r.pos = 0;
+        r.ext_begin = (uint32_t)ext_eid.size();
+        for (int i = 0; i < 3; i++) r.eid[i] = r.to[i] = NONE;
+        uint32_t i = 0;
+        for (uint32_t e = h.head_out[n]; e != NONE; e = h.e_next_out[e], i++) {
+            if (i < 3) { r.eid[i] = e; r.to[i] = h.e_to[e]; }
+            else { ext_eid.push_back(e); ext_to.push_back(h.e_to[e]); }
+        }
+    }
+    if (record_format == 1)
+        return new mtg_walks{euler_cycles_lean(lean.data(), V, ext_eid.data(), ext_to.data(), h.e_from.data(), h.e_to.data(), E, &h.arena)};
+    HugeBuf<EulerNode3> wide(V, &h.arena);
+    return new mtg_walks{euler_cycles_from_lean(lean.data(), wide.p, V, ext_eid.data(), ext_to.data(), h.e_from.data(), h.e_to.data(), E, &h.arena)};
+}
 mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id) {
     return new mtg_walks{device_euler_cycles(g->g, device_id, &g_last_euler_kernel_ms)};
 }

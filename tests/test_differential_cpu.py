@@ -91,7 +91,10 @@ def test_euler_cycles_linked_list_equals_literal_on_larger_graph(oracle, product
     d1 = og.make_eulerian(k, len(pairs))
     d2 = G.make_eulerian(len(pairs), k)
     assert d1 == d2
-    assert og.euler_cycles() == G.euler_cycles()
+    want_cycles = og.euler_cycles()
+    assert want_cycles == G.euler_cycles()
+    assert want_cycles == G.euler_cycles_records(1)   # 32-byte records (the memory-lean walk, euler_lean.cpp)
+    assert want_cycles == G.euler_cycles_records(2)   # 256-byte records seeded from 32-byte ones (the device finish's route)
 
 
 def test_euler_walk_scratch_is_reused_between_calls_on_one_graph(oracle, product_lib):
