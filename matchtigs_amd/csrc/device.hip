@@ -577,7 +577,10 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 }
                 if (tid == 0) {
                     s.total = running;
-                    if (running > (uint32_t)SCAP) s.ovf = 1;  // staging too small -> larger level
+                    // staging too small -> larger level. The ranking below is quadratic in a source's candidates: fine up to the
+                    // few thousand the LDS levels can stage, not for the millions the global-workspace level could -- beyond
+                    // 32768 (10^9 comparisons, a few ms) that level hands the source to the dense level, which sorts (n log n).
+                    if (running > (uint32_t)SCAP || (GLOBAL_WS && running > 32768u)) s.ovf = 1;
                     else if constexpr (!COUNT) {
                         if (s.chunk_next + running > s.chunk_end) {
                             const unsigned long long grab = running > POOL_CHUNK ? (unsigned long long)running : POOL_CHUNK;

@@ -215,6 +215,23 @@ def test_ball_beyond_every_table_level(gpu, oracle):
     assert np.array_equal(got, keys)
 
 
+def test_many_candidates_in_a_mid_sized_ball(gpu, oracle):
+    """A ball that fits the global-workspace level's table but holds far more in-nodes than its quadratic ranking should ever see
+    (here ~100 000 per source): such sources go on to the dense level instead. Lists equal the oracle's."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(250_000, seed=3, k=100, mean_out_degree=1.8, mean_weight=1.0, self_mirror_frac=0.0)
+    lo, hi = 500, 504
+    G, dev, S, start, count, pool = _gpu_candidates(bg, 0, lo, hi)
+    levels = dev.last_sssp_levels()
+    assert levels[-1]["kernel"].startswith("dense_relax_kernel"), levels
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k, lo, hi)
+    assert np.diff(off)[lo:hi].max() > 32768
+    assert np.array_equal(count.astype(np.uint64), np.diff(off)[lo:hi])
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)])
+    assert np.array_equal(got, keys)
+
+
 @pytest.mark.parametrize("k", [70_000, 3_000_000])
 def test_k_beyond_16_bits(gpu, oracle, k):
     """k above 65535 (weights still fit 16 bits): distances beyond 15 bits skip the enumeration level, beyond 21 bits every
