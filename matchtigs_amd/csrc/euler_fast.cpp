@@ -370,17 +370,22 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
             while (fifo_tail - fifo_head >= (1u << 18) && !has_unused(ent_node[fifo[fifo_head]])) {
                 std::atomic<size_t> first_hit{fifo_tail};
                 const size_t base = fifo_head;
-                parallel_ranges(fifo_tail - base, [&](uint64_t lo, uint64_t hi) {
-                    for (uint64_t i = base + lo; i < base + hi; i++) {
-                        if (i + PF < base + hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
-                        if ((i & 1023) == 0 && first_hit.load(std::memory_order_relaxed) < i) return;
+                // tasks of 64 K entries handed out in FIFO order: all threads work on the earliest unfinished stretch, so the
+                // scan takes (position of the first hit) / (throughput of all threads) wherever that hit lies
+                constexpr uint64_t TASK = 1u << 16;
+                const uint64_t n_scan = fifo_tail - base;
+                parallel_tasks((n_scan + TASK - 1) / TASK, [&](uint64_t task) {
+                    const uint64_t lo = base + task * TASK, hi = std::min<uint64_t>(base + n_scan, lo + TASK);
+                    if (first_hit.load(std::memory_order_relaxed) < lo) return;
+                    for (uint64_t i = lo; i < hi; i++) {
+                        if (i + PF < hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
                         if (has_unused(ent_node[fifo[i]])) {
                             size_t cur = first_hit.load(std::memory_order_relaxed);
                             while (i < cur && !first_hit.compare_exchange_weak(cur, (size_t)i)) {}
                             return;
                         }
                     }
-                });
+                }, 64);
                 fifo_head = first_hit.load();  // everything before it is exhausted; the sequential loop takes it from here
                 break;
             }

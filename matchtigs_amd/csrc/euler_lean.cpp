@@ -8,6 +8,7 @@
 // out-edge, rotated there and continued ("insert the next closed walk before that entry": circular entry list + FIFO).
 // Memory: 32 B per node + 12 B per biedge instead of the 256-byte records of euler_fast.cpp, so the exact order is available
 // at the human-like size (2^30 nominal edges: 23 GB of records) -- one dependent DRAM access per step, no lookahead copies.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -128,17 +129,22 @@ Walks euler_cycles_lean(LeanNode *nodes, uint64_t V, const uint32_t *ext_eid, co
             if (fifo_tail - fifo_head >= (1u << 18) && !has_unused(ent_node[fifo[fifo_head]])) {
                 std::atomic<size_t> first_hit{fifo_tail};
                 const size_t base = fifo_head;
-                parallel_ranges(fifo_tail - base, [&](uint64_t lo, uint64_t hi) {
-                    for (uint64_t i = base + lo; i < base + hi; i++) {
-                        if (i + PF < base + hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
-                        if ((i & 1023) == 0 && first_hit.load(std::memory_order_relaxed) < i) return;
+                // tasks of 64 K entries handed out in FIFO order: all threads work on the earliest unfinished stretch, so the
+                // scan takes (position of the first hit) / (throughput of all threads) wherever that hit lies
+                constexpr uint64_t TASK = 1u << 16;
+                const uint64_t n_scan = fifo_tail - base;
+                parallel_tasks((n_scan + TASK - 1) / TASK, [&](uint64_t task) {
+                    const uint64_t lo = base + task * TASK, hi = std::min<uint64_t>(base + n_scan, lo + TASK);
+                    if (first_hit.load(std::memory_order_relaxed) < lo) return;
+                    for (uint64_t i = lo; i < hi; i++) {
+                        if (i + PF < hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
                         if (has_unused(ent_node[fifo[i]])) {
                             size_t cur = first_hit.load(std::memory_order_relaxed);
                             while (i < cur && !first_hit.compare_exchange_weak(cur, (size_t)i)) {}
                             return;
                         }
                     }
-                });
+                }, 64);
                 fifo_head = first_hit.load();  // everything before it is exhausted; the sequential loop takes it from here
             }
             while (fifo_head < fifo_tail) {
