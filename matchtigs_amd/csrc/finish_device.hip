@@ -507,6 +507,9 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipStreamSynchronize(st));
         n_brk += t_out.size();
     }
+    if (lap.on)
+        std::fprintf(stderr, "[mtg] device_finish:   Euleriser: %u units, %u self-mirror nodes, %u of %u steps by the parallel prefix, %llu by the sequential tail\n",
+                     N, n_sm, s_star, n_steps, (unsigned long long)(n_brk - n_sm_edges - s_star));
     const uint64_t E = first_brk + 2 * n_brk, n_dummy = E - E0;
     b_cin.release(); b_cout.release(); b_smf.release(); b_pin.release(); b_pout.release(); b_psm.release();
     b_sm.release(); b_anode.release(); b_bnode.release(); b_pairs.release();

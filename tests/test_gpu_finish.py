@@ -20,12 +20,15 @@ def gpu(product_lib):
     return product_lib
 
 
-def scramble(bg, seed):
-    """The same bigraph with node ids permuted at random (mirror nodes no longer neighbours)."""
+def scramble(bg, seed, fraction=1.0):
+    """The same bigraph with node ids permuted at random (mirror nodes no longer neighbours); fraction < 1 permutes only that
+    share of the nodes among themselves (the Euleriser's parallel prefix then stops somewhere in the middle)."""
     from matchtigs_amd import synth
 
     rng = np.random.default_rng(seed)
-    perm = rng.permutation(bg.n_nodes).astype(np.uint32)  # old -> new
+    perm = np.arange(bg.n_nodes, dtype=np.uint32)  # old -> new
+    chosen = np.flatnonzero(rng.random(bg.n_nodes) < fraction)
+    perm[chosen] = chosen[rng.permutation(len(chosen))].astype(np.uint32)
     mirror = np.empty_like(bg.mirror)
     mirror[perm] = perm[bg.mirror]
     return synth.Bigraph(mirror, perm[bg.edge_from], perm[bg.edge_to], bg.edge_weight.copy(), bg.k)
@@ -49,6 +52,27 @@ def _cases():
         out.append((name, bg))
         out.append((name + "-scrambled", scramble(bg, 17)))
     return out
+
+
+def test_euleriser_prefix_stops_in_the_middle(gpu):
+    """Partially scrambled numberings (0.1 % to 30 % of the nodes renumbered at random): the first irregular step of the
+    parallel Euleriser lies somewhere inside the sequence, the sequential tail takes over from there. Many seeds, graph after
+    the finish and tigs equal to the host stages'."""
+    from matchtigs_amd import api, synth
+
+    n = 0
+    for seed in range(24):
+        base = synth.g_csr(400 + 97 * seed, seed=100 + seed, k=[5, 9, 31][seed % 3], mean_out_degree=1.1 + 0.07 * (seed % 9),
+                           mean_weight=[1.5, 3.0, 8.0][seed % 3], self_mirror_frac=[0.0, 0.02, 0.1][seed % 3])
+        bg = scramble(base, seed, fraction=[0.001, 0.01, 0.05, 0.3][seed % 4])
+        pairs = _pairs_of(bg, bg.k)
+        H, D = _graphs(bg)
+        lim_h, ed_h = api.finish_greedytigs_np(H, pairs, bg.k, finish_stage=api.FinishStage.Host)
+        lim_d, ed_d = api.finish_greedytigs_np(D, pairs, bg.k, finish_stage=api.FinishStage.Device)
+        _same_graph(H, D)
+        assert np.array_equal(lim_h, lim_d) and np.array_equal(ed_h, ed_d), seed
+        n += api.last_finish_device_times()["breaking_biedges"]
+    assert n > 1000
 
 
 CASES = None
