@@ -132,7 +132,9 @@ struct Buf {
 // One stream per device for the finishing stages, created on first use; the device's default pool keeps freed memory.
 inline hipStream_t finish_stream(int device_id) {
     static hipStream_t streams[64] = {nullptr};
+    static std::mutex mu;
     if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
+    std::lock_guard<std::mutex> l(mu);
     if (!streams[device_id]) {
         HIP_CHECK(hipSetDevice(device_id));
         HIP_CHECK(hipStreamCreate(&streams[device_id]));
