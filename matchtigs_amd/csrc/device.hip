@@ -1961,7 +1961,12 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         if (occ < 1) MTG_DIE("replay_rounds_kernel does not fit a compute unit");
         w.grid = (unsigned)d->n_cu * (unsigned)std::min(occ, 2);
     }
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(w.grid, (S + REPLAY_BLOCK - 1) / REPLAY_BLOCK));
+    // as many workgroups as one admission window has thousands of sources (at least 64): the grid barrier of a round costs per
+    // workgroup, and more of them than a round has work for only lengthen it (2^24: 128 / 256 / 512 workgroups = 2.52 / 2.73 /
+    // 2.73 ms; 2^27, where a window fills the device: 9.6 / 8.0 / 7.9 ms)
+    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)w.grid, (S + REPLAY_BLOCK - 1) / REPLAY_BLOCK,
+                                                                       std::max<uint64_t>(64, (a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK)}));
+    if (const char *e = std::getenv("MTG_REPLAY_GRID")) grid = std::max(1u, std::min(grid, (unsigned)std::atoi(e)));  // (tuning only)
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
     HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
