@@ -1212,9 +1212,9 @@ struct ReplayWork {
     unsigned long long *resv[2] = {nullptr, nullptr};
     uint32_t tag_base = 0xFFFFFFFFu;          // reservation tags used so far (the arrays are never cleared between calls)
     Touch *touch = nullptr;
-    uint32_t *meta = nullptr, *src_mirror = nullptr;
+    uint32_t *src_mirror = nullptr;
     unsigned long long *claims = nullptr;
-    uint32_t *pair_count = nullptr, *pending[2] = {nullptr, nullptr}, *spill = nullptr;
+    uint32_t *pending[2] = {nullptr, nullptr}, *spill = nullptr;
     unsigned long long *final_off = nullptr, *block_sums = nullptr;
     unsigned long long *ctl = nullptr, *h_ctl = nullptr;  // control block (device / pinned host copy)
     mtg_pair *out = nullptr;
@@ -1733,7 +1733,7 @@ void device_free(Device *d) {
     (void)hipFree(d->d_fix);
     (void)hipFree(d->d_fix_dense);
     ReplayWork &w = d->replay;
-    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.meta, w.src_mirror, w.claims, w.pair_count, w.pending[0], w.pending[1], w.spill,
+    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.src_mirror, w.claims, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};
     for (void *b : rb) (void)hipFree(b);
     (void)hipHostFree(w.h_ctl);
@@ -1846,18 +1846,22 @@ int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) 
 // ------------------------------------------------------------------------------------------------
 // GPU claim replay (replay_kernels.inc): host driver
 // ------------------------------------------------------------------------------------------------
-static void scan_u32(Device *d, hipStream_t st, ReplayWork &w, const uint32_t *in, uint64_t n, unsigned long long *out,
-                     unsigned long long *d_total) {
+template <typename In>
+static void scan_values(hipStream_t st, ReplayWork &w, In in, uint64_t n, unsigned long long *out, unsigned long long *d_total) {
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb > w.cap_blocks) {
         if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
         HIP_CHECK(hipMalloc(&w.block_sums, nb * 8));
         w.cap_blocks = nb;
     }
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums);
+    hipLaunchKernelGGL(scan_reduce_kernel<In>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, w.block_sums, nb, d_total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums, out);
+    hipLaunchKernelGGL(scan_apply_kernel<In>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums, out);
     HIP_CHECK(hipGetLastError());
+}
+static void scan_u32(Device *d, hipStream_t st, ReplayWork &w, const uint32_t *in, uint64_t n, unsigned long long *out,
+                     unsigned long long *d_total) {
+    scan_values(st, w, ScanInU32{in}, n, out, d_total);
     (void)d;
 }
 
@@ -1888,7 +1892,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     if (V > w.cap_v) {
         if (w.state) { HIP_CHECK(hipFree(w.state)); HIP_CHECK(hipFree(w.resv[0])); HIP_CHECK(hipFree(w.resv[1])); }
-        HIP_CHECK(hipMalloc(&w.state, V * 8));
+        HIP_CHECK(hipMalloc(&w.state, (V + 2) * 8));  // (states are read in aligned pairs: the last pair may reach one word beyond V)
         HIP_CHECK(hipMalloc(&w.resv[0], V * 8));
         HIP_CHECK(hipMalloc(&w.resv[1], V * 8));
         w.cap_v = V;
@@ -1896,14 +1900,12 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     if (S > w.cap_s) {
         if (w.touch) {
-            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.meta)); HIP_CHECK(hipFree(w.src_mirror)); HIP_CHECK(hipFree(w.claims)); HIP_CHECK(hipFree(w.pair_count));
+            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.src_mirror)); HIP_CHECK(hipFree(w.claims));
             HIP_CHECK(hipFree(w.pending[0])); HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.final_off));
         }
         HIP_CHECK(hipMalloc(&w.touch, S * sizeof(Touch)));
-        HIP_CHECK(hipMalloc(&w.meta, S * 4));
         HIP_CHECK(hipMalloc(&w.src_mirror, S * 4));
         HIP_CHECK(hipMalloc(&w.claims, S * 8));
-        HIP_CHECK(hipMalloc(&w.pair_count, S * 4));
         HIP_CHECK(hipMalloc(&w.pending[0], S * 4));
         HIP_CHECK(hipMalloc(&w.pending[1], S * 4));
         HIP_CHECK(hipMalloc(&w.final_off, S * 8));
@@ -1931,13 +1933,13 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(replay_src_mirror_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, d->d_out_nodes, d_cand_count, d->d_mirror, S, w.src_mirror);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemsetAsync(w.pair_count, 0, S * 4, st));
+    HIP_CHECK(hipMemsetAsync(w.claims, 0, S * 8, st));
     HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
 
     ReplayArgs a{};
     a.out_nodes = d->d_out_nodes; a.state = w.state;
     a.cand_start = (const unsigned long long *)d_cand_start; a.cand_count = d_cand_count; a.pool = (const unsigned long long *)d_pool;
-    a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.meta = w.meta; a.src_mirror = w.src_mirror; a.claims = w.claims; a.pair_count = w.pair_count;
+    a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.src_mirror = w.src_mirror; a.claims = w.claims;
     a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
     a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
     // index-ordered admission windows: ~128 K sources each, between 4 and 48 of them (measured on the round-3 kernel, 2^27: 32 / 48 /
@@ -2002,7 +2004,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 
     // compaction in source order
     unsigned long long *cnt = &d->d_counters[C_OVF_LIST];
-    scan_u32(d, st, w, w.pair_count, S, w.final_off, cnt);
+    scan_values(st, w, ScanInClaims{w.claims}, S, w.final_off, cnt);
     read_counters(d, st);
     const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
     rt.lap("tail + scan");

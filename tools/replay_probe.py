@@ -13,13 +13,12 @@ for a in sys.argv[3:]:
     kw[k] = float(v) if "." in v else int(v)
 n_binodes = kw.pop("n_binodes", int((1 << log2) / 1.5 / 2))
 k = kw.pop("k", 31)
-bg = synth.g_csr(n_binodes, seed=kw.pop("seed", 1), k=k, **kw)
-G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+G = synth.g_csr_device(n_binodes, seed=kw.pop("seed", 1), k=k, **kw)  # (the GPU twin of synth.g_csr: same graph)
 dev = api.DeviceGraph(G, k)
 st = torch_glue.current_stream_ptr()
 S = dev.classify(st)
 bufs = torch_glue.run_sssp(dev, 0, S)
-print(f"V={bg.n_nodes} E={bg.n_edges} S={S} candidates={int(bufs.count[:S].sum())}")
+print(f"V={G.node_count()} E={G.edge_count()} S={S} candidates={int(bufs.count[:S].sum())}")
 for r in range(reps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
