@@ -1213,6 +1213,8 @@ struct ReplayWork {
     uint32_t tag_base = 0xFFFFFFFFu;          // reservation tags used so far (the arrays are never cleared between calls)
     Touch *touch = nullptr;
     uint32_t *src_mirror = nullptr;
+    Dense *dense = nullptr;                   // the sources that have candidates (replay_kernels.inc)
+    uint64_t cap_dense = 0;
     unsigned long long *claims = nullptr;
     uint32_t *pending[2] = {nullptr, nullptr}, *spill = nullptr;
     unsigned long long *final_off = nullptr, *block_sums = nullptr;
@@ -1733,7 +1735,7 @@ void device_free(Device *d) {
     (void)hipFree(d->d_fix);
     (void)hipFree(d->d_fix_dense);
     ReplayWork &w = d->replay;
-    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.src_mirror, w.claims, w.pending[0], w.pending[1], w.spill,
+    void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.src_mirror, w.dense, w.claims, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};
     for (void *b : rb) (void)hipFree(b);
     (void)hipHostFree(w.h_ctl);
@@ -1931,8 +1933,31 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // working copy of the classification state; per-source outputs start at "nothing claimed"
     hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(replay_src_mirror_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, d->d_out_nodes, d_cand_count, d->d_mirror, S, w.src_mirror);
-    HIP_CHECK(hipGetLastError());
+    // the sources that have candidates, in order, with the static words of their admission (Dense)
+    uint64_t n_dense = 0;
+    {
+        static_assert(DENSE_BLOCK == SCAN_BLOCK, "the dense fill uses the scan's block offsets");
+        const uint64_t nb = (S + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        if (nb > w.cap_blocks) {
+            if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
+            HIP_CHECK(hipMalloc(&w.block_sums, nb * 8));
+            w.cap_blocks = nb;
+        }
+        unsigned long long *total = &d->d_counters[C_OVF_LIST];
+        hipLaunchKernelGGL(scan_reduce_kernel<ScanInHasCand>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, ScanInHasCand{d_cand_count}, S, w.block_sums);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, w.block_sums, nb, total);
+        HIP_CHECK(hipGetLastError());
+        read_counters(d, st);
+        n_dense = d->h_counters[C_OVF_LIST];
+        if (n_dense > w.cap_dense) {
+            if (w.dense) HIP_CHECK(hipFree(w.dense));
+            HIP_CHECK(hipMalloc(&w.dense, n_dense * sizeof(Dense)));
+            w.cap_dense = n_dense;
+        }
+        hipLaunchKernelGGL(replay_dense_fill_kernel, dim3((unsigned)nb), dim3(DENSE_BLOCK), 0, st, d->d_out_nodes, d_cand_count,
+                           (const unsigned long long *)d_cand_start, (const unsigned long long *)d_pool, d->d_mirror, S, w.block_sums, w.dense, w.src_mirror);
+        HIP_CHECK(hipGetLastError());
+    }
     HIP_CHECK(hipMemsetAsync(w.claims, 0, S * 8, st));
     HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
 
@@ -1940,16 +1965,15 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     a.out_nodes = d->d_out_nodes; a.state = w.state;
     a.cand_start = (const unsigned long long *)d_cand_start; a.cand_count = d_cand_count; a.pool = (const unsigned long long *)d_pool;
     a.resv[0] = w.resv[0]; a.resv[1] = w.resv[1]; a.touch = w.touch; a.src_mirror = w.src_mirror; a.claims = w.claims;
-    a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
+    a.dense = w.dense; a.n_dense = n_dense; a.spill = w.spill; a.pending[0] = w.pending[0]; a.pending[1] = w.pending[1]; a.ctl = w.ctl; a.n_sources = S;
     a.tag_base = w.tag_base; a.max_rounds = REPLAY_MAX_ROUNDS;
-    // index-ordered admission windows: ~128 K sources each, between 4 and 48 of them (measured on the round-3 kernel, 2^27: 32 / 48 /
-    // 64 / 96 windows = 8.2 / 7.7 / 8.4 / 8.9 ms; 2^24: 8 / 16 / 24 windows = 3.8 / 3.15 / 2.7 ms, the conflict chains alone need 33
-    // rounds there) (a round costs a grid barrier plus one
-    // dependent-access chain, ~30-50 us, so tiny windows are latency bound; huge ones bring the waiting visits back)
+
+    // index-ordered admission windows over the dense list: ~32 K listed sources each, between 4 and 48 of them (a round costs a
+    // grid barrier plus one dependent-access chain, so tiny windows are latency bound; huge ones bring the waiting visits back)
     {
-        uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (S + (1u << 17) - 1) >> 17));
+        uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (n_dense + (1u << 15) - 1) >> 15));
         if (const char *e = std::getenv("MTG_REPLAY_WINDOWS")) n_win = std::max<uint64_t>(1, (uint64_t)std::atoll(e));  // (tuning only: the pair list does not depend on it)
-        a.window = std::max<uint64_t>((S + n_win - 1) / n_win, REPLAY_BLOCK);
+        a.window = std::max<uint64_t>((n_dense + n_win - 1) / n_win, REPLAY_BLOCK);
     }
 
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
@@ -1966,15 +1990,44 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // as many workgroups as one admission window has thousands of sources (at least 64): the grid barrier of a round costs per
     // workgroup, and more of them than a round has work for only lengthen it (2^24: 128 / 256 / 512 workgroups = 2.52 / 2.73 /
     // 2.73 ms; 2^27, where a window fills the device: 9.6 / 8.0 / 7.9 ms)
-    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)w.grid, (S + REPLAY_BLOCK - 1) / REPLAY_BLOCK,
-                                                                       std::max<uint64_t>(64, (a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK)}));
+    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)w.grid, (n_dense + REPLAY_BLOCK - 1) / REPLAY_BLOCK,
+                                                                       std::max<uint64_t>(64, 2 * ((a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK))}));
     if (const char *e = std::getenv("MTG_REPLAY_GRID")) grid = std::max(1u, std::min(grid, (unsigned)std::atoi(e)));  // (tuning only)
+#ifdef MTG_REPLAY_PROF
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) HIP_CHECK(hipMalloc(&d_prof, (size_t)1024 * 64 * 4 * 8));
+    HIP_CHECK(hipMemsetAsync(d_prof, 0, (size_t)1024 * 64 * 4 * 8, st));
+    a.prof = d_prof;
+#endif
+    // one workgroup in role_mod admits, the others check (the longer chain). Measured with the per-XCD barrier: 2^27 (the grid fills
+    // the device) role_mod 2 / 4 / 6 / 8 = 6.6 / 6.7 / 7.2 / 8.2 ms; 2^24 (64 workgroups) 2.7 / 2.2 / 2.4 / 2.8 ms
+    a.role_mod = grid >= w.grid ? 2u : 4u;
+    if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(2, std::atoi(e));  // (tuning only)
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
     HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
     HIP_CHECK(hipMemcpyAsync(w.h_ctl, w.ctl, RC_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     rt.lap("state init + rounds kernel");
+#ifdef MTG_REPLAY_PROF
+    {
+        std::vector<unsigned long long> hp((size_t)grid * 64 * 4);
+        HIP_CHECK(hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+        const int nr = std::min<int>(64, (int)w.h_ctl[RC_ROUNDS]);
+        for (int r = 0; r < nr; r += (r < 8 ? 1 : 8)) {
+            for (int role = 0; role < 2; role++) {
+                double sw = 0, mw = 0, sf = 0, mf = 0, sb = 0, mb = 0; int n = 0;
+                for (unsigned b = role; b < grid; b += 2) {
+                    const unsigned long long *t = &hp[((size_t)b * 64 + r) * 4];
+                    const double wk = (t[1] - t[0]) * 0.01, fl = (t[2] - t[1]) * 0.01, ba = (t[3] - t[2]) * 0.01;
+                    sw += wk; mw = std::max(mw, wk); sf += fl; mf = std::max(mf, fl); sb += ba; mb = std::max(mb, ba); n++;
+                }
+                if (n) std::fprintf(stderr, "[mtg] replay prof: round %2d %s: work mean %.1f max %.1f us, flush mean %.1f max %.1f, barrier wait mean %.1f max %.1f\n",
+                                    r, role ? "check" : "admit", sw / n, mw, sf / n, mf, sb / n, mb);
+            }
+        }
+    }
+#endif
     if (w.h_ctl[RC_ABORT]) MTG_DIE("claim replay: a workgroup never reached the grid barrier (watchdog)");
     const int rounds = (int)w.h_ctl[RC_ROUNDS];
     w.tag_base += (uint32_t)rounds + 2;
