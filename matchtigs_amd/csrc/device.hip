@@ -2002,7 +2002,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // one workgroup in role_mod admits, the others check (the longer chain). Measured with the per-XCD barrier: 2^27 (the grid fills
     // the device) role_mod 2 / 4 / 6 / 8 = 6.6 / 6.7 / 7.2 / 8.2 ms; 2^24 (64 workgroups) 2.7 / 2.2 / 2.4 / 2.8 ms
     a.role_mod = grid >= w.grid ? 2u : 4u;
-    if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(2, std::atoi(e));  // (tuning only)
+    if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(1, std::atoi(e));  // (tuning only)
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
     HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
