@@ -1222,7 +1222,7 @@ struct ReplayWork {
     mtg_pair *out = nullptr;
     mtg_pair *h_out = nullptr;                // pinned staging of the pair download (pageable D2H runs at a few GB/s)
     uint64_t cap_h_out = 0;
-    unsigned grid = 0;                        // co-resident workgroups of the cooperative launch
+    unsigned grid = 0, grid_small = 0;        // co-resident workgroups of the cooperative launch (workgroups of 1024 / of 256)
 };
 
 struct Device {
@@ -1973,39 +1973,36 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     {
         uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (n_dense + (1u << 15) - 1) >> 15));
         if (const char *e = std::getenv("MTG_REPLAY_WINDOWS")) n_win = std::max<uint64_t>(1, (uint64_t)std::atoll(e));  // (tuning only: the pair list does not depend on it)
-        a.window = std::max<uint64_t>((n_dense + n_win - 1) / n_win, REPLAY_BLOCK);
+        a.window = std::max<uint64_t>((n_dense + n_win - 1) / n_win, 256);
     }
-
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
-    // deadlock; fewer, larger workgroups keep the barrier cheap
+    // deadlock. Workgroups of 1024 when a round's tiles (a window to admit, about as many sources to check) fill the device, of 256
+    // when they do not (replay_kernels.inc); as many workgroups as a round has tiles, at least 64, at most what is co-resident.
     if (w.grid == 0) {
         int coop = 0;
         HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, d->dev));
         if (!coop) MTG_DIE("device %d does not support cooperative launches (needed by the claim replay's grid barrier)", d->dev);
-        int occ = 0;
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, replay_rounds_kernel, REPLAY_BLOCK, 0));
-        if (occ < 1) MTG_DIE("replay_rounds_kernel does not fit a compute unit");
+        int occ = 0, occ_small = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, replay_rounds_kernel<REPLAY_BLOCK>, REPLAY_BLOCK, 0));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_small, replay_rounds_kernel<REPLAY_BLOCK_SMALL>, REPLAY_BLOCK_SMALL, 0));
+        if (occ < 1 || occ_small < 1) MTG_DIE("replay_rounds_kernel does not fit a compute unit");
         w.grid = (unsigned)d->n_cu * (unsigned)std::min(occ, 2);
+        w.grid_small = (unsigned)d->n_cu * (unsigned)std::min(occ_small, 2);
     }
-    // as many workgroups as one admission window has thousands of sources (at least 64): the grid barrier of a round costs per
-    // workgroup, and more of them than a round has work for only lengthen it (2^24: 128 / 256 / 512 workgroups = 2.52 / 2.73 /
-    // 2.73 ms; 2^27, where a window fills the device: 9.6 / 8.0 / 7.9 ms)
-    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)w.grid, (n_dense + REPLAY_BLOCK - 1) / REPLAY_BLOCK,
-                                                                       std::max<uint64_t>(64, 2 * ((a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK))}));
+    bool small = 2 * ((a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK) < (uint64_t)d->n_cu;
+    if (const char *e = std::getenv("MTG_REPLAY_BLOCK")) small = std::atoi(e) < REPLAY_BLOCK;  // (tuning only)
+    const uint64_t block = small ? REPLAY_BLOCK_SMALL : REPLAY_BLOCK;
+    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(small ? w.grid_small : w.grid), (n_dense + block - 1) / block,
+                                                                       std::max<uint64_t>(64, 2 * ((a.window + block - 1) / block))}));
     if (const char *e = std::getenv("MTG_REPLAY_GRID")) grid = std::max(1u, std::min(grid, (unsigned)std::atoi(e)));  // (tuning only)
-#ifdef MTG_REPLAY_PROF
-    static unsigned long long *d_prof = nullptr;
-    if (!d_prof) HIP_CHECK(hipMalloc(&d_prof, (size_t)1024 * 64 * 4 * 8));
-    HIP_CHECK(hipMemsetAsync(d_prof, 0, (size_t)1024 * 64 * 4 * 8, st));
-    a.prof = d_prof;
-#endif
     // one workgroup in role_mod admits, the others check (the longer chain). Measured with the per-XCD barrier: 2^27 (the grid fills
     // the device) role_mod 2 / 4 / 6 / 8 = 6.6 / 6.7 / 7.2 / 8.2 ms; 2^24 (64 workgroups) 2.7 / 2.2 / 2.4 / 2.8 ms
-    a.role_mod = grid >= w.grid ? 2u : 4u;
+    a.role_mod = (!small && grid >= w.grid) ? 2u : 4u;
     if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(1, std::atoi(e));  // (tuning only)
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
-    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(replay_rounds_kernel), dim3(grid), dim3(REPLAY_BLOCK), kargs, 0, st));
+    HIP_CHECK(hipLaunchCooperativeKernel(small ? reinterpret_cast<void *>(replay_rounds_kernel<REPLAY_BLOCK_SMALL>) : reinterpret_cast<void *>(replay_rounds_kernel<REPLAY_BLOCK>),
+                                         dim3(grid), dim3((unsigned)block), kargs, 0, st));
     HIP_CHECK(hipMemcpyAsync(w.h_ctl, w.ctl, RC_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     rt.lap("state init + rounds kernel");
