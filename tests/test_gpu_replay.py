@@ -72,3 +72,36 @@ def test_gpu_replay_full_bench_size(oracle, product_lib):
     assert _pairs_equal(gpu_pairs, host_pairs)
     assert len(gpu_pairs) == 570447  # the oracle's count for this workload (test_full_bench_size_properties checks the list)
     print("reservation rounds:", dev.last_replay_rounds())
+
+
+@pytest.mark.parametrize("case", [
+    # unit weights, out-degree ~2.6, k = 31: balls of thousands of nodes -- candidate lists of hundreds to thousands of entries
+    # (beyond one pass of a wave, beyond the 10-bit indices of a touch record, beyond the 12-bit indices of a packed claims word)
+    dict(n_binodes=3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01),
+    dict(n_binodes=9000, seed=4, k=31, mean_out_degree=2.4, mean_weight=1.0, self_mirror_frac=0.0),
+    # degrees up to 9: multiplicities above 4, claims go to the spill array
+    dict(n_binodes=3000, seed=4, k=15, mean_out_degree=5.0, mean_weight=4.0, max_degree=9, self_mirror_frac=0.01),
+])
+def test_gpu_replay_long_lists_and_large_demands(case, product_lib):
+    """The paths of the claim replay that the bench graph hardly touches, against the host claim loop on the same lists: long
+    candidate lists (checked, reserved and admitted by the whole wave) and demands above four (spilled claim indices)."""
+    from matchtigs_amd import synth, torch_glue  # noqa: F401
+
+    bg = synth.g_csr(**case)
+    G, dev, gpu_pairs, host_pairs = _run(bg)
+    assert len(host_pairs) > 100
+    assert _pairs_equal(gpu_pairs, host_pairs)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gpu_replay_scrambled_numbering(seed, oracle, product_lib):
+    """Mirror nodes NOT numbered next to each other (node ids permuted at random): the paired 16-byte state accesses fall back to
+    single words, the source's and the candidates' mirrors are read on their own."""
+    from matchtigs_amd import synth
+    from test_gpu_finish import scramble
+
+    bg = scramble(synth.g_csr(20000, seed=seed, k=31, mean_out_degree=2.0, self_mirror_frac=0.02), 40 + seed)
+    G, dev, gpu_pairs, host_pairs = _run(bg)
+    want, _ = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight).greedy_pairs_np(bg.k)
+    assert _pairs_equal(host_pairs, want)
+    assert _pairs_equal(gpu_pairs, want)
