@@ -750,6 +750,9 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#ifdef MTG_ENUM_STATS
+__device__ unsigned long long g_enum_prof[16384][3];  // development build: per wave [start, end (100-MHz ticks), steps]
+#endif
 template <int WPB, int S1, int H1, int NB, bool QUAD>
 __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     if (lane == 0) s_cnt[wv] = ENUM_POOL_CHUNK;  // position inside the wave's pool chunk (no chunk yet)
 #ifdef MTG_ENUM_STATS
     uint32_t st_starved = 0, st_full = 0, st_budget = 0, st_steps = 0, st_lanes = 0;
+    const unsigned long long st_t0 = wall_clock64();
 #endif
 
     // ---- sources: chunks of 64 in a STATIC stride (chunk c belongs to wave c mod n_waves), held in registers: `ids` is the chunk
@@ -1099,6 +1103,8 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
     wave_ovf_flush(s_ovf[wv], n_overflow, a, lane);
 #ifdef MTG_ENUM_STATS
     if (lane == 0) {
+        const uint32_t wid = blockIdx.x * WPB + wv;
+        if (wid < 16384) { g_enum_prof[wid][0] = st_t0; g_enum_prof[wid][1] = wall_clock64(); g_enum_prof[wid][2] = st_steps; }
         atomicAdd(&a.counters[C_SETTLED], (unsigned long long)st_steps);
         atomicAdd(&a.counters[C_RELAXED], (unsigned long long)st_lanes);
         atomicAdd(&a.counters[C_EMITTED], (unsigned long long)st_starved);
@@ -1569,6 +1575,21 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     if (use_enum && n) std::fprintf(stderr, "[mtg] enum stats: wave steps %llu, lane steps %llu (%.1f of 64), starved %llu, block full %llu, step budget %llu, fix cursor %llu, pool cursor %llu\n",
                                     d->h_counters[C_SETTLED], d->h_counters[C_RELAXED], (double)d->h_counters[C_RELAXED] / (double)std::max<unsigned long long>(d->h_counters[C_SETTLED], 1),
                                     d->h_counters[C_EMITTED], d->h_counters[C_ATTEMPTS], d->h_counters[C_PUSHES], d->h_counters[C_FIX], d->h_counters[C_POOL]);
+    if (use_enum && n) {  // when the waves end, and how many steps they ran
+        static std::vector<unsigned long long> hp(16384 * 3);
+        HIP_CHECK(hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_enum_prof), hp.size() * 8));
+        std::vector<double> end_us, life_us, steps;
+        unsigned long long t_min = ~0ull;
+        for (int w = 0; w < 16384; w++) if (hp[3 * w + 1]) t_min = std::min(t_min, hp[3 * w]);
+        for (int w = 0; w < 16384; w++)
+            if (hp[3 * w + 1]) { end_us.push_back((hp[3 * w + 1] - t_min) * 0.01); life_us.push_back((hp[3 * w + 1] - hp[3 * w]) * 0.01); steps.push_back((double)hp[3 * w + 2]); }
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (v.size() - 1))]; };
+        std::fprintf(stderr, "[mtg] enum waves: %zu; end of wave (us after the first start) min %.0f p10 %.0f median %.0f p90 %.0f max %.0f; steps per wave min %.0f median %.0f max %.0f; us per step median %.3f\n",
+                     end_us.size(), pct(end_us, 0), pct(end_us, 0.1), pct(end_us, 0.5), pct(end_us, 0.9), pct(end_us, 1), pct(steps, 0), pct(steps, 0.5), pct(steps, 1),
+                     pct(life_us, 0.5) / std::max(1.0, pct(steps, 0.5)));
+        std::vector<unsigned long long> zero(16384 * 3, 0);
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_enum_prof), zero.data(), zero.size() * 8));
+    }
 #endif
     const uint64_t total_overflow = d->h_counters[C_OVERFLOW];
     // remaining levels over whatever overflowed the previous one; each launch appends the sources it could not finish
