@@ -162,7 +162,8 @@ const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d);
 
 /* Bounded many-to-many SSSP: for every source index i in [src_begin, src_end) writes its
  * candidate list L(s_i) = all in-nodes within k-1 of s_i (s_i excluded) as keys
- * (distance << 32 | node), ascending, into d_pool[d_cand_start[i-src_begin] ..+ d_cand_count[..]].
+ * (distance << 32 | node), ascending, into d_pool[d_cand_start[i-src_begin] ..+ d_cand_count[..]]
+ * (d_cand_start of a source with d_cand_count 0 is left as it was: the start of an empty list means nothing).
  * Returns 0 on success; 1 if pool_capacity was too small (*pool_needed tells the size to retry
  * with; outputs are then invalid). Sources whose ball does not fit the fast kernel's LDS tables
  * are re-run by larger kernel levels internally, down to a dense level without any limit on the ball

@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
             for (uint32_t r = 4; __any(r < c); r++)
                 if (r < c && room) a.pool[pos + r] = mem[hit_word(blk, r)];
             if (fin) {
-                a.cand_start[item] = pos;
+                if (c) a.cand_start[item] = pos;  // (the start of an empty list is never read: 7 of 10 sources save the scattered store)
                 a.cand_count[item] = c;
             } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
             // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
