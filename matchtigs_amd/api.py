@@ -311,7 +311,8 @@ class Bigraph:
         return _take_walks(self._L, self._L.mtg_euler_cycles(self._h))
 
     def euler_cycles_records(self, record_format: int) -> list[list[int]]:
-        """mtg_euler_cycles_records: 0 = wide records from adjacency, 1 = 32-byte records, 2 = wide records seeded from 32-byte ones."""
+        """mtg_euler_cycles_records: 0 = wide records from adjacency, 1 = 32-byte records, 2 = wide (256-byte) records seeded from
+        32-byte ones, 3 = 128-byte records seeded from 32-byte ones."""
         return _take_walks(self._L, self._L.mtg_euler_cycles_records(self._h, record_format))
 
     def euler_cycles_device(self, device_id: int = 0) -> list[list[int]]:

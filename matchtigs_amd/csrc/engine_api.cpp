@@ -219,7 +219,7 @@ mtg_walks *mtg_euler_cycles(const mtg_graph *g) { return new mtg_walks{euler_cyc
 mtg_walks *mtg_euler_cycles_records(const mtg_graph *g, int record_format) {
     const HostGraph &h = g->g;
     if (record_format == 0) return new mtg_walks{euler_cycles(h)};
-    if (record_format != 1 && record_format != 2) MTG_DIE("mtg_euler_cycles_records: unknown record format %d", record_format);
+    if (record_format < 1 || record_format > 3) MTG_DIE("mtg_euler_cycles_records: unknown record format %d", record_format);
     h.ensure_linked();
     const uint64_t V = h.node_count(), E = h.edge_count();
     std::vector<LeanNode> lean(V);
@@ -239,6 +239,10 @@ mtg_walks *mtg_euler_cycles_records(const mtg_graph *g, int record_format) {
     }
     if (record_format == 1)
         return new mtg_walks{euler_cycles_lean(lean.data(), V, ext_eid.data(), ext_to.data(), h.e_from.data(), h.e_to.data(), E, &h.arena)};
+    if (record_format == 3) {
+        HugeBuf<EulerNode2> mid(V, &h.arena);
+        return new mtg_walks{euler_cycles_from_lean_mid(lean.data(), mid.p, V, ext_eid.data(), ext_to.data(), h.e_from.data(), h.e_to.data(), E, &h.arena)};
+    }
     HugeBuf<EulerNode3> wide(V, &h.arena);
     return new mtg_walks{euler_cycles_from_lean(lean.data(), wide.p, V, ext_eid.data(), ext_to.data(), h.e_from.data(), h.e_to.data(), E, &h.arena)};
 }

@@ -33,9 +33,12 @@ Walks euler_cycles_generic(const HostGraph &g);
 
 
 // Everything after the records' own adjacency (phase A) is filled: copies of the heads' adjacency (phases B, C), the walk.
-static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+template <typename Rec>
+static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
                                 std::chrono::steady_clock::time_point t_begin, bool have_sub_levels);
+template <typename Rec>
+static void seed_from_lean(const LeanNode *lean, Rec *nodes, uint64_t V);
 
 Walks euler_cycles(const HostGraph &g) {
     const uint64_t E = g.edge_count();
@@ -90,19 +93,7 @@ Walks euler_cycles_from_lean(const LeanNode *lean, EulerNode3 *nodes, uint64_t V
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
     const auto t_begin = std::chrono::steady_clock::now();
     NumaPin pin(arena ? arena->node : -1);
-    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
-        for (uint64_t n = lo; n < hi; n++) {
-            EulerNode3 &r = nodes[n];
-            const LeanNode &l = lean[n];
-            for (int i = 0; i < 3; i++) { r.eid[i] = l.eid[i]; r.to[i] = l.to[i]; }
-            r.deg = l.deg;
-            r.pos = 0;
-            r.pad = 0;
-            r.sub_info = 0;
-            r.sub2_info = 0;
-            r.ext_begin = l.ext_begin;
-        }
-    });
+    seed_from_lean(lean, nodes, V);
     return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, false);
 }
 
@@ -114,9 +105,46 @@ Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_
     return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true);
 }
 
-static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+// seeds phase A of the records (own adjacency) from the 32-byte ones
+template <typename Rec>
+static void seed_from_lean(const LeanNode *lean, Rec *nodes, uint64_t V) {
+    parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++) {
+            Rec &r = nodes[n];
+            const LeanNode &l = lean[n];
+            for (int i = 0; i < 3; i++) { r.eid[i] = l.eid[i]; r.to[i] = l.to[i]; }
+            r.deg = l.deg;
+            r.pos = 0;
+            r.pad = 0;
+            r.sub_info = 0;
+            r.sub2_info = 0;
+            r.ext_begin = l.ext_begin;
+        }
+    });
+}
+
+Walks euler_cycles_from_lean_mid(const LeanNode *lean, EulerNode2 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
+                                 const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    seed_from_lean(lean, nodes, V);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, false);
+}
+
+Walks euler_cycles_from_mid(EulerNode2 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
+                            const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true);
+}
+
+template <typename Rec>
+static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
                                 std::chrono::steady_clock::time_point t_begin, bool have_sub_levels) {
+    constexpr bool L3 = Rec::LEVELS == 3;  // records with the heads' heads
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
     constexpr unsigned BUILD_THREADS = 128;  // phases B and C are random gathers: latency bound, so more threads than cores pay
@@ -124,15 +152,15 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {  // phase B: first 3 positions of each inline edge's head node
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 16 < hi) {
-                const EulerNode3 &a = nodes[n + 16];
+                const Rec &a = nodes[n + 16];
                 for (uint32_t j = 0; j < 3; j++)
                     if (a.to[j] != NONE) __builtin_prefetch(&nodes[a.to[j]]);
             }
-            EulerNode3 &r = nodes[n];
+            Rec &r = nodes[n];
             const uint32_t d = r.deg < 3 ? r.deg : 3;
             uint32_t info = 0;
             for (uint32_t j = 0; j < d; j++) {
-                const EulerNode3 &w = nodes[r.to[j]];
+                const Rec &w = nodes[r.to[j]];
                 const uint32_t c = w.deg < 3 ? w.deg : 3;
                 for (uint32_t q = 0; q < c; q++) { r.sub_eid[j][q] = w.eid[q]; r.sub_to[j][q] = w.to[q]; }
                 info |= (c | (w.deg > 3 ? 4u : 0u)) << (3 * j);
@@ -143,11 +171,12 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
     const auto t_b = std::chrono::steady_clock::now();
     // phase C: first 2 positions of each head's heads. The head w = to[j] already holds copies of ITS heads' adjacency
     // (phase B), so one gather of w's record serves all three (j, q) slots.
+    if constexpr (L3)
     if (!have_sub_levels)
     parallel_ranges(V, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++) {
             if (n + 12 < hi) {
-                const EulerNode3 &a = nodes[n + 12];
+                const Rec &a = nodes[n + 12];
                 for (uint32_t j = 0; j < 3; j++)
                     if (a.to[j] != NONE) {
                         const char *p = reinterpret_cast<const char *>(&nodes[a.to[j]]);
@@ -155,15 +184,16 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
                         __builtin_prefetch(p + 64);
                     }
             }
-            EulerNode3 &r = nodes[n];
+            Rec &r = nodes[n];
             const uint32_t d = r.deg < 3 ? r.deg : 3;
             uint32_t info = 0;
             for (uint32_t j = 0; j < d; j++) {
-                const EulerNode3 &w = nodes[r.to[j]];
+                const Rec &w = nodes[r.to[j]];
                 for (uint32_t q = 0; q < r.sub_cnt(j); q++) {
                     const uint32_t wc = w.sub_cnt(q);  // copied positions of x = w.to[q] (up to 3)
                     const uint32_t c = wc < 2 ? wc : 2;
-                    for (uint32_t t = 0; t < c; t++) { r.sub2_eid[j][q][t] = w.sub_eid[q][t]; r.sub2_to[j][q][t] = w.sub_to[q][t]; }
+                    if constexpr (L3)
+                        for (uint32_t t = 0; t < c; t++) { r.sub2_eid[j][q][t] = w.sub_eid[q][t]; r.sub2_to[j][q][t] = w.sub_to[q][t]; }
                     info |= (c | ((wc > 2 || w.sub_more(q)) ? 4u : 0u)) << (3 * (3 * j + q));
                 }
             }
@@ -193,7 +223,7 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
     auto set_used = [&](uint32_t e) { used[(e >> 1) >> 6] |= 1ull << ((e >> 1) & 63); };
     // first unused out-edge of `node` in iteration order; j_out = its adjacency position
     auto next_unused = [&](uint32_t node, uint32_t &to_out, uint32_t &j_out) -> uint32_t {
-        EulerNode3 &r = nodes[node];
+        Rec &r = nodes[node];
         while (r.pos < r.deg) {
             const uint32_t e = r.pos < 3 ? r.eid[r.pos] : ext_eid[r.ext_begin + r.pos - 3];
             if (!is_used(e)) {
@@ -232,14 +262,16 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
             const size_t w_begin = n_ent;
             uint32_t e = start_edge, from = start_node, to = start_to;
             // hint state: `H` is the last record read; level 2 = `from` is H->to[hj], level 3 = `from` is H->sub_to[hj][hq]
-            const EulerNode3 *H = nullptr;
+            const Rec *H = nullptr;
             uint32_t level = 0, hj = 0, hq = 0;
             auto prefetch_record = [&](uint32_t node) {
                 const char *p = reinterpret_cast<const char *>(&nodes[node]);
                 __builtin_prefetch(p);
                 __builtin_prefetch(p + 64);
-                __builtin_prefetch(p + 128);
-                __builtin_prefetch(p + 192);
+                if constexpr (sizeof(Rec) > 128) {
+                    __builtin_prefetch(p + 128);
+                    __builtin_prefetch(p + 192);
+                }
             };
             for (;;) {
                 set_used(e);
@@ -255,14 +287,19 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
                     uint32_t q = 0;
                     for (; q < cnt; q++)
                         if (!is_used(H->sub_eid[hj][q])) { e = H->sub_eid[hj][q]; to = H->sub_to[hj][q]; break; }
-                    if (e != NONE) { full = false; level = 3; hq = q; n_hinted++; }
-                    else if (!H->sub_more(hj)) { full = false; level = 0; }  // exhausted: the walk is stuck here
+                    if (e != NONE) {
+                        full = false; hq = q; n_hinted++;
+                        if constexpr (L3) level = 3;
+                        else { level = 0; prefetch_record(to); }  // (two levels: this was the record's last hint)
+                    } else if (!H->sub_more(hj)) { full = false; level = 0; }  // exhausted: the walk is stuck here
                 } else if (level == 3) {
-                    const uint32_t cnt = H->sub2_cnt(hj, hq);
-                    for (uint32_t t = 0; t < cnt; t++)
-                        if (!is_used(H->sub2_eid[hj][hq][t])) { e = H->sub2_eid[hj][hq][t]; to = H->sub2_to[hj][hq][t]; break; }
-                    if (e != NONE) { full = false; n_hinted++; prefetch_record(to); }
-                    else if (!H->sub2_more(hj, hq)) full = false;
+                    if constexpr (L3) {
+                        const uint32_t cnt = H->sub2_cnt(hj, hq);
+                        for (uint32_t t = 0; t < cnt; t++)
+                            if (!is_used(H->sub2_eid[hj][hq][t])) { e = H->sub2_eid[hj][hq][t]; to = H->sub2_to[hj][hq][t]; break; }
+                        if (e != NONE) { full = false; n_hinted++; prefetch_record(to); }
+                        else if (!H->sub2_more(hj, hq)) full = false;
+                    }
                     level = 0;
                 }
                 if (full) {
@@ -278,7 +315,7 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
                         // is still unused (right about half of the time, and a wrong guess costs nothing but a line fill);
                         // (b) start the fetches of all bitmap words the exact computation below can touch, so that its lookups
                         // overlap instead of queueing up.
-                        const EulerNode3 &r0 = nodes[from];
+                        const Rec &r0 = nodes[from];
                         const uint32_t j0 = r0.pos;
                         if (j0 < 3 && j0 < r0.deg) {
                             const uint32_t c1 = r0.sub_cnt(j0);
@@ -290,13 +327,16 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
                             for (uint32_t q = 0; q < c1; q++) {
                                 const uint32_t c2 = r0.sub2_cnt(j0, q);
                                 if (!c2) prefetch_record(r0.sub_to[j0][q]);
-                                for (uint32_t t = 0; t < c2; t++) prefetch_record(r0.sub2_to[j0][q][t]);
+                                if constexpr (L3)
+                                    for (uint32_t t = 0; t < c2; t++) prefetch_record(r0.sub2_to[j0][q][t]);
                             }
                             for (uint32_t p = j0; p < 3 && p < r0.deg; p++) touch_bit(r0.eid[p]);
                             for (uint32_t q = 0; q < c1; q++) {
                                 touch_bit(r0.sub_eid[j0][q]);
-                                const uint32_t c2 = r0.sub2_cnt(j0, q);
-                                for (uint32_t t = 0; t < c2; t++) touch_bit(r0.sub2_eid[j0][q][t]);
+                                if constexpr (L3) {
+                                    const uint32_t c2 = r0.sub2_cnt(j0, q);
+                                    for (uint32_t t = 0; t < c2; t++) touch_bit(r0.sub2_eid[j0][q][t]);
+                                }
                             }
                         }
                     }
@@ -314,9 +354,11 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
                             for (uint32_t q = 0; q < c1; q++)
                                 if (!is_used(H->sub_eid[j][q])) {
                                     pf = H->sub_to[j][q];
-                                    const uint32_t c2 = H->sub2_cnt(j, q);
-                                    for (uint32_t t = 0; t < c2; t++)
-                                        if (!is_used(H->sub2_eid[j][q][t])) { pf = H->sub2_to[j][q][t]; break; }
+                                    if constexpr (L3) {
+                                        const uint32_t c2 = H->sub2_cnt(j, q);
+                                        for (uint32_t t = 0; t < c2; t++)
+                                            if (!is_used(H->sub2_eid[j][q][t])) { pf = H->sub2_to[j][q][t]; break; }
+                                    }
                                     break;
                                 }
                             prefetch_record(pf);
@@ -356,7 +398,7 @@ static Walks euler_walk_records(EulerNode3 *nodes, const uint64_t V, const uint3
             // first narrowed down by host threads (read-only: each finds the first such entry of its chunk).
             start_edge = NONE;
             auto has_unused = [&](uint32_t node) -> bool {  // like next_unused, without moving the node's cursor
-                const EulerNode3 &r = nodes[node];
+                const Rec &r = nodes[node];
                 for (uint32_t p = r.pos; p < r.deg; p++)
                     if (!is_used(p < 3 ? r.eid[p] : ext_eid[r.ext_begin + p - 3])) return true;
                 return false;

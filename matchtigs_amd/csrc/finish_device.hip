@@ -249,6 +249,41 @@ __global__ __launch_bounds__(EB) void wide_build_kernel(uint64_t n_nodes, const 
     wide[v] = r;
 }
 
+// the 128-byte records (own adjacency + the first three positions of every head): one gather level
+__global__ __launch_bounds__(EB) void mid_build_slice_kernel(uint64_t first, uint64_t n_slice, uint64_t n_nodes, const LeanNode *lean, EulerNode2 *mid) {
+    const uint64_t s = gid();  // (records [first, first + n_slice) go to mid[0 .. n_slice): the slice that is downloaded next)
+    if (s >= n_slice) return;
+    const uint64_t v = first + s;
+    if (v >= n_nodes) return;
+    const LeanNode l = lean[v];
+    EulerNode2 r;
+    for (int i = 0; i < 3; i++) {
+        r.eid[i] = l.eid[i];
+        r.to[i] = l.to[i];
+    }
+    r.deg = l.deg;
+    r.pos = 0;
+    r.pad = 0;
+    r.sub2_info = 0;
+    r.ext_begin = l.ext_begin;
+    for (int i = 0; i < 4; i++) r.pad2[i] = 0;
+    const uint32_t d = l.deg < 3 ? l.deg : 3;
+    uint32_t info = 0;
+    for (uint32_t j = 0; j < 3; j++)
+        for (uint32_t q = 0; q < 3; q++) { r.sub_eid[j][q] = NONE; r.sub_to[j][q] = NONE; }
+    for (uint32_t j = 0; j < d; j++) {
+        const LeanNode w = lean[l.to[j]];
+        const uint32_t c = w.deg < 3 ? w.deg : 3;
+        info |= (c | (w.deg > 3 ? 4u : 0u)) << (3 * j);
+        for (uint32_t q = 0; q < c; q++) {
+            r.sub_eid[j][q] = w.eid[q];
+            r.sub_to[j][q] = w.to[q];
+        }
+    }
+    r.sub_info = (uint16_t)info;
+    mid[s] = r;
+}
+
 // ---- rotate + cut (greedytigs/mod.rs:726-789) ----------------------------------------------------------------------
 struct CutIds {
     uint32_t n_orig;     // darts >= n_orig are dummies
@@ -581,12 +616,34 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                     HIP_CHECK(hipMemcpyAsync(ext_eid.data(), d_xe, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
                     HIP_CHECK(hipMemcpyAsync(ext_to.data(), d_xt, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
                 }
-                // 256-byte records (two levels of copied adjacency: 2.6 steps per DRAM miss) while they fit comfortably, the
-                // 32-byte records themselves beyond (one miss per step, an eighth of the memory). Same walk either way;
-                // MTG_EULER_RECORDS=lean|wide overrides the choice (speed / memory only).
+                // 256-byte records (two levels of copied adjacency: 2.6 steps per DRAM miss) while they fit comfortably, 128-byte
+                // ones (one level: 1.9 steps per miss) up to 100 GB of them, the 32-byte records themselves beyond (one miss per
+                // step, an eighth of the memory). Same walk either way; MTG_EULER_RECORDS=lean|mid|wide overrides the choice
+                // (speed / memory only).
                 const char *rec = std::getenv("MTG_EULER_RECORDS");
                 const bool wide = rec ? std::strcmp(rec, "wide") == 0 : V * 256 <= (48ull << 30);
-                if (!wide) {
+                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30));
+                if (mid) {
+                    // built on the GPU (one gather level) and brought down in slices through pageable memory: these are the
+                    // graphs of a hundred gigabytes, where page-locking the arena would cost more than the copy
+                    HugeBuf<EulerNode2> mbuf(V, &g.arena);
+                    b_row.release(); b_adj.release(); b_need.release(); b_off.release();
+                    {
+                        Buf b_mid;
+                        const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / sizeof(EulerNode2));  // 1 GB of records at a time
+                        EulerNode2 *d_mid = b_mid.alloc<EulerNode2>(st, std::min<uint64_t>(V, slice));
+                        for (uint64_t lo = 0; lo < V; lo += slice) {
+                            const uint64_t n = std::min(slice, V - lo);
+                            mid_build_slice_kernel<<<grid_for(n), EB, 0, st>>>(lo, n, V, d_nodes, d_mid);
+                            HIP_CHECK(hipGetLastError());
+                            HIP_CHECK(hipMemcpyAsync(mbuf.p + lo, d_mid, n * sizeof(EulerNode2), hipMemcpyDeviceToHost, st));
+                        }
+                        HIP_CHECK(hipStreamSynchronize(st));
+                    }
+                    b_nodes.release(); b_xe.release(); b_xt.release();
+                    acc2 += lap.lap("walk records, two levels (GPU) + download");
+                    cycles = euler_cycles_from_mid(mbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                } else if (!wide) {
                     HugeBuf<LeanNode> nodes(V, &g.arena);
                     HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
                     HIP_CHECK(hipStreamSynchronize(st));

@@ -95,6 +95,7 @@ def test_euler_cycles_linked_list_equals_literal_on_larger_graph(oracle, product
     assert want_cycles == G.euler_cycles()
     assert want_cycles == G.euler_cycles_records(1)   # 32-byte records (the memory-lean walk, euler_lean.cpp)
     assert want_cycles == G.euler_cycles_records(2)   # 256-byte records seeded from 32-byte ones (the device finish's route)
+    assert want_cycles == G.euler_cycles_records(3)   # 128-byte records (two levels), for graphs too large for the 256-byte ones
 
 
 def test_euler_walk_scratch_is_reused_between_calls_on_one_graph(oracle, product_lib):

@@ -100,6 +100,7 @@ def test_kat_t4_euler_order_and_cut(kat, oracle, product_lib):
         G.make_eulerian(G.insert_pair_edges(pr), k)
         assert G.euler_cycles() == exp["greedy_euler_cycles"], "product cycles"
         assert G.euler_cycles_records(1) == exp["greedy_euler_cycles"] and G.euler_cycles_records(2) == exp["greedy_euler_cycles"]
+        assert G.euler_cycles_records(3) == exp["greedy_euler_cycles"]
         assert G.cut_cycles(exp["greedy_euler_cycles"], k) == exp["greedy_tigs"], "product cut"
         G2 = helpers.product_graph(mirror, frm, to, w)
         assert G2.finish_greedytigs(pr, k) == exp["greedy_tigs"], "product finish_greedytigs"
