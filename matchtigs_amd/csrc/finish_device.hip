@@ -415,6 +415,24 @@ void eulerise_tail(const HostGraph &g, const std::vector<uint32_t> &r_node, std:
 // GPU-built records, the reference's order) and cuts. Appends the dummy edges to g's edge arrays (unlinked). times_out[0..5] =
 // seconds of {upload + insertion + Euleriser, host-graph materialisation, Euler decomposition, cut + download}, [4] = kernel ms
 // of the device decomposition, [5] = number of breaking biedges.
+// host memory this process can still take: MemAvailable, and what the cgroup leaves (v2: memory.max - memory.current)
+static uint64_t host_available_bytes() {
+    uint64_t avail = ~0ull;
+    if (FILE *f = std::fopen("/proc/meminfo", "r")) {
+        char line[256];
+        unsigned long long kb = 0;
+        while (std::fgets(line, sizeof line, f))
+            if (std::sscanf(line, "MemAvailable: %llu kB", &kb) == 1) { avail = (uint64_t)kb << 10; break; }
+        std::fclose(f);
+    }
+    unsigned long long lim = 0, cur = 0;
+    bool have_lim = false, have_cur = false;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.max", "r")) { have_lim = std::fscanf(f, "%llu", &lim) == 1; std::fclose(f); }  // ("max" does not parse: no limit)
+    if (FILE *f = std::fopen("/sys/fs/cgroup/memory.current", "r")) { have_cur = std::fscanf(f, "%llu", &cur) == 1; std::fclose(f); }
+    if (have_lim && have_cur && lim > cur) avail = std::min<uint64_t>(avail, lim - cur);
+    return avail;
+}
+
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6]) {
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
     if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
@@ -620,9 +638,12 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 // ones (one level: 1.9 steps per miss) up to 100 GB of them, the 32-byte records themselves beyond (one miss per
                 // step, an eighth of the memory). Same walk either way; MTG_EULER_RECORDS=lean|mid|wide overrides the choice
                 // (speed / memory only).
+                // The larger formats are only chosen when the host has room for them next to the walk's entry arrays (16 bytes
+                // per dart) -- free memory as the kernel and the cgroup report it.
                 const char *rec = std::getenv("MTG_EULER_RECORDS");
-                const bool wide = rec ? std::strcmp(rec, "wide") == 0 : V * 256 <= (48ull << 30);
-                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30));
+                const uint64_t room = host_available_bytes(), walk_arrays = E * 16;
+                const bool wide = rec ? std::strcmp(rec, "wide") == 0 : (V * 256 <= (48ull << 30) && V * 256 + walk_arrays <= room / 4 * 3);
+                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30) && V * 128 + walk_arrays <= room / 4 * 3);
                 if (mid) {
                     // built on the GPU (one gather level) and brought down in slices through pageable memory: these are the
                     // graphs of a hundred gigabytes, where page-locking the arena would cost more than the copy
