@@ -105,3 +105,17 @@ def test_gpu_replay_scrambled_numbering(seed, oracle, product_lib):
     want, _ = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight).greedy_pairs_np(bg.k)
     assert _pairs_equal(host_pairs, want)
     assert _pairs_equal(gpu_pairs, want)
+
+
+@pytest.mark.parametrize("block", ["256", "1024"])
+def test_gpu_replay_both_workgroup_sizes(block, oracle, product_lib, monkeypatch):
+    """The rounds kernel is instantiated for workgroups of 1024 (rounds that fill the device) and of 256 (small inputs); the
+    choice is by input size, MTG_REPLAY_BLOCK forces it: both on the same graphs, against the oracle."""
+    from matchtigs_amd import synth
+
+    monkeypatch.setenv("MTG_REPLAY_BLOCK", block)
+    for case in (dict(n_binodes=20000, seed=6, k=31, mean_out_degree=2.6, mean_weight=2.0, self_mirror_frac=0.05),
+                 dict(n_binodes=3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01)):
+        bg = synth.g_csr(**case)
+        G, dev, gpu_pairs, host_pairs = _run(bg)
+        assert _pairs_equal(gpu_pairs, host_pairs), (block, case)
