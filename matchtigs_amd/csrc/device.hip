@@ -753,8 +753,11 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 #ifdef MTG_ENUM_STATS
 __device__ unsigned long long g_enum_prof[16384][3];  // development build: per wave [start, end (100-MHz ticks), steps]
 #endif
+#ifndef MTG_ENUM_WAVES_PER_SIMD
+#define MTG_ENUM_WAVES_PER_SIMD 1  // (experiments: 5 makes the compiler keep the registers within a fifth wave per SIMD)
+#endif
 template <int WPB, int S1, int H1, int NB, bool QUAD>
-__global__ __launch_bounds__(WPB * 64) void sssp_enum_kernel(SsspArgs a) {
+__global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_kernel(SsspArgs a) {
     static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
     constexpr int BE = ENUM_BE, BS = ENUM_BS;
     static_assert(BS >= BE, "block stride below the block size");
@@ -1581,15 +1584,17 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     if (use_enum && n) {  // when the waves end, and how many steps they ran
         static std::vector<unsigned long long> hp(16384 * 3);
         HIP_CHECK(hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_enum_prof), hp.size() * 8));
-        std::vector<double> end_us, life_us, steps;
+        std::vector<double> end_us, life_us, steps, start_us;
         unsigned long long t_min = ~0ull;
         for (int w = 0; w < 16384; w++) if (hp[3 * w + 1]) t_min = std::min(t_min, hp[3 * w]);
         for (int w = 0; w < 16384; w++)
-            if (hp[3 * w + 1]) { end_us.push_back((hp[3 * w + 1] - t_min) * 0.01); life_us.push_back((hp[3 * w + 1] - hp[3 * w]) * 0.01); steps.push_back((double)hp[3 * w + 2]); }
+            if (hp[3 * w + 1]) { start_us.push_back((hp[3 * w] - t_min) * 0.01); end_us.push_back((hp[3 * w + 1] - t_min) * 0.01); life_us.push_back((hp[3 * w + 1] - hp[3 * w]) * 0.01); steps.push_back((double)hp[3 * w + 2]); }
         auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(q * (v.size() - 1))]; };
         std::fprintf(stderr, "[mtg] enum waves: %zu; end of wave (us after the first start) min %.0f p10 %.0f median %.0f p90 %.0f max %.0f; steps per wave min %.0f median %.0f max %.0f; us per step median %.3f\n",
                      end_us.size(), pct(end_us, 0), pct(end_us, 0.1), pct(end_us, 0.5), pct(end_us, 0.9), pct(end_us, 1), pct(steps, 0), pct(steps, 0.5), pct(steps, 1),
                      pct(life_us, 0.5) / std::max(1.0, pct(steps, 0.5)));
+        std::fprintf(stderr, "[mtg] enum waves: start (us after the first) median %.0f p90 %.0f p99 %.0f max %.0f; life median %.0f p90 %.0f max %.0f us\n",
+                     pct(start_us, 0.5), pct(start_us, 0.9), pct(start_us, 0.99), pct(start_us, 1), pct(life_us, 0.5), pct(life_us, 0.9), pct(life_us, 1));
         std::vector<unsigned long long> zero(16384 * 3, 0);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_enum_prof), zero.data(), zero.size() * 8));
     }
