@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             if (c > 2) k2 = mem[hit_word(blk, 2)];
             if (c > 3) k3 = mem[hit_word(blk, 3)];
             bool fix = c > 4;
-            if (__any(c >= 2)) {  // (the first four keys of a longer list are put in order as well: the post-pass starts behind them)
+            if (__any(c >= 2 && c <= 4)) {  // (a longer list is sorted as a whole by the post-pass: no need to run the network for it alone)
                 auto cswap = [](unsigned long long &x, unsigned long long &y) {
                     const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
                     x = lo; y = hi;
