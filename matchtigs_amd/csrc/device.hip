@@ -2087,7 +2087,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     read_counters(d, st);
     const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
     rt.lap("tail + scan");
-    mtg_pair *host = (mtg_pair *)std::malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
+    mtg_pair *host = (mtg_pair *)big_malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));  // (the caller frees it with free())
     if (!host) MTG_DIE("out of memory");
     if (n_pairs) {
         if (n_pairs > w.cap_out) {
@@ -2120,12 +2120,19 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
                 HIP_CHECK(hipEventRecord(ev[i], st));
             }
             const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8, (uint64_t)std::thread::hardware_concurrency(), n_pairs >> 18}));
+            double dbg_wait = 0, dbg_copy = 0;
             auto worker = [&](unsigned t) {
                 for (uint64_t i = 0; i < n_slices; i++) {
                     const uint64_t lo = i * slice, n = std::min(slice, n_pairs - lo);
                     const uint64_t a0 = lo + n * t / T, a1 = lo + n * (t + 1) / T;
+                    const auto t0 = std::chrono::steady_clock::now();
                     HIP_CHECK(hipEventSynchronize(ev[i]));
+                    const auto t1 = std::chrono::steady_clock::now();
                     std::memcpy(host + a0, w.h_out + a0, (a1 - a0) * sizeof(mtg_pair));
+                    if (t == 0) {
+                        dbg_wait += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                        dbg_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+                    }
                 }
             };
             std::vector<std::thread> th;
@@ -2133,6 +2140,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             worker(0);
             for (auto &x : th) x.join();
             for (uint64_t i = 0; i < n_slices; i++) HIP_CHECK(hipEventDestroy(ev[i]));
+            if (rt.on) std::fprintf(stderr, "[mtg] replay: pair download: %llu slices, %u host threads; thread 0 waited %.3f ms for copies, copied for %.3f ms\n",
+                                    (unsigned long long)n_slices, T, dbg_wait, dbg_copy);
         }
     }
     rt.lap("compact + pair download");
