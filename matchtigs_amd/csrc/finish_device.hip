@@ -666,8 +666,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                     cycles = euler_cycles_from_mid(mbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                 } else if (!wide) {
                     HugeBuf<LeanNode> nodes(V, &g.arena);
-                    HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
-                    HIP_CHECK(hipStreamSynchronize(st));
+                    download_sliced(nodes.p, d_nodes, V * sizeof(LeanNode), st, device_id);
                     b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
                     acc2 += lap.lap("walk records (GPU) + download");
                     cycles = euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
@@ -700,8 +699,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         cycles = euler_cycles_from_wide(wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                     } else {
                         HugeBuf<LeanNode> nodes(V, &g.arena);
-                        HIP_CHECK(hipMemcpyAsync(nodes.p, d_nodes, V * sizeof(LeanNode), hipMemcpyDeviceToHost, st));
-                        HIP_CHECK(hipStreamSynchronize(st));
+                        download_sliced(nodes.p, d_nodes, V * sizeof(LeanNode), st, device_id);
                         b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
                         acc2 += lap.lap("walk records (GPU) + download");
                         cycles = euler_cycles_from_lean(nodes.p, wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
@@ -760,9 +758,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipGetLastError());
         tigs.edges.resize(n_kept);
         tigs.limits.resize(n_tigs);
-        if (n_kept) HIP_CHECK(hipMemcpyAsync(tigs.edges.data(), d_te, n_kept * 4, hipMemcpyDeviceToHost, st));
-        if (n_tigs) HIP_CHECK(hipMemcpyAsync(tigs.limits.data(), d_tl, n_tigs * 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
+        download_sliced(tigs.limits.data(), d_tl, n_tigs * 8, st, device_id);
     }
     if (times_out) times_out[3] = lap.lap("rotate + cut + download");
     b_from.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
