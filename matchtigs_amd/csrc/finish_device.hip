@@ -672,9 +672,9 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                     cycles = euler_cycles_lean(nodes.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                 } else {
                     // The wide records live in the graph's arena. A mapping that comes back for its second call belongs to a
-                    // caller that iterates: it is page-locked once (hipHostRegister), and from then on the GPU builds all three
-                    // levels and the records come down at PCIe speed. A first (or only) call fills levels two and three with
-                    // host threads instead: pinning 23 GB of fresh memory costs more than it saves a one-shot caller.
+                    // caller that iterates: it is page-locked once (hipHostRegister) and the records come down in one copy.
+                    // A first (or only) call does not pin (pinning 23 GB of fresh memory costs more than it saves a one-shot
+                    // caller): its records go through the pinned ring of download_sliced.
                     HugeBuf<EulerNode3> wbuf(V, &g.arena);
                     bool pinned = false;
                     const unsigned uses = g.arena.uses_of(wbuf.p, &pinned);
@@ -686,23 +686,22 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                             pinned = true;
                         } else (void)hipGetLastError();
                     }
-                    if (pinned) {
+                    {
+                        // all three levels on the GPU; into a page-locked arena the records travel in one copy, into a fresh
+                        // one through the pinned ring (host threads copy the slices out): 0.5 s either way at 2^27, where
+                        // filling levels two and three with host threads took 1.2 s
                         Buf b_wide;
                         EulerNode3 *d_wide = b_wide.alloc<EulerNode3>(st, V);
                         wide_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_nodes, d_wide);
                         HIP_CHECK(hipGetLastError());
-                        HIP_CHECK(hipMemcpyAsync(wbuf.p, d_wide, V * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
-                        HIP_CHECK(hipStreamSynchronize(st));
+                        if (pinned) {
+                            HIP_CHECK(hipMemcpyAsync(wbuf.p, d_wide, V * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
+                            HIP_CHECK(hipStreamSynchronize(st));
+                        } else download_sliced(wbuf.p, d_wide, V * sizeof(EulerNode3), st, device_id);
                         b_wide.release();
                         b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
                         acc2 += lap.lap("walk records, all levels (GPU) + download");
                         cycles = euler_cycles_from_wide(wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
-                    } else {
-                        HugeBuf<LeanNode> nodes(V, &g.arena);
-                        download_sliced(nodes.p, d_nodes, V * sizeof(LeanNode), st, device_id);
-                        b_row.release(); b_adj.release(); b_need.release(); b_off.release(); b_nodes.release(); b_xe.release(); b_xt.release();
-                        acc2 += lap.lap("walk records (GPU) + download");
-                        cycles = euler_cycles_from_lean(nodes.p, wbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                     }
                 }
             }
