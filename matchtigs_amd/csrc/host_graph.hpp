@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,19 +45,75 @@ inline void *big_malloc(size_t bytes) {
     return p;
 }
 
+// A few recently released large blocks are kept for the next request of about the same size: a caller that iterates (one tig set
+// after the other) otherwise pays the page faults of every fresh array and the unmapping of every released one -- at 2^27 the two
+// tig arrays (0.56 GB) cost ~8 ms to fault in and 21 ms to give back, of a 160-ms device-mode step. At most 8 blocks / 2 GB.
+struct BigBlockCache {
+    struct Entry { void *p; size_t bytes; };
+    std::mutex m;
+    Entry e[8];
+    int n = 0;
+    size_t total = 0;
+    static constexpr size_t LIMIT = 2ull << 30, HUGE = 2u << 20, SMALL = 8u << 20;
+    static size_t rounded(size_t bytes) { return (bytes + HUGE - 1) / HUGE * HUGE; }
+    void *take(size_t bytes) {  // best fit among the kept blocks, at most a quarter larger than asked for
+        const size_t want = rounded(bytes);
+        std::lock_guard<std::mutex> lock(m);
+        int best = -1;
+        for (int i = 0; i < n; i++)
+            if (e[i].bytes >= want && e[i].bytes <= want + want / 4 && (best < 0 || e[i].bytes < e[best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void *p = e[best].p;
+        total -= e[best].bytes;
+        e[best] = e[--n];
+        return p;
+    }
+    void give(void *p, size_t bytes) {  // (bytes = what the block was asked for: its rounded size is a lower bound of its real one)
+        const size_t have = rounded(bytes);
+        void *drop[9];
+        int n_drop = 0;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (have > LIMIT) drop[n_drop++] = p;
+            else {
+                while (n == 8 || total + have > LIMIT) {  // oldest first
+                    drop[n_drop++] = e[0].p;
+                    total -= e[0].bytes;
+                    for (int i = 1; i < n; i++) e[i - 1] = e[i];
+                    n--;
+                }
+                e[n++] = Entry{p, have};
+                total += have;
+            }
+        }
+        for (int i = 0; i < n_drop; i++) std::free(drop[i]);
+    }
+};
+inline BigBlockCache &big_block_cache() {
+    static BigBlockCache *c = new BigBlockCache;  // (never destroyed: blocks may be released during static destruction)
+    return *c;
+}
+
 // std::vector whose resize() leaves new elements uninitialised: the bulk edge insertion fills them from host threads,
-// and a sequential zero-fill of hundreds of MB first would cost as much as the fill itself. Large blocks come from big_malloc.
+// and a sequential zero-fill of hundreds of MB first would cost as much as the fill itself. Large blocks come from big_malloc
+// or from the cache of recently released ones.
 template <typename T>
 struct DefaultInitAlloc : std::allocator<T> {
     template <typename U>
     struct rebind { using other = DefaultInitAlloc<U>; };
     using std::allocator<T>::allocator;
     T *allocate(size_t n) {
-        void *p = big_malloc(n * sizeof(T));
+        const size_t bytes = n * sizeof(T);
+        void *p = bytes >= BigBlockCache::SMALL ? big_block_cache().take(bytes) : nullptr;
+        if (!p) p = big_malloc(bytes);
         if (!p) throw std::bad_alloc();
         return static_cast<T *>(p);
     }
-    void deallocate(T *p, size_t) noexcept { std::free(p); }
+    void deallocate(T *p, size_t n) noexcept {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= BigBlockCache::SMALL) big_block_cache().give(p, bytes);
+        else std::free(p);
+    }
     template <typename U>
     void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
     template <typename U, typename... A>
