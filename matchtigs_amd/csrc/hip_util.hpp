@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -112,29 +113,83 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 
 // Stream-ordered allocation from the device's default memory pool (which the callers tell to keep freed memory: the work
 // arrays of a call cost milliseconds to map afresh, and a driver that finishes graph after graph reuses them).
+// Device work arrays of the finishing stages. Every call asks for the same sizes again, so released blocks are kept per device and
+// handed back by size (first fit within a quarter above the request); what is not there comes from hipMalloc. (The runtime's
+// stream-ordered pool -- hipMallocAsync with the release threshold at its maximum -- was used until the end of round 3: on some
+// boxes the twelve allocations at the head of the Euler decomposition then took 0.5 to 4.7 s on some steps, nothing on the others.)
+// All users run on the one finish stream of their device, so a block released earlier on that stream is free when it is used again.
+struct DeviceBlockCache {
+    std::mutex m;
+    std::multimap<size_t, void *> free_blocks;
+    size_t held = 0;
+    static constexpr size_t GRAIN = 1u << 20;
+    static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 1) + GRAIN - 1) / GRAIN * GRAIN; }
+    void *take(size_t bytes) {
+        const size_t want = rounded(bytes);
+        {
+            std::lock_guard<std::mutex> lock(m);
+            auto it = free_blocks.lower_bound(want);
+            if (it != free_blocks.end() && it->first <= want + want / 4) {
+                void *p = it->second;
+                held -= it->first;
+                free_blocks.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {  // out of memory with blocks of other sizes held back: give them up and try again
+            (void)hipGetLastError();
+            trim();
+            HIP_CHECK(hipMalloc(&p, want));
+        }
+        return p;
+    }
+    void give(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> lock(m);
+        free_blocks.emplace(rounded(bytes), p);
+        held += rounded(bytes);
+    }
+    void trim() {
+        std::multimap<size_t, void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            drop.swap(free_blocks);
+            held = 0;
+        }
+        for (auto &kv : drop) (void)hipFree(kv.second);
+    }
+};
+inline DeviceBlockCache &device_block_cache(int device_id) {
+    static DeviceBlockCache *caches = new DeviceBlockCache[64];  // (never destroyed: buffers may be released during static destruction)
+    if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
+    return caches[device_id];
+}
+
 struct Buf {
     void *p = nullptr;
-    hipStream_t st = nullptr;
+    size_t bytes = 0;
+    int device = 0;
     Buf() = default;
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
     ~Buf() { release(); }
     void release() {
-        if (p) (void)hipFreeAsync(p, st);
+        if (p) device_block_cache(device).give(p, bytes);
         p = nullptr;
     }
     template <typename T>
-    T *alloc(hipStream_t stream, uint64_t n) {
+    T *alloc(hipStream_t, uint64_t n) {  // (the stream says nothing any more: blocks are ordered by the device's one finish stream)
         release();
-        st = stream;
-        HIP_CHECK(hipMallocAsync(&p, (n ? n : 1) * sizeof(T), st));
+        HIP_CHECK(hipGetDevice(&device));
+        bytes = (n ? n : 1) * sizeof(T);
+        p = device_block_cache(device).take(bytes);
         return (T *)p;
     }
     template <typename T>
     T *as() const { return (T *)p; }
 };
 
-// One stream per device for the finishing stages, created on first use; the device's default pool keeps freed memory.
+// One stream per device for the finishing stages, created on first use.
 inline hipStream_t finish_stream(int device_id) {
     static hipStream_t streams[64] = {nullptr};
     static std::mutex mu;
@@ -143,10 +198,6 @@ inline hipStream_t finish_stream(int device_id) {
     if (!streams[device_id]) {
         HIP_CHECK(hipSetDevice(device_id));
         HIP_CHECK(hipStreamCreate(&streams[device_id]));
-        hipMemPool_t pool;
-        HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
-        uint64_t keep = UINT64_MAX;
-        HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
     }
     return streams[device_id];
 }
@@ -248,9 +299,7 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
 
 inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 32ull << 30) {
     if (bytes_used < threshold) return;
-    hipMemPool_t pool;
-    HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
-    HIP_CHECK(hipMemPoolTrimTo(pool, 0));
+    device_block_cache(device_id).trim();
 }
 
 }  // namespace hu

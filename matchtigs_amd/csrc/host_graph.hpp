@@ -41,7 +41,8 @@ inline void *big_malloc(size_t bytes) {
     if (bytes < (8u << 20)) return std::malloc(bytes ? bytes : 1);
     const size_t rounded = (bytes + HUGE - 1) / HUGE * HUGE;
     void *p = std::aligned_alloc(HUGE, rounded);
-    if (p) advise_huge(p, rounded);
+    static const bool no_thp = std::getenv("MTG_NO_THP") != nullptr;  // (measurements only)
+    if (p && !no_thp) advise_huge(p, rounded);
     return p;
 }
 
