@@ -570,11 +570,15 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     acc0 += lap.lap("upload + insertion + Euleriser");
     if (times_out) { times_out[0] = acc0; times_out[5] = (double)n_brk; }
 
-    // ---- the dummy edges join the host graph's edge arrays (unlinked: a host stage that walks adjacency links them first) ----
+    // ---- the dummy edges join the host graph's edge arrays (unlinked: a host stage that walks adjacency links them first).
+    // With the device decomposition nothing on the host needs them before the call returns: the 33 bytes per dart are then written
+    // by a thread of their own while the GPU decomposes and cuts (joined at the end). ----
+    Buf b_to;
+    std::thread append_thread;
+    hipEvent_t ev_appended = nullptr;
     {
         bool long_pair = false;
         for (uint64_t i = 0; i < n_pairs && !long_pair; i++) long_pair = pairs[i].distance >= k;
-        Buf b_to;
         uint32_t *d_to = b_to.alloc<uint32_t>(st, n_dummy);
         if (n_dummy) head_kernel<<<grid_for(n_dummy), EB, 0, st>>>(d_from, d_mirror, E0, E, d_to);
         HIP_CHECK(hipGetLastError());
@@ -583,18 +587,27 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             HIP_CHECK(hipMemcpyAsync(g.e_from.data() + E0, d_from + E0, n_dummy * 4, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipMemcpyAsync(g.e_to.data() + E0, d_to, n_dummy * 4, hipMemcpyDeviceToHost, st));
         }
-        parallel_ranges(n_dummy / 2, [&](uint64_t lo, uint64_t hi) {  // meanwhile: weights, dummy ids (1-based, :681 / mod.rs:573)
-            for (uint64_t i = lo; i < hi; i++) {
-                const uint64_t e = E0 + 2 * i;
-                const uint64_t w = i < n_pairs ? pairs[i].distance : k;
-                g.e_weight[e] = g.e_weight[e + 1] = w;
-                g.e_dummy[e] = g.e_dummy[e + 1] = i + 1;
-                g.e_unitig[e] = g.e_unitig[e + 1] = 0;
-                g.e_fwd[e] = 1;
-                g.e_fwd[e + 1] = 0;
-            }
-        });
-        HIP_CHECK(hipStreamSynchronize(st));
+        auto fill = [&g, pairs, n_pairs, k, E0, n_dummy]() {  // weights, dummy ids (1-based, :681 / mod.rs:573)
+            parallel_ranges(n_dummy / 2, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) {
+                    const uint64_t e = E0 + 2 * i;
+                    const uint64_t w = i < n_pairs ? pairs[i].distance : k;
+                    g.e_weight[e] = g.e_weight[e + 1] = w;
+                    g.e_dummy[e] = g.e_dummy[e + 1] = i + 1;
+                    g.e_unitig[e] = g.e_unitig[e + 1] = 0;
+                    g.e_fwd[e] = 1;
+                    g.e_fwd[e + 1] = 0;
+                }
+            });
+        };
+        if (euler_mode == MTG_EULER_DEVICE && n_dummy >= (1u << 20)) {
+            HIP_CHECK(hipEventCreateWithFlags(&ev_appended, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ev_appended, st));  // (behind the two copies)
+            append_thread = std::thread(fill);
+        } else {
+            fill();
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         g.first_breaking_edge = first_brk;
         g.breaking_weight = k;
         g.dummies_canonical = !long_pair;
@@ -761,6 +774,14 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         download_sliced(tigs.limits.data(), d_tl, n_tigs * 8, st, device_id);
     }
     if (times_out) times_out[3] = lap.lap("rotate + cut + download");
+    if (append_thread.joinable()) {
+        append_thread.join();
+        HIP_CHECK(hipEventSynchronize(ev_appended));
+        HIP_CHECK(hipEventDestroy(ev_appended));
+        const double waited = lap.lap("host graph: dummy edges (rest, after the GPU stages)");
+        if (times_out) times_out[1] += waited;
+    }
+    b_to.release();
     b_from.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
     HIP_CHECK(hipStreamSynchronize(st));
     finish_trim(device_id, E * 40 + V * 28);
