@@ -1386,7 +1386,7 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
         // table[H] u64 | stage[SCAP] u64 | log[QCAP] u32 | stage_src[SCAP] u16
         ws_stride = H + (uint64_t)cfg.scap + ((uint64_t)cfg.qcap + 1) / 2 + ((uint64_t)cfg.scap + 3) / 4;
         grid = std::min<uint64_t>(grid, n_batches);
-        HIP_CHECK(hipMalloc(&ws, grid * ws_stride * 8));
+        hu::device_malloc(&ws, grid * ws_stride * 8);
     }
     grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, n_batches));
     args.ws = ws;
@@ -1454,12 +1454,12 @@ static void run_dense_level(Device *d, hipStream_t st, const SsspArgs &a, const 
     std::sort(list.begin(), list.end());
     uint32_t *d_dist = nullptr, *d_stamp = nullptr, *d_front[2] = {nullptr, nullptr};
     unsigned long long *d_keys = nullptr, *d_n = nullptr;
-    HIP_CHECK(hipMalloc(&d_dist, V * 4));
-    HIP_CHECK(hipMalloc(&d_stamp, V * 4));
-    HIP_CHECK(hipMalloc(&d_front[0], V * 4));
-    HIP_CHECK(hipMalloc(&d_front[1], V * 4));
-    HIP_CHECK(hipMalloc(&d_keys, V * 8));
-    HIP_CHECK(hipMalloc(&d_n, 16));
+    hu::device_malloc(&d_dist, V * 4);
+    hu::device_malloc(&d_stamp, V * 4);
+    hu::device_malloc(&d_front[0], V * 4);
+    hu::device_malloc(&d_front[1], V * 4);
+    hu::device_malloc(&d_keys, V * 8);
+    hu::device_malloc(&d_n, 16);
     std::vector<unsigned long long> keys;
     std::vector<uint32_t> sources(1);
     for (const uint32_t idx : list) {
@@ -1529,15 +1529,15 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each + the post-pass work list
         for (int i = 0; i < 2; i++) {
             if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
-            HIP_CHECK(hipMalloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+            hu::device_malloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t));
         }
         if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
 
         // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/7 of every chunk incl. its tag) + three open chunks per wave
         const uint64_t fix_slots = std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * 3 * ENUM_FIX_CHUNK;
-        HIP_CHECK(hipMalloc(&d->d_fix, fix_slots * sizeof(uint32_t)));
+        hu::device_malloc(&d->d_fix, fix_slots * sizeof(uint32_t));
         if (d->d_fix_dense) HIP_CHECK(hipFree(d->d_fix_dense));
-        HIP_CHECK(hipMalloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+        hu::device_malloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
@@ -1698,21 +1698,21 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     uint32_t *d_from = nullptr, *d_to = nullptr, *d_fill = nullptr, *d_need = nullptr;
     uint16_t *d_w = nullptr;
     unsigned long long *d_ext_off = nullptr;
-    HIP_CHECK(hipMalloc(&d_from, std::max<uint64_t>(E, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_to, std::max<uint64_t>(E, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_w, std::max<uint64_t>(E, 1) * 2));
-    HIP_CHECK(hipMalloc(&d_fill, std::max<uint64_t>(V, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_need, std::max<uint64_t>(V, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8));
-    HIP_CHECK(hipMalloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeBlock)));
-    HIP_CHECK(hipMalloc(&d->d_odeg, std::max<uint64_t>(V, 1) * 4));
-    HIP_CHECK(hipMalloc(&d->d_cls, std::max<uint64_t>(V, 1)));
-    HIP_CHECK(hipMalloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4));
-    HIP_CHECK(hipMalloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4));
-    HIP_CHECK(hipMalloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4));
+    hu::device_malloc(&d_from, std::max<uint64_t>(E, 1) * 4);
+    hu::device_malloc(&d_to, std::max<uint64_t>(E, 1) * 4);
+    hu::device_malloc(&d_w, std::max<uint64_t>(E, 1) * 2);
+    hu::device_malloc(&d_fill, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d_need, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8);
+    hu::device_malloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeBlock));
+    hu::device_malloc(&d->d_odeg, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d->d_cls, std::max<uint64_t>(V, 1));
+    hu::device_malloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4);
     d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
-    HIP_CHECK(hipMalloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4));  // source counts | positive multiplicities per block
-    HIP_CHECK(hipMalloc(&d->d_counters, C_COUNT * sizeof(unsigned long long)));
+    hu::device_malloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4);  // source counts | positive multiplicities per block
+    hu::device_malloc(&d->d_counters, C_COUNT * sizeof(unsigned long long));
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
@@ -1735,8 +1735,8 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         ext_total = d->h_counters[C_OVF_LIST];
     }
     d->ext_n = ext_total;
-    HIP_CHECK(hipMalloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4));
-    HIP_CHECK(hipMalloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2));
+    hu::device_malloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4);
+    hu::device_malloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2);
     if (V) {
         if (E) hipLaunchKernelGGL(build_fill_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_ext_off, d_fill, d->d_recs, d->d_ext_col);
         hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_to, d_w, d->d_recs,
@@ -1746,7 +1746,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     }
     // the finishing stages on this GPU start from the same two arrays: leave them with the graph instead of uploading them again
     uint32_t *d_mirror_copy = nullptr;
-    HIP_CHECK(hipMalloc(&d_mirror_copy, std::max<uint64_t>(V, 1) * 4));
+    hu::device_malloc(&d_mirror_copy, std::max<uint64_t>(V, 1) * 4);
     if (V) HIP_CHECK(hipMemcpyAsync(d_mirror_copy, d->d_mirror, V * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
     hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
@@ -1808,7 +1808,7 @@ void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int3
     if (mult && d->V) HIP_CHECK(hipMemcpyAsync(mult, d->d_mult, d->V * 4, hipMemcpyDeviceToHost, st));
     if (live && d->V) {
         uint8_t *d_live = nullptr;
-        HIP_CHECK(hipMalloc(&d_live, d->V));
+        hu::device_malloc(&d_live, d->V);
         hipLaunchKernelGGL(export_live_kernel, dim3((unsigned)((d->V + 255) / 256)), dim3(256), 0, st, d->d_cls, (uint32_t)d->V, d_live);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(live, d_live, d->V, hipMemcpyDeviceToHost, st));
@@ -1833,8 +1833,8 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
     const uint64_t n = src_end - src_begin;
     unsigned long long *d_start = nullptr;
     uint32_t *d_count = nullptr;
-    HIP_CHECK(hipMalloc(&d_start, std::max<uint64_t>(n, 1) * 8));
-    HIP_CHECK(hipMalloc(&d_count, std::max<uint64_t>(n, 1) * 4));
+    hu::device_malloc(&d_start, std::max<uint64_t>(n, 1) * 8);
+    hu::device_malloc(&d_count, std::max<uint64_t>(n, 1) * 4);
     const double keep_ms = d->last_kernel_ms;
     run_levels(d, (hipStream_t)stream, 1, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
     d->last_kernel_ms = keep_ms;
@@ -1848,8 +1848,8 @@ void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_d
     const uint64_t n = d->n_sources;
     unsigned long long *d_start = nullptr;
     uint32_t *d_count = nullptr;
-    HIP_CHECK(hipMalloc(&d_start, std::max<uint64_t>(n, 1) * 8));
-    HIP_CHECK(hipMalloc(&d_count, std::max<uint64_t>(n, 1) * 4));
+    hu::device_malloc(&d_start, std::max<uint64_t>(n, 1) * 8);
+    hu::device_malloc(&d_count, std::max<uint64_t>(n, 1) * 4);
     mtg_sssp_stats st{};
     run_levels(d, (hipStream_t)stream, 2, 0, n, nullptr, 0, d_start, d_count, nullptr, &st);
     HIP_CHECK(hipFree(d_start));
@@ -1882,7 +1882,7 @@ static void scan_values(hipStream_t st, ReplayWork &w, In in, uint64_t n, unsign
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb > w.cap_blocks) {
         if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
-        HIP_CHECK(hipMalloc(&w.block_sums, nb * 8));
+        hu::device_malloc(&w.block_sums, nb * 8);
         w.cap_blocks = nb;
     }
     hipLaunchKernelGGL(scan_reduce_kernel<In>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, n, w.block_sums);
@@ -1923,9 +1923,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     if (V > w.cap_v) {
         if (w.state) { HIP_CHECK(hipFree(w.state)); HIP_CHECK(hipFree(w.resv[0])); HIP_CHECK(hipFree(w.resv[1])); }
-        HIP_CHECK(hipMalloc(&w.state, (V + 2) * 8));  // (states are read in aligned pairs: the last pair may reach one word beyond V)
-        HIP_CHECK(hipMalloc(&w.resv[0], V * 8));
-        HIP_CHECK(hipMalloc(&w.resv[1], V * 8));
+        hu::device_malloc(&w.state, (V + 2) * 8);  // (states are read in aligned pairs: the last pair may reach one word beyond V)
+        hu::device_malloc(&w.resv[0], V * 8);
+        hu::device_malloc(&w.resv[1], V * 8);
         w.cap_v = V;
         w.tag_base = 0xFFFFFFFFu;  // forces the clear below
     }
@@ -1934,22 +1934,22 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.src_mirror)); HIP_CHECK(hipFree(w.claims));
             HIP_CHECK(hipFree(w.pending[0])); HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.final_off));
         }
-        HIP_CHECK(hipMalloc(&w.touch, S * sizeof(Touch)));
-        HIP_CHECK(hipMalloc(&w.src_mirror, S * 4));
-        HIP_CHECK(hipMalloc(&w.claims, S * 8));
-        HIP_CHECK(hipMalloc(&w.pending[0], S * 4));
-        HIP_CHECK(hipMalloc(&w.pending[1], S * 4));
-        HIP_CHECK(hipMalloc(&w.final_off, S * 8));
+        hu::device_malloc(&w.touch, S * sizeof(Touch));
+        hu::device_malloc(&w.src_mirror, S * 4);
+        hu::device_malloc(&w.claims, S * 8);
+        hu::device_malloc(&w.pending[0], S * 4);
+        hu::device_malloc(&w.pending[1], S * 4);
+        hu::device_malloc(&w.final_off, S * 8);
         w.cap_s = S;
     }
     const uint64_t spill_need = std::max<uint64_t>(d->total_demand, 1);  // a source emits at most its demand (classification)
     if (spill_need > w.cap_spill) {
         if (w.spill) HIP_CHECK(hipFree(w.spill));
-        HIP_CHECK(hipMalloc(&w.spill, spill_need * 4));
+        hu::device_malloc(&w.spill, spill_need * 4);
         w.cap_spill = spill_need;
     }
     if (!w.ctl) {
-        HIP_CHECK(hipMalloc(&w.ctl, RC_COUNT * 8));
+        hu::device_malloc(&w.ctl, RC_COUNT * 8);
         HIP_CHECK(hipHostMalloc(&w.h_ctl, RC_COUNT * 8));
     }
     // reservation tags decrease with every round of every call, so the two reservation arrays are never cleared; only when
@@ -1969,7 +1969,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         const uint64_t nb = (S + SCAN_BLOCK - 1) / SCAN_BLOCK;
         if (nb > w.cap_blocks) {
             if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
-            HIP_CHECK(hipMalloc(&w.block_sums, nb * 8));
+            hu::device_malloc(&w.block_sums, nb * 8);
             w.cap_blocks = nb;
         }
         unsigned long long *total = &d->d_counters[C_OVF_LIST];
@@ -1980,7 +1980,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         n_dense = d->h_counters[C_OVF_LIST];
         if (n_dense > w.cap_dense) {
             if (w.dense) HIP_CHECK(hipFree(w.dense));
-            HIP_CHECK(hipMalloc(&w.dense, n_dense * sizeof(Dense)));
+            hu::device_malloc(&w.dense, n_dense * sizeof(Dense));
             w.cap_dense = n_dense;
         }
         hipLaunchKernelGGL(replay_dense_fill_kernel, dim3((unsigned)nb), dim3(DENSE_BLOCK), 0, st, d->d_out_nodes, d_cand_count,
@@ -2092,7 +2092,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (n_pairs) {
         if (n_pairs > w.cap_out) {
             if (w.out) HIP_CHECK(hipFree(w.out));
-            HIP_CHECK(hipMalloc(&w.out, n_pairs * sizeof(mtg_pair)));
+            hu::device_malloc(&w.out, n_pairs * sizeof(mtg_pair));
             w.cap_out = n_pairs;
         }
         hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
@@ -2169,11 +2169,11 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     }
     unsigned long long *d_start = nullptr, *d_pool = nullptr;
     uint32_t *d_count = nullptr;
-    HIP_CHECK(hipMalloc(&d_start, S * 8));
-    HIP_CHECK(hipMalloc(&d_count, S * 4));
+    hu::device_malloc(&d_start, S * 8);
+    hu::device_malloc(&d_count, S * 4);
     uint64_t cap = std::max<uint64_t>(S * 2 + std::min<uint64_t>((S + 63) / 64, (uint64_t)d->n_cu * 8) * ENUM_POOL_CHUNK, 1024);  // keys + per-wave chunk slack
     for (;;) {
-        HIP_CHECK(hipMalloc(&d_pool, cap * 8));
+        hu::device_malloc(&d_pool, cap * 8);
         uint64_t needed = 0;
         if (run_levels(d, st, 0, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr) == 0) break;
         HIP_CHECK(hipFree(d_pool));
@@ -2226,9 +2226,9 @@ std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int part
     }
     uint32_t *d_work = nullptr;
     unsigned long long *d_prefix = nullptr, *d_cut = nullptr;
-    HIP_CHECK(hipMalloc(&d_work, S * 4));
-    HIP_CHECK(hipMalloc(&d_prefix, S * 8));
-    HIP_CHECK(hipMalloc(&d_cut, (size_t)parts * 8));
+    hu::device_malloc(&d_work, S * 4);
+    hu::device_malloc(&d_prefix, S * 8);
+    hu::device_malloc(&d_cut, (size_t)parts * 8);
     HIP_CHECK(hipMemsetAsync(d_cut, 0, (size_t)parts * 8, st));
     hipLaunchKernelGGL(source_work_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, d->d_out_nodes, d->d_odeg, S, d_work);
     scan_u32(d, st, d->replay, d_work, S, d_prefix, &d->d_counters[C_OVF_LIST]);
@@ -2266,11 +2266,11 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
             HIP_CHECK(hipSetDevice(d->dev));
             const uint64_t lo = cuts[(size_t)i], hi = cuts[(size_t)i + 1], n = hi - lo;
             if (!n) return;
-            HIP_CHECK(hipMalloc(&p.start, n * 8));
-            HIP_CHECK(hipMalloc(&p.count, n * 4));
+            hu::device_malloc(&p.start, n * 8);
+            hu::device_malloc(&p.count, n * 4);
             uint64_t cap = std::max<uint64_t>(n * 2 + std::min<uint64_t>((n + 63) / 64, (uint64_t)d->n_cu * 8) * ENUM_POOL_CHUNK, 1024);
             for (;;) {
-                HIP_CHECK(hipMalloc(&p.pool, cap * 8));
+                hu::device_malloc(&p.pool, cap * 8);
                 uint64_t needed = 0;
                 if (run_levels(d, nullptr, 0, lo, hi, p.pool, cap, p.start, p.count, &needed, nullptr) == 0) { p.used = needed; break; }
                 HIP_CHECK(hipFree(p.pool));
@@ -2287,9 +2287,9 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
     for (const Part &p : parts) pool_total += p.used;
     unsigned long long *g_start = nullptr, *g_pool = nullptr;
     uint32_t *g_count = nullptr;
-    HIP_CHECK(hipMalloc(&g_start, S * 8));
-    HIP_CHECK(hipMalloc(&g_count, S * 4));
-    HIP_CHECK(hipMalloc(&g_pool, std::max<uint64_t>(pool_total, 1) * 8));
+    hu::device_malloc(&g_start, S * 8);
+    hu::device_malloc(&g_count, S * 4);
+    hu::device_malloc(&g_pool, std::max<uint64_t>(pool_total, 1) * 8);
     uint64_t off = 0;
     for (int i = 0; i < n_dev; i++) {
         const Part &p = parts[(size_t)i];
@@ -2331,11 +2331,11 @@ void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &c
     if (!S) return;
     unsigned long long *d_start = nullptr, *d_pool = nullptr;
     uint32_t *d_count = nullptr;
-    HIP_CHECK(hipMalloc(&d_start, S * 8));
-    HIP_CHECK(hipMalloc(&d_count, S * 4));
+    hu::device_malloc(&d_start, S * 8);
+    hu::device_malloc(&d_count, S * 4);
     uint64_t cap = std::max<uint64_t>(S * 4, 1024);
     for (;;) {
-        HIP_CHECK(hipMalloc(&d_pool, cap * 8));
+        hu::device_malloc(&d_pool, cap * 8);
         uint64_t needed = 0;
         const int rc = run_levels(d, st, 0, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr);
         if (rc == 0) {

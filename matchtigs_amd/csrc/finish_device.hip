@@ -458,8 +458,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         const bool keep = !g.device_cache;
         uint32_t *up_from = nullptr, *up_mirror = nullptr;
         if (keep) {
-            HIP_CHECK(hipMalloc(&up_from, std::max<uint64_t>(E0, 1) * 4));
-            HIP_CHECK(hipMalloc(&up_mirror, std::max<uint64_t>(V, 1) * 4));
+            hu::device_malloc(&up_from, std::max<uint64_t>(E0, 1) * 4);
+            hu::device_malloc(&up_mirror, std::max<uint64_t>(V, 1) * 4);
         } else {
             up_from = b_from0_tmp.alloc<uint32_t>(st, E0);
             up_mirror = b_mirror_tmp.alloc<uint32_t>(st, V);

@@ -122,7 +122,7 @@ struct DeviceBlockCache {
     std::mutex m;
     std::multimap<size_t, void *> free_blocks;
     size_t held = 0;
-    static constexpr size_t GRAIN = 1u << 20;
+    static constexpr size_t GRAIN = 1u << 20, HOLD_LIMIT = 192ull << 30;
     static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 1) + GRAIN - 1) / GRAIN * GRAIN; }
     void *take(size_t bytes) {
         const size_t want = rounded(bytes);
@@ -145,9 +145,15 @@ struct DeviceBlockCache {
         return p;
     }
     void give(void *p, size_t bytes) {
-        std::lock_guard<std::mutex> lock(m);
-        free_blocks.emplace(rounded(bytes), p);
-        held += rounded(bytes);
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (held + rounded(bytes) <= HOLD_LIMIT) {
+                free_blocks.emplace(rounded(bytes), p);
+                held += rounded(bytes);
+                return;
+            }
+        }
+        (void)hipFree(p);  // (more than HOLD_LIMIT kept already: calls of that size are trimmed at their end anyway)
     }
     void trim() {
         std::multimap<size_t, void *> drop;
@@ -163,6 +169,18 @@ inline DeviceBlockCache &device_block_cache(int device_id) {
     static DeviceBlockCache *caches = new DeviceBlockCache[64];  // (never destroyed: buffers may be released during static destruction)
     if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
     return caches[device_id];
+}
+
+// hipMalloc for the engine's long-lived device arrays: when the device is full, the blocks the finish keeps for its next call are
+// given up before the allocation is tried again.
+template <typename T>
+inline void device_malloc(T **p, size_t bytes) {
+    if (hipMalloc((void **)p, bytes) == hipSuccess) return;
+    (void)hipGetLastError();
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    device_block_cache(dev).trim();
+    HIP_CHECK(hipMalloc((void **)p, bytes));
 }
 
 struct Buf {

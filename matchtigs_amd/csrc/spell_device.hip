@@ -18,6 +18,7 @@
 #include <string>
 
 #include "device.hpp"
+#include "hip_util.hpp"
 
 namespace mtg {
 
@@ -248,9 +249,9 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     uint8_t *d_fwd = nullptr;
     unsigned long long *d_seq_off = nullptr, *d_limits = nullptr, *d_start = nullptr, *d_bsum = nullptr, *d_tot = nullptr;
     const uint64_t n_words = (n_bases + 15) / 16;
-    HIP_CHECK(hipMalloc(&d_ascii, std::max<uint64_t>(n_bases, 1)));
-    HIP_CHECK(hipMalloc(&d_packed, std::max<uint64_t>(n_words, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_tot, 16));
+    hu::device_malloc(&d_ascii, std::max<uint64_t>(n_bases, 1));
+    hu::device_malloc(&d_packed, std::max<uint64_t>(n_words, 1) * 4);
+    hu::device_malloc(&d_tot, 16);
     HIP_CHECK(hipMemcpyAsync(d_ascii, seqs, n_bases, hipMemcpyHostToDevice, st));
     const unsigned long long none = ~0ull;
     HIP_CHECK(hipMemcpyAsync(d_tot + 1, &none, 8, hipMemcpyHostToDevice, st));
@@ -260,18 +261,18 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     PodVec<uint32_t> h_unitig(n_orig), h_dw(std::max<uint64_t>(n_dummy, 1));
     for (uint64_t e = 0; e < n_orig; e++) h_unitig[e] = (uint32_t)g.e_unitig[e];
     for (uint64_t e = 0; e < n_dummy; e++) h_dw[e] = (uint32_t)std::min<uint64_t>(g.e_weight[n_orig + e], 0xFFFFFFFFull);
-    HIP_CHECK(hipMalloc(&d_unitig, std::max<uint64_t>(n_orig, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_fwd, std::max<uint64_t>(n_orig, 1)));
-    HIP_CHECK(hipMalloc(&d_dw, std::max<uint64_t>(n_dummy, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_seq_off, (U + 1) * 8));
-    HIP_CHECK(hipMalloc(&d_edges, std::max<uint64_t>(P, 1) * 4));
-    HIP_CHECK(hipMalloc(&d_limits, std::max<uint64_t>(n_walks, 1) * 8));
-    HIP_CHECK(hipMalloc(&d_ws, (P + 1) * 4));
-    HIP_CHECK(hipMalloc(&d_lo, (P + 1) * 4));
-    HIP_CHECK(hipMalloc(&d_hi, (P + 1) * 4));
-    HIP_CHECK(hipMalloc(&d_start, (P + 2) * 8));
+    hu::device_malloc(&d_unitig, std::max<uint64_t>(n_orig, 1) * 4);
+    hu::device_malloc(&d_fwd, std::max<uint64_t>(n_orig, 1));
+    hu::device_malloc(&d_dw, std::max<uint64_t>(n_dummy, 1) * 4);
+    hu::device_malloc(&d_seq_off, (U + 1) * 8);
+    hu::device_malloc(&d_edges, std::max<uint64_t>(P, 1) * 4);
+    hu::device_malloc(&d_limits, std::max<uint64_t>(n_walks, 1) * 8);
+    hu::device_malloc(&d_ws, (P + 1) * 4);
+    hu::device_malloc(&d_lo, (P + 1) * 4);
+    hu::device_malloc(&d_hi, (P + 1) * 4);
+    hu::device_malloc(&d_start, (P + 2) * 8);
     const uint64_t nb = (P + 1 + 1023) / 1024;
-    HIP_CHECK(hipMalloc(&d_bsum, nb * 8));
+    hu::device_malloc(&d_bsum, nb * 8);
     if (n_orig) {
         HIP_CHECK(hipMemcpyAsync(d_unitig, h_unitig.data(), n_orig * 4, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(d_fwd, g.e_fwd.data(), n_orig, hipMemcpyHostToDevice, st));
@@ -301,7 +302,7 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     d_ascii = nullptr;
     double ms = 0.0;
     if (n_walks) {
-        HIP_CHECK(hipMalloc(&d_out, total));
+        hu::device_malloc(&d_out, total);
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
