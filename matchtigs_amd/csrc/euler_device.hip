@@ -111,28 +111,35 @@ __global__ __launch_bounds__(EB) void sort_buckets_kernel(uint64_t n_nodes, cons
 }
 
 // ---- step 2: mirror-symmetric pairing --------------------------------------------------------------------------
-__global__ __launch_bounds__(EB) void succ_kernel(const uint32_t *from, const uint32_t *mirror, uint64_t n_darts, const uint32_t *row,
-                                                 const uint32_t *adj, const uint32_t *pos, uint32_t *succ, uint32_t *parent,
-                                                 uint32_t *error) {
+// Dart e = (u -> v) is followed by the out-dart of v in the slot that e ^ 1 = (mirror v -> mirror u) has in the bucket of mirror v
+// (for a self-mirror node: the neighbouring slot), which makes the successor function commute with mirroring.
+// Evaluated from the nodes' side: the j-th in-dart of v is the mirror of the j-th out-dart of mirror(v) (both buckets in
+// ascending dart id), so a node reads its own bucket and its mirror's and writes the successors -- no slot array, no per-dart
+// lookups of from / mirror / row (buckets + pairing: 32 -> see DESIGN 3.6).
+__global__ __launch_bounds__(EB) void succ_node_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
+                                                      uint32_t *succ, uint32_t *error) {
     const uint64_t i = gid();
-    if (i >= n_darts) return;
-    const uint32_t e = (uint32_t)i;
-    const uint32_t vm = from[e ^ 1];  // e = (u -> v)  <=>  e^1 = (mirror v -> mirror u)
-    const uint32_t v = mirror[vm];
-    const uint32_t dv = row[v + 1] - row[v];
-    uint32_t j = pos[e ^ 1];
+    if (i >= n_nodes) return;
+    const uint32_t v = (uint32_t)i, vm = mirror[v];
+    const uint32_t lo = row[v], dv = row[v + 1] - lo;
     if (v == vm) {
         if (dv & 1) {
             atomicOr(error, 1u);
             return;
         }
-        j ^= 1;
-    } else if (dv != row[vm + 1] - row[vm]) {
+        for (uint32_t j = 0; j < dv; j++) succ[adj[lo + j] ^ 1u] = adj[lo + (j ^ 1u)];
+        return;
+    }
+    const uint32_t lom = row[vm];
+    if (dv != row[vm + 1] - lom) {
         atomicOr(error, 1u);  // not Eulerian
         return;
     }
-    succ[e] = adj[row[v] + j];
-    parent[e] = e;
+    for (uint32_t j = 0; j < dv; j++) succ[adj[lom + j] ^ 1u] = adj[lo + j];
+}
+__global__ __launch_bounds__(EB) void iota_kernel(uint32_t *a, uint64_t n) {
+    const uint64_t i = gid();
+    if (i < n) a[i] = (uint32_t)i;
 }
 
 // ---- step 3: trail labels ----------------------------------------------------------------------------------------
@@ -356,7 +363,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small;
     uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1);
     uint32_t *d_adj = b_adj.alloc<uint32_t>(st, E);
-    uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, E);  // bucket slots until the pairing is done, then the second union-find
+    uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, E);  // the second union-find
     uint32_t *d_succ = b_succ.alloc<uint32_t>(st, E);
     uint32_t *d_comp = b_comp.alloc<uint32_t>(st, E);  // trail union-find -> trail labels -> component labels, in place
     uint32_t *d_flag = b_flag.alloc<uint32_t>(st, E);
@@ -381,10 +388,11 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("allocations");
 
     // 1. buckets
-    device_build_buckets(st, d_from, E, V, d_row, d_adj, d_pos2);
+    device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr);
     lap("buckets");
     // 2. pairing, 3. trail labels
-    succ_kernel<<<grid_for(E), EB, 0, st>>>(d_from, d_mirror, E, d_row, d_adj, d_pos2, d_succ, d_comp, d_error);
+    succ_node_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_succ, d_error);
+    iota_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, E);
     uint32_t h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
