@@ -78,17 +78,17 @@ __device__ __forceinline__ bool uf_union(uint32_t *parent, uint32_t a, uint32_t 
 
 // ---- step 1: bucket darts by from-node ------------------------------------------------------------------------
 // (dart ids are 32-bit and may use all 32 bits: element indices are computed in 64 bits, hu::gid())
-__global__ __launch_bounds__(EB) void degree_kernel(const uint32_t *from, uint64_t n_darts, uint32_t *deg) {
+// (the count and the dart's place in its bucket come from the same atomic: `rank` is read back, coalesced, by the fill -- one random
+// atomic per dart instead of two)
+__global__ __launch_bounds__(EB) void degree_rank_kernel(const uint32_t *from, uint64_t n_darts, uint32_t *deg, uint32_t *rank) {
     const uint64_t e = gid();
-    if (e < n_darts) atomicAdd(&deg[from[e]], 1u);
+    if (e < n_darts) rank[e] = atomicAdd(&deg[from[e]], 1u);
 }
-__global__ __launch_bounds__(EB) void fill_kernel(const uint32_t *from, uint64_t n_darts, const uint32_t *row, uint32_t *cursor,
+__global__ __launch_bounds__(EB) void fill_kernel(const uint32_t *from, uint64_t n_darts, const uint32_t *row, const uint32_t *rank,
                                                  uint32_t *adj) {
     const uint64_t e = gid();
     if (e >= n_darts) return;
-    const uint32_t u = from[e];
-    const uint32_t p = atomicAdd(&cursor[u], 1u);
-    adj[row[u] + p] = (uint32_t)e;
+    adj[row[from[e]] + rank[e]] = (uint32_t)e;
 }
 
 // buckets are filled in atomic order; sorting each node's few out-darts by id makes slots (and with them the whole
@@ -336,16 +336,17 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
 }  // namespace
 
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
-void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos) {
-    Buf b_cursor, b_bsum, b_tot;
-    uint32_t *d_cursor = b_cursor.alloc<uint32_t>(st, V);
+// (d_scratch: E words of scratch, or null)
+void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos,
+                          uint32_t *d_scratch) {
+    Buf b_rank, b_bsum, b_tot;
+    uint32_t *d_rank = d_scratch ? d_scratch : b_rank.alloc<uint32_t>(st, E);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(V + 1) + 1);
     uint32_t *d_tot = b_tot.alloc<uint32_t>(st, 1);
     HIP_CHECK(hipMemsetAsync(d_row, 0, (V + 1) * 4, st));
-    HIP_CHECK(hipMemsetAsync(d_cursor, 0, V * 4, st));
-    degree_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row);
+    degree_rank_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_rank);
     scan_u32<uint32_t>(st, d_row, V + 1, d_row, d_bsum, d_tot);
-    fill_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_cursor, d_adj);
+    fill_kernel<<<grid_for(E), EB, 0, st>>>(d_from, E, d_row, d_rank, d_adj);
     sort_buckets_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_pos);
     HIP_CHECK(hipGetLastError());
 }
@@ -388,7 +389,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("allocations");
 
     // 1. buckets
-    device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr);
+    device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr, d_pos2);  // (d_pos2 is free until the trail labels)
     lap("buckets");
     // 2. pairing, 3. trail labels
     succ_node_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_succ, d_error);

@@ -13,7 +13,8 @@ namespace mtg {
 
 // euler_device.hip
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id (row: u32[V + 1]); pos[e] = slot of e in its bucket (may be null)
-void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos);
+void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos,
+                          uint32_t *d_scratch = nullptr);
 // Euler bicycles of the Eulerian bigraph given by from[E] (mirror of dart e is e ^ 1) and mirror[V], all on the device:
 // closed walks back to back in b_out (u32[E / 2]), their lengths / start offsets in b_clen / b_cbase (u32[*n_cycles]).
 void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E, uint64_t V, hu::Buf &b_out,
