@@ -227,6 +227,8 @@ inline void edge_cache_free(DeviceEdgeCache *c) {
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_from);
     (void)hipFree(c->d_mirror);
+    if (c->d_row0) (void)hipFree(c->d_row0);
+    if (c->d_adj0) (void)hipFree(c->d_adj0);
     (void)hipSetDevice(cur);
 }
 // the cache of g on `device`, or null (another device, or a graph whose sizes changed: never the case after build)
@@ -258,8 +260,20 @@ inline void edge_cache_put(const HostGraph &g, int device, uint32_t *d_from, uin
     g.device_cache.reset(c);
 }
 
-// Hands the pool's cached memory back to the driver when a call worked on more than `threshold` bytes (the next stage's plain
-// hipMalloc cannot use memory the stream-ordered pool is sitting on; small calls keep their arrays mapped for the next one).
+// Attaches the buckets of the original darts to the graph's cache on `device` (takes ownership; frees them if there is no such
+// cache or it has buckets already).
+inline void edge_cache_set_buckets(const HostGraph &g, int device, uint32_t *d_row0, uint32_t *d_adj0) {
+    std::lock_guard<std::mutex> l(edge_cache_mutex());
+    DeviceEdgeCache *c = g.device_cache.get();
+    if (c && c->device == device && !c->d_row0) {
+        c->d_row0 = d_row0;
+        c->d_adj0 = d_adj0;
+        return;
+    }
+    (void)hipFree(d_row0);
+    (void)hipFree(d_adj0);
+}
+
 // Device -> pageable host memory through a pinned ring: while slice i + 1 crosses PCIe at full rate, host threads copy slice i out
 // of the ring (a plain hipMemcpy into pageable memory is staged by the runtime on one thread: 15-20 GB/s here). Synchronises the
 // stream. Small copies take the plain path.
@@ -315,6 +329,8 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
     HIP_CHECK(hipStreamSynchronize(st));
 }
 
+// Gives the finish's kept device blocks back to the driver when a call worked on more than `threshold` bytes (small calls keep
+// their arrays for the next one).
 inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 32ull << 30) {
     if (bytes_used < threshold) return;
     device_block_cache(device_id).trim();

@@ -141,6 +141,9 @@ struct DeviceEdgeCache {
     int device = -1;
     uint64_t n_edges = 0, n_nodes = 0;
     void *d_from = nullptr, *d_mirror = nullptr;
+    // the original darts bucketed by from-node (row0[V + 1], adj0[n_edges] in ascending dart id): a static function of the graph,
+    // built by the first device finish on it; the buckets of an Eulerised dart set are this plus the dummy darts' (whose ids are all larger)
+    void *d_row0 = nullptr, *d_adj0 = nullptr;
     void (*free_fn)(DeviceEdgeCache *) = nullptr;
 };
 struct DeviceEdgeCacheDeleter {
