@@ -114,7 +114,7 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 // Stream-ordered allocation from the device's default memory pool (which the callers tell to keep freed memory: the work
 // arrays of a call cost milliseconds to map afresh, and a driver that finishes graph after graph reuses them).
 // Device work arrays of the finishing stages. Every call asks for the same sizes again, so released blocks are kept per device and
-// handed back by size (first fit within a quarter above the request); what is not there comes from hipMalloc. (The runtime's
+// handed back by size (the smallest that fits, at most twice the request); what is not there comes from hipMalloc. (The runtime's
 // stream-ordered pool -- hipMallocAsync with the release threshold at its maximum -- was used until the end of round 3: on some
 // boxes the twelve allocations at the head of the Euler decomposition then took 0.5 to 4.7 s on some steps, nothing on the others.)
 // All users run on the one finish stream of their device, so a block released earlier on that stream is free when it is used again.
@@ -124,18 +124,23 @@ struct DeviceBlockCache {
     size_t held = 0;
     static constexpr size_t GRAIN = 1u << 20, HOLD_LIMIT = 192ull << 30;
     static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 1) + GRAIN - 1) / GRAIN * GRAIN; }
-    void *take(size_t bytes) {
+    // the smallest kept block that holds `bytes` and is at most twice as large (a stage's arrays fit the blocks an earlier stage of
+    // the same call gave back: the first call on a large graph allocates less from the driver, where a gigabyte costs ~50 ms on some
+    // boxes); *block_bytes = the block's real size, to be handed to give()
+    void *take(size_t bytes, size_t *block_bytes) {
         const size_t want = rounded(bytes);
         {
             std::lock_guard<std::mutex> lock(m);
             auto it = free_blocks.lower_bound(want);
-            if (it != free_blocks.end() && it->first <= want + want / 4) {
+            if (it != free_blocks.end() && it->first <= 2 * want) {
                 void *p = it->second;
+                *block_bytes = it->first;
                 held -= it->first;
                 free_blocks.erase(it);
                 return p;
             }
         }
+        *block_bytes = want;
         void *p = nullptr;
         if (hipMalloc(&p, want) != hipSuccess) {  // out of memory with blocks of other sizes held back: give them up and try again
             (void)hipGetLastError();
@@ -144,12 +149,12 @@ struct DeviceBlockCache {
         }
         return p;
     }
-    void give(void *p, size_t bytes) {
+    void give(void *p, size_t block_bytes) {
         {
             std::lock_guard<std::mutex> lock(m);
-            if (held + rounded(bytes) <= HOLD_LIMIT) {
-                free_blocks.emplace(rounded(bytes), p);
-                held += rounded(bytes);
+            if (held + block_bytes <= HOLD_LIMIT) {
+                free_blocks.emplace(block_bytes, p);
+                held += block_bytes;
                 return;
             }
         }
@@ -185,14 +190,14 @@ inline void device_malloc(T **p, size_t bytes) {
 
 struct Buf {
     void *p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, block_bytes = 0;
     int device = 0;
     Buf() = default;
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
     ~Buf() { release(); }
     void release() {
-        if (p) device_block_cache(device).give(p, bytes);
+        if (p) device_block_cache(device).give(p, block_bytes);
         p = nullptr;
     }
     template <typename T>
@@ -200,7 +205,7 @@ struct Buf {
         release();
         HIP_CHECK(hipGetDevice(&device));
         bytes = (n ? n : 1) * sizeof(T);
-        p = device_block_cache(device).take(bytes);
+        p = device_block_cache(device).take(bytes, &block_bytes);
         return (T *)p;
     }
     template <typename T>
