@@ -183,11 +183,24 @@ int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_
 const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+/* Goal-directed pruning (k <= 255): with the device graph the engine computes lb(v) = distance from v to the nearest
+ * initial in-node and keeps it beside every edge weight. A search then skips a successor v reached at distance d when d + lb(v)
+ * exceeds k-1 -- no in-node behind v can be within the bound, so the candidate lists are unchanged (the reference truncates its
+ * searches as well, by target_amount, greedytigs/mod.rs:323-335) -- and sources that cannot reach any in-node within the bound
+ * are not searched at all. mtg_sssp_count keeps counting FULL balls (the unit of work of SURVEY 8d, equal to a full-ball
+ * Dijkstra's counters); mtg_sssp_count_visited counts what the pruned search visits: stats->sources = sources searched,
+ * settled_nodes / relaxed_edges = distinct (source, node) pairs it settles and their out-edges, emitted = the same candidates.
+ * Aborts when the device graph / plan does not prune (mtg_sssp_prunes() == 0). */
+void mtg_sssp_count_visited(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+int mtg_sssp_prunes(const mtg_device *d);
+/* Sources the enumeration level of the last mtg_sssp_candidates call searched (0 when it does not prune). */
+uint64_t mtg_last_sssp_searched_sources(const mtg_device *d);
 /* Which SSSP level plan runs: 0 = default (table-free path enumeration per lane + sorting post-pass, then the cooperative
  * cascade for the sources it hands on; the level gathers its 64-byte node blocks per lane, or four lanes per block once the
  * blocks exceed 3 GB), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the counting kernels
  * use), 2 / 3 = plan 0 with the four-lanes-per-block / per-lane form of the gathers regardless of the graph's size (same
- * results; lets small graphs exercise both forms). Returns the plan in force. */
+ * results; lets small graphs exercise both forms); 4 / 6 / 7 = plans 0 / 2 / 3 WITHOUT the goal-directed pruning (full balls, every
+ * source searched; same results: A/B runs and tests). Returns the plan in force. */
 int mtg_set_sssp_plan(mtg_device *d, int plan);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified

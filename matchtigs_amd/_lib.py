@@ -151,6 +151,9 @@ def load():
         "mtg_last_sssp_levels": (C.c_int, [vp, P(C.c_double), P(u64), C.c_int]),
         "mtg_last_sssp_level_name": (C.c_char_p, [vp, C.c_int]),
         "mtg_sssp_count": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
+        "mtg_sssp_count_visited": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
+        "mtg_sssp_prunes": (C.c_int, [vp]),
+        "mtg_last_sssp_searched_sources": (u64, [vp]),
         "mtg_set_sssp_plan": (C.c_int, [vp, C.c_int]),
         "mtg_replay_claims_device": (u64, [vp, vp, u64, vp, vp, vp, P(P(MtgPair))]),
         "mtg_last_replay_rounds": (C.c_int, [vp]),

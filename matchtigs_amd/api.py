@@ -462,9 +462,21 @@ class DeviceGraph:
         self._L.mtg_sssp_count(self._d, stream, src_begin, src_end, C.byref(st))
         return st.as_dict()
 
+    def sssp_count_visited(self, src_begin: int, src_end: int, stream: int = 0) -> dict:
+        """Units of the search the default plan really runs (goal-directed pruning; mtg_engine.h): sources = sources searched."""
+        st = _lib.MtgSsspStats()
+        self._L.mtg_sssp_count_visited(self._d, stream, src_begin, src_end, C.byref(st))
+        return st.as_dict()
+
+    def prunes(self) -> bool:
+        return bool(self._L.mtg_sssp_prunes(self._d))
+
+    def last_searched_sources(self) -> int:
+        return int(self._L.mtg_last_sssp_searched_sources(self._d))
+
     def set_plan(self, plan: int) -> int:
         """0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only, 2 / 3 = plan 0 with
-        quad-cooperative / per-lane block gathers regardless of the graph size (mtg_engine.h)."""
+        quad-cooperative / per-lane block gathers regardless of the graph size, + 4 = without the goal-directed pruning (mtg_engine.h)."""
         return int(self._L.mtg_set_sssp_plan(self._d, plan))
 
 

@@ -66,12 +66,15 @@ enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
 // weight slot holds 0xFFFF (never within a bound < 0x8000), and a grandchild slot holds the weight of the whole two-edge path.
 struct alignas(64) NodeBlock {
     uint32_t nbr[4];   // words 0-3: inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
-    uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path); unused slots 0xFFFF
+    uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path); unused slots 0xFFFF.
+                       //            k <= 255 ("8:8 format"): low byte = that weight, high byte = min(255, weight + lb(child)), lb(v) = the
+                       //            distance from v to the nearest initial in-node (0 for an in-node): the goal-directed lower bound
     uint8_t deg;       // word 6: inline degree 0..4 (0 if F_EXT)
     uint8_t flags;     //         F_TARGET (initial in-node, greedytigs/mod.rs:231-240) | F_EXT
     uint16_t cmeta;    //         bit j (0-3): child j is an in-node; bit 4+j: child j is NOT embedded below (it needs its own gather)
     uint32_t gnbr[6];  // words 7-12: out-neighbours of the embedded children, children in order, each child's edges in order
     uint16_t gw[6];    // words 13-15: weight of the path node -> child -> that neighbour, saturated at 0xFFFF; unused slots 0xFFFF
+                       //            (8:8 format: low byte = path weight, high byte = path weight + lb(that neighbour), both saturated at 255)
 };
 static_assert(sizeof(NodeBlock) == 64, "NodeBlock must be 64 bytes");
 constexpr int GSLOTS = 6;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uin
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < n ? counts[i] : 0;
-        dem += i < n ? block_demand[i] : 0u;
+        dem += (block_demand && i < n) ? block_demand[i] : 0u;
         uint32_t incl = v;
         for (int d = 1; d < 64; d <<= 1) {
             uint32_t t = __shfl_up(incl, d);
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uin
     for (int dd = 32; dd >= 1; dd >>= 1) dem += __shfl_down(dem, dd);
     if (lane == 0 && dem) atomicAdd(&dem_sum, dem);
     __syncthreads();
-    if (threadIdx.x == 0) { *total_out = carry; *demand_out = dem_sum; }
+    if (threadIdx.x == 0) { *total_out = carry; if (demand_out) *demand_out = dem_sum; }
 }
 
 __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_t *cls, uint32_t n_nodes,
@@ -175,6 +178,60 @@ __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_
 __global__ void export_live_kernel(const uint8_t *cls, uint32_t n_nodes, uint8_t *live) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < n_nodes) live[n] = (cls[n] & F_TARGET) ? 1 : 0;
+}
+
+// The sources of [src_begin, src_begin + n) that can reach an in-node within the bound at all (reach[], build_lb_kernel), in
+// order: the only ones the enumeration level searches -- the others have an empty candidate list by construction. Two streaming
+// passes (count per workgroup, single-workgroup scan in between, ordered write); the second one also zeroes every candidate count
+// of the range (a search only stores the count of a non-empty list).
+constexpr int ACT_BLOCK = 256, ACT_PER = 8;  // sources per workgroup = 2048
+__global__ __launch_bounds__(ACT_BLOCK) void active_count_kernel(const uint32_t *sources, const uint8_t *reach, uint64_t src_begin, uint64_t n,
+                                                                 uint32_t *block_counts) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * (ACT_BLOCK * ACT_PER);
+    uint32_t c = 0;
+#pragma unroll
+    for (int p = 0; p < ACT_PER; p++) {
+        const uint64_t i = base + (uint64_t)p * ACT_BLOCK + threadIdx.x;
+        c += (i < n && reach[sources[src_begin + i]]) ? 1u : 0u;
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_down(c, dd);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
+}
+__global__ __launch_bounds__(ACT_BLOCK) void active_write_kernel(const uint32_t *sources, const uint8_t *reach, uint64_t src_begin, uint64_t n,
+                                                                 const uint32_t *block_offsets, uint32_t *act_index, uint32_t *act_node,
+                                                                 uint32_t *cand_count) {
+    __shared__ uint32_t wave_cnt[ACT_PER][ACT_BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * (ACT_BLOCK * ACT_PER);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t node[ACT_PER];
+    unsigned long long bal[ACT_PER];
+#pragma unroll
+    for (int p = 0; p < ACT_PER; p++) {
+        const uint64_t i = base + (uint64_t)p * ACT_BLOCK + threadIdx.x;
+        node[p] = i < n ? sources[src_begin + i] : 0u;
+        const bool act = i < n && reach[node[p]];
+        if (i < n) cand_count[i] = 0u;
+        bal[p] = __ballot(act);
+        if (lane == 0) wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]);
+    }
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int p = 0; p < ACT_PER; p++) {
+        for (int j = 0; j < ACT_BLOCK / 64; j++) {
+            if (j == wv && (bal[p] >> lane) & 1ull) {
+                const uint32_t pos = off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull));
+                act_index[pos] = (uint32_t)(src_begin + base + (uint64_t)p * ACT_BLOCK + threadIdx.x);
+                act_node[pos] = node[p];
+            }
+            off += wave_cnt[p][j];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -243,7 +300,85 @@ __global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const
     }
     blocks[n] = b;
 }
+// ------------------------------------------------------------------------------------------------
+// Goal-directed lower bounds (k <= 255): lb(v) = distance from v to the nearest initial in-node, 0 for an in-node, "infinite" beyond
+// k - 1. A function of the graph alone, like the in-node flags. A search at node u with distance d only ever needs the successor v
+// over an edge of weight w if d + w + lb(v) <= k - 1: every in-node behind v is at least that far from the source, so dropping v
+// can never drop a candidate -- the lists stay exactly Dijkstra's (greedytigs/mod.rs:324-335; the reference truncates its search
+// too, by target_amount). On the bench graph 7 of 10 sources have no in-node within the bound at all and the remaining searches
+// visit a third of their balls.
+// dist(v -> t) in G = dist(mirror t -> mirror v) in G (every edge has its mirror edge with the same weight), so ONE bounded
+// multi-source search from the mirrors of the in-nodes gives D(x) = lb(mirror x). Dial's buckets without queues: weights are >= 1,
+// so the nodes with D == r are final in round r; round r relaxes their out-edges with atomicMin. k - 1 rounds of a streaming pass
+// over D plus one 32-byte gather per reached node, once per device graph.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t LB_INF = 0xFFFFFFFFu;
+__global__ void lb_init_kernel(const uint32_t *odeg, const uint32_t *mirror, uint64_t n_nodes, uint32_t *D) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint32_t m = mirror[n];
+    const NodeClass c = classify_node(odeg[m], m == n ? 0u : odeg[n], m == n);  // class of mirror(n)
+    D[n] = (c.cls & F_TARGET) ? 0u : LB_INF;
+}
+// (first halves still hold plain 16-bit weights here: build_lb_kernel rewrites them afterwards)
+__global__ void lb_round_kernel(const NodeBlock *blocks, const uint32_t *ext_col, const uint16_t *ext_w, uint64_t n_nodes, uint32_t r, uint32_t K1,
+                                uint32_t *D) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes || D[n] != r) return;
+    const uint4 *rp = reinterpret_cast<const uint4 *>(blocks + n);
+    const uint4 lo = rp[0], hi = rp[1];
+    const uint32_t nb[4] = {lo.x, lo.y, lo.z, lo.w};
+    const uint32_t wt[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+    if ((hi.z >> 8) & F_EXT) {
+        const uint64_t b = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+        for (uint32_t e = 0; e < lo.z; e++) {
+            const uint32_t nd = r + ext_w[b + e];
+            if (nd <= K1) atomicMin(&D[ext_col[b + e]], nd);
+        }
+    } else {
+        const uint32_t dg = hi.z & 0xFFu;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t nd = r + wt[j];
+            if (j < dg && nd <= K1) atomicMin(&D[nb[j]], nd);
+        }
+    }
+}
+__global__ void lb_mirror_kernel(const uint32_t *mirror, const uint32_t *D, uint64_t n_nodes, uint8_t *lb8) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    const uint32_t v = D[mirror[n]];
+    lb8[n] = (uint8_t)(v < 255u ? v : 255u);
+}
+// first halves into the 8:8 format; reach[n] = 1 iff some successor of n can still lead to an in-node within the bound (a source
+// without one has an empty candidate list and is never searched)
+__global__ void build_lb_kernel(uint64_t n_nodes, NodeBlock *blocks, const uint32_t *ext_col, const uint16_t *ext_w, const uint8_t *lb8, uint32_t K1,
+                                uint8_t *reach) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    uint32_t *me = reinterpret_cast<uint32_t *>(blocks + n);
+    const uint32_t meta = me[6];
+    uint32_t best = 255u;
+    if ((meta >> 8) & F_EXT) {  // spilled adjacency keeps plain weights (no pruning behind such a node)
+        const uint64_t b = (uint64_t)me[0] | ((uint64_t)me[1] << 32);
+        for (uint32_t e = 0; e < me[2]; e++) best = min(best, (uint32_t)ext_w[b + e] + lb8[ext_col[b + e]]);
+    } else {
+        const uint32_t dg = meta & 0xFFu;
+        uint32_t slot[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+        for (uint32_t j = 0; j < dg; j++) {
+            const uint32_t w = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;  // <= k <= 255
+            const uint32_t wl = min(255u, w + lb8[me[j]]);
+            slot[j] = (wl << 8) | w;
+            best = min(best, wl);
+        }
+        me[4] = slot[0] | (slot[1] << 16);
+        me[5] = slot[2] | (slot[3] << 16);
+    }
+    reach[n] = best <= K1 ? 1 : 0;
+}
+
 // second half of every block: the children's in-node flags and, while they fit, the children's out-edges
+template <bool W8>
 __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
@@ -262,13 +397,19 @@ __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
         const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + me[j]);  // first half only: never written by this kernel
         const uint32_t cmt = ch[6];
         const uint32_t cflags = (cmt >> 8) & 0xFFu, cdeg = cmt & 0xFFu;
-        const uint32_t wj = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+        const uint32_t sj = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+        const uint32_t wj = W8 ? (sj & 0xFFu) : sj;
         if (cflags & F_TARGET) cmeta |= 1u << j;
         if (open && !(cflags & F_EXT) && used + cdeg <= (uint32_t)GSLOTS) {
             for (uint32_t t = 0; t < cdeg; t++) {
                 gn[used + t] = ch[t];
-                const uint32_t sum = wj + ((ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu);
-                gwt[used + t] = sum < 0xFFFFu ? sum : 0xFFFFu;
+                const uint32_t st = (ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu;
+                if constexpr (W8) {  // path weight | path weight + lb(grandchild), each saturated at 255 (> any bound of this format)
+                    gwt[used + t] = min(255u, wj + (st & 0xFFu)) | (min(255u, wj + (st >> 8)) << 8);
+                } else {
+                    const uint32_t sum = wj + st;
+                    gwt[used + t] = sum < 0xFFFFu ? sum : 0xFFFFu;
+                }
             }
             used += cdeg;
         } else {
@@ -309,6 +450,7 @@ enum Counter : int {
     C_DEMAND = 12,   // classification: sum of the positive multiplicities (bounds the number of pairs)
     C_FIX_CLASS0 = 13,  // enumeration level's post-pass: number of work-list entries per length class (13, 14, 15)
     C_FIX_CURSOR0 = 16, // ... and the cursors of its compaction (16, 17, 18)
+    C_ACTIVE = 19,      // sources of the launch's range that can reach an in-node within the bound (the only ones searched)
     C_COUNT = 24
 };
 
@@ -331,6 +473,10 @@ struct SsspArgs {
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
     uint32_t *fix_list;          // out (enumeration level): post-pass work list in chunks of ENUM_FIX_CHUNK slots (cursor: C_FIX): slot 0 = the
                                  // chunk's length class, then indices (relative to src_begin) of lists of that class, FIX_NONE = unused
+    uint32_t wmask;              // inline weight slots: 0xFF in the 8:8 format (k <= 255: weight | weight + lower bound << 8), else 0xFFFF
+    uint32_t prune;              // cooperative levels: 1 = skip a successor whose lower bound puts every in-node behind it beyond the bound
+    const uint32_t *act_index;   // enumeration level with pruning: the searched sources (absolute indices, ascending) ...
+    const uint32_t *act_node;    // ... and their nodes; their number is counters[C_ACTIVE] (it never travels to the host before the launch)
 };
 
 template <bool GLOBAL_WS>
@@ -494,9 +640,10 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 const uint32_t flags = (meta >> 8) & 0xFFu;
                 if (j == 0 && (flags & F_TARGET)) M::fand(&table[slot], ~1ull);  // node property: confirmed in-node
                 uint32_t pushed_ovf = 0;
-                auto relax = [&](uint32_t nb, uint32_t wt) {
+                auto relax = [&](uint32_t nb, uint32_t wt, uint32_t wl) {  // wl = weight + lower bound of nb (= wt without one)
                     const uint32_t nd = d + wt;
                     if (nd > a.K1) return;
+                    if (a.prune && d + wl > a.K1) return;  // no in-node behind nb within the bound (build_lb_kernel)
                     uint32_t nslot = 0;
                     const int r = tbl_relax<LOGH, GLOBAL_WS>(table, src, nb, nd, nslot);
                     if (r > 0) {
@@ -507,12 +654,13 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 };
                 if (!(flags & F_EXT)) {
                     const uint32_t deg = meta & 0xFFu;
-                    if (j < deg) relax(nb_j, (w_pair >> ((j & 1u) * 16)) & 0xFFFFu);
+                    const uint32_t wslot = (w_pair >> ((j & 1u) * 16)) & 0xFFFFu;
+                    if (j < deg) relax(nb_j, wslot & a.wmask, a.wmask == 0xFFu ? wslot >> 8 : wslot);
                     if constexpr (COUNT) { if (j == 0) atomicAdd(&s.bt_attempts, (unsigned long long)deg); }
                 } else if (j == 0) {  // spilled adjacency (more than 4 out-edges): one lane walks the list
                     const uint64_t eb = ((uint64_t)rw[1] << 32) | nb_j;  // j == 0: nb_j is word 0
                     const uint32_t deg = rw[2];
-                    for (uint32_t q = 0; q < deg; q++) relax(a.ext_col[eb + q], a.ext_w[eb + q]);
+                    for (uint32_t q = 0; q < deg; q++) relax(a.ext_col[eb + q], a.ext_w[eb + q], a.ext_w[eb + q]);
                     if constexpr (COUNT) atomicAdd(&s.bt_attempts, (unsigned long long)deg);
                 }
                 if (pushed_ovf) s.ovf = 1;
@@ -756,8 +904,11 @@ __device__ unsigned long long g_enum_prof[16384][3];  // development build: per 
 #ifndef MTG_ENUM_WAVES_PER_SIMD
 #define MTG_ENUM_WAVES_PER_SIMD 1  // (experiments: 5 makes the compiler keep the registers within a fifth wave per SIMD)
 #endif
-template <int WPB, int S1, int H1, int NB, bool QUAD>
+// W8: the blocks are in the 8:8 format (k <= 255). PRUNE (needs W8): successors are tested against distance + weight + lower bound,
+// and the sources come from the launch's list of sources that can reach an in-node at all (act_index / act_node, counters[C_ACTIVE]).
+template <int WPB, int S1, int H1, int NB, bool QUAD, bool W8, bool PRUNE>
 __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_kernel(SsspArgs a) {
+    static_assert(W8 || !PRUNE, "the lower bounds live in the 8:8 format");
     static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
     constexpr int BE = ENUM_BE, BS = ENUM_BS;
     static_assert(BS >= BE, "block stride below the block size");
@@ -787,22 +938,28 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     // ---- sources: chunks of 64 in a STATIC stride (chunk c belongs to wave c mod n_waves), held in registers: `ids` is the chunk
     // being handed out, `ahead` the wave's next one (loaded a whole chunk before it is needed). A lane that needs a source gets
     // the next unused one by a cross-lane permute: no atomic, no memory round trip, no LDS. ----
-    const unsigned long long n_items = a.n_items;
+    const unsigned long long n_items = PRUNE ? a.counters[C_ACTIVE] : a.n_items;
     const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB;
     unsigned long long next_chunk = (unsigned long long)blockIdx.x * WPB + wv;  // chunk that `ahead` will hold (wave-uniform)
     uint32_t cur_base = 0, cur_len = 0, cur_pos = 0, nxt_base = 0, nxt_len = 0;  // wave-uniform
     uint32_t ids = 0, ahead = 0;
+    uint32_t ids_item = 0, ahead_item = 0;  // PRUNE: the sources' indices relative to src_begin (without a list they are cur_base + position)
     // (measured and dropped: the last quarter of the chunks handed out by a global counter, requested two chunks ahead so that the
     // atomic is never waited for -- 7 % slower at 2^27 and no better lane utilisation at 2^24)
     auto prefetch_chunk = [&]() {
         const unsigned long long lo = next_chunk * 64;
         nxt_base = (uint32_t)lo;
         nxt_len = lo >= n_items ? 0u : (n_items - lo < 64 ? (uint32_t)(n_items - lo) : 64u);
-        ahead = (uint32_t)lane < nxt_len ? a.sources[a.src_begin + lo + lane] : 0u;
+        if constexpr (PRUNE) {
+            ahead = (uint32_t)lane < nxt_len ? a.act_node[lo + lane] : 0u;
+            ahead_item = (uint32_t)lane < nxt_len ? (uint32_t)(a.act_index[lo + lane] - a.src_begin) : 0u;
+        } else {
+            ahead = (uint32_t)lane < nxt_len ? a.sources[a.src_begin + lo + lane] : 0u;
+        }
         next_chunk += n_waves;
     };
     prefetch_chunk();
-    ids = ahead; cur_base = nxt_base; cur_len = nxt_len;
+    ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
     prefetch_chunk();
     bool exhausted = cur_len == 0;
     auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src) -> bool {
@@ -814,11 +971,16 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const int sel = (int)((idx & 63u) << 2);
         const uint32_t from_cur = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ids), from_nxt = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ahead);
         new_src = second ? from_nxt : from_cur;
-        new_item = second ? nxt_base + idx - 64u : cur_base + idx;
+        if constexpr (PRUNE) {
+            const uint32_t item_cur = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ids_item), item_nxt = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ahead_item);
+            new_item = second ? item_nxt : item_cur;
+        } else {
+            new_item = second ? nxt_base + idx - 64u : cur_base + idx;
+        }
         cur_pos += (uint32_t)__popcll(need);
         if (cur_pos >= 64u) {
             cur_pos -= 64u;
-            ids = ahead; cur_base = nxt_base; cur_len = nxt_len;
+            ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
             prefetch_chunk();  // in flight while the chunk that just became current is handed out
         }
         exhausted = cur_pos >= cur_len;
@@ -914,8 +1076,22 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const uint32_t meta = b1.z;
         const uint32_t nb[4] = {b0.x, b0.y, b0.z, b0.w};
         const uint32_t gn[GSLOTS] = {b1.w, b2.x, b2.y, b2.z, b2.w, b3.x};
-        const uint32_t dc[4] = {d + (b1.x & 0xFFFFu), d + (b1.x >> 16), d + (b1.y & 0xFFFFu), d + (b1.y >> 16)};
-        const uint32_t dg[GSLOTS] = {d + (b3.y & 0xFFFFu), d + (b3.y >> 16), d + (b3.z & 0xFFFFu), d + (b3.z >> 16), d + (b3.w & 0xFFFFu), d + (b3.w >> 16)};
+        // distance of a child / grandchild, and (PRUNE) the smallest distance of any in-node through it
+        uint32_t dc[4], dg[GSLOTS], lc[4], lg[GSLOTS];
+        {
+            const uint32_t cs[4] = {b1.x & 0xFFFFu, b1.x >> 16, b1.y & 0xFFFFu, b1.y >> 16};
+            const uint32_t gs[GSLOTS] = {b3.y & 0xFFFFu, b3.y >> 16, b3.z & 0xFFFFu, b3.z >> 16, b3.w & 0xFFFFu, b3.w >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                dc[j] = d + (W8 ? (cs[j] & 0xFFu) : cs[j]);
+                lc[j] = PRUNE ? d + (cs[j] >> 8) : dc[j];
+            }
+#pragma unroll
+            for (int t = 0; t < GSLOTS; t++) {
+                dg[t] = d + (W8 ? (gs[t] & 0xFFu) : gs[t]);
+                lg[t] = PRUNE ? d + (gs[t] >> 8) : dg[t];
+            }
+        }
         const bool is_ext = active && (meta & ((uint32_t)F_EXT << 8));
         bool hv[5], pv[4 + GSLOTS];
         hv[0] = active && !cur_chk && (meta & ((uint32_t)F_TARGET << 8)) && u != src_node;  // forbid_source_target, greedytigs/mod.rs:329
@@ -923,13 +1099,13 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             hv[1 + j] = dc[j] <= K1 && (meta & (0x10000u << j)) && nb[j] != src_node;
-            pv[j] = dc[j] <= K1 && (meta & (0x100000u << j));
+            pv[j] = lc[j] <= K1 && (meta & (0x100000u << j));
             nh_f += hv[1 + j] ? 1u : 0u;
             sp_f += pv[j] ? 1u : 0u;
         }
 #pragma unroll
         for (int t = 0; t < GSLOTS; t++) {
-            pv[4 + t] = dg[t] <= K1;
+            pv[4 + t] = lg[t] <= K1;
             sp_f += pv[4 + t] ? 1u : 0u;
         }
         if (__any(is_ext)) {  // spilled adjacency (more than 4 out-edges; never in a de Bruijn graph): count first
@@ -1267,7 +1443,13 @@ struct Device {
     uint64_t last_level_sources[8] = {0};
     std::string last_level_name[8];
     int plan = 0;  // 0 = table-free path enumeration per lane, then the cooperative cascade for the heaviest sources (the form of its gathers
-                   // chosen by the size of the graph); 1 = cascade only; 2 / 3 = plan 0 with quad-cooperative / per-lane gathers regardless of size
+                   // chosen by the size of the graph); 1 = cascade only; 2 / 3 = plan 0 with quad-cooperative / per-lane gathers regardless of size;
+                   // + 4 = without the goal-directed pruning (full balls, every source searched: A/B runs and tests)
+    bool w8 = false;                 // blocks in the 8:8 format with lower bounds (k <= 255)
+    uint8_t *d_reach = nullptr;      // [V] w8: 1 = some successor can still lead to an in-node within the bound
+    uint32_t *d_act_index = nullptr, *d_act_node = nullptr, *d_act_blocks = nullptr;  // the searched sources of the last launch (cap: act_cap)
+    uint64_t act_cap = 0;
+    uint64_t last_active_sources = 0;
     int n_cu = 256;
     uint64_t graph_bytes = 0;
     ReplayWork replay;
@@ -1303,9 +1485,10 @@ static LevelCfg make_cfg() {
 
 constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_NB = MTG_ENUM_NB;  // 40 KB of LDS per workgroup: 4 workgroups = 16 waves per CU
 constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
-static std::string enum_level_name(bool quad) {
-    char b[96];
-    std::snprintf(b, sizeof b, "sssp_enum_kernel<%d,%d,%d,%d,%s> + fix_compact_kernel + sort_lists_kernel", ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane");
+static std::string enum_level_name(bool quad, bool prune) {
+    char b[160];
+    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_count/write_kernel + " : "",
+                  ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
     return b;
 }
 
@@ -1337,24 +1520,53 @@ static float elapsed_ms(Device *d) {
 
 static bool enum_uses_quad_gathers(const Device *d) {
     // beyond ~3 GB of family blocks every lane-request pays an address translation: quad-cooperative gathers (see the kernel)
-    return d->plan == 2 || (d->plan == 0 && d->V * sizeof(NodeBlock) > (3ull << 30));
+    return (d->plan & 3) == 2 || ((d->plan & 3) == 0 && d->V * sizeof(NodeBlock) > (3ull << 30));
+}
+static bool enum_prunes(const Device *d) { return d->w8 && !(d->plan & 4) && (d->plan & 3) != 1; }  // (plan 1 = the plain cascade: full balls)
+
+// the searched sources of [src_begin, src_begin + n): d_act_index / d_act_node, their number in counters[C_ACTIVE]; zeroes cand_count
+static void launch_active_list(Device *d, hipStream_t st, const SsspArgs &args, uint64_t n) {
+    if (d->act_cap < n) {
+        for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node, (void *)d->d_act_blocks}) if (p) HIP_CHECK(hipFree(p));
+        hu::device_malloc(&d->d_act_index, n * 4);
+        hu::device_malloc(&d->d_act_node, n * 4);
+        hu::device_malloc(&d->d_act_blocks, ((n + ACT_BLOCK * ACT_PER - 1) / (ACT_BLOCK * ACT_PER)) * 4);
+        d->act_cap = n;
+    }
+    const unsigned nb = (unsigned)((n + ACT_BLOCK * ACT_PER - 1) / (ACT_BLOCK * ACT_PER));
+    hipLaunchKernelGGL(active_count_kernel, dim3(nb), dim3(ACT_BLOCK), 0, st, args.sources, d->d_reach, args.src_begin, n, d->d_act_blocks);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_act_blocks, nb, &args.counters[C_ACTIVE], (const uint32_t *)nullptr,
+                       (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(active_write_kernel, dim3(nb), dim3(ACT_BLOCK), 0, st, args.sources, d->d_reach, args.src_begin, n, d->d_act_blocks,
+                       d->d_act_index, d->d_act_node, args.cand_count);
+    HIP_CHECK(hipGetLastError());
 }
 
 static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     if (args.n_items == 0) return;
-    const bool quad = enum_uses_quad_gathers(d);
-    sssp_fn fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false>;
+    const bool quad = enum_uses_quad_gathers(d), prune = enum_prunes(d);
+    sssp_fn fn;
+    if (prune) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, true, true> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, true, true>;
+    else if (d->w8) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, true, false> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, true, false>;
+    else fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, false, false> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, false, false>;
     int occ = 1;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, ENUM_WPB * 64, 0));
     if (occ < 1) occ = 1;
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
     if (debug) std::fprintf(stderr, "[mtg] enumeration level: %d workgroups of %d waves per CU\n", occ, ENUM_WPB);
+    // (with pruning the number of searched sources stays on the GPU: the grid is sized for all of them, waves without a chunk leave at once)
     const uint64_t waves_needed = (args.n_items + 63) / 64;
     // (always the full grid: 8 waves per CU with twice the chunks per wave measured 20 % slower at 2^24, 65 % slower at 2^22)
     uint64_t grid = std::min<uint64_t>((uint64_t)d->n_cu * (uint64_t)occ, (waves_needed + ENUM_WPB - 1) / ENUM_WPB);
     grid = std::max<uint64_t>(grid, 1);
     HIP_CHECK(hipEventRecord(d->ev0, st));
-    HIP_CHECK(hipMemsetAsync(args.cand_count, 0, args.n_items * sizeof(uint32_t), st));  // (part of the level: see the kernel's result stores)
+    if (prune) {
+        launch_active_list(d, st, args, args.n_items);
+        args.act_index = d->d_act_index;
+        args.act_node = d->d_act_node;
+    } else {
+        HIP_CHECK(hipMemsetAsync(args.cand_count, 0, args.n_items * sizeof(uint32_t), st));  // (part of the level: see the kernel's result stores)
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
     const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
@@ -1408,7 +1620,7 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
 // on top of the ball: only sources that overflowed the 2^22-entry global-workspace level land here (none on any genome graph;
 // the reference's search has no such limit either, greedytigs/mod.rs:548-551), and the price buys "no abort on legal input".
 // ------------------------------------------------------------------------------------------------
-__global__ void dense_relax_kernel(const NodeBlock *recs, const uint32_t *ext_col, const uint16_t *ext_w, uint32_t K1, const uint32_t *frontier,
+__global__ void dense_relax_kernel(const NodeBlock *recs, const uint32_t *ext_col, const uint16_t *ext_w, uint32_t K1, uint32_t wmask, const uint32_t *frontier,
                                    uint64_t n_front, uint32_t round, uint32_t *dist, uint32_t *stamp, uint32_t *next, unsigned long long *n_next) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_front) return;
@@ -1425,7 +1637,7 @@ __global__ void dense_relax_kernel(const NodeBlock *recs, const uint32_t *ext_co
         const uint64_t b = (uint64_t)r.nbr[0] | ((uint64_t)r.nbr[1] << 32);
         for (uint32_t e = 0; e < r.nbr[2]; e++) relax(ext_col[b + e], ext_w[b + e]);
     } else {
-        for (uint32_t e = 0; e < r.deg; e++) relax(r.nbr[e], r.w[e]);
+        for (uint32_t e = 0; e < r.deg; e++) relax(r.nbr[e], r.w[e] & wmask);
     }
 }
 __global__ void dense_collect_kernel(const NodeBlock *recs, uint64_t n_nodes, uint32_t source, uint32_t K1, const uint32_t *dist,
@@ -1474,7 +1686,7 @@ static void run_dense_level(Device *d, hipStream_t st, const SsspArgs &a, const 
         for (uint32_t round = 0; n_front; round++) {
             if (round == 0xFFFFFFFEu) MTG_DIE("dense search level: round counter exhausted");
             HIP_CHECK(hipMemsetAsync(d_n, 0, 8, st));
-            hipLaunchKernelGGL(dense_relax_kernel, dim3((unsigned)((n_front + 255) / 256)), dim3(256), 0, st, a.recs, a.ext_col, a.ext_w, a.K1,
+            hipLaunchKernelGGL(dense_relax_kernel, dim3((unsigned)((n_front + 255) / 256)), dim3(256), 0, st, a.recs, a.ext_col, a.ext_w, a.K1, a.wmask,
                                d_front[cur], n_front, round, d_dist, d_stamp, d_front[cur ^ 1], d_n);
             HIP_CHECK(hipGetLastError());
             unsigned long long h = 0;
@@ -1526,6 +1738,11 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     a.sources = d->d_out_nodes; a.src_index = nullptr; a.n_items = n; a.src_begin = src_begin;
     a.K1 = d->K1; a.pool = d_pool; a.pool_cap = pool_cap; a.cand_start = d_cand_start; a.cand_count = d_cand_count;
     a.counters = d->d_counters;
+    a.wmask = d->w8 ? 0xFFu : 0xFFFFu;
+    // count_mode 3 = the units of the pruned search (what the default plan really visits): the counting kernels over the searched sources only
+    const bool prune_count = count_mode == 3;
+    a.prune = (prune_count || !count) && enum_prunes(d) ? 1u : 0u;
+    if (prune_count && !enum_prunes(d)) MTG_DIE("mtg_sssp_count_visited: this device graph / plan does not prune (k > 255 or plan + 4)");
     if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each + the post-pass work list
         for (int i = 0; i < 2; i++) {
             if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
@@ -1545,7 +1762,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
-    const bool use_enum = d->plan != 1 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
+    const bool use_enum = (d->plan & 3) != 1 && !count && d->K1 < 0x8000u;  // (the enumeration level keeps 15-bit distances on its stack)
     const bool dense_only = d->K1 >= (1u << 21);  // (the cooperative levels keep 21-bit distances in their table entries)
     if (dense_only) {  // every source straight to the dense level: correct for any bound, O(V) per source
         if (count) MTG_DIE("the counting kernels need k - 1 < 2^21");
@@ -1565,18 +1782,31 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
         if (pool_needed) *pool_needed = d->h_counters[C_POOL];
         return small ? 1 : 0;
     }
+    uint64_t n_first = n;  // sources the first level really launches over
     if (use_enum) launch_enum(d, st, a);
-    else launch_level(d, st, coop_level(first_coop, false), count, a);
+    else if (prune_count) {
+        if (n) {
+            launch_active_list(d, st, a, n);
+            read_counters(d, st);
+            n_first = d->h_counters[C_ACTIVE];
+            SsspArgs b = a;
+            b.src_index = d->d_act_index;
+            b.n_items = n_first;
+            launch_level(d, st, coop_level(first_coop, false), count, b);
+        }
+    } else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
+    if (use_enum && enum_prunes(d)) d->last_active_sources = d->h_counters[C_ACTIVE];
     d->last_n_levels = 0;
-    if (n) {
+    if (n && n_first) {
         total_ms += elapsed_ms(d);
         d->last_level_ms[0] = elapsed_ms(d); d->last_level_sources[0] = n; d->last_n_levels = 1;
-        d->last_level_name[0] = use_enum ? enum_level_name(enum_uses_quad_gathers(d)) : coop_level(first_coop, false).name();
+        d->last_level_name[0] = use_enum ? enum_level_name(enum_uses_quad_gathers(d), enum_prunes(d)) : coop_level(first_coop, false).name();
     }
     static const bool debug = std::getenv("MTG_DEBUG") != nullptr;
-    if (debug && n) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources, %.3f ms, %llu overflowed, cum settled %llu\n", use_enum ? "enum" : "coop level 0",
-                                 (unsigned long long)n, elapsed_ms(d), (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
+    if (debug && n && n_first) std::fprintf(stderr, "[mtg] level0 (%s): %llu sources (%llu searched), %.3f ms, %llu overflowed, cum settled %llu\n", use_enum ? "enum" : "coop level 0",
+                                 (unsigned long long)n, (unsigned long long)(use_enum && enum_prunes(d) ? d->h_counters[C_ACTIVE] : n_first), elapsed_ms(d),
+                                 (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
 #ifdef MTG_ENUM_STATS
     if (use_enum && n) std::fprintf(stderr, "[mtg] enum stats: wave steps %llu, lane steps %llu (%.1f of 64), starved %llu, block full %llu, step budget %llu, fix cursor %llu, pool cursor %llu\n",
                                     d->h_counters[C_SETTLED], d->h_counters[C_RELAXED], (double)d->h_counters[C_RELAXED] / (double)std::max<unsigned long long>(d->h_counters[C_SETTLED], 1),
@@ -1741,7 +1971,26 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         if (E) hipLaunchKernelGGL(build_fill_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_ext_off, d_fill, d->d_recs, d->d_ext_col);
         hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_to, d_w, d->d_recs,
                            d->d_ext_col, d->d_ext_w);
-        hipLaunchKernelGGL(build_children_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs);
+        d->w8 = k <= 255;
+        if (d->w8) {  // goal-directed lower bounds: k - 1 rounds over a 32-bit distance array, then the 8:8 format of the weight slots
+            uint32_t *d_D = nullptr;
+            uint8_t *d_lb8 = nullptr;
+            hu::device_malloc(&d_D, V * 4);
+            hu::device_malloc(&d_lb8, V);
+            hu::device_malloc(&d->d_reach, V);
+            hipLaunchKernelGGL(lb_init_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, d->d_mirror, V, d_D);
+            for (uint32_t r = 0; r < d->K1; r++)
+                hipLaunchKernelGGL(lb_round_kernel, dim3(vb), dim3(256), 0, st, d->d_recs, d->d_ext_col, d->d_ext_w, V, r, d->K1, d_D);
+            hipLaunchKernelGGL(lb_mirror_kernel, dim3(vb), dim3(256), 0, st, d->d_mirror, d_D, V, d_lb8);
+            hipLaunchKernelGGL(build_lb_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d->d_reach);
+            hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(hipFree(d_D));
+            HIP_CHECK(hipFree(d_lb8));
+        } else {
+            hipLaunchKernelGGL(build_children_kernel<false>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
+        }
         HIP_CHECK(hipGetLastError());
     }
     // the finishing stages on this GPU start from the same two arrays: leave them with the graph instead of uploading them again
@@ -1751,14 +2000,15 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipStreamSynchronize(st));
     hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
     for (void *p : {(void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
-    d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13;
+    d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13 + (d->w8 ? V : 0);
     return d;
 }
 
 void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
-    void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters};
+    void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters,
+                    d->d_reach, d->d_act_index, d->d_act_node, d->d_act_blocks};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
@@ -1841,6 +2091,25 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
     HIP_CHECK(hipFree(d_start));
     HIP_CHECK(hipFree(d_count));
 }
+
+// the same counters for the search the default plan really runs: only the sources that can reach an in-node, successors pruned by
+// their lower bounds (settled = distinct (source, node) pairs visited, relaxed = their out-edges, emitted = the same candidates)
+void device_sssp_count_visited(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t n = src_end - src_begin;
+    unsigned long long *d_start = nullptr;
+    uint32_t *d_count = nullptr;
+    hu::device_malloc(&d_start, std::max<uint64_t>(n, 1) * 8);
+    hu::device_malloc(&d_count, std::max<uint64_t>(n, 1) * 4);
+    const double keep_ms = d->last_kernel_ms;
+    run_levels(d, (hipStream_t)stream, 3, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
+    if (stats) stats->sources = d->h_counters[C_ACTIVE];
+    d->last_kernel_ms = keep_ms;
+    HIP_CHECK(hipFree(d_start));
+    HIP_CHECK(hipFree(d_count));
+}
+bool device_prunes(const Device *d) { return enum_prunes(d); }
+uint64_t device_last_active_sources(const Device *d) { return d->last_active_sources; }
 
 // greedytigs/mod.rs:647-673 counters in the engine's terms (see mtg_dijkstra_performance_data): one source per workgroup
 void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out) {
@@ -2150,7 +2419,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 }
 
 int device_set_plan(Device *d, int plan) {
-    if (plan >= 0 && plan <= 3) d->plan = plan;
+    if (plan >= 0 && plan <= 7) d->plan = (plan & 3) == 1 ? 1 : plan;
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }

@@ -22,6 +22,9 @@ uint64_t device_n_sources(const Device *d);
 int device_sssp(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, uint64_t *d_pool, uint64_t pool_cap,
                 uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed);
 void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+void device_sssp_count_visited(Device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
+bool device_prunes(const Device *d);
+uint64_t device_last_active_sources(const Device *d);
 double device_last_kernel_ms(const Device *d);
 const char *device_last_level_name(const Device *d, int level);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);

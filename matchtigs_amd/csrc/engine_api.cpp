@@ -173,6 +173,11 @@ const char *mtg_last_sssp_level_name(const mtg_device *d, int level) { return de
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
     device_sssp_count(d->d, stream, src_begin, src_end, stats);
 }
+void mtg_sssp_count_visited(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats) {
+    device_sssp_count_visited(d->d, stream, src_begin, src_end, stats);
+}
+int mtg_sssp_prunes(const mtg_device *d) { return device_prunes(d->d) ? 1 : 0; }
+uint64_t mtg_last_sssp_searched_sources(const mtg_device *d) { return device_last_active_sources(d->d); }
 int mtg_set_sssp_plan(mtg_device *d, int plan) { return device_set_plan(d->d, plan); }
 uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
                                   const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out) {

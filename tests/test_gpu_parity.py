@@ -74,8 +74,67 @@ def test_classification_matches_oracle(gpu, oracle, idx):
     assert np.array_equal(li, o_live), name
 
 
-@pytest.mark.parametrize("plan", [0, 1, 2])  # 0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only,
-#                                               2 = plan 0 with the quad-cooperative gathers large graphs get (mtg_set_sssp_plan)
+def _pruned_search_units(bg):
+    """Independent count of what the goal-directed search visits (mtg_sssp_count_visited): lb(v) = distance to the nearest initial
+    in-node by a multi-source Dijkstra over the reversed edges; a source is searched iff some successor c has w + lb(c) <= k-1; a
+    search relaxes u -> v at distance d + w only if d + w + lb(v) <= k-1. Returns (searched sources, settled, relaxed edges)."""
+    import heapq
+
+    V, K1 = bg.n_nodes, bg.k - 1
+    fr, to = bg.edge_from.astype(np.int64), bg.edge_to.astype(np.int64)
+    w = np.minimum(bg.edge_weight.astype(np.int64), bg.k)
+    mir = bg.mirror.astype(np.int64)
+
+    def csr(a, b):
+        order = np.argsort(a, kind="stable")
+        row = np.zeros(V + 1, np.int64)
+        np.add.at(row, a + 1, 1)
+        return np.cumsum(row), b[order], w[order]
+
+    row, col, ww = csr(fr, to)
+    rrow, rcol, rww = csr(to, fr)
+    odeg = np.diff(row)
+    sm = mir == np.arange(V)
+    diff = np.where(sm, odeg & 1, odeg - odeg[mir])
+    target = diff > 0
+    source = np.where(sm, diff != 0, diff < 0)
+    INF = 1 << 40
+    lb = np.full(V, INF, np.int64)
+    heap = [(0, int(t)) for t in np.nonzero(target)[0]]
+    lb[target] = 0
+    while heap:
+        d, u = heapq.heappop(heap)
+        if d > lb[u]:
+            continue
+        for i in range(rrow[u], rrow[u + 1]):
+            nd = d + int(rww[i])
+            if nd <= K1 and nd < lb[rcol[i]]:
+                lb[rcol[i]] = nd
+                heapq.heappush(heap, (nd, int(rcol[i])))
+    searched = settled = relaxed = 0
+    for s in np.nonzero(source)[0]:
+        if not any(int(ww[i]) + lb[col[i]] <= K1 for i in range(row[s], row[s + 1])):
+            continue
+        searched += 1
+        dist = {int(s): 0}
+        heap = [(0, int(s))]
+        while heap:
+            d, u = heapq.heappop(heap)
+            if d > dist[u]:
+                continue
+            settled += 1
+            relaxed += int(row[u + 1] - row[u])
+            for i in range(row[u], row[u + 1]):
+                v, nd = int(col[i]), d + int(ww[i])
+                if nd + lb[v] <= K1 and nd < dist.get(v, INF):
+                    dist[v] = nd
+                    heapq.heappush(heap, (nd, v))
+    return searched, settled, relaxed
+
+
+@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4, 6])  # 0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only,
+#   2 / 3 = plan 0 with the quad-cooperative gathers large graphs get / the per-lane ones, 4 / 6 = plans 0 / 2 without the
+#   goal-directed pruning (mtg_set_sssp_plan)
 @pytest.mark.parametrize("idx", range(5))
 def test_t1_candidate_lists(gpu, oracle, idx, plan):
     name, bg = graphs()[idx]
@@ -92,9 +151,16 @@ def test_t1_candidate_lists(gpu, oracle, idx, plan):
     assert cnt["settled_nodes"] == st["settled_nodes"], (name, cnt, st)
     assert cnt["relaxed_edges"] == st["relaxed_edges"], (name, cnt, st)
     assert cnt["emitted"] == len(keys)
+    assert dev.prunes() == (bg.k <= 255 and plan in (0, 2, 3))
+    if plan == 0:  # ... and the units of the pruned search == an independent count of what the lower bounds leave
+        vis = dev.sssp_count_visited(0, S)
+        searched, settled, relaxed = _pruned_search_units(bg)
+        assert (vis["sources"], vis["settled_nodes"], vis["relaxed_edges"], vis["emitted"]) == (searched, settled, relaxed, len(keys)), (name, vis)
+        assert dev.last_searched_sources() == searched
+        assert int((count > 0).sum()) <= searched <= S
 
 
-@pytest.mark.parametrize("plan", [0, 2])
+@pytest.mark.parametrize("plan", [0, 2, 4])
 def test_t1_long_lists_from_the_enumeration_level(gpu, oracle, plan):
     """Short unitigs and many in-nodes: the enumeration level itself finishes sources with 5-8, 9-16 and more than 16 candidates
     (its three post-pass length classes: work-list compaction + lane-parallel sort) and lists that name a node along two paths."""
