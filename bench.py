@@ -207,16 +207,26 @@ def main():
                 t4 = time.perf_counter()
                 ph["download"] = t4 - t3
                 pairs = graph.replay_claims(on, mu, li, cs, cc, po)
-            else:  # claim loop on the GPU (deterministic reservations); only the matched pairs are downloaded
+            resident = not args.host_replay and not args.host_finish
+            if not args.host_replay:  # claim loop on the GPU (deterministic reservations)
                 t4 = time.perf_counter()
                 ph["download"] = 0.0
-                pairs = dev.replay_claims_device(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
+                if resident:  # ... whose pairs stay in HBM for the finish on the same GPU (as in mtg_compute_tigs_cfg)
+                    n_pairs = dev.replay_claims_resident(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
+                else:
+                    pairs = dev.replay_claims_device(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
+                    n_pairs = len(pairs)
                 po = pool_all
                 result_info["replay_rounds"] = dev.last_replay_rounds()
                 result_info["replay_visits"] = dev.last_replay_visits()
+            else:
+                n_pairs = len(pairs)
             t5 = time.perf_counter()
             ph["replay"] = t5 - t4
-            tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, mode, local_rank, finish_stage)
+            if resident:
+                tigs_lim, tigs_edges = api.finish_greedytigs_resident_np(graph, dev, k, mode, local_rank, finish_stage)
+            else:
+                tigs_lim, tigs_edges = api.finish_greedytigs_np(graph, pairs, k, mode, local_rank, finish_stage)
             t6 = time.perf_counter()
             ph["finish"] = t6 - t5
             hp = api.last_phase_seconds()
@@ -225,7 +235,7 @@ def main():
             ph["insert_eulerise"], ph["euler"], ph["cut"] = hp["eulerise"], hp["euler"], hp["cut"]
             if mode == api.EulerMode.Device:
                 ph["euler_device_kernels"] = api.last_euler_kernel_ms() * 1e-3
-            result_info.update(S=int(S), pairs=int(len(pairs)), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
+            result_info.update(S=int(S), pairs=int(n_pairs), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
                                candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
             del tigs_lim, tigs_edges
             graph.reset()

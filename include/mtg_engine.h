@@ -209,6 +209,15 @@ int mtg_set_sssp_plan(mtg_device *d, int plan);
  * *pairs_out (HOST memory, malloc'd, free with mtg_free) holds them in the reference's push order. */
 uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
                                   const uint32_t *d_cand_count, const uint64_t *d_pool, mtg_pair **pairs_out);
+/* The same claim loop, but the pairs STAY in the HBM of d's GPU (no download): for a finish on the same GPU, which takes them from
+ * there (mtg_finish_greedytigs_resident) -- mtg_compute_tigs_cfg works this way. Returns the number of pairs. They remain valid until
+ * the next claim replay on d or mtg_device_free(d). */
+uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
+                                    const uint32_t *d_cand_count, const uint64_t *d_pool);
+/* Device pointer to those pairs (NULL when there are none) and their number. */
+const mtg_pair *mtg_resident_pairs(const mtg_device *d, uint64_t *n_pairs_out);
+/* A host copy of them (malloc'd, free with mtg_free), in the reference's push order. */
+uint64_t mtg_download_resident_pairs(mtg_device *d, mtg_pair **pairs_out);
 /* Reservation rounds the last mtg_replay_claims_device needed. */
 int mtg_last_replay_rounds(const mtg_device *d);
 /* Source visits of those rounds (sum of the pending-list lengths): the unit of the replay's cost model. */
@@ -296,6 +305,21 @@ double mtg_last_euler_kernel_ms(void); /* of the last device decomposition on th
  * decomposition, or the reference-order host walk over GPU-built records), rotate + cut (greedytigs/mod.rs:726-789). Appends the
  * dummy edges to g like the host stages do (same ids, weights and dummy ids). n_pairs == 0 is the Eulertig finish. */
 mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
+/* mtg_finish_greedytigs_cfg with the matched pairs the last claim replay on `d` left in HBM (mtg_replay_claims_resident): when the
+ * finish runs on d's GPU (cfg->device_ids[0], finish_stage AUTO / DEVICE, a graph without dummy edges) nothing is uploaded and
+ * only the dummy weights come down, beside the GPU stages; otherwise the pairs take the way through the host. Same tigs either way. */
+mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg_config *cfg);
+/* Device memory the library keeps BETWEEN calls, and how to get it back:
+ *  - the finishing stages keep the work arrays of the last call on a GPU for the next one (a caller that finishes graph after graph
+ *    pays no allocation); a call frees what it did not touch itself, so at most one call's arrays are held, and calls that worked
+ *    on more than 32 GB keep nothing. mtg_device_memory_held tells how much that is right now, mtg_release_device_memory gives
+ *    all of it back to the driver (e.g. before another allocator of the process needs the HBM);
+ *  - a graph keeps the device copy of its original edges, its mirror array and the buckets of its original darts on the GPU of
+ *    its first device stage (<= 8 B per edge + 8 B per node) until mtg_graph_free / mtg_graph_release_device_cache.
+ * Neither changes a result; the next call simply allocates / uploads again. */
+void mtg_release_device_memory(int device_id);
+uint64_t mtg_device_memory_held(int device_id);
+void mtg_graph_release_device_cache(mtg_graph *g);
 /* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,
  * [2] Euler bicycles, [3] rotate + cut + tig download; [4] kernel ms of the device decomposition; [5] breaking biedges added. */
 void mtg_last_finish_device_times(double out[6]);

@@ -209,6 +209,13 @@ def load():
         "mtg_write_tigs_gfa_file": (u64, [vp, vp, u64, vp, C.c_char_p, C.c_char_p, C.c_int]),
         "mtg_compute_tigs": (vp, [vp, u64, u64, C.c_int]),
         "mtg_finish_device": (vp, [vp, vp, u64, P(MtgConfig)]),
+        "mtg_finish_greedytigs_resident": (vp, [vp, vp, P(MtgConfig)]),
+        "mtg_release_device_memory": (None, [C.c_int]),
+        "mtg_device_memory_held": (u64, [C.c_int]),
+        "mtg_graph_release_device_cache": (None, [vp]),
+        "mtg_replay_claims_resident": (u64, [vp, vp, u64, vp, vp, vp]),
+        "mtg_resident_pairs": (vp, [vp, P(u64)]),
+        "mtg_download_resident_pairs": (u64, [vp, P(P(MtgPair))]),
         "mtg_last_finish_device_times": (None, [P(C.c_double)]),
         "mtg_synth_g_csr": (vp, [u64, u64, u64, u64, u64, vp, u64, C.c_int, C.c_int]),
         "mtg_last_phase_seconds": (None, [P(C.c_double)]),

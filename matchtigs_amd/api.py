@@ -237,6 +237,10 @@ class Bigraph:
     def handle(self) -> int:
         return self._h
 
+    def release_device_cache(self) -> None:
+        """mtg_graph_release_device_cache: the device copy of the original edges (+ their buckets) goes back to the driver."""
+        self._L.mtg_graph_release_device_cache(self._h)
+
     def reset(self) -> None:
         """Drop all dummy edges again (the reference clones its graph instead, bin.rs:1069)."""
         self._L.mtg_graph_reset(self._h)
@@ -444,6 +448,15 @@ class DeviceGraph:
         n = self._L.mtg_replay_claims_device(self._d, stream, self.n_sources, d_cand_start, d_cand_count, d_pool, C.byref(pp))
         return _adopt_pairs(self._L, pp, n)
 
+    def replay_claims_resident(self, d_cand_start: int, d_cand_count: int, d_pool: int, stream: int = 0) -> int:
+        """The claim loop on the GPU; the pairs stay in HBM for finish_greedytigs_resident_np. Returns their number."""
+        return int(self._L.mtg_replay_claims_resident(self._d, stream, self.n_sources, d_cand_start, d_cand_count, d_pool))
+
+    def download_resident_pairs(self) -> np.ndarray:
+        pp = C.POINTER(_lib.MtgPair)()
+        n = self._L.mtg_download_resident_pairs(self._d, C.byref(pp))
+        return _adopt_pairs(self._L, pp, n)
+
     def last_replay_rounds(self) -> int:
         return int(self._L.mtg_last_replay_rounds(self._d))
 
@@ -633,6 +646,23 @@ def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int, euler_mode: 
     p = np.ascontiguousarray(pairs)
     c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,), finish_stage=finish_stage).to_c()
     return _take_walks_np(L, L.mtg_finish_greedytigs_cfg(graph.handle, _ptr(p) if len(p) else None, len(p), C.byref(c)))
+
+
+def finish_greedytigs_resident_np(graph: Bigraph, device: "DeviceGraph", k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
+                                  device_id: int = 0, finish_stage: FinishStage = FinishStage.Auto):
+    """mtg_finish_greedytigs_resident: the finish over the pairs the last replay_claims_resident left on the GPU."""
+    L = _lib.load()
+    c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,), finish_stage=finish_stage).to_c()
+    return _take_walks_np(L, L.mtg_finish_greedytigs_resident(graph.handle, device.handle, C.byref(c)))
+
+
+def release_device_memory(device_id: int = 0) -> None:
+    """mtg_release_device_memory: the work arrays the finishing stages keep on that GPU between calls."""
+    _lib.load().mtg_release_device_memory(device_id)
+
+
+def device_memory_held(device_id: int = 0) -> int:
+    return int(_lib.load().mtg_device_memory_held(device_id))
 
 
 def last_finish_device_times() -> dict:

@@ -94,26 +94,28 @@ __device__ __forceinline__ NodeClass classify_node(uint32_t out_deg, uint32_t ou
 // ------------------------------------------------------------------------------------------------
 // Classification kernels (greedytigs/mod.rs:229-245): compact arrays only (out-degree, mirror -> multiplicity, class byte)
 // ------------------------------------------------------------------------------------------------
-constexpr int CLS_BLOCK = 256;
+constexpr int CLS_BLOCK = 256, CLS_PER = 8;  // nodes per workgroup = 2048 (the single-workgroup scan in between sees V / 2048 counts)
+constexpr int CLS_NODES = CLS_BLOCK * CLS_PER;
 
 __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *odeg, const uint32_t *mirror, uint32_t n_nodes, int32_t *mult,
                                                              uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
     __shared__ uint32_t wave_dem[CLS_BLOCK / 64];
-    const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
-    bool is_source = false;
-    uint32_t pos = 0;
-    if (n < n_nodes) {
+    uint32_t cnt = 0, pos = 0;
+#pragma unroll
+    for (int p = 0; p < CLS_PER; p++) {
+        const uint64_t n64 = (uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x;
+        if (n64 >= n_nodes) continue;
+        const uint32_t n = (uint32_t)n64;
         const uint32_t m = mirror[n];
         const NodeClass c = classify_node(odeg[n], m == n ? 0u : odeg[m], m == n);
-        is_source = c.cls & F_SOURCE;
+        cnt += (c.cls & F_SOURCE) ? 1u : 0u;
         mult[n] = c.diff;  // 0 for balanced nodes
         cls[n] = c.cls;
-        pos = c.diff > 0 ? (uint32_t)c.diff : 0u;
+        pos += c.diff > 0 ? (uint32_t)c.diff : 0u;
     }
-    const unsigned long long b = __ballot(is_source);
-    for (int dd = 32; dd >= 1; dd >>= 1) pos += __shfl_down(pos, dd);
-    if ((threadIdx.x & 63) == 0) { wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b); wave_dem[threadIdx.x >> 6] = pos; }
+    for (int dd = 32; dd >= 1; dd >>= 1) { pos += __shfl_down(pos, dd); cnt += __shfl_down(cnt, dd); }
+    if ((threadIdx.x & 63) == 0) { wave_cnt[threadIdx.x >> 6] = cnt; wave_dem[threadIdx.x >> 6] = pos; }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t s = 0, dm = 0;
@@ -160,18 +162,24 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uin
 
 __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_t *cls, uint32_t n_nodes,
                                                                     const uint32_t *block_offsets, uint32_t *out_nodes) {
-    __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
-    const uint32_t n = blockIdx.x * CLS_BLOCK + threadIdx.x;
-    const bool is_source = n < n_nodes && (cls[n] & F_SOURCE);
-    const unsigned long long b = __ballot(is_source);
+    __shared__ uint32_t wave_cnt[CLS_PER][CLS_BLOCK / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(b);
+    unsigned long long bal[CLS_PER];
+#pragma unroll
+    for (int p = 0; p < CLS_PER; p++) {
+        const uint64_t n = (uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x;
+        bal[p] = __ballot(n < n_nodes && (cls[n] & F_SOURCE));
+        if (lane == 0) wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]);
+    }
     __syncthreads();
-    if (is_source) {
-        uint32_t off = block_offsets[blockIdx.x];
-        for (int j = 0; j < wv; j++) off += wave_cnt[j];
-        off += (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        out_nodes[off] = n;  // ascending: lane order within wave, wave order within block, block order
+    uint32_t off = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int p = 0; p < CLS_PER; p++) {  // ascending: lane order within a wave, wave order within a pass, pass order, block order
+        for (int j = 0; j < CLS_BLOCK / 64; j++) {
+            if (j == wv && ((bal[p] >> lane) & 1ull))
+                out_nodes[off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull))] = (uint32_t)((uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x);
+            off += wave_cnt[p][j];
+        }
     }
 }
 
@@ -1454,6 +1462,7 @@ struct Device {
     uint64_t graph_bytes = 0;
     ReplayWork replay;
     int last_replay_rounds = 0;
+    uint64_t last_n_pairs = 0;        // pairs of the last claim replay; they stay in replay.out until the next one (or device_take_pairs)
     uint64_t last_replay_visits = 0;  // sum over the rounds of the pending-list lengths (first RC_TRACE_ROUNDS rounds)
 };
 
@@ -1940,7 +1949,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     hu::device_malloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4);
     hu::device_malloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4);
     hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4);
-    d->n_cls_blocks = (V + CLS_BLOCK - 1) / CLS_BLOCK;
+    d->n_cls_blocks = (V + CLS_NODES - 1) / CLS_NODES;
     hu::device_malloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4);  // source counts | positive multiplicities per block
     hu::device_malloc(&d->d_counters, C_COUNT * sizeof(unsigned long long));
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
@@ -2185,8 +2194,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         }
     } rt;
     if (S == 0) {
-        *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        if (pairs_out) *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
         d->last_replay_rounds = 0;
+        d->last_n_pairs = 0;
         if (rounds_out) *rounds_out = 0;
         return 0;
     }
@@ -2356,16 +2366,24 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     read_counters(d, st);
     const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
     rt.lap("tail + scan");
+    d->last_n_pairs = n_pairs;
+    if (n_pairs > w.cap_out || !w.out) {
+        if (w.out) HIP_CHECK(hipFree(w.out));
+        hu::device_malloc(&w.out, std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
+        w.cap_out = std::max<uint64_t>(n_pairs, 1);
+    }
+    if (n_pairs) {
+        hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (!pairs_out) {  // the pairs stay in HBM for a finish on this GPU (device_resident_pairs / device_take_pairs)
+        HIP_CHECK(hipStreamSynchronize(st));
+        rt.lap("compact (pairs stay on the GPU)");
+        return n_pairs;
+    }
     mtg_pair *host = (mtg_pair *)big_malloc(std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));  // (the caller frees it with free())
     if (!host) MTG_DIE("out of memory");
     if (n_pairs) {
-        if (n_pairs > w.cap_out) {
-            if (w.out) HIP_CHECK(hipFree(w.out));
-            hu::device_malloc(&w.out, n_pairs * sizeof(mtg_pair));
-            w.cap_out = n_pairs;
-        }
-        hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
-        HIP_CHECK(hipGetLastError());
         if (n_pairs < (1u << 18)) {
             HIP_CHECK(hipMemcpyAsync(host, w.out, n_pairs * sizeof(mtg_pair), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
@@ -2423,6 +2441,36 @@ int device_set_plan(Device *d, int plan) {
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
+int device_id_of(const Device *d) { return d->dev; }
+// the pairs of the last claim replay as they lie in HBM (valid until the next replay on this device)
+const mtg_pair *device_resident_pairs(const Device *d, uint64_t *n_out) {
+    if (n_out) *n_out = d->last_n_pairs;
+    return d->last_n_pairs ? d->replay.out : nullptr;
+}
+// the same, handed over: the caller owns the device array now (hipFree) -- lets the device graph go before the finish starts
+mtg_pair *device_take_pairs(Device *d, uint64_t *n_out) {
+    if (n_out) *n_out = d->last_n_pairs;
+    mtg_pair *p = d->replay.out;
+    d->replay.out = nullptr;
+    d->replay.cap_out = 0;
+    d->last_n_pairs = 0;
+    return p;
+}
+void device_free_array(int device_id, void *p) {
+    if (!p) return;
+    (void)hipSetDevice(device_id);
+    (void)hipFree(p);
+}
+// host copy of the resident pairs (malloc'd)
+uint64_t device_download_pairs(Device *d, mtg_pair **pairs_out) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    const uint64_t n = d->last_n_pairs;
+    mtg_pair *host = (mtg_pair *)big_malloc(std::max<uint64_t>(n, 1) * sizeof(mtg_pair));
+    if (!host) MTG_DIE("out of memory");
+    if (n) HIP_CHECK(hipMemcpy(host, d->replay.out, n * sizeof(mtg_pair), hipMemcpyDeviceToHost));
+    *pairs_out = host;
+    return n;
+}
 uint64_t device_last_replay_visits(const Device *d) { return d->last_replay_visits; }
 
 // one-shot path: SSSP candidates for all sources into engine-owned device buffers (pool grown on demand), then the
@@ -2432,7 +2480,8 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     HIP_CHECK(hipSetDevice(d->dev));
     const uint64_t S = d->n_sources;
     if (!S) {
-        *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        if (pairs_out) *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        d->last_n_pairs = 0;
         if (rounds_out) *rounds_out = 0;
         return 0;
     }
@@ -2520,7 +2569,8 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
     for (int i = 1; i < n_dev; i++)
         if (devs[i]->V != d0->V || devs[i]->n_sources != S) MTG_DIE("device_pairs_multi: the devices hold different graphs");
     if (!S) {
-        *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        if (pairs_out) *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
+        d0->last_n_pairs = 0;
         if (rounds_out) *rounds_out = 0;
         return 0;
     }

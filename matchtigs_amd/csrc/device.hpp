@@ -34,14 +34,27 @@ uint64_t device_last_replay_visits(const Device *d);
 void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out);
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
                        const uint64_t *d_pool, mtg_pair **pairs_out, int *rounds_out);
+// (pairs_out == nullptr in device_replay / device_pairs / device_pairs_multi: the pairs are not downloaded, they stay in the HBM of the
+// (first) device for a finish there)
 uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out);
+int device_id_of(const Device *d);
+const mtg_pair *device_resident_pairs(const Device *d, uint64_t *n_out);
+mtg_pair *device_take_pairs(Device *d, uint64_t *n_out);
+void device_free_array(int device_id, void *p);
+uint64_t device_download_pairs(Device *d, mtg_pair **pairs_out);
 // SURVEY 8e inside the library: sources block-partitioned by work over the devices, candidate lists gathered on devs[0]
 uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out, int *rounds_out, double *gather_ms_out);
 std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int parts);
 // euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
 Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out);
 // finish_device.hip: insertion + Euleriser + Euler bicycles + cut on the GPU (see mtg_finish_device)
-Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6]);
+// (d_pairs_resident: the n_pairs pairs as they lie in the HBM of `device_id`, e.g. left there by the claim replay -- `pairs` may then be null:
+// nothing is uploaded, and the host graph gets its dummy weights from a download that runs beside the GPU stages)
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6],
+                    const mtg_pair *d_pairs_resident = nullptr);
+void device_release_memory(int device_id);
+uint64_t device_memory_held(int device_id);
+void device_release_graph_cache(const HostGraph &g);
 // synth_device.hip: the G-csr generator on the GPU
 HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t n_unitigs, uint64_t seed, uint64_t k,
                               const uint64_t *thresholds, uint64_t n_thresholds, int max_degree, int device_id);

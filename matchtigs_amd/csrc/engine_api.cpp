@@ -184,6 +184,19 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
     if (!d || !pairs_out) MTG_DIE("mtg_replay_claims_device: null argument");
     return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
+uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
+                                    const uint32_t *d_cand_count, const uint64_t *d_pool) {
+    if (!d) MTG_DIE("mtg_replay_claims_resident: null argument");
+    return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, nullptr, nullptr);
+}
+const mtg_pair *mtg_resident_pairs(const mtg_device *d, uint64_t *n_pairs_out) {
+    if (!d) MTG_DIE("mtg_resident_pairs: null argument");
+    return device_resident_pairs(d->d, n_pairs_out);
+}
+uint64_t mtg_download_resident_pairs(mtg_device *d, mtg_pair **pairs_out) {
+    if (!d || !pairs_out) MTG_DIE("mtg_download_resident_pairs: null argument");
+    return device_download_pairs(d->d, pairs_out);
+}
 int mtg_last_replay_rounds(const mtg_device *d) { return device_last_replay_rounds(d->d); }
 uint64_t mtg_last_replay_visits(const mtg_device *d) { return device_last_replay_visits(d->d); }
 uint64_t mtg_compute_pairs(mtg_device *const *devices, int n_devices, mtg_pair **pairs_out) {
@@ -273,11 +286,11 @@ static bool use_device_finish(const HostGraph &g, const mtg_pair *pairs, uint64_
     if (!ok && forced) MTG_DIE("finish_stage = MTG_FINISH_DEVICE needs a graph without dummy edges and matched pairs shorter than k");
     return ok;
 }
-static mtg_walks *finish_on_device(HostGraph &g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config &cfg) {
+static mtg_walks *finish_on_device(HostGraph &g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config &cfg, const mtg_pair *d_pairs_resident = nullptr) {
     log_info("Making graph Eulerian by adding breaking dummy edges");
     log_info("Finding Eulerian bicycle");
     double *t = g_last_finish_times;
-    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t)};
+    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t, d_pairs_resident)};
     g_phase[5] = t[0] + t[1];
     g_phase[6] = t[2];
     g_phase[7] = t[3];
@@ -343,6 +356,28 @@ mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pai
     forced.finish_stage = MTG_FINISH_DEVICE;
     (void)use_device_finish(g->g, pairs, n_pairs, forced);
     return finish_on_device(g->g, pairs, n_pairs, forced);
+}
+mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg_config *cfg) {
+    check_config(cfg, "mtg_finish_greedytigs_resident");
+    if (!g || !g->g.built || !d) MTG_DIE("mtg_finish_greedytigs_resident: graph is not built / null device");
+    uint64_t n_pairs = 0;
+    const mtg_pair *d_pairs = device_resident_pairs(d->d, &n_pairs);
+    if (use_device_finish(g->g, nullptr, 0, *cfg) && device_id_of(d->d) == cfg->device_ids[0]) {
+        mtg_walks *tigs = finish_on_device(g->g, nullptr, n_pairs, *cfg, d_pairs);
+        log_info("Found %zu greedytigs", tigs->w.limits.size());
+        return tigs;
+    }
+    // host finish, or a finish on another GPU: through the host, like mtg_finish_greedytigs_cfg
+    mtg_pair *pairs = nullptr;
+    n_pairs = device_download_pairs(d->d, &pairs);
+    mtg_walks *tigs = mtg_finish_greedytigs_cfg(g, pairs, n_pairs, cfg);
+    std::free(pairs);
+    return tigs;
+}
+void mtg_release_device_memory(int device_id) { device_release_memory(device_id); }
+uint64_t mtg_device_memory_held(int device_id) { return device_memory_held(device_id); }
+void mtg_graph_release_device_cache(mtg_graph *g) {
+    if (g) device_release_graph_cache(g->g);
 }
 void mtg_last_finish_device_times(double out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_last_finish_times[i];
@@ -659,8 +694,17 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
             g_phase[1] = t2 - t1;
             log_info("Found %llu nodes with missing outgoing edges", (unsigned long long)S);
             // SSSP candidates (sharded over the devices) and the claim loop both run on the GPU; only the matched pairs come back
+            // ... and stay in the HBM of the first GPU when the finish runs there too (the default)
+            const bool resident = use_device_finish(g->g, nullptr, 0, *cfg) && device_id_of(dev->d) == cfg->device_ids[0];
             mtg_pair *pairs = nullptr;
-            const uint64_t n_pairs = mtg_compute_pairs(devs.data(), n_dev, &pairs);
+            uint64_t n_pairs = 0;
+            {
+                std::vector<Device *> dd((size_t)n_dev);
+                for (int i = 0; i < n_dev; i++) dd[(size_t)i] = devs[(size_t)i]->d;
+                double gather_ms = 0;
+                n_pairs = device_pairs_multi(dd.data(), n_dev, resident ? nullptr : &pairs, nullptr, &gather_ms);
+                g_last_gather_ms = gather_ms;
+            }
             double t3 = now_s();
             g_phase[2] = t3 - t2;  // SSSP + gather + replay + pair download
             for (int i = 1; i < n_dev; i++) mtg_device_free(devs[(size_t)i]);
@@ -676,10 +720,18 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
                     log_info("Dijktras had an average maximum heap size of %.0f", (double)p.sum_max_distance_array_size / (double)p.dijkstras);  // sic, :669-671
                 }
             }
+            mtg_pair *d_pairs = resident ? device_take_pairs(dev->d, nullptr) : nullptr;  // (ours now: the device graph can go before the finish)
             mtg_device_free(dev);
             log_info("Found %llu shortest paths", (unsigned long long)n_pairs);
-            mtg_walks *tigs = mtg_finish_greedytigs_cfg(g, pairs, n_pairs, cfg);
-            std::free(pairs);
+            mtg_walks *tigs;
+            if (resident) {
+                tigs = finish_on_device(g->g, nullptr, n_pairs, *cfg, d_pairs);
+                log_info("Found %zu greedytigs", tigs->w.limits.size());
+                device_free_array(cfg->device_ids[0], d_pairs);
+            } else {
+                tigs = mtg_finish_greedytigs_cfg(g, pairs, n_pairs, cfg);
+                std::free(pairs);
+            }
             return tigs;
         }
         case 2:

@@ -15,8 +15,9 @@
 //   2. pair every in-dart of a node with an out-dart, mirror-symmetrically: for dart e = (u -> v), j = slot of
 //      e^1 among the out-darts of mirror(v); succ[e] = out(v)[j] (self-mirror v: out(v)[j ^ 1]). By construction
 //      succ[succ[e] ^ 1] = e ^ 1, so the closed trails succ defines come in disjoint mirror pairs.
-//   3. label the trails (lock-free union-find over darts, root = smallest dart id); a biedge component is a
-//      trail together with its mirror trail.
+//   3. label the trail PAIRS (a trail together with its mirror trail) by a lock-free union-find over the BIEDGES (root = smallest
+//      biedge id): the passage e -> succ[e] and its mirror passage succ[e]^1 -> e^1 join the same two biedges, so one of the two
+//      does the union -- half the atomics and half the label arrays of a union-find over darts, same components.
 //   4. spanning forest over (biedge components x binodes): rounds of deterministic hooking -- every binode proposes,
 //      for each passage whose component differs from its passage 0's, to hang the larger component root below the
 //      smaller; a root accepts its smallest proposal (64-bit atomicMin) -- until every binode sees one component.
@@ -142,10 +143,13 @@ __global__ __launch_bounds__(EB) void iota_kernel(uint32_t *a, uint64_t n) {
     if (i < n) a[i] = (uint32_t)i;
 }
 
-// ---- step 3: trail labels ----------------------------------------------------------------------------------------
+// ---- step 3: labels of the trail pairs, over biedges ---------------------------------------------------------------
+// (the passage e -> f and its mirror f^1 -> e^1 name the same two biedges: the one with the smaller in-dart does the union)
 __global__ __launch_bounds__(EB) void union_succ_kernel(const uint32_t *succ, uint64_t n_darts, uint32_t *parent) {
     const uint64_t e = gid();
-    if (e < n_darts) uf_union(parent, (uint32_t)e, succ[e]);
+    if (e >= n_darts) return;
+    const uint32_t f = succ[e];
+    if ((uint32_t)e < (f ^ 1u)) uf_union(parent, (uint32_t)e >> 1, f >> 1);
 }
 // In place: parent[e] = root of e for EVERY e when the kernel ends. The find must not compress here: a path-halving store of
 // another thread (parent[e] = some ancestor it read earlier) could land after this thread's parent[e] = root and leave a
@@ -158,20 +162,8 @@ __global__ __launch_bounds__(EB) void flatten_kernel(uint32_t *parent, uint64_t 
     while ((next = __hip_atomic_load(&parent[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != cur) cur = next;
     __hip_atomic_store(&parent[e], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one thread per biedge, in place over the flattened trail labels: comp[e] = comp[e^1] = smaller trail label of the pair
-// {trail of e, trail of e^1}; the second union-find starts as identity
-__global__ __launch_bounds__(EB) void comp_kernel(uint32_t *label_to_comp, uint64_t n_biedges, uint32_t *parent2) {
-    const uint64_t b = gid();
-    if (b >= n_biedges) return;
-    const uint32_t a = label_to_comp[2 * b], c = label_to_comp[2 * b + 1];
-    const uint32_t m = a < c ? a : c;
-    label_to_comp[2 * b] = m;
-    label_to_comp[2 * b + 1] = m;
-    parent2[2 * b] = (uint32_t)(2 * b);
-    parent2[2 * b + 1] = (uint32_t)(2 * b + 1);
-}
-
 // ---- step 4: spanning forest (deterministic hooking rounds) + successor rotation ------------------------------
+// Component labels and roots are biedge ids (the smallest biedge of the trail pair / of the merged component).
 // Round: every binode proposes, for each passage i >= 1 whose component root differs from passage 0's, to hang the
 // LARGER root below the smaller one; a root keeps the smallest proposal (smaller target root, then smaller passage
 // dart) by a 64-bit atomicMin, so the outcome does not depend on thread timing. Roots only ever hang below smaller ids,
@@ -191,13 +183,13 @@ __device__ __forceinline__ void for_each_passage(const uint32_t *mirror, const u
     }
 }
 __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
-                                                    const uint32_t *comp, uint32_t *parent2, unsigned long long *best) {
+                                                    const uint32_t *comp, uint32_t *parent2, unsigned long long *best, uint32_t *proposed) {
     const uint64_t vi = gid();
     if (vi >= n_nodes) return;
     const uint32_t v = (uint32_t)vi;
     uint32_t r0 = 0;
     for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t, uint32_t b) {
-        const uint32_t r = uf_find(parent2, comp[b]);
+        const uint32_t r = uf_find(parent2, comp[b >> 1]);
         if (i == 0) {
             r0 = r;
             return;
@@ -207,20 +199,19 @@ __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uin
         const unsigned long long key = ((unsigned long long)lo << 32) | b;
         // a long trail receives one proposal per shared binode: filter the losers before they queue up on its word
         if (key < __hip_atomic_load(&best[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[hi], key);
+        *proposed = 1u;  // (every proposing thread stores the same value: a round without proposals ends the hooking)
     });
 }
 // `best` holds ~0 everywhere except at the roots that received a proposal this round; the kernel resets what it consumes,
 // so the array is cleared once per call and not once per round
-__global__ __launch_bounds__(EB) void hook_kernel(uint64_t n_darts, uint32_t *parent2, unsigned long long *best, uint32_t *selected,
-                                                 uint32_t *changed) {
+__global__ __launch_bounds__(EB) void hook_kernel(uint64_t n_biedges, uint32_t *parent2, unsigned long long *best, uint32_t *selected) {
     const uint64_t r = gid();
-    if (r >= n_darts) return;
+    if (r >= n_biedges) return;
     const unsigned long long p = best[r];
     if (p == ~0ull) return;
     best[r] = ~0ull;
     parent2[r] = (uint32_t)(p >> 32);  // r was a root when it was proposed for, and only this thread writes it
     selected[(uint32_t)p] = 1u;        // the passage whose out-dart this is joins its node's rotation
-    *changed = 1u;
 }
 __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
                                                    const uint32_t *selected, uint32_t *succ) {
@@ -259,7 +250,7 @@ __global__ __launch_bounds__(EB) void splitter_flag_kernel(const uint32_t *comp,
     bool root = false, split = false;
     if (in) {
         const uint32_t e = (uint32_t)i;
-        root = uf_find(parent2, comp[e]) == e;  // smallest dart of its connected component
+        root = !(e & 1u) && uf_find(parent2, comp[e >> 1]) == (e >> 1);  // smallest dart of its connected component
         split = root || hash_splitter(e);
         flag[e] = split ? 1u : 0u;
     }
@@ -405,17 +396,19 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small;
     uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1);
     uint32_t *d_adj = b_adj.alloc<uint32_t>(st, E);
-    uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, E);  // the second union-find
+    const uint64_t n_b = E / 2;  // biedges
+    // (scratch of the bucket build over all darts when there are no kept buckets, then the second union-find, over biedges)
+    uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, d_row0 ? n_b : E);
     uint32_t *d_succ = b_succ.alloc<uint32_t>(st, E);
-    uint32_t *d_comp = b_comp.alloc<uint32_t>(st, E);  // trail union-find -> trail labels -> component labels, in place
+    uint32_t *d_comp = b_comp.alloc<uint32_t>(st, n_b);  // union-find over biedges -> labels of the trail pairs, in place
     uint32_t *d_flag = b_flag.alloc<uint32_t>(st, E);
     uint32_t *d_sidx = b_sidx.alloc<uint32_t>(st, E);
     const uint64_t n_words = (E + 31) / 32;
     uint32_t *d_sbits = b_sbits.alloc<uint32_t>(st, n_words);
     uint32_t *d_rbits = b_rbits.alloc<uint32_t>(st, n_words);
-    unsigned long long *d_best = b_best.alloc<unsigned long long>(st, E);
+    unsigned long long *d_best = b_best.alloc<unsigned long long>(st, n_b);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(E) + 2);
-    uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] changed
+    uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] a binode proposed in this round
     uint32_t *d_error = d_small, *d_total = d_small + 1;
     HIP_CHECK(hipMemsetAsync(d_small, 0, 32, st));
     static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
@@ -435,30 +428,30 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("buckets");
     // 2. pairing, 3. trail labels
     succ_node_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_succ, d_error);
-    iota_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, E);
+    iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b);
     uint32_t h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: the graph is not Eulerian (greedytigs/mod.rs:708)");
     lap("pairing");
     union_succ_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, E, d_comp);
-    flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, E);
+    flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b);
     uint32_t *d_parent2 = d_pos2;
-    comp_kernel<<<grid_for(E / 2), EB, 0, st>>>(d_comp, E / 2, d_parent2);
+    iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
     lap("trail labels");
     // 4. merge the trails of every connected component
     HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`, reused as the splitter flags afterwards
-    HIP_CHECK(hipMemsetAsync(d_best, 0xFF, E * 8, st));
+    HIP_CHECK(hipMemsetAsync(d_best, 0xFF, n_b * 8, st));
     int hook_rounds = 0;
-    for (;; hook_rounds++) {
+    for (;; hook_rounds++) {  // (a round in which no binode sees two components is the last: nothing to hook, nothing to flatten)
         if (hook_rounds > 64) MTG_DIE("device_euler_cycles: internal error (component hooking does not converge)");
         HIP_CHECK(hipMemsetAsync(d_small + 4, 0, 4, st));
-        propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best);
-        hook_kernel<<<grid_for(E), EB, 0, st>>>(E, d_parent2, d_best, d_flag, d_small + 4);
-        flatten_kernel<<<grid_for(E), EB, 0, st>>>(d_parent2, E);
+        propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best, d_small + 4);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (!h_small[4]) break;
+        hook_kernel<<<grid_for(n_b), EB, 0, st>>>(n_b, d_parent2, d_best, d_flag);
+        flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
     }
     lap("hooking rounds");
     b_best.release();

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <vector>
 
@@ -358,11 +359,11 @@ __global__ __launch_bounds__(EB) void cut_flags_kernel(const uint32_t *rot, uint
 }
 __global__ __launch_bounds__(EB) void cut_write_kernel(const uint32_t *rot, uint64_t n, const uint32_t *keep, const uint32_t *end,
                                                       const uint32_t *kpos, const uint32_t *tpos, uint32_t *tig_edges,
-                                                      unsigned long long *tig_limits) {
+                                                      uint32_t *tig_limits) {
     const uint64_t q = gid();
     if (q >= n || !keep[q]) return;
     tig_edges[kpos[q]] = rot[q];
-    if (end[q]) tig_limits[tpos[q]] = (unsigned long long)kpos[q] + 1;
+    if (end[q]) tig_limits[tpos[q]] = kpos[q] + 1;  // (fewer than 2^31 biedges: the limits travel as 32-bit words and are widened on the host)
 }
 
 struct Lap {
@@ -437,8 +438,40 @@ static uint64_t host_available_bytes() {
     return avail;
 }
 
-Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6]) {
+// What the library keeps between calls on a GPU, given back on request (mtg_release_device_memory / mtg_graph_release_device_cache):
+// the finish's block cache, and a graph's device copy of its original edges with their buckets.
+void device_release_memory(int device_id) {
+    if (device_id < 0 || device_id >= device_count()) return;
+    HIP_CHECK(hipSetDevice(device_id));
+    HIP_CHECK(hipStreamSynchronize(finish_stream(device_id)));
+    device_block_cache(device_id).trim();
+}
+uint64_t device_memory_held(int device_id) {
+    if (device_id < 0 || device_id >= 64) return 0;
+    return device_block_cache(device_id).held_bytes();
+}
+void device_release_graph_cache(const HostGraph &g) {
+    std::lock_guard<std::mutex> l(edge_cache_mutex());
+    g.device_cache.reset();
+}
+
+// second stream per device: downloads that run beside the finish stream's kernels
+static hipStream_t finish_side_stream(int device_id) {
+    static hipStream_t streams[64] = {nullptr};
+    static std::mutex mu;
+    if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
+    std::lock_guard<std::mutex> l(mu);
+    if (!streams[device_id]) {
+        HIP_CHECK(hipSetDevice(device_id));
+        HIP_CHECK(hipStreamCreateWithFlags(&streams[device_id], hipStreamNonBlocking));
+    }
+    return streams[device_id];
+}
+
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6],
+                    const mtg_pair *d_pairs_resident) {
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
+    if (n_pairs && !pairs && !d_pairs_resident) MTG_DIE("device_finish: null pairs");
     if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
     if (k < 1 || k > 0xFFFFFFFFull) MTG_DIE("device_finish: k out of range");
     Walks tigs;
@@ -500,9 +533,14 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             d_adj0 = (const uint32_t *)cache->d_adj0;
         }
     }
-    mtg_pair *d_pairs = b_pairs.alloc<mtg_pair>(st, n_pairs);
+    // the pairs: where the claim replay left them in this GPU's HBM, else uploaded
+    const mtg_pair *d_pairs = d_pairs_resident;
+    if (!d_pairs) {
+        mtg_pair *up = b_pairs.alloc<mtg_pair>(st, n_pairs);
+        if (n_pairs) HIP_CHECK(hipMemcpyAsync(up, pairs, n_pairs * sizeof(mtg_pair), hipMemcpyHostToDevice, st));
+        d_pairs = up;
+    }
     uint32_t *d_deg = b_deg.alloc<uint32_t>(st, V);
-    if (n_pairs) HIP_CHECK(hipMemcpyAsync(d_pairs, pairs, n_pairs * sizeof(mtg_pair), hipMemcpyHostToDevice, st));
     if (d_row0) row_degree_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row0, d_deg);
     else {
         HIP_CHECK(hipMemsetAsync(d_deg, 0, V * 4, st));
@@ -601,23 +639,22 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     // by a thread of their own while the GPU decomposes and cuts (joined at the end). ----
     Buf b_to;
     std::thread append_thread;
-    hipEvent_t ev_appended = nullptr;
+    hipEvent_t ev_heads = nullptr;
+    std::unique_ptr<uint32_t[]> h_pw;  // resident pairs: their weights for the host graph (4 of the 16 bytes of a pair); not zero-filled
     {
-        bool long_pair = false;
-        for (uint64_t i = 0; i < n_pairs && !long_pair; i++) long_pair = pairs[i].distance >= k;
+        bool long_pair = false;  // (resident pairs come from the claim loop: every distance is <= k - 1)
+        for (uint64_t i = 0; pairs && i < n_pairs && !long_pair; i++) long_pair = pairs[i].distance >= k;
         uint32_t *d_to = b_to.alloc<uint32_t>(st, n_dummy);
         if (n_dummy) head_kernel<<<grid_for(n_dummy), EB, 0, st>>>(d_from, d_mirror, E0, E, d_to);
         HIP_CHECK(hipGetLastError());
         g.append_unlinked(n_dummy);
-        if (n_dummy) {
-            HIP_CHECK(hipMemcpyAsync(g.e_from.data() + E0, d_from + E0, n_dummy * 4, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipMemcpyAsync(g.e_to.data() + E0, d_to, n_dummy * 4, hipMemcpyDeviceToHost, st));
-        }
-        auto fill = [&g, pairs, n_pairs, k, E0, n_dummy]() {  // weights, dummy ids (1-based, :681 / mod.rs:573)
+        if (!pairs) h_pw.reset(new uint32_t[std::max<uint64_t>(n_pairs, 1)]);
+        uint32_t *h_pw_p = h_pw.get();
+        auto fill = [&g, pairs, h_pw_p, n_pairs, k, E0, n_dummy]() {  // weights, dummy ids (1-based, :681 / mod.rs:573)
             parallel_ranges(n_dummy / 2, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) {
                     const uint64_t e = E0 + 2 * i;
-                    const uint64_t w = i < n_pairs ? pairs[i].distance : k;
+                    const uint64_t w = i < n_pairs ? (pairs ? pairs[i].distance : (uint64_t)h_pw_p[i]) : k;
                     g.e_weight[e] = g.e_weight[e + 1] = w;
                     g.e_dummy[e] = g.e_dummy[e + 1] = i + 1;
                     g.e_unitig[e] = g.e_unitig[e + 1] = 0;
@@ -626,13 +663,30 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 }
             });
         };
+        // copies into the (pageable) host arrays keep the calling thread until they are done: 0.45 GB = 10 ms at 2^27
+        auto download = [&g, h_pw_p, d_from, d_to, d_pw, pairs, n_pairs, E0, n_dummy](hipStream_t s) {
+            if (!pairs && n_pairs) HIP_CHECK(hipMemcpyAsync(h_pw_p, d_pw, n_pairs * 4, hipMemcpyDeviceToHost, s));
+            if (n_dummy) {
+                HIP_CHECK(hipMemcpyAsync(g.e_from.data() + E0, d_from + E0, n_dummy * 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(g.e_to.data() + E0, d_to, n_dummy * 4, hipMemcpyDeviceToHost, s));
+            }
+            HIP_CHECK(hipStreamSynchronize(s));
+        };
         if (euler_mode == MTG_EULER_DEVICE && n_dummy >= (1u << 20)) {
-            HIP_CHECK(hipEventCreateWithFlags(&ev_appended, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(ev_appended, st));  // (behind the two copies)
-            append_thread = std::thread(fill);
+            // nothing on the host needs the dummy edges before the call returns: a thread of its own brings them down on the
+            // device's side stream and writes the 33 bytes per dart while the GPU decomposes and cuts (joined at the end)
+            HIP_CHECK(hipEventCreateWithFlags(&ev_heads, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ev_heads, st));  // (behind the dart, weight and head kernels)
+            append_thread = std::thread([download, fill, ev_heads, device_id]() {
+                HIP_CHECK(hipSetDevice(device_id));
+                hipStream_t side = finish_side_stream(device_id);
+                HIP_CHECK(hipStreamWaitEvent(side, ev_heads, 0));
+                download(side);
+                fill();
+            });
         } else {
+            download(st);
             fill();
-            HIP_CHECK(hipStreamSynchronize(st));
         }
         g.first_breaking_edge = first_brk;
         g.breaking_weight = k;
@@ -792,19 +846,19 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipStreamSynchronize(st));
         const uint64_t n_kept = h_small[7], n_tigs = h_small[8];
         uint32_t *d_te = b_te.alloc<uint32_t>(st, n_kept);
-        unsigned long long *d_tl = b_tl.alloc<unsigned long long>(st, n_tigs);
+        uint32_t *d_tl = b_tl.alloc<uint32_t>(st, n_tigs);
         cut_write_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_keep, d_end, d_kpos, d_tpos, d_te, d_tl);
         HIP_CHECK(hipGetLastError());
         tigs.edges.resize(n_kept);
         tigs.limits.resize(n_tigs);
         download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
-        download_sliced(tigs.limits.data(), d_tl, n_tigs * 8, st, device_id);
+        // (the limits cross PCIe as 32-bit words and are widened by the host threads that empty the download ring)
+        download_sliced_widen(tigs.limits.data(), d_tl, n_tigs, st, device_id);
     }
     if (times_out) times_out[3] = lap.lap("rotate + cut + download");
     if (append_thread.joinable()) {
         append_thread.join();
-        HIP_CHECK(hipEventSynchronize(ev_appended));
-        HIP_CHECK(hipEventDestroy(ev_appended));
+        HIP_CHECK(hipEventDestroy(ev_heads));
         const double waited = lap.lap("host graph: dummy edges (rest, after the GPU stages)");
         if (times_out) times_out[1] += waited;
     }

@@ -119,9 +119,11 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 // boxes the twelve allocations at the head of the Euler decomposition then took 0.5 to 4.7 s on some steps, nothing on the others.)
 // All users run on the one finish stream of their device, so a block released earlier on that stream is free when it is used again.
 struct DeviceBlockCache {
+    struct Kept { void *p; uint64_t gen; };
     std::mutex m;
-    std::multimap<size_t, void *> free_blocks;
+    std::multimap<size_t, Kept> free_blocks;
     size_t held = 0;
+    uint64_t gen = 1;  // number of the running call: a block given back carries it
     static constexpr size_t GRAIN = 1u << 20, HOLD_LIMIT = 192ull << 30;
     static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 1) + GRAIN - 1) / GRAIN * GRAIN; }
     // the smallest kept block that holds `bytes` and is at most twice as large (a stage's arrays fit the blocks an earlier stage of
@@ -133,7 +135,7 @@ struct DeviceBlockCache {
             std::lock_guard<std::mutex> lock(m);
             auto it = free_blocks.lower_bound(want);
             if (it != free_blocks.end() && it->first <= 2 * want) {
-                void *p = it->second;
+                void *p = it->second.p;
                 *block_bytes = it->first;
                 held -= it->first;
                 free_blocks.erase(it);
@@ -153,21 +155,43 @@ struct DeviceBlockCache {
         {
             std::lock_guard<std::mutex> lock(m);
             if (held + block_bytes <= HOLD_LIMIT) {
-                free_blocks.emplace(block_bytes, p);
+                free_blocks.emplace(block_bytes, Kept{p, gen});
                 held += block_bytes;
                 return;
             }
         }
         (void)hipFree(p);  // (more than HOLD_LIMIT kept already: calls of that size are trimmed at their end anyway)
     }
+    // End of a call: what it did not touch goes back to the driver, so the cache never holds more than the last call's own arrays
+    // (a driver that finishes graphs of different sizes would otherwise collect blocks of every size it has ever seen, out of
+    // reach of the other allocators of the process).
+    void end_call() {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (auto it = free_blocks.begin(); it != free_blocks.end();) {
+                if (it->second.gen < gen) {
+                    drop.push_back(it->second.p);
+                    held -= it->first;
+                    it = free_blocks.erase(it);
+                } else ++it;
+            }
+            gen++;
+        }
+        for (void *p : drop) (void)hipFree(p);
+    }
     void trim() {
-        std::multimap<size_t, void *> drop;
+        std::multimap<size_t, Kept> drop;
         {
             std::lock_guard<std::mutex> lock(m);
             drop.swap(free_blocks);
             held = 0;
         }
-        for (auto &kv : drop) (void)hipFree(kv.second);
+        for (auto &kv : drop) (void)hipFree(kv.second.p);
+    }
+    size_t held_bytes() {
+        std::lock_guard<std::mutex> lock(m);
+        return held;
     }
 };
 inline DeviceBlockCache &device_block_cache(int device_id) {
@@ -188,6 +212,19 @@ inline void device_malloc(T **p, size_t bytes) {
     HIP_CHECK(hipMalloc((void **)p, bytes));
 }
 
+// One stream per device for the finishing stages, created on first use.
+inline hipStream_t finish_stream(int device_id) {
+    static hipStream_t streams[64] = {nullptr};
+    static std::mutex mu;
+    if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
+    std::lock_guard<std::mutex> l(mu);
+    if (!streams[device_id]) {
+        HIP_CHECK(hipSetDevice(device_id));
+        HIP_CHECK(hipStreamCreate(&streams[device_id]));
+    }
+    return streams[device_id];
+}
+
 struct Buf {
     void *p = nullptr;
     size_t bytes = 0, block_bytes = 0;
@@ -201,9 +238,11 @@ struct Buf {
         p = nullptr;
     }
     template <typename T>
-    T *alloc(hipStream_t, uint64_t n) {  // (the stream says nothing any more: blocks are ordered by the device's one finish stream)
+    T *alloc(hipStream_t st, uint64_t n) {
         release();
         HIP_CHECK(hipGetDevice(&device));
+        // a kept block is reused without an event in between: that is only ordered if every user works on the device's one finish stream
+        if (st != finish_stream(device)) MTG_DIE("hu::Buf: work arrays of the finishing stages belong on the finish stream of device %d", device);
         bytes = (n ? n : 1) * sizeof(T);
         p = device_block_cache(device).take(bytes, &block_bytes);
         return (T *)p;
@@ -211,19 +250,6 @@ struct Buf {
     template <typename T>
     T *as() const { return (T *)p; }
 };
-
-// One stream per device for the finishing stages, created on first use.
-inline hipStream_t finish_stream(int device_id) {
-    static hipStream_t streams[64] = {nullptr};
-    static std::mutex mu;
-    if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
-    std::lock_guard<std::mutex> l(mu);
-    if (!streams[device_id]) {
-        HIP_CHECK(hipSetDevice(device_id));
-        HIP_CHECK(hipStreamCreate(&streams[device_id]));
-    }
-    return streams[device_id];
-}
 
 // ---- device-resident original edges of a host graph (HostGraph::device_cache) ----
 inline void edge_cache_free(DeviceEdgeCache *c) {
@@ -283,14 +309,12 @@ inline void edge_cache_set_buckets(const HostGraph &g, int device, uint32_t *d_r
 // of the ring (a plain hipMemcpy into pageable memory is staged by the runtime on one thread: 15-20 GB/s here). Synchronises the
 // stream. Small copies take the plain path.
 constexpr int MAX_FINISH_DEVICES = 64;
-inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStream_t st, int device_id) {
+// `put(dst_offset_bytes_of_the_source, src, n_bytes)` moves a piece of a slice from the ring to its place: a plain memcpy, or a
+// conversion on the way (download_sliced_widen below)
+template <typename Put>
+inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st, int device_id, Put &&put) {
     constexpr size_t SLICE = 16u << 20;
     constexpr int NS = 4;
-    if (bytes < 4 * SLICE) {
-        if (bytes) HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        return;
-    }
     struct Ring {
         std::mutex m;  // one download at a time per device
         char *slot[NS] = {nullptr, nullptr, nullptr, nullptr};
@@ -315,8 +339,8 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
             while (recorded.load(std::memory_order_acquire) < (long)i) std::this_thread::yield();
             HIP_CHECK(hipEventSynchronize(r.ev[i % NS]));
             const size_t off = i * SLICE, n = std::min(SLICE, bytes - off);
-            const size_t a0 = n * t / T, a1 = n * (t + 1) / T;
-            std::memcpy((char *)dst + off + a0, r.slot[i % NS] + a0, a1 - a0);
+            const size_t a0 = (n / 8 * t / T) * 8, a1 = t + 1 == T ? n : (n / 8 * (t + 1) / T) * 8;  // (8-byte aligned shares)
+            put(off + a0, r.slot[i % NS] + a0, a1 - a0);
             done[i].fetch_add(1, std::memory_order_release);
         }
     };
@@ -333,12 +357,35 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
     for (auto &x : th) x.join();
     HIP_CHECK(hipStreamSynchronize(st));
 }
+inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStream_t st, int device_id) {
+    if (bytes < (64u << 20)) {
+        if (bytes) HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return;
+    }
+    download_sliced_with(d_src, bytes, st, device_id, [dst](size_t off, const char *src, size_t n) { std::memcpy((char *)dst + off, src, n); });
+}
+// n 32-bit words on the device -> n 64-bit words on the host: half the bytes over PCIe, widened by the threads that empty the ring
+inline void download_sliced_widen(uint64_t *dst, const uint32_t *d_src, size_t n, hipStream_t st, int device_id) {
+    if (n * 4 < (64u << 20)) {
+        std::vector<uint32_t> tmp(n);
+        if (n) HIP_CHECK(hipMemcpyAsync(tmp.data(), d_src, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; i++) dst[i] = tmp[i];
+        return;
+    }
+    download_sliced_with(d_src, n * 4, st, device_id, [dst](size_t off, const char *src, size_t bytes) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
+        uint64_t *out = dst + off / 4;
+        for (size_t i = 0; i < bytes / 4; i++) out[i] = w[i];
+    });
+}
 
 // Gives the finish's kept device blocks back to the driver when a call worked on more than `threshold` bytes (small calls keep
 // their arrays for the next one).
 inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 32ull << 30) {
-    if (bytes_used < threshold) return;
-    device_block_cache(device_id).trim();
+    if (bytes_used < threshold) device_block_cache(device_id).end_call();  // (keeps this call's arrays, frees what it did not touch)
+    else device_block_cache(device_id).trim();
 }
 
 }  // namespace hu

@@ -189,6 +189,108 @@ def test_device_finish_device_euler_invariants(gpu, idx):
     assert np.array_equal(np.sort(orig >> 1), np.arange(bg.n_edges // 2, dtype=orig.dtype))
 
 
+def _resident(bg, k):
+    """Device graph of bg with the claim replay's pairs left in HBM (mtg_replay_claims_resident)."""
+    from matchtigs_amd import api, torch_glue
+
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify()
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    n = dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr())
+    return G, dev, n
+
+
+@pytest.mark.parametrize("idx", range(N_CASES))
+def test_resident_pairs_finish_equals_finish_from_host_pairs(gpu, idx):
+    """The pairs never leave the GPU between claim replay and finish (what mtg_compute_tigs_cfg does): same pair list as the
+    downloading replay, same graph afterwards and same tigs as the finish that is handed host pairs -- both Euler modes."""
+    from matchtigs_amd import api
+
+    name, bg = case(idx)
+    k = bg.k
+    pairs = _pairs_of(bg, k)
+    G, dev, n = _resident(bg, k)
+    assert n == len(pairs)
+    got = dev.download_resident_pairs()
+    assert np.array_equal(got, pairs), name
+    for mode in (api.EulerMode.HostReferenceOrder, api.EulerMode.Device):
+        A, B = _graphs(bg)
+        lim_a, ed_a = api.finish_greedytigs_np(A, pairs, k, euler_mode=mode, finish_stage=api.FinishStage.Device)
+        lim_b, ed_b = api.finish_greedytigs_resident_np(B, dev, k, euler_mode=mode, finish_stage=api.FinishStage.Device)
+        _same_graph(A, B)
+        assert np.array_equal(lim_a, lim_b) and np.array_equal(ed_a, ed_b), (name, mode)
+    # finish_stage HOST: the resident pairs take the way through the host
+    A, B = _graphs(bg)
+    lim_a, ed_a = api.finish_greedytigs_np(A, pairs, k, finish_stage=api.FinishStage.Host)
+    lim_b, ed_b = api.finish_greedytigs_resident_np(B, dev, k, finish_stage=api.FinishStage.Host)
+    _same_graph(A, B)
+    assert np.array_equal(lim_a, lim_b) and np.array_equal(ed_a, ed_b), name
+
+
+def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(gpu):
+    """A graph with more than 2^20 dummy darts: in device Euler mode the dummy edges reach the host graph on a side stream from a
+    thread of their own, the tig limits travel as 32-bit words. Graph and tigs as after the finish from host pairs, twice."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    k = 31
+    G = synth.g_csr_device(1 << 21, seed=5, k=k)
+    ex = G.export()
+    bg = synth.Bigraph(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"], k)
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify()
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    n = dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr())
+    pairs = dev.download_resident_pairs()
+    assert n == len(pairs) > 0
+    H = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    lim_h, ed_h = api.finish_greedytigs_np(H, pairs, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    assert H.edge_count() - bg.n_edges >= 1 << 20
+    eh = H.export()
+    for _ in range(2):
+        lim_d, ed_d = api.finish_greedytigs_resident_np(G, dev, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+        eg = G.export()
+        for key in eh:
+            assert np.array_equal(eh[key], eg[key]), key
+        assert np.array_equal(lim_h, lim_d) and np.array_equal(ed_h, ed_d)
+        G.reset()
+    # ... and the host Euleriser agrees on the graph
+    H2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    api.finish_greedytigs_np(H2, pairs, k, finish_stage=api.FinishStage.Host)
+    e2 = H2.export()
+    for key in eh:
+        assert np.array_equal(eh[key], e2[key]), key
+
+
+def test_kept_device_memory_is_bounded_and_can_be_released(gpu):
+    """The finish keeps the work arrays of its LAST call only (a smaller call after a larger one frees what it did not touch), and
+    mtg_release_device_memory / mtg_graph_release_device_cache return everything; results do not change."""
+    from matchtigs_amd import api, synth
+
+    k = 31
+    small = synth.g_csr(3000, seed=22, k=k)
+    api.release_device_memory(0)
+    assert api.device_memory_held(0) == 0
+    GB = synth.g_csr_device(1 << 20, seed=21, k=k)  # work arrays of tens of MB (blocks are kept in units of 1 MB)
+    dev = api.DeviceGraph(GB, k)
+    dev.classify()
+    pb = api.compute_pairs([dev])
+    del dev
+    want = api.finish_greedytigs_np(GB, pb, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    held_big = api.device_memory_held(0)
+    assert held_big > 0
+    GS = api.Bigraph.from_edges(small.mirror, small.edge_from, small.edge_to, small.edge_weight)
+    ps = _pairs_of(small, k)
+    api.finish_greedytigs_np(GS, ps, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    assert api.device_memory_held(0) < held_big  # the large call's arrays are gone
+    api.release_device_memory(0)
+    assert api.device_memory_held(0) == 0
+    GB.reset()
+    GB.release_device_cache()
+    again = api.finish_greedytigs_np(GB, pb, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    assert np.array_equal(want[0], again[0]) and np.array_equal(want[1], again[1])
+
+
 @pytest.mark.parametrize("args", [
     dict(n_binodes=12, seed=9, k=7, mean_weight=2.0, self_mirror_frac=0.2),
     dict(n_binodes=300, seed=3, k=5, mean_weight=2.0, self_mirror_frac=0.05),
