@@ -65,8 +65,41 @@ def size_label(log2_edges: int) -> str:
     if log2_edges <= 25:
         return "C. elegans-like"
     if log2_edges <= 29:
-        return "human-like"
-    return "human-like (full) / pangenome-like"
+        return "human-like (inside SURVEY 8's estimate of a human genome's unitig count, U = 10^7..10^8; the nominal size of SURVEY 8d is 2^30)"
+    if log2_edges == 30:
+        return "human nominal (SURVEY 8d: 2^30)"
+    return "661k-pangenome-like (SURVEY 8d: 2^31)"
+
+
+def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, visits: int, kept: int, tigs: int) -> dict:
+    """Algorithmic bytes per stage of ONE step = the sum over the stage's kernels of the arrays each must read and write once
+    (a gathered array counts once per gathering pass; DESIGN.md 3.9 derives every term). V nodes, E0 original darts, P matched
+    pairs, N Euleriser units, E darts after the finish, D = E - E0 dummy darts, n = E / 2 biedges, M = E / 64 splitters."""
+    D, n = E - E0, E // 2
+    M = E // 64 + 1
+    import math
+    wy = max(1, math.ceil(math.log2(2 * M)))
+    buckets = 32 * V + 44 * D + 4 * E0 + 4 * E  # dummy darts bucketed + one streaming merge with the kept buckets of the original darts
+    return {
+        "classify": 18 * V + 4 * S,                                # classify (odeg, mirror -> mult, cls) + compaction (cls -> out_nodes)
+        # state copy 17 V; dense list + claims words + pair-count scan 48 S; admission 187 B per listed source; 67.2 B per check
+        # visit (DESIGN 3.5); compaction 32 B per pair
+        "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
+        "insert_eulerise": 88 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
+        "decomposition": buckets + 48 * V + int(104.4 * E) + (100 + 16 * wy) * M,
+        "records": buckets + 732 * V + 12 * E,
+        "cut": 108 * n + 4 * P + 4 * kept + 4 * tigs,
+    }
+
+
+def stage_traffic(args, world: int, mode: str):
+    """PMC traffic per stage (profiles/stage_traffic.json, tools/stage_traffic.py over separate rocprofv3 --pmc passes of this very
+    command) for this workload and Euler mode, or {}."""
+    try:
+        allj = json.loads((ROOT / "profiles" / "stage_traffic.json").read_text())
+    except (OSError, ValueError):
+        return {}
+    return (allj.get(f"{workload_key(args, world)}:{mode}") or {}).get("stages", {})
 
 
 def host_cores() -> int:
@@ -102,6 +135,10 @@ def main():
     ap.add_argument("--device-mode-steps", type=int, default=None,
                     help="timed steps of the second mode (device Euler decomposition) after the headline region, reported as "
                          "the device_mode block (default: as many as --steps)")
+    ap.add_argument("--no-cold-steps", dest="cold_steps", action="store_false", help="skip the two cold (first-call) steps")
+    ap.add_argument("--full-size-log2", type=int, default=30,
+                    help="after the timed regions: ONE device-mode step at this G-csr size (SURVEY 8d's nominal human size) when the box "
+                         "has the memory (>= 170 GB of HBM and >= 140 GB of host memory free); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
@@ -160,6 +197,7 @@ def main():
 
     bufs = None
     result_info: dict = {}
+    count_ref = [None]  # the candidate counts of the last step (number of sources with candidates, for the replay's byte model)
 
     def sync_barrier():
         torch.cuda.synchronize()
@@ -175,7 +213,9 @@ def main():
         cuts = api.partition_sources(dev, world)
         ranges_by_work = [(cuts[r], cuts[r + 1]) for r in range(world)]
 
-    def step(mode, acc, kernel_ms=None, level_ms=None):
+    stage_ms: dict[str, dict[str, list]] = {"host": {}, "device": {}}  # per Euler mode: stage -> GPU ms (HIP events) of every timed step
+
+    def step(mode, acc, kernel_ms=None, level_ms=None, stages=None):
         nonlocal bufs
         ph = {}
         t0 = time.perf_counter()
@@ -217,6 +257,7 @@ def main():
                     pairs = dev.replay_claims_device(start_all.data_ptr(), count_all.data_ptr(), pool_all.data_ptr(), stream)
                     n_pairs = len(pairs)
                 po = pool_all
+                count_ref[0] = count_all
                 result_info["replay_rounds"] = dev.last_replay_rounds()
                 result_info["replay_visits"] = dev.last_replay_visits()
             else:
@@ -235,6 +276,13 @@ def main():
             ph["insert_eulerise"], ph["euler"], ph["cut"] = hp["eulerise"], hp["euler"], hp["cut"]
             if mode == api.EulerMode.Device:
                 ph["euler_device_kernels"] = api.last_euler_kernel_ms() * 1e-3
+            if stages is not None and not args.host_finish and not args.host_replay:
+                fs = api.last_finish_device_stage_ms()
+                rp = dev.last_replay_ms()
+                for kk, v in (("replay_rounds_kernel", rp["rounds_kernel_ms"]), ("replay", rp["gpu_ms"]), ("insert_eulerise", fs["insert_eulerise_ms"]),
+                              ("records", fs["records_ms"]), ("decomposition", fs["decomposition_ms"]), ("cut", fs["cut_ms"])):
+                    stages.setdefault(kk, []).append(v)
+                result_info.update(darts=fs["darts"], units=fs["units"])
             result_info.update(S=int(S), pairs=int(n_pairs), tigs=int(len(tigs_lim)), tig_edges=int(len(tigs_edges)),
                                candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
             del tigs_lim, tigs_edges
@@ -248,9 +296,10 @@ def main():
         for _ in range(n_warm):
             step(mode, {})
         sync_barrier()
+        stages = stage_ms["device" if mode == api.EulerMode.Device else "host"]
         t_begin = time.perf_counter()
         for _ in range(n_steps):
-            step(mode, acc, kernel_ms, level_ms)
+            step(mode, acc, kernel_ms, level_ms, stages)
         sync_barrier()
         elapsed = time.perf_counter() - t_begin
         if world > 1:
@@ -258,6 +307,38 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed / max(n_steps, 1) * 1e3, acc
+
+    # ---- cold steps: the FIRST step on a fresh graph, as a one-shot caller sees it (the reference is only ever used that way):
+    # nothing kept from an earlier call -- the library's device block cache is released, the graph has no device buckets, no
+    # page-locked arena, the candidate buffers are new. Each mode gets a graph of its own; the device-graph build is reported beside.
+    cold = None
+    if world == 1 and args.cold_steps and args.workload == "g_csr":
+        cold = {}
+        for name, mode in (("device", api.EulerMode.Device), ("host", euler_mode)):
+            if name == "host" and args.euler == "device":
+                continue
+            api.release_device_memory(local_rank)
+            t0c = time.perf_counter()
+            g2 = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k, device_id=local_rank)
+            t1c = time.perf_counter()
+            d2 = api.DeviceGraph(g2, k, local_rank)
+            d2.set_plan(args.plan)
+            torch.cuda.synchronize()
+            t2c = time.perf_counter()
+            keep = (graph, dev, bufs)
+            graph, dev, bufs = g2, d2, None
+            phc: dict[str, float] = {}
+            step(mode, phc)
+            torch.cuda.synchronize()
+            t3c = time.perf_counter()
+            cold[name] = {"step_ms": round((t3c - t2c) * 1e3, 2), "device_graph_build_ms": round((t2c - t1c) * 1e3, 2),
+                          "generate_ms": round((t1c - t0c) * 1e3, 2), "phases_ms": {kk: round(v * 1e3, 2) for kk, v in phc.items()}}
+            graph, dev, bufs = keep
+            del g2, d2
+            torch.cuda.empty_cache()
+        api.release_device_memory(local_rank)
+        cold["note"] = ("first step on a fresh graph after mtg_release_device_memory: device work arrays allocated, buckets of the original "
+                        "darts built, host result arrays and the walk's arena mapped for the first time")
 
     # ---- second mode, first class: the same step with the parallel Euler decomposition on the GPU, in its own timed region.
     # It runs BEFORE the headline region: the two modes use different sets of device work arrays, and the runtime's stream-ordered
@@ -280,9 +361,12 @@ def main():
     S = dev.n_sources
     lo, hi = (ranges_by_work if ranges_by_work is not None else mdist.partition_sources(S, world))[rank]
     stats = dev.sssp_count(lo, hi, stream)
+    # ... and what the goal-directed search really visits (pruned by the nearest-in-node lower bounds): the bytes the stage needs
+    visited = dev.sssp_count_visited(lo, hi, stream) if dev.prunes() else None
     local_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+    vz = visited or {"relaxed_edges": 0, "settled_nodes": 0, "emitted": 0, "sources": 0}
     tot = torch.tensor([stats["relaxed_edges"], stats["settled_nodes"], stats["emitted"], stats["relax_attempts"],
-                        stats["overflow_sources"]], dtype=torch.int64, device="cuda")
+                        stats["overflow_sources"], vz["relaxed_edges"], vz["settled_nodes"], vz["emitted"], vz["sources"]], dtype=torch.int64, device="cuda")
     # per-N scaling figures of the stages that DO shard (the whole step is bound by rank 0's finish): max over ranks
     kmax = torch.tensor([local_kernel_ms, phases_acc.get("sssp", 0.0) / max(args.steps, 1) * 1e3,
                          phases_acc.get("allgather", 0.0) / max(args.steps, 1) * 1e3], dtype=torch.float64, device="cuda")
@@ -292,10 +376,16 @@ def main():
     tot = [int(x) for x in tot.tolist()]
     kmax = [float(x) for x in kmax.tolist()]
     total_stats = dict(relaxed_edges=tot[0], settled_nodes=tot[1], emitted=tot[2], relax_attempts=tot[3], overflow_sources=tot[4])
+    total_visited = dict(relaxed_edges=tot[5], settled_nodes=tot[6], emitted=tot[7], searched_sources=tot[8]) if visited else None
 
+    device_graph_bytes = dev.graph_bytes()
     if rank == 0:
-        # roofline of the dominant GPU stage (the SSSP stage = its level kernels) on THIS rank's launch
-        alg_bytes = algorithmic_bytes(stats)
+        # roofline of the dominant GPU stage of the sharded part (the SSSP stage = its level kernels) on THIS rank's launch.
+        # Bytes: SURVEY 8d's per-unit figures x the units the launch really processes -- with the goal-directed pruning that is the
+        # visited set (mtg_sssp_count_visited), not the full balls; the full-ball figure is kept beside it as the throughput in the
+        # reference's units (a full-ball Dijkstra's edges per second).
+        alg_bytes_full = algorithmic_bytes(stats)
+        alg_bytes = algorithmic_bytes(visited) if visited else alg_bytes_full
         achieved = alg_bytes / (local_kernel_ms * 1e-3) / 1e9 if local_kernel_ms > 0 else 0.0
         kernels = []
         if level_ms:
@@ -310,13 +400,49 @@ def main():
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic, "traffic_note": traffic_note,
+            "bytes_note": ("algorithmic bytes = 5 B x relaxed edges + 12 B x settled nodes + 12 B x candidates of the search the launch runs: "
+                           "the goal-directed (pruned) search when the device graph carries lower bounds (units in 'visited_per_step'), "
+                           "else full balls; 'full_ball_equivalent' prices the same time against the full-ball units of 'units_per_step'"),
             "gather_ceiling_note": "dependent random 64-B block gathers saturate at ~54 G/s below 3 GB of blocks and at ~44 G/s (one request "
-                                   "per lane and line; 19 G/s with four) at 5.7 GB, tools/gather_bench_tlb.hip: floor for the enumeration "
-                                   "level = visited family blocks (~0.55 x settled_nodes) / that rate",
+                                   "per lane and line; 19 G/s with four) at 5.7 GB, tools/gather_bench_tlb.hip",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(local_kernel_ms, 4),
+            "full_ball_equivalent": {"algorithmic_bytes_per_launch": alg_bytes_full,
+                                     "achieved": round(alg_bytes_full / (local_kernel_ms * 1e-3) / 1e9, 3) if local_kernel_ms > 0 else 0.0,
+                                     "frac": round(alg_bytes_full / (local_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if local_kernel_ms > 0 else 0.0},
             "kernel_sssp_edges_per_s": round(stats["relaxed_edges"] / (local_kernel_ms * 1e-3), 1) if local_kernel_ms > 0 else 0.0,
             "work_efficiency_attempts_per_edge": round(stats["relax_attempts"] / max(stats["relaxed_edges"], 1), 4),
         }
+        # ---- the other GPU stages of the step, each against the HBM roofline: GPU time from HIP events inside the engine (on the
+        # stream the kernels run on), algorithmic bytes from stage_models(), counter traffic from profiles/stage_traffic.json ----
+        roofline_stages = None
+        if world == 1 and (stage_ms["host"] or stage_ms["device"]):
+            count_last = count_ref[0]
+            n_dense = int((count_last > 0).sum().item()) if count_last is not None else 0
+            models = stage_models(n_nodes, n_edges, result_info.get("pairs", 0), result_info.get("units", 0), result_info.get("darts", 0),
+                                  result_info.get("S", 0), n_dense, result_info.get("replay_visits") or 0, result_info.get("tig_edges", 0),
+                                  result_info.get("tigs", 0))
+            names = {"replay": "claim replay: replay_state_init + dense list + replay_rounds_kernel + pair-count scan + compaction",
+                     "insert_eulerise": "matched-pair darts + Euleriser: degree / need / 3 scans / expand / zip_check / zip_emit / head kernels",
+                     "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, splitter walks, ranking, write",
+                     "records": "walk records (reference-order mode): bucket merge + lean_build + wide_build kernels (the records' download is not in it)",
+                     "cut": "rotate + cut: cycle heads / rotation / rotate_cycles / cut_flags / 3 scans / cut_write (the tig download is not in it)"}
+            roofline_stages = []
+            for mode_name in ("device", "host"):
+                tr = stage_traffic(args, world, mode_name)
+                for st_name in ("replay", "insert_eulerise", "decomposition", "records", "cut"):
+                    vals = [v for v in stage_ms[mode_name].get(st_name, []) if v > 0]
+                    if not vals:
+                        continue
+                    ms = float(np.mean(vals))
+                    b = models[st_name]
+                    entry = {"stage": st_name, "euler_mode": mode_name, "kernels": names[st_name], "bound": "hbm", "avg_launch_ms": round(ms, 4),
+                             "algorithmic_bytes": int(b), "achieved": round(b / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "traffic": (tr.get(st_name) or {}).get("traffic_bytes")}
+                    if st_name == "replay":
+                        rk = [v for v in stage_ms[mode_name].get("replay_rounds_kernel", []) if v > 0]
+                        entry["rounds_kernel_ms"] = round(float(np.mean(rk)), 4) if rk else None
+                    roofline_stages.append(entry)
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             ex = graph.export()
@@ -326,9 +452,22 @@ def main():
             del bg
             gpu_stage_s = sum(phases_acc.get(kk, 0.0) for kk in ("classify", "sssp", "allgather", "download", "replay")) / max(args.steps, 1)
             cpu_baseline["gpu_same_stage_edges_per_s"] = round(total_stats["relaxed_edges"] / max(gpu_stage_s, 1e-9), 1)
+            if "stage" in cpu_baseline and args.workload == "g_csr" and args.log2_edges > 24:
+                # the WHOLE path on the CPU next to the whole step on the GPU: the oracle's literal Hierholzer does not finish the bench
+                # graph in the budget, so both run on a bounded sample of the same workload family (G-csr 2^24, same generator and seed)
+                cpu_baseline["whole_path_sample"] = whole_path_sample(args, k, local_rank)
         extra_seeds = None
         if world == 1 and args.workload == "g_csr" and args.extra_seeds:
             extra_seeds = sssp_stage_of_seeds(args, [int(x) for x in args.extra_seeds.split(",") if x.strip()], local_rank)
+        # ---- one step at SURVEY 8d's nominal human size, after everything else (the 2^27 graph is given back first) ----
+        full_size = None
+        if world == 1 and args.workload == "g_csr" and args.full_size_log2 and args.full_size_log2 > args.log2_edges >= 26:  # (the headline configuration only)
+            del dev, graph, bufs
+            dev = graph = bufs = None
+            count_ref[0] = None
+            torch.cuda.empty_cache()
+            api.release_device_memory(local_rank)
+            full_size = full_size_step(args, k, local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {
             "metric": "greedy-matchtigs SSSP edges/s (whole hot-path step: classify+SSSP+claim+Euler+cut)",
@@ -340,6 +479,7 @@ def main():
                        "pairs": result_info.get("pairs"), "tigs": result_info.get("tigs"),
                        "candidates": result_info.get("candidates"), "parallelism": f"sources/{world}"},
             "units_per_step": total_stats,
+            "visited_per_step": total_visited,
             "phases_ms": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in phases_acc.items()},
             "euler_mode": args.euler,
             "device_mode": device_mode,
@@ -348,8 +488,11 @@ def main():
             "scaling_stages_ms": {"sssp_kernels": round(kmax[0], 4), "sssp_stage": round(kmax[1], 4), "allgather": round(kmax[2], 4)},
             "level0_finish_rate": (round(1.0 - kernels[1]["sources"] / max(kernels[0]["sources"], 1), 6) if len(kernels) > 1 else 1.0) if kernels else None,
             "setup_s": round(t_gen, 2), "setup_graph_s": round(t_graph, 2),
-            "device_graph_bytes": dev.graph_bytes(),
+            "device_graph_bytes": device_graph_bytes,
             "roofline": roofline,
+            "roofline_stages": roofline_stages,
+            "cold_step_ms": cold,
+            "full_size": full_size,
             # claim replay (one cooperative kernel): cost model = source visits x (32-B touch record + 8-B state and 8-B reservation
             # word for the source's own binode and for each of its ~1.2 live candidates) + 64-bit atomics of the failed visits
             "replay": {"rounds": result_info.get("replay_rounds"), "source_visits": result_info.get("replay_visits"),
@@ -363,6 +506,84 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_free_bytes() -> int:
+    """Host memory this process can still take: MemAvailable, and what the cgroup leaves."""
+    avail = 1 << 62
+    try:
+        for line in Path("/proc/meminfo").read_text().splitlines():
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) << 10
+    except (OSError, ValueError):
+        pass
+    try:
+        lim = Path("/sys/fs/cgroup/memory.max").read_text().strip()
+        cur = int(Path("/sys/fs/cgroup/memory.current").read_text())
+        if lim != "max":
+            avail = min(avail, int(lim) - cur)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def full_size_step(args, k: int, device_id: int):
+    """ONE device-mode step of the whole path at G-csr 2^full_size_log2 (2^30 = "human-like" nominal), cold, on a graph
+    generated on the GPU -- only when the box has the memory (170 GB of HBM, 140 GB of host memory free at 2^30)."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    lg = args.full_size_log2
+    scale = 1 << max(lg - 30, 0)
+    free_hbm, _ = torch.cuda.mem_get_info()
+    free_host = host_free_bytes()
+    need_hbm, need_host = 170 * scale << 30, 140 * scale << 30
+    if free_hbm < need_hbm or free_host < need_host:
+        return {"log2_edges": lg, "skipped": f"needs {need_hbm >> 30} GB of HBM and {need_host >> 30} GB of host memory free; "
+                                             f"this box has {free_hbm >> 30} / {free_host >> 30} GB"}
+    stream = torch_glue.current_stream_ptr()
+    t0 = time.perf_counter()
+    g = synth.g_csr_device(int((1 << lg) / 1.5 / 2), seed=args.seed, k=k, device_id=device_id)
+    t1 = time.perf_counter()
+    d = api.DeviceGraph(g, k, device_id)
+    d.set_plan(args.plan)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    S = d.classify(stream)
+    b = torch_glue.run_sssp(d, 0, S)
+    stage_ms = d.last_sssp_kernel_ms()
+    levels = d.last_sssp_levels()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    n_pairs = d.replay_claims_resident(b.start.data_ptr(), b.count.data_ptr(), b.pool.data_ptr(), stream)
+    rp = d.last_replay_ms()
+    t4 = time.perf_counter()
+    del b
+    torch.cuda.empty_cache()
+    lim, ed = api.finish_greedytigs_resident_np(g, d, k, api.EulerMode.Device, device_id, api.FinishStage.Auto)
+    t5 = time.perf_counter()
+    fs = api.last_finish_device_stage_ms()
+    hp = api.last_phase_seconds()
+    n_tigs, n_tig_edges, e_after = int(len(lim)), int(len(ed)), int(g.edge_count())
+    del lim, ed
+    vis = d.sssp_count_visited(0, S, stream) if d.prunes() else None
+    full = d.sssp_count(0, S, stream)
+    bytes_v = algorithmic_bytes(vis) if vis else algorithmic_bytes(full)
+    out = {"log2_edges": lg, "size_label": size_label(lg), "V": int(g.node_count()), "E": int(g.original_edge_count()),
+           "sources": int(S), "pairs": int(n_pairs), "tigs": n_tigs, "tig_edges": n_tig_edges, "darts_after_finish": e_after,
+           "ms_step": round((t5 - t2) * 1e3, 1), "generate_s": round(t1 - t0, 2), "device_graph_build_s": round(t2 - t1, 2),
+           "phases_ms": {"classify_sssp": round((t3 - t2) * 1e3, 2), "replay": round((t4 - t3) * 1e3, 2), "finish": round((t5 - t4) * 1e3, 1),
+                         "insert_eulerise": round(hp["eulerise"] * 1e3, 1), "euler": round(hp["euler"] * 1e3, 1), "cut": round(hp["cut"] * 1e3, 1)},
+           "sssp_stage_ms": round(stage_ms, 3), "sssp_levels": [{"kernel": x["kernel"], "ms": round(x["ms"], 3), "sources": x["sources"]} for x in levels],
+           "frac": round(bytes_v / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if stage_ms > 0 else None,
+           "frac_full_ball_equivalent": round(algorithmic_bytes(full) / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if stage_ms > 0 else None,
+           "units_full_ball": full, "units_visited": vis,
+           "replay_rounds_kernel_ms": round(rp["rounds_kernel_ms"], 3), "decomposition_gpu_ms": round(fs["decomposition_ms"], 2),
+           "insert_eulerise_gpu_ms": round(fs["insert_eulerise_ms"], 2), "cut_gpu_ms": round(fs["cut_ms"], 2),
+           "note": "one cold device-mode step (every stage on the GPU, pairs resident, tigs downloaded); the device graph is built before the clock starts, like the headline"}
+    del d, g
+    torch.cuda.empty_cache()
+    api.release_device_memory(device_id)
+    return out
 
 
 def sssp_stage_of_seeds(args, seeds, device_id) -> dict:
@@ -457,6 +678,49 @@ def run_cpu_baseline(bg, k: int, budget_s: float, dev, stream, full_ball_edges_a
             "cpu_examined_edges_per_s": round(st_mt["relaxed_edges"] / dt_mt, 1), "pairs": int(len(pairs_mt)),
         },
     }
+
+
+def whole_path_sample(args, k: int, device_id: int) -> dict:
+    """Whole path (Dijkstra + claims, Eulerisation, Euler walk, cut) by the oracle on 1 core, and the whole step of this engine in both
+    Euler modes, on the SAME G-csr 2^24 graph (1/8 of the bench workload's edges; ~10 s of CPU work)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    from matchtigs_amd import api, synth, torch_glue
+
+    lg = 24
+    g = synth.g_csr_device(int((1 << lg) / 1.5 / 2), seed=args.seed, k=k, device_id=device_id)
+    d = api.DeviceGraph(g, k, device_id)
+    d.set_plan(args.plan)
+    stream = torch_glue.current_stream_ptr()
+    gpu_ms = {}
+    for name, mode in (("device", api.EulerMode.Device), ("host", api.EulerMode.HostReferenceOrder)):
+        best = None
+        for _ in range(2):  # (the second run is the warm one)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            S = d.classify(stream)
+            b = torch_glue.run_sssp(d, 0, S)
+            d.replay_claims_resident(b.start.data_ptr(), b.count.data_ptr(), b.pool.data_ptr(), stream)
+            lim, ed = api.finish_greedytigs_resident_np(g, d, k, mode, device_id, api.FinishStage.Auto)
+            n_tigs = int(len(lim))
+            del lim, ed
+            g.reset()
+            best = (time.perf_counter() - t0) * 1e3
+        gpu_ms[name] = round(best, 2)
+    full = d.sssp_count(0, S, stream)["relaxed_edges"]
+    ex = g.export()
+    og = oracle_lib.OracleGraph.from_arrays(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"])
+    del ex
+    stages, st = og.whole_path_timed(k)
+    total = sum(stages.values())
+    del d, g
+    torch.cuda.empty_cache()
+    return {"workload": f"G-csr 2^{lg} (the bench generator and seed, 1/{1 << (args.log2_edges - lg)} of its edges)", "cores": 1, "kind": "port",
+            "cpu_whole_path_seconds": round(total, 2), "cpu_stage_seconds": {kk: round(v, 3) for kk, v in stages.items()},
+            "cpu_value_edges_per_s": round(full / total, 1), "cpu_tigs": st["tigs"], "gpu_tigs": n_tigs,
+            "gpu_step_ms_reference_order": gpu_ms["host"], "gpu_step_ms_device_mode": gpu_ms["device"],
+            "gpu_value_edges_per_s_reference_order": round(full / (gpu_ms["host"] * 1e-3), 1),
+            "note": "same graph, same unit (its full-ball SSSP edges / whole-path seconds); the GPU figures include every download to the host"}
 
 
 def run_cpu_baseline_mt(bg, k: int, stages_1core: dict) -> dict:

@@ -218,6 +218,9 @@ uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sour
 const mtg_pair *mtg_resident_pairs(const mtg_device *d, uint64_t *n_pairs_out);
 /* A host copy of them (malloc'd, free with mtg_free), in the reference's push order. */
 uint64_t mtg_download_resident_pairs(mtg_device *d, mtg_pair **pairs_out);
+/* GPU time (HIP events, ms) of the last claim replay on d: [0] the rounds kernel (replay_rounds_kernel), [1] all of its GPU work
+ * (state copy, dense list, rounds, pair-count scan, compaction). */
+void mtg_last_replay_ms(const mtg_device *d, double out[2]);
 /* Reservation rounds the last mtg_replay_claims_device needed. */
 int mtg_last_replay_rounds(const mtg_device *d);
 /* Source visits of those rounds (sum of the pending-list lengths): the unit of the replay's cost model. */
@@ -323,6 +326,11 @@ void mtg_graph_release_device_cache(mtg_graph *g);
 /* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,
  * [2] Euler bicycles, [3] rotate + cut + tig download; [4] kernel ms of the device decomposition; [5] breaking biedges added. */
 void mtg_last_finish_device_times(double out[6]);
+/* GPU time (HIP events on the finish stream, ms) of the stages of the last mtg_finish_device on this thread, for the per-stage
+ * rooflines of bench.py: [0] matched-pair darts + Euleriser kernels, [1] buckets + walk records (reference-order mode),
+ * [2] Euler decomposition (device mode), [3] rotate + cut kernels (without the tig download); [4] darts after the finish,
+ * [5] Euleriser units (missing in-edges). */
+void mtg_last_finish_device_stage_ms(double out[6]);
 /* The two finishing paths with an explicit configuration (euler_mode, finish_stage, device_ids[0]). */
 mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
 mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg);

@@ -214,9 +214,11 @@ def load():
         "mtg_device_memory_held": (u64, [C.c_int]),
         "mtg_graph_release_device_cache": (None, [vp]),
         "mtg_replay_claims_resident": (u64, [vp, vp, u64, vp, vp, vp]),
+        "mtg_last_replay_ms": (None, [vp, P(C.c_double)]),
         "mtg_resident_pairs": (vp, [vp, P(u64)]),
         "mtg_download_resident_pairs": (u64, [vp, P(P(MtgPair))]),
         "mtg_last_finish_device_times": (None, [P(C.c_double)]),
+        "mtg_last_finish_device_stage_ms": (None, [P(C.c_double)]),
         "mtg_synth_g_csr": (vp, [u64, u64, u64, u64, u64, vp, u64, C.c_int, C.c_int]),
         "mtg_last_phase_seconds": (None, [P(C.c_double)]),
         "matchtigs_initialise": (None, []),

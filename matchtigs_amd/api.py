@@ -457,6 +457,11 @@ class DeviceGraph:
         n = self._L.mtg_download_resident_pairs(self._d, C.byref(pp))
         return _adopt_pairs(self._L, pp, n)
 
+    def last_replay_ms(self) -> dict:
+        out = (C.c_double * 2)()
+        self._L.mtg_last_replay_ms(self._d, out)
+        return {"rounds_kernel_ms": float(out[0]), "gpu_ms": float(out[1])}
+
     def last_replay_rounds(self) -> int:
         return int(self._L.mtg_last_replay_rounds(self._d))
 
@@ -671,6 +676,14 @@ def last_finish_device_times() -> dict:
     _lib.load().mtg_last_finish_device_times(out)
     return {"insert_eulerise_s": out[0], "host_graph_s": out[1], "euler_s": out[2], "cut_s": out[3], "euler_kernel_ms": out[4],
             "breaking_biedges": int(out[5])}
+
+
+def last_finish_device_stage_ms() -> dict:
+    """GPU ms per stage of the last device finish (mtg_last_finish_device_stage_ms) + its dart and unit counts."""
+    out = (C.c_double * 6)()
+    _lib.load().mtg_last_finish_device_stage_ms(out)
+    return {"insert_eulerise_ms": out[0], "records_ms": out[1], "decomposition_ms": out[2], "cut_ms": out[3], "darts": int(out[4]),
+            "units": int(out[5])}
 
 
 def last_performance_data() -> dict:

@@ -1441,6 +1441,8 @@ struct Device {
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_r[4] = {nullptr, nullptr, nullptr, nullptr};  // claim replay: start, before / after the rounds kernel, end of the GPU work
+    double last_replay_kernel_ms = 0.0, last_replay_gpu_ms = 0.0;
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
@@ -1955,6 +1957,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
+    for (auto &e : d->ev_r) HIP_CHECK(hipEventCreate(&e));
     if (E) {
         HIP_CHECK(hipMemcpyAsync(d_from, g.e_from.data(), E * 4, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(d_to, g.e_to.data(), E * 4, hipMemcpyHostToDevice, st));
@@ -2031,6 +2034,7 @@ void device_free(Device *d) {
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
+    for (auto e : d->ev_r) (void)hipEventDestroy(e);
     delete d;
 }
 
@@ -2238,6 +2242,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         HIP_CHECK(hipMemsetAsync(w.resv[1], 0xFF, V * 8, st));
         w.tag_base = 0;
     }
+    HIP_CHECK(hipEventRecord(d->ev_r[0], st));
     // working copy of the classification state; per-source outputs start at "nothing claimed"
     hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
     HIP_CHECK(hipGetLastError());
@@ -2309,8 +2314,10 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(1, std::atoi(e));  // (tuning only)
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
+    HIP_CHECK(hipEventRecord(d->ev_r[1], st));
     HIP_CHECK(hipLaunchCooperativeKernel(small ? reinterpret_cast<void *>(replay_rounds_kernel<REPLAY_BLOCK_SMALL>) : reinterpret_cast<void *>(replay_rounds_kernel<REPLAY_BLOCK>),
                                          dim3(grid), dim3((unsigned)block), kargs, 0, st));
+    HIP_CHECK(hipEventRecord(d->ev_r[2], st));
     HIP_CHECK(hipMemcpyAsync(w.h_ctl, w.ctl, RC_COUNT * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     rt.lap("state init + rounds kernel");
@@ -2376,8 +2383,16 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
         HIP_CHECK(hipGetLastError());
     }
+    HIP_CHECK(hipEventRecord(d->ev_r[3], st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    {
+        float a_ms = 0, b_ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&a_ms, d->ev_r[1], d->ev_r[2]));
+        HIP_CHECK(hipEventElapsedTime(&b_ms, d->ev_r[0], d->ev_r[3]));
+        d->last_replay_kernel_ms = a_ms;
+        d->last_replay_gpu_ms = b_ms;
+    }
     if (!pairs_out) {  // the pairs stay in HBM for a finish on this GPU (device_resident_pairs / device_take_pairs)
-        HIP_CHECK(hipStreamSynchronize(st));
         rt.lap("compact (pairs stay on the GPU)");
         return n_pairs;
     }
@@ -2441,6 +2456,7 @@ int device_set_plan(Device *d, int plan) {
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
+void device_last_replay_ms(const Device *d, double out[2]) { out[0] = d->last_replay_kernel_ms; out[1] = d->last_replay_gpu_ms; }
 int device_id_of(const Device *d) { return d->dev; }
 // the pairs of the last claim replay as they lie in HBM (valid until the next replay on this device)
 const mtg_pair *device_resident_pairs(const Device *d, uint64_t *n_out) {

@@ -30,6 +30,7 @@ const char *device_last_level_name(const Device *d, int level);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_plan(Device *d, int plan);
 int device_last_replay_rounds(const Device *d);
+void device_last_replay_ms(const Device *d, double out[2]);
 uint64_t device_last_replay_visits(const Device *d);
 void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out);
 uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start, const uint32_t *d_cand_count,
@@ -50,7 +51,8 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
 // finish_device.hip: insertion + Euleriser + Euler bicycles + cut on the GPU (see mtg_finish_device)
 // (d_pairs_resident: the n_pairs pairs as they lie in the HBM of `device_id`, e.g. left there by the claim replay -- `pairs` may then be null:
 // nothing is uploaded, and the host graph gets its dummy weights from a download that runs beside the GPU stages)
-Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6],
+// (times_out: 12 values, see mtg_last_finish_device_times / mtg_last_finish_device_stage_ms)
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
                     const mtg_pair *d_pairs_resident = nullptr);
 void device_release_memory(int device_id);
 uint64_t device_memory_held(int device_id);

@@ -37,7 +37,7 @@ static bool g_log_initialised = false;
 static thread_local double g_last_euler_kernel_ms = 0;
 static thread_local double g_last_gather_ms = 0;
 static thread_local mtg_dijkstra_performance_data g_last_perf = {};
-static thread_local double g_last_finish_times[6] = {0, 0, 0, 0, 0, 0};
+static thread_local double g_last_finish_times[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static void check_config(const mtg_config *cfg, const char *who) {
     if (!cfg) MTG_DIE("%s: null configuration", who);
@@ -184,6 +184,7 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
     if (!d || !pairs_out) MTG_DIE("mtg_replay_claims_device: null argument");
     return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
+void mtg_last_replay_ms(const mtg_device *d, double out[2]) { device_last_replay_ms(d->d, out); }
 uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
                                     const uint32_t *d_cand_count, const uint64_t *d_pool) {
     if (!d) MTG_DIE("mtg_replay_claims_resident: null argument");
@@ -381,6 +382,10 @@ void mtg_graph_release_device_cache(mtg_graph *g) {
 }
 void mtg_last_finish_device_times(double out[6]) {
     for (int i = 0; i < 6; i++) out[i] = g_last_finish_times[i];
+}
+void mtg_last_finish_device_stage_ms(double out[6]) {
+    const double *t = g_last_finish_times;
+    out[0] = t[6]; out[1] = t[7]; out[2] = t[4]; out[3] = t[8]; out[4] = t[9]; out[5] = t[10];
 }
 mtg_graph *mtg_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t n_unitigs, uint64_t seed, uint64_t k,
                            const uint64_t *weight_thresholds, uint64_t n_thresholds, int max_degree, int device_id) {

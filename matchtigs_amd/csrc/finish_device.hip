@@ -468,20 +468,38 @@ static hipStream_t finish_side_stream(int device_id) {
     return streams[device_id];
 }
 
-Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[6],
+Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
                     const mtg_pair *d_pairs_resident) {
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
     if (n_pairs && !pairs && !d_pairs_resident) MTG_DIE("device_finish: null pairs");
     if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
     if (k < 1 || k > 0xFFFFFFFFull) MTG_DIE("device_finish: k out of range");
     Walks tigs;
-    for (int i = 0; i < 6 && times_out; i++) times_out[i] = 0;
+    for (int i = 0; i < 12 && times_out; i++) times_out[i] = 0;
     if (E0 == 0 && n_pairs == 0) return tigs;
     if (device_count() <= device_id) MTG_DIE("device_finish: no MI355X/HIP device %d (there is no CPU fallback for this path)", device_id);
     HIP_CHECK(hipSetDevice(device_id));
     hipStream_t st = finish_stream(device_id);
     Lap lap;
     static_assert(sizeof(Pair) == sizeof(mtg_pair), "pair layout");
+    // GPU time of the stages (HIP events on the finish stream; read at the end): [0,1] insertion + Euleriser kernels, [2,3] buckets +
+    // walk records (reference-order mode), [4,5] rotate + cut kernels; the decomposition has its own pair (device_euler_decompose)
+    struct StageEvents {
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool set[6] = {false, false, false, false, false, false};
+        void mark(int i, hipStream_t s) {
+            if (!ev[i]) HIP_CHECK(hipEventCreate(&ev[i]));
+            HIP_CHECK(hipEventRecord(ev[i], s));
+            set[i] = true;
+        }
+        double ms(int a, int b) {
+            if (!set[a] || !set[b]) return 0.0;
+            float v = 0;
+            HIP_CHECK(hipEventElapsedTime(&v, ev[a], ev[b]));
+            return v;
+        }
+        ~StageEvents() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+    } sev;
 
     // ---- original darts + mirror: left on this GPU by an earlier stage of the graph (HostGraph::device_cache), else uploaded
     // now and left there for the next call; the pairs ----
@@ -533,6 +551,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             d_adj0 = (const uint32_t *)cache->d_adj0;
         }
     }
+    sev.mark(0, st);
     // the pairs: where the claim replay left them in this GPU's HBM, else uploaded
     const mtg_pair *d_pairs = d_pairs_resident;
     if (!d_pairs) {
@@ -647,6 +666,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         uint32_t *d_to = b_to.alloc<uint32_t>(st, n_dummy);
         if (n_dummy) head_kernel<<<grid_for(n_dummy), EB, 0, st>>>(d_from, d_mirror, E0, E, d_to);
         HIP_CHECK(hipGetLastError());
+        sev.mark(1, st);
         g.append_unlinked(n_dummy);
         if (!pairs) h_pw.reset(new uint32_t[std::max<uint64_t>(n_pairs, 1)]);
         uint32_t *h_pw_p = h_pw.get();
@@ -706,6 +726,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         {
             Buf b_row, b_adj, b_need, b_off, b_tot, b_nodes, b_xe, b_xt;
             uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1), *d_adj = b_adj.alloc<uint32_t>(st, E);
+            sev.mark(2, st);
             if (d_row0) device_build_buckets_merged(st, d_from, E0, E, V, d_row0, d_adj0, d_row, d_adj);
             else device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr);
             uint32_t *d_need = b_need.alloc<uint32_t>(st, V), *d_off = b_off.alloc<uint32_t>(st, V), *d_tot = b_tot.alloc<uint32_t>(st, 1);
@@ -723,6 +744,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 uint32_t *d_xe = b_xe.alloc<uint32_t>(st, ext_total), *d_xt = b_xt.alloc<uint32_t>(st, ext_total);
                 lean_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_from, d_mirror, d_off, d_nodes, d_xe, d_xt);
                 HIP_CHECK(hipGetLastError());
+                sev.mark(3, st);
                 std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
                 if (ext_total) {
                     HIP_CHECK(hipMemcpyAsync(ext_eid.data(), d_xe, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
@@ -788,6 +810,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         EulerNode3 *d_wide = b_wide.alloc<EulerNode3>(st, V);
                         wide_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_nodes, d_wide);
                         HIP_CHECK(hipGetLastError());
+                        sev.mark(3, st);
                         if (pinned) {
                             HIP_CHECK(hipMemcpyAsync(wbuf.p, d_wide, V * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
                             HIP_CHECK(hipStreamSynchronize(st));
@@ -829,6 +852,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         uint32_t *d_head = b_head.alloc<uint32_t>(st, n), *d_hscan = b_hscan.alloc<uint32_t>(st, n);
         unsigned long long *d_rotkey = b_rotkey.alloc<unsigned long long>(st, n_cycles);
         uint32_t *d_rot = b_rot.alloc<uint32_t>(st, n);
+        sev.mark(4, st);
         HIP_CHECK(hipMemsetAsync(d_head, 0, n * 4, st));
         HIP_CHECK(hipMemsetAsync(d_rotkey, 0, (uint64_t)std::max<uint32_t>(n_cycles, 1) * 8, st));
         cycle_heads_kernel<<<grid_for(n_cycles), EB, 0, st>>>(n_cycles, d_cbase, d_head);
@@ -849,6 +873,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         uint32_t *d_tl = b_tl.alloc<uint32_t>(st, n_tigs);
         cut_write_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_keep, d_end, d_kpos, d_tpos, d_te, d_tl);
         HIP_CHECK(hipGetLastError());
+        sev.mark(5, st);
         tigs.edges.resize(n_kept);
         tigs.limits.resize(n_tigs);
         download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
@@ -865,6 +890,14 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     b_to.release();
     b_from.release(); b_pw.release(); b_clen.release(); b_cbase.release(); b_bsum.release(); b_small.release();
     HIP_CHECK(hipStreamSynchronize(st));
+    if (times_out) {  // [6] insertion + Euleriser, [7] buckets + walk records, [8] rotate + cut: GPU ms; [9] darts, [10] units, [11] closed walks
+        times_out[6] = sev.ms(0, 1);
+        times_out[7] = sev.ms(2, 3);
+        times_out[8] = sev.ms(4, 5);
+        times_out[9] = (double)E;
+        times_out[10] = (double)N;
+        times_out[11] = (double)n_cycles;
+    }
     finish_trim(device_id, E * 40 + V * 28);
     return tigs;
 }

@@ -20,15 +20,30 @@ def test_bench_json_line(product_lib):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "device_mode", "scaling_stages_ms", "seeds"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "device_mode", "scaling_stages_ms", "seeds",
+                "roofline_stages", "cold_step_ms", "visited_per_step", "full_size"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - d["units_per_step"]["relaxed_edges"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and rf["kernels"][0]["kernel"].startswith("sssp_enum_kernel")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernels"] and "sssp_enum_kernel" in rf["kernels"][0]["kernel"]
     assert "traffic" in rf and "traffic_note" in rf
+    # the pruned search visits no more than the full balls and emits the same candidates; the roofline prices the visited bytes
+    vis, full = d["visited_per_step"], d["units_per_step"]
+    assert vis["emitted"] == full["emitted"] and vis["settled_nodes"] <= full["settled_nodes"] and vis["relaxed_edges"] <= full["relaxed_edges"]
+    assert rf["algorithmic_bytes_per_launch"] == 5 * vis["relaxed_edges"] + 12 * vis["settled_nodes"] + 12 * vis["emitted"]
+    assert rf["full_ball_equivalent"]["algorithmic_bytes_per_launch"] == 5 * full["relaxed_edges"] + 12 * full["settled_nodes"] + 12 * full["emitted"]
+    # every other GPU stage of the step has its own roofline entry (HIP-event time, byte model, frac), in both Euler modes
+    stages = {(x["stage"], x["euler_mode"]) for x in d["roofline_stages"]}
+    assert {("replay", "device"), ("insert_eulerise", "device"), ("decomposition", "device"), ("cut", "device"),
+            ("replay", "host"), ("insert_eulerise", "host"), ("records", "host"), ("cut", "host")} <= stages
+    for x in d["roofline_stages"]:
+        assert x["avg_launch_ms"] > 0 and x["algorithmic_bytes"] > 0 and abs(x["frac"] - x["achieved"] / 8000.0) < 1e-4
+    cs = d["cold_step_ms"]
+    assert cs["device"]["step_ms"] > 0 and cs["host"]["step_ms"] > 0 and cs["device"]["device_graph_build_ms"] > 0
+    assert d["full_size"] is None  # (only the headline configuration runs the nominal-size step)
     dm = d["device_mode"]
     assert dm["ms_per_step"] > 0 and dm["tigs"] == d["config"]["tigs"] and "finish" in dm["phases_ms"]   # T3 across the two modes
     assert set(d["seeds"]) == {"2", "3"} and all(v["sssp_stage_ms"] > 0 for v in d["seeds"].values())

@@ -13,7 +13,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = re.sub(r"^void\s+", "", name)
+    name = re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "")  # (before the argument list is cut at its first parenthesis)
     name = re.sub(r"\(.*\)$", "", name)
     return name.replace("mtg::", "").replace("(anonymous namespace)::", "")
 
