@@ -24,9 +24,15 @@ MARKERS = [
     ("row_degree_kernel", "insert_eulerise"),
     ("pair_degree_kernel", "insert_eulerise"),
     ("degree_rank_offset_kernel", "buckets"),   # re-labelled below: decomposition (device mode) or records (reference order)
-    ("degree_rank_kernel", "buckets"),
     ("cycle_heads_kernel", "cut"),
 ]
+# once per graph, inside its first finish (before the degrees are read): the kept buckets of the original darts -- not a stage of a step
+ONE_OFF = ("degree_rank_kernel", "fill_kernel")
+# kernels whose reads are dependent random accesses of 4 to 64 bytes (one request each, counted as issued); the others stream
+# coalesced 4-byte words, where gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
+GATHER = ("sssp_enum_kernel", "sssp_kernel", "replay_rounds_kernel", "walk_measure_kernel", "walk_write_kernel", "union_succ_kernel",
+          "propose_kernel", "flatten_kernel", "rotate_kernel", "wyllie_kernel", "wide_build_kernel", "mid_build_slice_kernel", "lean_build_kernel",
+          "zip_check_kernel", "sort_lists_kernel", "replay_compact_kernel", "replay_dense_fill_kernel", "root_len_kernel", "succ_node_kernel")
 ORDER = ["classify", "sssp", "replay", "insert_eulerise", "buckets", "cut"]
 # kernels that only occur in one kind of step tell which stage the buckets belong to
 DEVICE_ONLY = ("succ_node_kernel", "union_succ_kernel", "walk_measure_kernel")
@@ -61,8 +67,16 @@ def main():
             # counting, other seeds): "post", not counted. The counting instantiations of sssp_kernel are instrumentation as well.
             stage_of = {}
             cur = "setup"
+            one_off = False
             for did in order:
                 nm = names[did]
+                if nm.split("<")[0] in ONE_OFF:
+                    one_off = True  # (lasts until the step's next marker: the scans and the bucket sort in between belong to it)
+                elif one_off and any(sub in nm for sub, _ in MARKERS):
+                    one_off = False
+                if one_off:
+                    stage_of[did] = "one_off_kept_buckets"
+                    continue
                 if "sssp_kernel<" in nm and "true" in [x.strip() for x in nm[nm.index("<") + 1:].rstrip(">").split(",")][-2:-1]:
                     cur = "post"
                 for sub, st in MARKERS:
@@ -94,13 +108,16 @@ def main():
                 steps = max(steps, sum(1 for did in order if "classify_kernel" in names[did]))
             for did in order:
                 st = stage_of[did]
-                if st in ("setup", "post"):
+                if st in ("setup", "post", "one_off_kept_buckets"):
                     continue
                 if "__amd_rocclr_copyBuffer" in names[did]:  # the runtime's copy kernels (staged downloads on the side stream run beside
                     st = "copies"                             # any stage): their own bucket
+                gather = names[did].split("<")[0] in GATHER
                 for c in ("FETCH_SIZE", "WRITE_SIZE"):
                     if c in rows[did]:
                         per_stage[st][c] += rows[did][c] * 1024.0
+                        if c == "FETCH_SIZE":
+                            per_stage[st]["FETCH_CORRECTED"] += rows[did][c] * 1024.0 * (1.0 if gather else 2.0)
                 if has_fetch:
                     n_dispatch[st] += 1
                     kernels[st].add(names[did].split("<")[0])
@@ -110,11 +127,11 @@ def main():
         f, w = per_stage[st].get("FETCH_SIZE", 0.0) / steps, per_stage[st].get("WRITE_SIZE", 0.0) / steps
         # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of coalesced streaming reads (128-B requests
         # tallied at 64 B; confirmed here on classify_kernel / replay_state_init_kernel / build_ext_need_kernel, whose reads are
-        # known: 0.50 of them) -> doubled for the streaming stages; the gather stages (sssp, replay: random 64-byte and 8-byte
-        # accesses, one request each) keep the raw figure, as calibrated in round 1 (profiles/r01_final.md)
-        corr = 1.0 if st in ("sssp", "replay") else 2.0
-        res[st] = {"fetch_bytes_raw": int(f), "fetch_correction": corr, "fetch_bytes": int(f * corr), "write_bytes": int(w),
-                   "traffic_bytes": int(f * corr + w), "dispatches_per_step": round(n_dispatch[st] / steps, 1), "kernels": sorted(kernels[st])}
+        # known: 0.50 of them) -> doubled for the streaming kernels; the gather kernels (GATHER above: dependent random accesses,
+        # one 64-byte request each) keep the raw figure, as calibrated in round 1 (profiles/r01_final.md)
+        fc = per_stage[st].get("FETCH_CORRECTED", 0.0) / steps
+        res[st] = {"fetch_bytes_raw": int(f), "fetch_bytes": int(fc), "write_bytes": int(w), "traffic_bytes": int(fc + w),
+                   "dispatches_per_step": round(n_dispatch[st] / steps, 1), "kernels": sorted(kernels[st])}
     try:
         allj = json.loads(open(out).read())
     except (OSError, ValueError):
