@@ -150,11 +150,16 @@ def classify(g: PyBigraph):
     return out_nodes, live, mult
 
 
-def greedy_pairs(g: PyBigraph, k):
-    """greedytigs/mod.rs:301-523, single thread."""
+def greedy_pairs(g: PyBigraph, k, events=None):
+    """greedytigs/mod.rs:301-523, single thread. `events` (a dict) counts how often the corner rules fire (tests/fuzz_small.py)."""
     out_nodes, live, mult = classify(g)
     stats = {"settled_nodes": 0, "relaxed_edges": 0}
     res = []
+
+    def ev(name):
+        if events is not None:
+            events[name] = events.get(name, 0) + 1
+
     for o in out_nodes:
         o_sm = g.mirror[o] == o
         om = g.mirror[o]
@@ -162,18 +167,26 @@ def greedy_pairs(g: PyBigraph, k):
         assert 0 <= M <= 4
         if M == 0:
             continue
+        if M >= 3:
+            ev("demand_3_or_4")
+        if o_sm:
+            ev("self_mirror_source")
         while M > 0:
             T = M + 1
             D = dijkstra(g, o, live, T, k - 1, stats)
             if not D:
                 break
             abort = len(D) < T
+            if len(D) >= 2 and any(D[i][1] == D[i + 1][1] for i in range(len(D) - 1)):
+                ev("equal_distance_tie")
             for (t, d) in D:
                 self_edge = False
                 if t == om:
                     if M < 2:
+                        ev("own_mirror_skipped")
                         continue
                     self_edge = True
+                    ev("self_mirror_edge")
                 t_sm = g.mirror[t] == t
                 tm = g.mirror[t]
                 M = mult[o] if o_sm else -mult[o]
@@ -181,7 +194,12 @@ def greedy_pairs(g: PyBigraph, k):
                     break
                 if not self_edge and mult[t] == 0:
                     live[t] = False
+                    ev("stale_target")
                     continue
+                if d == k - 1:
+                    ev("distance_k_minus_1")
+                if t_sm:
+                    ev("self_mirror_target")
                 res.append((o, t, d))
                 red = 2 if self_edge else 1
                 if o_sm:
