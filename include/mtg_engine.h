@@ -73,6 +73,9 @@ enum { MTG_EULER_HOST_REFERENCE_ORDER = 0, MTG_EULER_DEVICE = 1 };
 enum { MTG_FINISH_AUTO = 0, MTG_FINISH_HOST = 1, MTG_FINISH_DEVICE = 2 };
 #define MTG_MAX_DEVICES 8
 typedef struct {
+    uint64_t struct_size;              /* sizeof(mtg_config) of the header the caller was built against: set by mtg_config_init, checked by
+                                          every function that takes a configuration (a mismatch aborts with a message instead of reading
+                                          shifted fields). ALWAYS fill a configuration through mtg_config_init. New fields are appended. */
     uint64_t threads;                  /* greedytigs/mod.rs:42 */
     uint64_t k;                        /* :44 */
     double staged_parallelism_divisor; /* :47, 0 = None */
@@ -84,10 +87,11 @@ typedef struct {
                                           #tigs / cumulative length, different order) */
     int32_t n_devices;                 /* GPUs to shard the SSSP sources over; >= 1 */
     int32_t device_ids[MTG_MAX_DEVICES];
-    int32_t finish_stage;              /* MTG_FINISH_AUTO / _HOST / _DEVICE */
     /* MatchtigAlgorithmConfiguration (matchtigs/mod.rs:33-45), tig algorithm 4 only; may be NULL otherwise */
     const char *matching_file_prefix; /* the instance goes to <prefix>.minimalperfectmatching, the matcher writes <that>.solution */
     const char *matcher_path;         /* blossom5-compatible executable: `<matcher> -e <instance> -w <solution>` */
+    int32_t finish_stage;              /* MTG_FINISH_AUTO / _HOST / _DEVICE (appended in round 3) */
+    int32_t reserved0;
 } mtg_config;
 /* GreedytigAlgorithmConfiguration::new(threads, k) (greedytigs/mod.rs:62-72): staged None, factor 0, HashbrownHashMap,
  * StdBinaryHeap, performance data None; engine fields: host Euler walk, one device (id 0). */
@@ -218,6 +222,11 @@ uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sour
 const mtg_pair *mtg_resident_pairs(const mtg_device *d, uint64_t *n_pairs_out);
 /* A host copy of them (malloc'd, free with mtg_free), in the reference's push order. */
 uint64_t mtg_download_resident_pairs(mtg_device *d, mtg_pair **pairs_out);
+/* Geometry of the claim replay's cooperative launch, for measurements and tests (0 = the engine's choice for that parameter): number
+ * of index-ordered admission windows, threads per workgroup (1024 or 256), workgroups, one admitting workgroup in `role_mod`, and
+ * plain_barrier != 0 = every workgroup releases at the grid barrier (without the per-XCD stage that leans on gfx942 / gfx950
+ * hardware). The pair list never depends on any of them. (The library reads no environment variable for this.) */
+void mtg_set_replay_tuning(mtg_device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier);
 /* GPU time (HIP events, ms) of the last claim replay on d: [0] the rounds kernel (replay_rounds_kernel), [1] all of its GPU work
  * (state copy, dense list, rounds, pair-count scan, compaction). */
 void mtg_last_replay_ms(const mtg_device *d, double out[2]);

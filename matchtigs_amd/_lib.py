@@ -41,6 +41,7 @@ class MtgConfig(C.Structure):
     """mtg_config (include/mtg_engine.h): the fields of GreedytigAlgorithmConfiguration + euler_mode / device_ids."""
 
     _fields_ = [
+        ("struct_size", C.c_uint64),
         ("threads", C.c_uint64),
         ("k", C.c_uint64),
         ("staged_parallelism_divisor", C.c_double),
@@ -51,9 +52,10 @@ class MtgConfig(C.Structure):
         ("euler_mode", C.c_int32),
         ("n_devices", C.c_int32),
         ("device_ids", C.c_int32 * MTG_MAX_DEVICES),
-        ("finish_stage", C.c_int32),
         ("matching_file_prefix", C.c_char_p),
         ("matcher_path", C.c_char_p),
+        ("finish_stage", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -215,6 +217,7 @@ def load():
         "mtg_graph_release_device_cache": (None, [vp]),
         "mtg_replay_claims_resident": (u64, [vp, vp, u64, vp, vp, vp]),
         "mtg_last_replay_ms": (None, [vp, P(C.c_double)]),
+        "mtg_set_replay_tuning": (None, [vp, u64, C.c_int, C.c_int, C.c_int, C.c_int]),
         "mtg_resident_pairs": (vp, [vp, P(u64)]),
         "mtg_download_resident_pairs": (u64, [vp, P(P(MtgPair))]),
         "mtg_last_finish_device_times": (None, [P(C.c_double)]),

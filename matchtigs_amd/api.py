@@ -457,6 +457,10 @@ class DeviceGraph:
         n = self._L.mtg_download_resident_pairs(self._d, C.byref(pp))
         return _adopt_pairs(self._L, pp, n)
 
+    def set_replay_tuning(self, windows: int = 0, block: int = 0, grid: int = 0, role_mod: int = 0, plain_barrier: bool = False) -> None:
+        """mtg_set_replay_tuning: launch geometry of the claim replay (0 = the engine's choice); never changes the pair list."""
+        self._L.mtg_set_replay_tuning(self._d, windows, block, grid, role_mod, 1 if plain_barrier else 0)
+
     def last_replay_ms(self) -> dict:
         out = (C.c_double * 2)()
         self._L.mtg_last_replay_ms(self._d, out)

@@ -1463,6 +1463,10 @@ struct Device {
     int n_cu = 256;
     uint64_t graph_bytes = 0;
     ReplayWork replay;
+    // claim replay tuning (0 = the engine's choice; never changes a result: tests run the rounds under several settings)
+    uint64_t tune_windows = 0;
+    int tune_block = 0, tune_grid = 0, tune_role_mod = 0;
+    bool tune_plain_barrier = false;  // every workgroup releases at the grid barrier (no per-XCD stage)
     int last_replay_rounds = 0;
     uint64_t last_n_pairs = 0;        // pairs of the last claim replay; they stay in replay.out until the next one (or device_take_pairs)
     uint64_t last_replay_visits = 0;  // sum over the rounds of the pending-list lengths (first RC_TRACE_ROUNDS rounds)
@@ -2285,7 +2289,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // grid barrier plus one dependent-access chain, so tiny windows are latency bound; huge ones bring the waiting visits back)
     {
         uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (n_dense + (1u << 15) - 1) >> 15));
-        if (const char *e = std::getenv("MTG_REPLAY_WINDOWS")) n_win = std::max<uint64_t>(1, (uint64_t)std::atoll(e));  // (tuning only: the pair list does not depend on it)
+        if (d->tune_windows) n_win = d->tune_windows;  // (tuning only: the pair list does not depend on it)
         a.window = std::max<uint64_t>((n_dense + n_win - 1) / n_win, 256);
     }
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
@@ -2303,15 +2307,16 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         w.grid_small = (unsigned)d->n_cu * (unsigned)std::min(occ_small, 2);
     }
     bool small = 2 * ((a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK) < (uint64_t)d->n_cu;
-    if (const char *e = std::getenv("MTG_REPLAY_BLOCK")) small = std::atoi(e) < REPLAY_BLOCK;  // (tuning only)
+    if (d->tune_block) small = d->tune_block < REPLAY_BLOCK;  // (tuning only)
     const uint64_t block = small ? REPLAY_BLOCK_SMALL : REPLAY_BLOCK;
     unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(small ? w.grid_small : w.grid), (n_dense + block - 1) / block,
                                                                        std::max<uint64_t>(64, 2 * ((a.window + block - 1) / block))}));
-    if (const char *e = std::getenv("MTG_REPLAY_GRID")) grid = std::max(1u, std::min(grid, (unsigned)std::atoi(e)));  // (tuning only)
+    if (d->tune_grid) grid = std::max(1u, std::min(grid, (unsigned)d->tune_grid));  // (tuning only)
     // one workgroup in role_mod admits, the others check (the longer chain). Measured with the per-XCD barrier: 2^27 (the grid fills
     // the device) role_mod 2 / 4 / 6 / 8 = 6.6 / 6.7 / 7.2 / 8.2 ms; 2^24 (64 workgroups) 2.7 / 2.2 / 2.4 / 2.8 ms
     a.role_mod = (!small && grid >= w.grid) ? 2u : 4u;
-    if (const char *e = std::getenv("MTG_REPLAY_ROLE_MOD")) a.role_mod = (uint32_t)std::max(1, std::atoi(e));  // (tuning only)
+    if (d->tune_role_mod) a.role_mod = (uint32_t)std::max(1, d->tune_role_mod);  // (tuning only)
+    a.plain_barrier = d->tune_plain_barrier ? 1u : 0u;
     void *kargs[] = {&a};
     rt.lap("buffers + launches");
     HIP_CHECK(hipEventRecord(d->ev_r[1], st));
@@ -2456,6 +2461,9 @@ int device_set_plan(Device *d, int plan) {
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
+void device_set_replay_tuning(Device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier) {
+    d->tune_windows = windows; d->tune_block = block; d->tune_grid = grid; d->tune_role_mod = role_mod; d->tune_plain_barrier = plain_barrier != 0;
+}
 void device_last_replay_ms(const Device *d, double out[2]) { out[0] = d->last_replay_kernel_ms; out[1] = d->last_replay_gpu_ms; }
 int device_id_of(const Device *d) { return d->dev; }
 // the pairs of the last claim replay as they lie in HBM (valid until the next replay on this device)

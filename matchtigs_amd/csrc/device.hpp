@@ -30,6 +30,7 @@ const char *device_last_level_name(const Device *d, int level);
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_plan(Device *d, int plan);
 int device_last_replay_rounds(const Device *d);
+void device_set_replay_tuning(Device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier);
 void device_last_replay_ms(const Device *d, double out[2]);
 uint64_t device_last_replay_visits(const Device *d);
 void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_data *out);

@@ -41,6 +41,9 @@ static thread_local double g_last_finish_times[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0,
 
 static void check_config(const mtg_config *cfg, const char *who) {
     if (!cfg) MTG_DIE("%s: null configuration", who);
+    if (cfg->struct_size != sizeof(mtg_config))
+        MTG_DIE("%s: mtg_config.struct_size = %llu, this library's mtg_config has %zu bytes: fill the configuration with mtg_config_init, and "
+                "build against the mtg_engine.h of this library", who, (unsigned long long)cfg->struct_size, sizeof(mtg_config));
     if (cfg->k < 1) MTG_DIE("%s: k must be >= 1", who);
     if (cfg->n_devices < 1 || cfg->n_devices > MTG_MAX_DEVICES) MTG_DIE("%s: n_devices = %d is out of range [1, %d]", who, cfg->n_devices, MTG_MAX_DEVICES);
     if (cfg->euler_mode != MTG_EULER_HOST_REFERENCE_ORDER && cfg->euler_mode != MTG_EULER_DEVICE) MTG_DIE("%s: unknown euler_mode %d", who, cfg->euler_mode);
@@ -185,6 +188,10 @@ uint64_t mtg_replay_claims_device(mtg_device *d, void *stream, uint64_t n_source
     return device_replay(d->d, stream, n_sources, d_cand_start, d_cand_count, d_pool, pairs_out, nullptr);
 }
 void mtg_last_replay_ms(const mtg_device *d, double out[2]) { device_last_replay_ms(d->d, out); }
+void mtg_set_replay_tuning(mtg_device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier) {
+    if (!d) MTG_DIE("mtg_set_replay_tuning: null device");
+    device_set_replay_tuning(d->d, windows, block, grid, role_mod, plain_barrier);
+}
 uint64_t mtg_replay_claims_resident(mtg_device *d, void *stream, uint64_t n_sources, const uint64_t *d_cand_start,
                                     const uint32_t *d_cand_count, const uint64_t *d_pool) {
     if (!d) MTG_DIE("mtg_replay_claims_resident: null argument");
@@ -320,6 +327,7 @@ static mtg_walks *eulerise_and_cut(HostGraph &g, uint64_t dummy_edge_id, const m
 void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k) {  // GreedytigAlgorithmConfiguration::new, greedytigs/mod.rs:62-72
     if (!cfg) MTG_DIE("mtg_config_init: null configuration");
     std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
     cfg->threads = threads;
     cfg->k = k;
     cfg->staged_parallelism_divisor = 0.0;

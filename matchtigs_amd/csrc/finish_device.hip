@@ -227,6 +227,12 @@ __global__ __launch_bounds__(EB) void wide_build_kernel(uint64_t n_nodes, const 
         r.eid[i] = l.eid[i];
         r.to[i] = l.to[i];
     }
+    for (int j = 0; j < 3; j++)  // (unused copies hold NONE, as in the 128-byte records: no uninitialised words reach the host)
+        for (int q = 0; q < 3; q++) {
+            r.sub_eid[j][q] = NONE;
+            r.sub_to[j][q] = NONE;
+            for (int t = 0; t < 2; t++) { r.sub2_eid[j][q][t] = NONE; r.sub2_to[j][q][t] = NONE; }
+        }
     r.deg = l.deg;
     r.pos = 0;
     r.pad = 0;

@@ -83,11 +83,15 @@ static void link_range(const HostGraph &g, uint64_t lo, uint64_t hi) {
     }, T);
 }
 
+// (const, but it writes the adjacency lists the first time a read-only stage needs them after a device finish: two threads that
+// call read-only functions on one graph meet at the lock; the fast path is one acquire load)
 void HostGraph::ensure_linked() const {
     const uint64_t total = e_from.size();
+    if (__atomic_load_n(&linked_edges, __ATOMIC_ACQUIRE) >= total) return;
+    std::lock_guard<std::mutex> lock(*link_mutex);
     if (linked_edges >= total) return;
     link_range(*this, linked_edges, total);
-    linked_edges = total;
+    __atomic_store_n(&linked_edges, total, __ATOMIC_RELEASE);
 }
 
 void HostGraph::append_unlinked(uint64_t n_new) {

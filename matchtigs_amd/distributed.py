@@ -64,7 +64,9 @@ def allgather_candidates(start: torch.Tensor, count: torch.Tensor, pool: torch.T
     pool_all = torch.empty(sum(pool_sizes), dtype=torch.int64, device=dev)
     lo, hi = ranges[rank]
     off = sum(pool_sizes[:rank])
-    start_all[lo:hi] = start[: hi - lo] + off  # own block: rebased before it travels
+    # own block: rebased before it travels. The engine leaves the start of an EMPTY list untouched (mtg_sssp_candidates): such
+    # words are set to 0 here, so that nothing uninitialised is broadcast and every start indexes the concatenated pool.
+    start_all[lo:hi] = torch.where(count[: hi - lo] > 0, start[: hi - lo] + off, torch.zeros_like(start[: hi - lo]))
     count_all[lo:hi] = count[: hi - lo]
     pool_all[off:off + pool_used] = pool[:pool_used]
     pending = []

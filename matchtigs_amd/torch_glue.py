@@ -46,7 +46,9 @@ def run_sssp(dev: DeviceGraph, src_begin: int, src_end: int, bufs: CandidateBuff
 
 
 def candidates_to_numpy(bufs: CandidateBuffers):
-    start = bufs.start[: bufs.n].cpu().numpy().view(np.uint64)
+    """Host copies; the start of an empty list (left untouched by the engine) is reported as 0."""
     count = bufs.count[: bufs.n].cpu().numpy().view(np.uint32)
+    start = bufs.start[: bufs.n].cpu().numpy().view(np.uint64).copy()
+    start[count == 0] = 0
     pool = bufs.pool[: bufs.used].cpu().numpy().view(np.uint64)
     return start, count, pool

@@ -167,3 +167,8 @@ def test_config_struct_defaults_and_validation(product_lib):
             "c = _lib.MtgConfig(); L.mtg_config_init(C.byref(c), 1, 5); c.heap_type = 9\nL.mtg_compute_eulertigs_cfg(G.handle, C.byref(c))\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(_lib.REPO_DIR))
     assert r.returncode != 0 and "Unknown heap type" in r.stderr
+    # a configuration that did not go through mtg_config_init (or comes from another header) is refused by its size field
+    assert c.struct_size == C.sizeof(_lib.MtgConfig) and c.finish_stage == 0
+    code2 = code.replace("c.heap_type = 9", "c.struct_size = 96")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=str(_lib.REPO_DIR))
+    assert r.returncode != 0 and "struct_size" in r.stderr

@@ -11,7 +11,7 @@ def _pairs_equal(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in ("out", "in", "dist"))
 
 
-def _run(bg, plan=None):
+def _run(bg, plan=None, tuning=None):
     import torch  # noqa: F401
     from matchtigs_amd import api, torch_glue
 
@@ -19,6 +19,8 @@ def _run(bg, plan=None):
     dev = api.DeviceGraph(G, bg.k)
     if plan is not None:
         dev.set_plan(plan)
+    if tuning:
+        dev.set_replay_tuning(**tuning)
     S = dev.classify(torch_glue.current_stream_ptr())
     bufs = torch_glue.run_sssp(dev, 0, S)
     gpu_pairs = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(),
@@ -107,15 +109,36 @@ def test_gpu_replay_scrambled_numbering(seed, oracle, product_lib):
     assert _pairs_equal(gpu_pairs, want)
 
 
-@pytest.mark.parametrize("block", ["256", "1024"])
-def test_gpu_replay_both_workgroup_sizes(block, oracle, product_lib, monkeypatch):
+@pytest.mark.parametrize("block", [256, 1024])
+def test_gpu_replay_both_workgroup_sizes(block, oracle, product_lib):
     """The rounds kernel is instantiated for workgroups of 1024 (rounds that fill the device) and of 256 (small inputs); the
-    choice is by input size, MTG_REPLAY_BLOCK forces it: both on the same graphs, against the oracle."""
+    choice is by input size, mtg_set_replay_tuning forces it: both on the same graphs, against the host loop."""
     from matchtigs_amd import synth
 
-    monkeypatch.setenv("MTG_REPLAY_BLOCK", block)
     for case in (dict(n_binodes=20000, seed=6, k=31, mean_out_degree=2.6, mean_weight=2.0, self_mirror_frac=0.05),
                  dict(n_binodes=3000, seed=9, k=31, mean_out_degree=2.6, mean_weight=1.0, self_mirror_frac=0.01)):
         bg = synth.g_csr(**case)
-        G, dev, gpu_pairs, host_pairs = _run(bg)
+        G, dev, gpu_pairs, host_pairs = _run(bg, tuning=dict(block=block))
         assert _pairs_equal(gpu_pairs, host_pairs), (block, case)
+
+
+def test_gpu_replay_grid_barrier_forms_and_launch_geometries(oracle, product_lib):
+    """The grid barrier's per-XCD stage (one release per XCD: leans on gfx942 / gfx950 hardware) against the plain form (every
+    workgroup releases: the memory model alone), and other window counts / role splits / grids -- on a graph of 2^24 nominal edges,
+    where the rounds fill the device: the same pair list as the host loop under every setting."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    k = 31
+    G = synth.g_csr_device(int((1 << 24) / 3), seed=4, k=k)
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify(torch_glue.current_stream_ptr())
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    start, count, pool = torch_glue.candidates_to_numpy(bufs)
+    on, mu, li = dev.classify_download()
+    host_pairs = G.replay_claims(on, mu, li, start, count, pool)
+    assert len(host_pairs) > 100000
+    for tuning in (dict(), dict(plain_barrier=True), dict(windows=7, role_mod=3), dict(windows=96, plain_barrier=True, role_mod=1),
+                   dict(block=256, grid=100), dict(block=256, plain_barrier=True)):
+        dev.set_replay_tuning(**tuning)
+        got = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), torch_glue.current_stream_ptr())
+        assert _pairs_equal(got, host_pairs), tuning
