@@ -604,8 +604,10 @@ def sssp_stage_of_seeds(args, seeds, device_id) -> dict:
             b = torch_glue.run_sssp(d, 0, S, b)
             ms.append(d.last_sssp_kernel_ms())
         st = d.sssp_count(0, S, torch_glue.current_stream_ptr())
+        vis = d.sssp_count_visited(0, S, torch_glue.current_stream_ptr()) if d.prunes() else st
         out[str(seed)] = {"V": g.node_count(), "E": g.edge_count(), "sources": int(S), "sssp_stage_ms": round(float(np.mean(ms)), 4),
-                          "frac": round(algorithmic_bytes(st) / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+                          "frac": round(algorithmic_bytes(vis) / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                          "frac_full_ball_equivalent": round(algorithmic_bytes(st) / (float(np.mean(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
         del b, d, g
         torch.cuda.empty_cache()
     return out

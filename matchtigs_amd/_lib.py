@@ -187,6 +187,7 @@ def load():
         "mtg_compute_tigs_cfg": (vp, [vp, u64, P(MtgConfig)]),
         "mtg_last_performance_data": (None, [P(MtgDijkstraPerformanceData)]),
         "mtg_last_euler_kernel_ms": (C.c_double, []),
+        "mtg_set_euler_device_tuning": (None, [C.c_int]),
         "mtg_walks_count": (u64, [vp]),
         "mtg_walks_total_edges": (u64, [vp]),
         "mtg_walks_export": (None, [vp, vp, vp]),

@@ -49,6 +49,7 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
 std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int parts);
 // euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
 Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_out);
+void device_euler_force_bitmap(int on);
 // finish_device.hip: insertion + Euleriser + Euler bicycles + cut on the GPU (see mtg_finish_device)
 // (d_pairs_resident: the n_pairs pairs as they lie in the HBM of `device_id`, e.g. left there by the claim replay -- `pairs` may then be null:
 // nothing is uploaded, and the host graph gets its dummy weights from a download that runs beside the GPU stages)

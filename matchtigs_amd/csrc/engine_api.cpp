@@ -276,6 +276,7 @@ mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id) {
     return new mtg_walks{device_euler_cycles(g->g, device_id, &g_last_euler_kernel_ms)};
 }
 double mtg_last_euler_kernel_ms(void) { return g_last_euler_kernel_ms; }
+void mtg_set_euler_device_tuning(int splitter_bitmap) { device_euler_force_bitmap(splitter_bitmap); }
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k) {
     return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
 }

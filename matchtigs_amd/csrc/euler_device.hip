@@ -32,6 +32,7 @@
 // always gives the same walks. Everything is integer gather/scatter work; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <vector>
@@ -183,10 +184,15 @@ __device__ __forceinline__ void for_each_passage(const uint32_t *mirror, const u
     }
 }
 __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
-                                                    const uint32_t *comp, uint32_t *parent2, unsigned long long *best, uint32_t *proposed) {
+                                                    const uint32_t *comp, uint32_t *parent2, unsigned long long *best, uint32_t *proposed,
+                                                    uint8_t *active, int first_round) {
     const uint64_t vi = gid();
     if (vi >= n_nodes) return;
     const uint32_t v = (uint32_t)vi;
+    // components only ever merge: a binode whose passages were all in one component in an earlier round has nothing to propose in
+    // any later one (the last round, which only finds out that nobody proposes, then reads one byte per node)
+    if (!first_round && !active[v]) return;
+    bool mine = false;
     uint32_t r0 = 0;
     for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t, uint32_t b) {
         const uint32_t r = uf_find(parent2, comp[b >> 1]);
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uin
         // a long trail receives one proposal per shared binode: filter the losers before they queue up on its word
         if (key < __hip_atomic_load(&best[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[hi], key);
         *proposed = 1u;  // (every proposing thread stores the same value: a round without proposals ends the hooking)
+        mine = true;
     });
+    active[v] = mine ? 1 : 0;
 }
 // `best` holds ~0 everywhere except at the roots that received a proposal this round; the kernel resets what it consumes,
 // so the array is cleared once per call and not once per round
@@ -265,6 +273,18 @@ __global__ __launch_bounds__(EB) void splitter_compact_kernel(const uint32_t *fl
     const uint64_t e = gid();
     if (e < n_darts && flag[e]) splitters[sidx[e]] = (uint32_t)e;
 }
+// While dart ids leave bit 31 free (fewer than 2^31 darts) the walks do not look the splitter bitmap up at every step: the
+// PREDECESSOR of every splitter carries the mark in bit 31 of its successor word -- pred(x) = succ[x ^ 1] ^ 1, by the mirror symmetry
+// of the pairing -- set by one thread per splitter. One random load per step instead of two (walk_measure 6.8 -> see DESIGN 3.6).
+constexpr uint32_t SUCC_MARK = 0x80000000u;
+__global__ __launch_bounds__(EB) void mark_pred_kernel(uint32_t *succ, const uint32_t *splitters, uint32_t n_split) {
+    const uint64_t i = gid();
+    if (i >= n_split) return;
+    const uint32_t x = splitters[i];
+    const uint32_t p = (succ[x ^ 1u] & ~SUCC_MARK) ^ 1u;  // (the word of x ^ 1 may carry a mark of its own already)
+    atomicOr(&succ[p], SUCC_MARK);
+}
+template <bool MARKED>
 __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, const uint32_t *splitters, const uint32_t *sidx,
                                                          const uint32_t *split_bits, const uint32_t *root_bits, uint32_t n_split,
                                                          uint64_t n_darts, uint32_t *seg_len, uint32_t *next_split, uint32_t *jump,
@@ -272,12 +292,25 @@ __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, 
     const uint64_t i = gid();
     if (i >= n_split) return;
     const uint32_t s = splitters[i];
-    uint32_t x = succ[s], len = 1;
-    while (!bit_of(split_bits, x)) {
-        x = succ[x];
-        if (++len == 0 || len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
-            atomicOr(error, 2u);
-            break;
+    uint32_t x, len = 1;
+    if constexpr (MARKED) {
+        uint32_t w = succ[s];
+        while (!(w & SUCC_MARK)) {
+            w = succ[w];
+            if (++len == 0 || len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
+                atomicOr(error, 2u);
+                break;
+            }
+        }
+        x = w & ~SUCC_MARK;
+    } else {
+        x = succ[s];
+        while (!bit_of(split_bits, x)) {
+            x = succ[x];
+            if (++len == 0 || len > n_darts) {
+                atomicOr(error, 2u);
+                break;
+            }
         }
     }
     const uint32_t nxt = sidx[x];
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(EB) void root_len_kernel(const uint32_t *rflag, con
     if (i >= n_split || !rflag[i]) return;
     cyc_len[ridx[i]] = seg_len[i] + dist[next_split[i]];  // next == i (single splitter): dist 0
 }
+template <bool MARKED>
 __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, const uint32_t *splitters, const uint32_t *rflag,
                                                        const uint32_t *ridx, const uint32_t *jump, const uint32_t *dist,
                                                        const uint32_t *seg_len, const uint32_t *cyc_len, const uint32_t *cyc_base,
@@ -320,11 +354,15 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
     const uint32_t len = seg_len[i];
     for (uint32_t j = 0; j < len; j++) {
         out[p++] = x;
-        x = succ[x];
+        x = MARKED ? (succ[x] & ~SUCC_MARK) : succ[x];
     }
 }
 
 }  // namespace
+
+// (tests: the bitmap form of the splitter test, which graphs with 2^31 darts or more always use, on small graphs too)
+static std::atomic<int> g_force_bitmap{0};
+void device_euler_force_bitmap(int on) { g_force_bitmap.store(on ? 1 : 0); }
 
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
 // The buckets of darts [0, E) from the kept buckets of the original darts [0, E0) (row0 / adj0) and fresh ones of the dummy darts
@@ -393,7 +431,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
 
-    Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small;
+    Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small, b_active;
     uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1);
     uint32_t *d_adj = b_adj.alloc<uint32_t>(st, E);
     const uint64_t n_b = E / 2;  // biedges
@@ -407,6 +445,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_sbits = b_sbits.alloc<uint32_t>(st, n_words);
     uint32_t *d_rbits = b_rbits.alloc<uint32_t>(st, n_words);
     unsigned long long *d_best = b_best.alloc<unsigned long long>(st, n_b);
+    uint8_t *d_active = b_active.alloc<uint8_t>(st, V);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(E) + 2);
     uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] a binode proposed in this round
     uint32_t *d_error = d_small, *d_total = d_small + 1;
@@ -446,7 +485,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     for (;; hook_rounds++) {  // (a round in which no binode sees two components is the last: nothing to hook, nothing to flatten)
         if (hook_rounds > 64) MTG_DIE("device_euler_cycles: internal error (component hooking does not converge)");
         HIP_CHECK(hipMemsetAsync(d_small + 4, 0, 4, st));
-        propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best, d_small + 4);
+        propose_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_comp, d_parent2, d_best, d_small + 4, d_active, hook_rounds == 0 ? 1 : 0);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (!h_small[4]) break;
@@ -455,6 +494,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     }
     lap("hooking rounds");
     b_best.release();
+    b_active.release();
     rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_flag, d_succ);
     // 5. ranking
     splitter_flag_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, d_parent2, E, d_flag, d_sbits, d_rbits);
@@ -478,7 +518,13 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_rflag = b_rflag.alloc<uint32_t>(st, M);
     uint32_t *d_ridx = b_ridx.alloc<uint32_t>(st, M);
     splitter_compact_kernel<<<grid_for(E), EB, 0, st>>>(d_flag, d_sidx, E, d_split);
-    walk_measure_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
+    const bool marked = E < 0x80000000ull && !g_force_bitmap;  // bit 31 of a successor word is free: it marks "my successor is a splitter"
+    if (marked) {
+        mark_pred_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, M);
+        walk_measure_kernel<true><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
+    } else {
+        walk_measure_kernel<false><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
+    }
     int cur = 0;
     for (uint64_t span = 1; span < (uint64_t)M * 2; span <<= 1) {  // after r rounds a pointer spans 2^r reduced elements
         wyllie_kernel<<<grid_for(M), EB, 0, st>>>(d_jump[cur], d_dist[cur], M, d_jump[cur ^ 1], d_dist[cur ^ 1]);
@@ -503,8 +549,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[3] != E / 2)
         MTG_DIE("device_euler_cycles: internal error (closed walks cover %u of %llu biedges)", h_small[3], (unsigned long long)(E / 2));
-    walk_write_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M,
-                                                   d_out);
+    if (marked) walk_write_kernel<true><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
+    else walk_write_kernel<false><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev1, st));
     HIP_CHECK(hipStreamSynchronize(st));

@@ -162,3 +162,23 @@ def test_device_euler_is_reproducible(gpu):
         b = G.euler_cycles_device_np()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     check_bicycles(G.export(), a[0], a[1])
+
+
+def test_device_euler_splitter_mark_and_bitmap_forms_agree(gpu):
+    """The segment walks find the next splitter by a mark in bit 31 of its predecessor's successor word (fewer than 2^31 darts) or by
+    a bitmap lookup per step (always from 2^31 darts on; forced here by mtg_set_euler_device_tuning): identical walks."""
+    from matchtigs_amd import _lib, api, synth
+
+    L = _lib.load()
+    for seed, n, deg in ((13, 200000, 1.2), (5, 60000, 2.0), (9, 300, 1.5)):
+        bg = synth.g_csr(n, seed=seed, k=31, mean_out_degree=deg)
+        G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        G.make_eulerian(0, bg.k)
+        a = G.euler_cycles_device_np()
+        L.mtg_set_euler_device_tuning(1)
+        try:
+            b = G.euler_cycles_device_np()
+        finally:
+            L.mtg_set_euler_device_tuning(0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (seed, n)
+        check_bicycles(G.export(), a[0], a[1])
