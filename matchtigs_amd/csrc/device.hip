@@ -2209,10 +2209,15 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         return 0;
     }
     if (V > w.cap_v) {
-        if (w.state) { HIP_CHECK(hipFree(w.state)); HIP_CHECK(hipFree(w.resv[0])); HIP_CHECK(hipFree(w.resv[1])); }
+        if (w.state) HIP_CHECK(hipFree(w.state));
+        for (int i = 0; i < 2; i++) if (w.resv[i]) { HIP_CHECK(hipFree(w.resv[i])); w.resv[i] = nullptr; }
+#if MTG_REPLAY_RECORDS
+        hu::device_malloc(&w.state, ((V + 1) / 2) * 64);  // one 64-byte record per pair of numeric neighbours: states + both reservation words
+#else
         hu::device_malloc(&w.state, (V + 2) * 8);  // (states are read in aligned pairs: the last pair may reach one word beyond V)
         hu::device_malloc(&w.resv[0], V * 8);
         hu::device_malloc(&w.resv[1], V * 8);
+#endif
         w.cap_v = V;
         w.tag_base = 0xFFFFFFFFu;  // forces the clear below
     }
@@ -2242,14 +2247,22 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // reservation tags decrease with every round of every call, so the two reservation arrays are never cleared; only when
     // the 32-bit tag space is used up (or the arrays are new)
     if ((uint64_t)w.tag_base + REPLAY_MAX_ROUNDS + 128 >= 0xFFFFFFF0ull) {
+#if MTG_REPLAY_RECORDS
+        HIP_CHECK(hipMemsetAsync(w.state, 0xFF, ((V + 1) / 2) * 64, st));  // (the states are written next)
+#else
         HIP_CHECK(hipMemsetAsync(w.resv[0], 0xFF, V * 8, st));
         HIP_CHECK(hipMemsetAsync(w.resv[1], 0xFF, V * 8, st));
+#endif
         w.tag_base = 0;
     }
     HIP_CHECK(hipEventRecord(d->ev_r[0], st));
     // working copy of the classification state; per-source outputs start at "nothing claimed"
-    hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
-    HIP_CHECK(hipGetLastError());
+    {
+        ReplayArgs ia{};
+        ia.state = w.state; ia.resv[0] = w.resv[0]; ia.resv[1] = w.resv[1];
+        hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, ia);
+        HIP_CHECK(hipGetLastError());
+    }
     // the sources that have candidates, in order, with the static words of their admission (Dense)
     uint64_t n_dense = 0;
     {
