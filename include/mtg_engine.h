@@ -236,6 +236,17 @@ int mtg_last_replay_rounds(const mtg_device *d);
 uint64_t mtg_last_replay_visits(const mtg_device *d);
 
 /* ---- multi-GPU ------------------------------------------------------------- */
+/* Two forms, by design:
+ *  - INSIDE the library (this function, mtg_config.device_ids): ONE process drives n GPUs from n host threads, and the candidate
+ *    lists travel to the first GPU as peer copies (hipMemcpyPeerAsync over xGMI: three copies per device, counts / starts / keys).
+ *    The library does not link RCCL: a collective library adds nothing to a gather whose pieces already sit in one address space
+ *    and whose replay order IS the device order, and it would make libmatchtigs.so depend on a communicator the reference's
+ *    callers (clib.rs: one thread, no runtime) do not have.
+ *  - ONE PROCESS PER GPU (matchtigs_amd/distributed.py, what bench.py runs under torch.distributed.run): the same exchange as
+ *    grouped broadcasts at exact sizes over torch.distributed's "nccl" backend = RCCL over xGMI. This is the form north_star words
+ *    ("RCCL all-gather of matched pairs"), and the only one in which ranks do not share an address space.
+ * Both give the pair list of one GPU bit for bit (tests: gloo world 2 / 3, several resident copies on one GPU). Neither has run on
+ * two distinct GPUs yet: the development pool hands out one GPU per job. */
 /* SSSP + gather + claim replay over ALL classified sources of n_devices resident copies of the SAME graph (each created
  * with mtg_device_create on its GPU and classified): the ascending source list is cut into contiguous blocks of equal
  * estimated work (1 + out-degree of the source), device i searches block i from its own host thread, the candidate lists
