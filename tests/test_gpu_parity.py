@@ -316,6 +316,28 @@ def test_k_beyond_16_bits(gpu, oracle, k):
     assert api.GreedytigAlgorithm.compute_tigs(H, api.GreedytigAlgorithmConfiguration(1, k)) == want
 
 
+@pytest.mark.parametrize("plan", [0, 2, 1])
+@pytest.mark.parametrize("k,mean_weight", [(255, 40.0), (256, 40.0), (300, 50.0), (1000, 150.0), (20000, 2500.0)])
+def test_k_around_the_two_weight_formats(gpu, oracle, k, mean_weight, plan):
+    """k <= 255: the blocks carry weight | weight + lower bound in one byte each and the enumeration level prunes; 256 <= k < 32768:
+    plain 16-bit weights, the enumeration level without pruning. Both sides of the border and well inside the second range, under
+    the per-lane and the quad gathers and the plain cascade: candidate lists and full-ball counters equal the oracle's."""
+    from matchtigs_amd import synth
+
+    bg = synth.g_csr(4000, seed=k, k=k, mean_out_degree=1.7, mean_weight=mean_weight, self_mirror_frac=0.01)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
+    assert dev.prunes() == (k <= 255 and plan != 1)
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(k)
+    assert np.array_equal(count.astype(np.uint64), np.diff(off)), (k, plan)
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)]) if S else np.zeros(0, np.uint64)
+    assert np.array_equal(got, keys), (k, plan)
+    assert len(keys) > 500  # (the bound reaches well beyond single edges)
+    levels = dev.last_sssp_levels()
+    assert ("sssp_enum_kernel" in levels[0]["kernel"]) == (plan != 1)
+    cnt = dev.sssp_count(0, S)
+    assert (cnt["settled_nodes"], cnt["relaxed_edges"], cnt["emitted"]) == (st["settled_nodes"], st["relaxed_edges"], len(keys))
+
+
 @pytest.mark.parametrize("plan", [0, 1, 2])
 def test_high_degree_nodes_use_spill_adjacency(gpu, oracle, plan):
     """Nodes with more than 4 out-edges (not a de Bruijn graph, but legal through the C-ABI) take the CSR spill path."""
