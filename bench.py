@@ -88,7 +88,7 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
         "insert_eulerise": 88 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
         "decomposition": buckets + 48 * V + int(104.4 * E) + (100 + 16 * wy) * M,
         "records": buckets + 732 * V + 12 * E,
-        "cut": 108 * n + 4 * P + 4 * kept + 4 * tigs,
+        "cut": 12 * n + 4 * P + 4 * kept + 4 * tigs,                 # three passes over the closed walks (rotation, count, emit) + the tigs
     }
 
 

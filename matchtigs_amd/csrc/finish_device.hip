@@ -296,56 +296,83 @@ __global__ __launch_bounds__(EB) void mid_build_slice_kernel(uint64_t first, uin
 }
 
 // ---- rotate + cut (greedytigs/mod.rs:726-789) ----------------------------------------------------------------------
+// Round 4: three passes over the closed walks instead of fifteen kernels. A workgroup takes CUT_CHUNK consecutive positions of
+// the back-to-back cycles; which cycle a position belongs to comes from the slice of the cycle offsets that overlaps the chunk
+// (found by two binary searches, held in LDS: a chunk of 2048 positions meets at most 2049 cycles) -- no per-position head flags,
+// no scan over the positions. The rotated cycle is never materialised: rotated position j of cycle c reads cyc[base + (j + r) % len].
+//   rotation_kernel  the rotation point of every cycle (one 64-bit atomicMax per cycle)
+//   cut_count_kernel kept edges and tig ends per chunk (-> two scans over the chunk counts)
+//   cut_emit_kernel  the same flags again, ranked inside the chunk, written to their final places
 struct CutIds {
     uint32_t n_orig;     // darts >= n_orig are dummies
     uint32_t first_brk;  // darts >= first_brk are breaking edges (weight k); matched dummies in between have pair_w
 };
-__global__ __launch_bounds__(EB) void cycle_heads_kernel(uint32_t n_cycles, const uint32_t *cbase, uint32_t *head) {
-    const uint64_t r = gid();
-    if (r < n_cycles) head[cbase[r]] = 1u;
+constexpr int CUT_PER = 8, CUT_CHUNK = EB * CUT_PER;
+
+struct CycleSlice {
+    uint32_t base[CUT_CHUNK + 2];  // offsets of the cycles c0 .. c0 + n - 1 that overlap the chunk (ascending)
+    uint32_t c0, n;
+};
+// cycles overlapping positions [q0, q1): c0 = the cycle of q0, n = their number (every cycle has at least one position)
+__device__ __forceinline__ void load_cycle_slice(CycleSlice &sl, const uint32_t *cbase, uint32_t n_cycles, uint64_t q0, uint64_t q1) {
+    if (threadIdx.x == 0) {
+        auto cycle_of = [&](uint64_t q) {  // largest c with cbase[c] <= q
+            uint32_t lo = 0, hi = n_cycles;
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (cbase[mid] <= q) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
+        sl.c0 = cycle_of(q0);
+        sl.n = cycle_of(q1 - 1) - sl.c0 + 1;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < sl.n; i += EB) sl.base[i] = cbase[sl.c0 + i];
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t slice_cycle_of(const CycleSlice &sl, uint64_t q) {  // index into the slice
+    uint32_t lo = 0, hi = sl.n;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (sl.base[mid] <= q) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 // rotation point (:737-748): the first dummy that is strictly longer than every dummy before it = the first occurrence of the
 // largest dummy weight = max over dummies of (weight, -position). One 64-bit atomicMax per cycle; a wave that lies inside one
 // cycle reduces first, and a key that cannot win is filtered by a plain load (a giant cycle's 10^7 breaking edges would
 // otherwise queue up on one word).
-__global__ __launch_bounds__(EB) void rotation_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *head, const uint32_t *hscan,
-                                                     const uint32_t *cbase, CutIds ids, uint32_t k, const uint32_t *pair_w,
-                                                     unsigned long long *rotkey) {
-    const uint64_t p = gid();
-    unsigned long long key = 0;
-    uint32_t c = 0xFFFFFFFFu;
-    if (p < n) {
-        c = hscan[p] + head[p] - 1;
-        const uint32_t e = cyc[p];
-        if (e >= ids.n_orig) {
-            const uint32_t w = e >= ids.first_brk ? k : pair_w[(e - ids.n_orig) >> 1];
-            if (w > 0) key = ((unsigned long long)w << 32) | (0xFFFFFFFFu - (uint32_t)(p - cbase[c]));
+__global__ __launch_bounds__(EB) void rotation_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *cbase, uint32_t n_cycles, CutIds ids, uint32_t k,
+                                                     const uint32_t *pair_w, unsigned long long *rotkey) {
+    __shared__ CycleSlice sl;
+    const uint64_t q0 = (uint64_t)blockIdx.x * CUT_CHUNK, q1 = q0 + CUT_CHUNK < n ? q0 + CUT_CHUNK : n;
+    load_cycle_slice(sl, cbase, n_cycles, q0, q1);
+#pragma unroll
+    for (int i = 0; i < CUT_PER; i++) {
+        const uint64_t p = q0 + (uint64_t)i * EB + threadIdx.x;
+        unsigned long long key = 0;
+        uint32_t c = 0xFFFFFFFFu;
+        if (p < n) {
+            const uint32_t ci = slice_cycle_of(sl, p);
+            c = sl.c0 + ci;
+            const uint32_t e = cyc[p];
+            if (e >= ids.n_orig) {
+                const uint32_t w = e >= ids.first_brk ? k : pair_w[(e - ids.n_orig) >> 1];
+                if (w > 0) key = ((unsigned long long)w << 32) | (0xFFFFFFFFu - (uint32_t)(p - sl.base[ci]));
+            }
         }
-    }
-    const uint32_t c0 = __shfl(c, 0, 64);
-    if (__all(c == c0 || p >= n)) {  // the whole wave is in one cycle
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(key, off, 64);
-            key = o > key ? o : key;
+        const uint32_t c_first = __shfl(c, 0, 64);
+        if (__all(c == c_first || p >= n)) {  // the whole wave is in one cycle
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off, 64);
+                key = o > key ? o : key;
+            }
+            if ((threadIdx.x & 63) != 0) key = 0;
+            c = c_first;
         }
-        if ((threadIdx.x & 63) != 0) key = 0;
-        c = c0;
+        if (key && key > __hip_atomic_load(&rotkey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&rotkey[c], key);
     }
-    if (key && key > __hip_atomic_load(&rotkey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&rotkey[c], key);
-}
-// rot[q] = the cycle rotated to its rotation point (:746-748), still back to back
-__global__ __launch_bounds__(EB) void rotate_cycles_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *head, const uint32_t *hscan,
-                                                          const uint32_t *cbase, const uint32_t *clen, const unsigned long long *rotkey,
-                                                          uint32_t *rot) {
-    const uint64_t p = gid();
-    if (p >= n) return;
-    const uint32_t c = hscan[p] + head[p] - 1;
-    const uint32_t base = cbase[c], len = clen[c];
-    const unsigned long long key = rotkey[c];
-    const uint32_t r = key ? 0xFFFFFFFFu - (uint32_t)key : 0u;
-    const uint32_t j = (uint32_t)(p - base);
-    const uint32_t jr = j >= r ? j - r : j + len - r;
-    rot[base + jr] = cyc[p];
 }
 // cut(j) = breaking edge, or any dummy at rotated index 0 (:767-769) or at the last index (the tail rule :779-788 drops a
 // trailing dummy, which is the same as cutting there). keep = !cut; a kept edge ends a tig if it is the cycle's last edge or its
@@ -353,23 +380,81 @@ __global__ __launch_bounds__(EB) void rotate_cycles_kernel(const uint32_t *cyc, 
 __device__ __forceinline__ bool is_cut(uint32_t e, uint32_t j, uint32_t len, const CutIds &ids) {
     return e >= ids.first_brk || (e >= ids.n_orig && (j == 0 || j + 1 == len));
 }
-__global__ __launch_bounds__(EB) void cut_flags_kernel(const uint32_t *rot, uint64_t n, const uint32_t *head, const uint32_t *hscan,
-                                                      const uint32_t *cbase, const uint32_t *clen, CutIds ids, uint32_t *keep, uint32_t *end) {
-    const uint64_t q = gid();
-    if (q >= n) return;
-    const uint32_t c = hscan[q] + head[q] - 1;
-    const uint32_t j = (uint32_t)(q - cbase[c]), len = clen[c];
-    const bool kp = !is_cut(rot[q], j, len, ids);
-    keep[q] = kp ? 1u : 0u;
-    end[q] = (kp && (j + 1 == len || is_cut(rot[q + 1], j + 1, len, ids))) ? 1u : 0u;
+// edge at rotated position q (and whether it is kept / ends a tig); cycles rotated by their rotation point (:746-748)
+struct CutAt { uint32_t e; bool keep, end; };
+__device__ __forceinline__ CutAt cut_at(const CycleSlice &sl, uint64_t q, const uint32_t *cyc, const uint32_t *clen, const unsigned long long *rotkey,
+                                        const CutIds &ids) {
+    const uint32_t ci = slice_cycle_of(sl, q), c = sl.c0 + ci;
+    const uint32_t base = sl.base[ci], len = clen[c];
+    const unsigned long long key = rotkey[c];
+    const uint32_t r = key ? 0xFFFFFFFFu - (uint32_t)key : 0u;
+    const uint32_t j = (uint32_t)(q - base);
+    auto rot_at = [&](uint32_t jj) {  // cyc[base + (jj + r) % len] without the division (r < len, jj < len)
+        const uint32_t t = len - r;   // positions jj < t come from jj + r, the others from jj - t
+        return cyc[(uint64_t)base + (jj < t ? jj + r : jj - t)];
+    };
+    CutAt a;
+    a.e = rot_at(j);
+    a.keep = !is_cut(a.e, j, len, ids);
+    a.end = a.keep && (j + 1 == len || is_cut(rot_at(j + 1), j + 1, len, ids));
+    return a;
 }
-__global__ __launch_bounds__(EB) void cut_write_kernel(const uint32_t *rot, uint64_t n, const uint32_t *keep, const uint32_t *end,
-                                                      const uint32_t *kpos, const uint32_t *tpos, uint32_t *tig_edges,
-                                                      uint32_t *tig_limits) {
-    const uint64_t q = gid();
-    if (q >= n || !keep[q]) return;
-    tig_edges[kpos[q]] = rot[q];
-    if (end[q]) tig_limits[tpos[q]] = kpos[q] + 1;  // (fewer than 2^31 biedges: the limits travel as 32-bit words and are widened on the host)
+__global__ __launch_bounds__(EB) void cut_count_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *cbase, const uint32_t *clen, uint32_t n_cycles,
+                                                      const unsigned long long *rotkey, CutIds ids, uint32_t *chunk_keep, uint32_t *chunk_end) {
+    __shared__ CycleSlice sl;
+    __shared__ uint32_t s_keep, s_end;
+    if (threadIdx.x == 0) { s_keep = 0; s_end = 0; }
+    const uint64_t q0 = (uint64_t)blockIdx.x * CUT_CHUNK, q1 = q0 + CUT_CHUNK < n ? q0 + CUT_CHUNK : n;
+    load_cycle_slice(sl, cbase, n_cycles, q0, q1);
+    uint32_t nk = 0, ne = 0;
+#pragma unroll
+    for (int i = 0; i < CUT_PER; i++) {
+        const uint64_t q = q0 + (uint64_t)i * EB + threadIdx.x;
+        if (q >= n) continue;
+        const CutAt a = cut_at(sl, q, cyc, clen, rotkey, ids);
+        nk += a.keep ? 1u : 0u;
+        ne += a.end ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { nk += __shfl_down(nk, off, 64); ne += __shfl_down(ne, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_keep, nk); atomicAdd(&s_end, ne); }
+    __syncthreads();
+    if (threadIdx.x == 0) { chunk_keep[blockIdx.x] = s_keep; chunk_end[blockIdx.x] = s_end; }
+}
+// (chunk_keep / chunk_end: exclusive scans of the counts. Limits travel as 32-bit words: fewer than 2^31 biedges.)
+__global__ __launch_bounds__(EB) void cut_emit_kernel(const uint32_t *cyc, uint64_t n, const uint32_t *cbase, const uint32_t *clen, uint32_t n_cycles,
+                                                     const unsigned long long *rotkey, CutIds ids, const uint32_t *chunk_keep, const uint32_t *chunk_end,
+                                                     uint32_t *tig_edges, uint32_t *tig_limits) {
+    __shared__ CycleSlice sl;
+    __shared__ uint32_t w_keep[CUT_PER][EB / 64], w_end[CUT_PER][EB / 64];
+    const uint64_t q0 = (uint64_t)blockIdx.x * CUT_CHUNK, q1 = q0 + CUT_CHUNK < n ? q0 + CUT_CHUNK : n;
+    load_cycle_slice(sl, cbase, n_cycles, q0, q1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t e[CUT_PER];
+    unsigned long long bk[CUT_PER], be[CUT_PER];
+#pragma unroll
+    for (int i = 0; i < CUT_PER; i++) {
+        const uint64_t q = q0 + (uint64_t)i * EB + threadIdx.x;
+        CutAt a{0u, false, false};
+        if (q < n) a = cut_at(sl, q, cyc, clen, rotkey, ids);
+        e[i] = a.e;
+        bk[i] = __ballot(a.keep);
+        be[i] = __ballot(a.end);
+        if (lane == 0) { w_keep[i][wv] = (uint32_t)__popcll(bk[i]); w_end[i][wv] = (uint32_t)__popcll(be[i]); }
+    }
+    __syncthreads();
+    uint32_t ko = chunk_keep[blockIdx.x], eo = chunk_end[blockIdx.x];  // ranks in position order: pass, wave, lane
+#pragma unroll
+    for (int i = 0; i < CUT_PER; i++) {
+        for (int w = 0; w < EB / 64; w++) {
+            if (w == wv && ((bk[i] >> lane) & 1ull)) {
+                const uint32_t kp = ko + (uint32_t)__popcll(bk[i] & ((1ull << lane) - 1ull));
+                tig_edges[kp] = e[i];
+                if ((be[i] >> lane) & 1ull) tig_limits[eo + (uint32_t)__popcll(be[i] & ((1ull << lane) - 1ull))] = kp + 1;
+            }
+            ko += w_keep[i][w];
+            eo += w_end[i][w];
+        }
+    }
 }
 
 struct Lap {
@@ -854,30 +939,23 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     {
         const uint64_t n = E / 2;
         const uint32_t *d_cyc = b_cyc.as<uint32_t>(), *d_clen = b_clen.as<uint32_t>(), *d_cbase = b_cbase.as<uint32_t>();
-        Buf b_head, b_hscan, b_rotkey, b_rot, b_keep, b_end, b_kpos, b_tpos, b_te, b_tl;
-        uint32_t *d_head = b_head.alloc<uint32_t>(st, n), *d_hscan = b_hscan.alloc<uint32_t>(st, n);
+        Buf b_rotkey, b_ck, b_ce, b_te, b_tl;
+        const uint64_t n_chunks = (n + CUT_CHUNK - 1) / CUT_CHUNK;
         unsigned long long *d_rotkey = b_rotkey.alloc<unsigned long long>(st, n_cycles);
-        uint32_t *d_rot = b_rot.alloc<uint32_t>(st, n);
+        uint32_t *d_ck = b_ck.alloc<uint32_t>(st, n_chunks), *d_ce = b_ce.alloc<uint32_t>(st, n_chunks);
         sev.mark(4, st);
-        HIP_CHECK(hipMemsetAsync(d_head, 0, n * 4, st));
         HIP_CHECK(hipMemsetAsync(d_rotkey, 0, (uint64_t)std::max<uint32_t>(n_cycles, 1) * 8, st));
-        cycle_heads_kernel<<<grid_for(n_cycles), EB, 0, st>>>(n_cycles, d_cbase, d_head);
-        scan_u32<uint32_t>(st, d_head, n, d_hscan, d_bsum, d_small + 6);
         CutIds ids{(uint32_t)E0, (uint32_t)first_brk};
-        rotation_kernel<<<grid_for(n), EB, 0, st>>>(d_cyc, n, d_head, d_hscan, d_cbase, ids, (uint32_t)k, d_pw, d_rotkey);
-        rotate_cycles_kernel<<<grid_for(n), EB, 0, st>>>(d_cyc, n, d_head, d_hscan, d_cbase, d_clen, d_rotkey, d_rot);
-        b_cyc.release();
-        uint32_t *d_keep = b_keep.alloc<uint32_t>(st, n), *d_end = b_end.alloc<uint32_t>(st, n);
-        uint32_t *d_kpos = b_kpos.alloc<uint32_t>(st, n), *d_tpos = b_tpos.alloc<uint32_t>(st, n);
-        cut_flags_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_head, d_hscan, d_cbase, d_clen, ids, d_keep, d_end);
-        scan_u32<uint32_t>(st, d_keep, n, d_kpos, d_bsum, d_small + 7);
-        scan_u32<uint32_t>(st, d_end, n, d_tpos, d_bsum, d_small + 8);
+        rotation_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, n_cycles, ids, (uint32_t)k, d_pw, d_rotkey);
+        cut_count_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, d_clen, n_cycles, d_rotkey, ids, d_ck, d_ce);
+        scan_u32<uint32_t>(st, d_ck, n_chunks, d_ck, d_bsum, d_small + 7);
+        scan_u32<uint32_t>(st, d_ce, n_chunks, d_ce, d_bsum, d_small + 8);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         const uint64_t n_kept = h_small[7], n_tigs = h_small[8];
         uint32_t *d_te = b_te.alloc<uint32_t>(st, n_kept);
         uint32_t *d_tl = b_tl.alloc<uint32_t>(st, n_tigs);
-        cut_write_kernel<<<grid_for(n), EB, 0, st>>>(d_rot, n, d_keep, d_end, d_kpos, d_tpos, d_te, d_tl);
+        cut_emit_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, d_clen, n_cycles, d_rotkey, ids, d_ck, d_ce, d_te, d_tl);
         HIP_CHECK(hipGetLastError());
         sev.mark(5, st);
         tigs.edges.resize(n_kept);
