@@ -85,7 +85,7 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
         # state copy 17 V; dense list + claims words + pair-count scan 48 S; admission 187 B per listed source; 67.2 B per check
         # visit; compaction 32 B per pair
         "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
-        "insert_eulerise": 88 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
+        "insert_eulerise": 48 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
         "decomposition": buckets + 48 * V + int(104.4 * E) + (100 + 16 * wy) * M,
         "records": buckets + 732 * V + 12 * E,
         "cut": 12 * n + 4 * P + 4 * kept + 4 * tigs,                 # three passes over the closed walks (rotation, count, emit) + the tigs

@@ -72,37 +72,73 @@ __global__ __launch_bounds__(EB) void pair_darts_kernel(const mtg_pair *pairs, u
     pair_w[i] = (uint32_t)pairs[i].distance;
 }
 // find_non_eulerian_binodes_with_differences (mod.rs:408-427): cin = missing in-edges (diff > 0), cout = missing out-edges
-// (diff < 0), smf = self-mirror node with odd degree (difference-0 entry)
-__global__ __launch_bounds__(EB) void need_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, uint32_t *cin, uint32_t *cout,
-                                                 uint32_t *smf) {
-    const uint64_t v = gid();
-    if (v >= n_nodes) return;
+// (diff < 0), sm = self-mirror node with odd degree (difference-0 entry)
+struct Need { uint32_t ci, co, sm; };
+__device__ __forceinline__ Need need_of(uint32_t v, const uint32_t *mirror, const uint32_t *deg) {
     const uint32_t mv = mirror[v], d = deg[v];
-    uint32_t ci = 0, co = 0, sm = 0;
-    if (mv == v) sm = d & 1u;
+    Need nd{0u, 0u, 0u};
+    if (mv == v) nd.sm = d & 1u;
     else {
         const uint32_t dm = deg[mv];
-        if (d > dm) ci = d - dm;
-        else co = dm - d;
+        if (d > dm) nd.ci = d - dm;
+        else nd.co = dm - d;
     }
-    cin[v] = ci;
-    cout[v] = co;
-    smf[v] = sm;
+    return nd;
 }
-__global__ __launch_bounds__(EB) void sm_compact_kernel(uint64_t n_nodes, const uint32_t *smf, const uint32_t *p_sm, uint32_t *sm_list) {
-    const uint64_t v = gid();
-    if (v < n_nodes && smf[v]) sm_list[p_sm[v]] = (uint32_t)v;
+// Round 4: two passes over the nodes instead of twelve kernels (need, three scans of three kernels, self-mirror compaction,
+// expansion). A workgroup takes NEED_CHUNK consecutive nodes, 8 per thread: pass 1 sums the three counters per chunk (three small
+// scans over the chunk sums follow), pass 2 recomputes them, ranks them inside the chunk and writes everything that depends on the
+// ranks: the counters and their exclusive prefixes (the zip's per-unit tests gather them), the self-mirror list, and the two unit
+// orders -- order A: out-nodes descending (A-offset of o = N - p_out[o] - cout[o]), order B: in-nodes ascending (B-offset of
+// t = p_in[t]).
+constexpr int NEED_PER = 8, NEED_CHUNK = EB * NEED_PER;
+__global__ __launch_bounds__(EB) void need_count_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, uint32_t *chunk_in,
+                                                       uint32_t *chunk_out, uint32_t *chunk_sm) {
+    const uint64_t v0 = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)threadIdx.x * NEED_PER;
+    uint32_t si = 0, so = 0, ss = 0;
+#pragma unroll
+    for (int i = 0; i < NEED_PER; i++)
+        if (v0 + i < n_nodes) {
+            const Need nd = need_of((uint32_t)(v0 + i), mirror, deg);
+            si += nd.ci; so += nd.co; ss += nd.sm;
+        }
+    uint32_t ti, to, ts;
+    block_exclusive_scan<uint32_t>(si, &ti);
+    block_exclusive_scan<uint32_t>(so, &to);
+    block_exclusive_scan<uint32_t>(ss, &ts);
+    if (threadIdx.x == 0) { chunk_in[blockIdx.x] = ti; chunk_out[blockIdx.x] = to; chunk_sm[blockIdx.x] = ts; }
 }
-// order A: out-nodes descending (A-offset of o = N - p_out[o] - cout[o]); order B: in-nodes ascending (B-offset of t = p_in[t])
-__global__ __launch_bounds__(EB) void expand_kernel(uint64_t n_nodes, const uint32_t *cin, const uint32_t *cout, const uint32_t *p_in,
-                                                   const uint32_t *p_out, uint32_t n_units, uint32_t *a_node, uint32_t *b_node) {
-    const uint64_t v = gid();
-    if (v >= n_nodes) return;
-    const uint32_t ci = cin[v], co = cout[v];
-    for (uint32_t j = 0; j < ci; j++) b_node[p_in[v] + j] = (uint32_t)v;
-    if (co) {
-        const uint32_t base = n_units - p_out[v] - co;
-        for (uint32_t j = 0; j < co; j++) a_node[base + j] = (uint32_t)v;
+// (chunk_*: exclusive scans of the chunk sums; n_units = N, the total of the in- (= out-) counters, read from device memory)
+__global__ __launch_bounds__(EB) void need_emit_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, const uint32_t *chunk_in,
+                                                      const uint32_t *chunk_out, const uint32_t *chunk_sm, const uint32_t *n_units_ptr, uint32_t *cin,
+                                                      uint32_t *cout, uint32_t *p_in, uint32_t *p_out, uint32_t *sm_list, uint32_t *a_node,
+                                                      uint32_t *b_node) {
+    const uint64_t v0 = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)threadIdx.x * NEED_PER;
+    Need nd[NEED_PER];
+    uint32_t si = 0, so = 0, ss = 0;
+#pragma unroll
+    for (int i = 0; i < NEED_PER; i++) {
+        nd[i] = Need{0u, 0u, 0u};
+        if (v0 + i < n_nodes) nd[i] = need_of((uint32_t)(v0 + i), mirror, deg);
+        si += nd[i].ci; so += nd[i].co; ss += nd[i].sm;
+    }
+    uint32_t tot;
+    uint32_t ri = chunk_in[blockIdx.x] + block_exclusive_scan<uint32_t>(si, &tot);
+    uint32_t ro = chunk_out[blockIdx.x] + block_exclusive_scan<uint32_t>(so, &tot);
+    uint32_t rs = chunk_sm[blockIdx.x] + block_exclusive_scan<uint32_t>(ss, &tot);
+    const uint32_t n_units = *n_units_ptr;
+#pragma unroll
+    for (int i = 0; i < NEED_PER; i++) {
+        if (v0 + i >= n_nodes) break;
+        const uint32_t v = (uint32_t)(v0 + i), ci = nd[i].ci, co = nd[i].co;
+        cin[v] = ci; cout[v] = co; p_in[v] = ri; p_out[v] = ro;
+        for (uint32_t j = 0; j < ci; j++) b_node[ri + j] = v;
+        if (co) {
+            const uint32_t base = n_units - ro - co;
+            for (uint32_t j = 0; j < co; j++) a_node[base + j] = v;
+        }
+        if (nd[i].sm) sm_list[rs] = v;
+        ri += ci; ro += co; rs += nd[i].sm;
     }
 }
 // first irregular step (see the header): min over s of "a cursor would have to skip at step s"
@@ -594,7 +630,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
 
     // ---- original darts + mirror: left on this GPU by an earlier stage of the graph (HostGraph::device_cache), else uploaded
     // now and left there for the next call; the pairs ----
-    Buf b_pairs, b_deg, b_cin, b_cout, b_smf, b_pin, b_pout, b_psm, b_bsum, b_small;
+    Buf b_pairs, b_deg, b_cin, b_cout, b_pin, b_pout, b_bsum, b_small;
     Buf b_from0_tmp, b_mirror_tmp;  // only when the graph's cache lives on another GPU
     const uint32_t *d_from0 = nullptr, *d_mirror = nullptr;
     if (const DeviceEdgeCache *cache = edge_cache_get(g, device_id)) {
@@ -659,21 +695,23 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     if (n_pairs) pair_degree_kernel<<<grid_for(n_pairs), EB, 0, st>>>(d_pairs, n_pairs, d_mirror, d_deg);
 
     // ---- imbalance, unit orders ----
-    uint32_t *d_cin = b_cin.alloc<uint32_t>(st, V), *d_cout = b_cout.alloc<uint32_t>(st, V), *d_smf = b_smf.alloc<uint32_t>(st, V);
-    uint32_t *d_pin = b_pin.alloc<uint32_t>(st, V), *d_pout = b_pout.alloc<uint32_t>(st, V), *d_psm = b_psm.alloc<uint32_t>(st, V);
+    uint32_t *d_cin = b_cin.alloc<uint32_t>(st, V), *d_cout = b_cout.alloc<uint32_t>(st, V);
+    uint32_t *d_pin = b_pin.alloc<uint32_t>(st, V), *d_pout = b_pout.alloc<uint32_t>(st, V);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(std::max<uint64_t>(V, (E0 + 2 * n_pairs) / 2 + 1) * 2) + 2);
     uint32_t *d_small = b_small.alloc<uint32_t>(st, 16);  // [0] error, [1] N_in, [2] N_out, [3] n_sm, [4] s*, [5] residual nodes, [6..] cut totals
     HIP_CHECK(hipMemsetAsync(d_small, 0, 64, st));
-    need_kernel<<<grid_for(V), EB, 0, st>>>(V, d_mirror, d_deg, d_cin, d_cout, d_smf);
-    scan_u32<uint32_t>(st, d_cin, V, d_pin, d_bsum, d_small + 1);
-    scan_u32<uint32_t>(st, d_cout, V, d_pout, d_bsum, d_small + 2);
-    scan_u32<uint32_t>(st, d_smf, V, d_psm, d_bsum, d_small + 3);
+    const uint64_t need_chunks = (V + NEED_CHUNK - 1) / NEED_CHUNK;
+    Buf b_chunks;
+    uint32_t *d_chunks = b_chunks.alloc<uint32_t>(st, 3 * need_chunks);  // per chunk of nodes: missing in-edges | missing out-edges | odd self-mirror nodes
+    need_count_kernel<<<(unsigned)need_chunks, EB, 0, st>>>(V, d_mirror, d_deg, d_chunks, d_chunks + need_chunks, d_chunks + 2 * need_chunks);
+    scan_u32<uint32_t>(st, d_chunks, need_chunks, d_chunks, d_bsum, d_small + 1);
+    scan_u32<uint32_t>(st, d_chunks + need_chunks, need_chunks, d_chunks + need_chunks, d_bsum, d_small + 2);
+    scan_u32<uint32_t>(st, d_chunks + 2 * need_chunks, need_chunks, d_chunks + 2 * need_chunks, d_bsum, d_small + 3);
     uint32_t h_small[16];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     double acc0 = 0;
-    if (lap.on) acc0 += lap.lap("  upload, degrees, imbalance scans");
-    b_deg.release();
+    if (lap.on) acc0 += lap.lap("  upload, degrees, imbalance counts");
     const uint32_t N = h_small[1], n_sm = h_small[3];
     if (h_small[2] != N) MTG_DIE("device_finish: internal error (missing in-edges %u != missing out-edges %u)", N, h_small[2]);
     const uint32_t delta = n_sm & 1u, n_sm_edges = (n_sm + 1) / 2;
@@ -693,8 +731,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     const uint64_t first_brk = E0 + 2 * n_pairs;
     uint32_t *d_sm = b_sm.alloc<uint32_t>(st, n_sm);
     uint32_t *d_anode = b_anode.alloc<uint32_t>(st, N), *d_bnode = b_bnode.alloc<uint32_t>(st, N);
-    if (n_sm) sm_compact_kernel<<<grid_for(V), EB, 0, st>>>(V, d_smf, d_psm, d_sm);
-    if (N) expand_kernel<<<grid_for(V), EB, 0, st>>>(V, d_cin, d_cout, d_pin, d_pout, N, d_anode, d_bnode);
+    need_emit_kernel<<<(unsigned)need_chunks, EB, 0, st>>>(V, d_mirror, d_deg, d_chunks, d_chunks + need_chunks, d_chunks + 2 * need_chunks, d_small + 1,
+                                                           d_cin, d_cout, d_pin, d_pout, d_sm, d_anode, d_bnode);
     if (n_sm) sm_emit_kernel<<<grid_for(n_sm_edges), EB, 0, st>>>(n_sm, d_sm, d_bnode, d_mirror, d_from + first_brk);
     uint32_t s_star = n_steps;
     if (n_steps) {
@@ -738,7 +776,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         std::fprintf(stderr, "[mtg] device_finish:   Euleriser: %u units, %u self-mirror nodes, %u of %u steps by the parallel prefix, %llu by the sequential tail\n",
                      N, n_sm, s_star, n_steps, (unsigned long long)(n_brk - n_sm_edges - s_star));
     const uint64_t E = first_brk + 2 * n_brk, n_dummy = E - E0;
-    b_cin.release(); b_cout.release(); b_smf.release(); b_pin.release(); b_pout.release(); b_psm.release();
+    b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release(); b_deg.release(); b_chunks.release();
     b_sm.release(); b_anode.release(); b_bnode.release(); b_pairs.release();
     HIP_CHECK(hipStreamSynchronize(st));
     acc0 += lap.lap("upload + insertion + Euleriser");
