@@ -92,53 +92,70 @@ __device__ __forceinline__ Need need_of(uint32_t v, const uint32_t *mirror, cons
 // orders -- order A: out-nodes descending (A-offset of o = N - p_out[o] - cout[o]), order B: in-nodes ascending (B-offset of
 // t = p_in[t]).
 constexpr int NEED_PER = 8, NEED_CHUNK = EB * NEED_PER;
+// (node of pass i and thread t of a chunk: chunk * NEED_CHUNK + i * EB + t -- consecutive lanes, consecutive nodes: coalesced loads
+// and stores; ascending node order = pass, wave, lane)
 __global__ __launch_bounds__(EB) void need_count_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, uint32_t *chunk_in,
                                                        uint32_t *chunk_out, uint32_t *chunk_sm) {
-    const uint64_t v0 = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)threadIdx.x * NEED_PER;
+    __shared__ uint32_t s_in, s_out, s_sm;
+    if (threadIdx.x == 0) { s_in = 0; s_out = 0; s_sm = 0; }
+    __syncthreads();
     uint32_t si = 0, so = 0, ss = 0;
 #pragma unroll
-    for (int i = 0; i < NEED_PER; i++)
-        if (v0 + i < n_nodes) {
-            const Need nd = need_of((uint32_t)(v0 + i), mirror, deg);
+    for (int i = 0; i < NEED_PER; i++) {
+        const uint64_t v = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)i * EB + threadIdx.x;
+        if (v < n_nodes) {
+            const Need nd = need_of((uint32_t)v, mirror, deg);
             si += nd.ci; so += nd.co; ss += nd.sm;
         }
-    uint32_t ti, to, ts;
-    block_exclusive_scan<uint32_t>(si, &ti);
-    block_exclusive_scan<uint32_t>(so, &to);
-    block_exclusive_scan<uint32_t>(ss, &ts);
-    if (threadIdx.x == 0) { chunk_in[blockIdx.x] = ti; chunk_out[blockIdx.x] = to; chunk_sm[blockIdx.x] = ts; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { si += __shfl_down(si, off, 64); so += __shfl_down(so, off, 64); ss += __shfl_down(ss, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_in, si); atomicAdd(&s_out, so); atomicAdd(&s_sm, ss); }
+    __syncthreads();
+    if (threadIdx.x == 0) { chunk_in[blockIdx.x] = s_in; chunk_out[blockIdx.x] = s_out; chunk_sm[blockIdx.x] = s_sm; }
 }
 // (chunk_*: exclusive scans of the chunk sums; n_units = N, the total of the in- (= out-) counters, read from device memory)
 __global__ __launch_bounds__(EB) void need_emit_kernel(uint64_t n_nodes, const uint32_t *mirror, const uint32_t *deg, const uint32_t *chunk_in,
                                                       const uint32_t *chunk_out, const uint32_t *chunk_sm, const uint32_t *n_units_ptr, uint32_t *cin,
                                                       uint32_t *cout, uint32_t *p_in, uint32_t *p_out, uint32_t *sm_list, uint32_t *a_node,
                                                       uint32_t *b_node) {
-    const uint64_t v0 = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)threadIdx.x * NEED_PER;
+    __shared__ uint32_t w_in[NEED_PER][EB / 64], w_out[NEED_PER][EB / 64], w_sm[NEED_PER][EB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     Need nd[NEED_PER];
-    uint32_t si = 0, so = 0, ss = 0;
+    uint32_t xi[NEED_PER], xo[NEED_PER], xs[NEED_PER];  // exclusive prefixes inside the wave
 #pragma unroll
     for (int i = 0; i < NEED_PER; i++) {
+        const uint64_t v = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)i * EB + threadIdx.x;
         nd[i] = Need{0u, 0u, 0u};
-        if (v0 + i < n_nodes) nd[i] = need_of((uint32_t)(v0 + i), mirror, deg);
-        si += nd[i].ci; so += nd[i].co; ss += nd[i].sm;
+        if (v < n_nodes) nd[i] = need_of((uint32_t)v, mirror, deg);
+        uint32_t a = nd[i].ci, b = nd[i].co, c = nd[i].sm;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ua = __shfl_up(a, off, 64), ub = __shfl_up(b, off, 64), uc = __shfl_up(c, off, 64);
+            if (lane >= off) { a += ua; b += ub; c += uc; }
+        }
+        xi[i] = a - nd[i].ci; xo[i] = b - nd[i].co; xs[i] = c - nd[i].sm;
+        if (lane == 63) { w_in[i][wv] = a; w_out[i][wv] = b; w_sm[i][wv] = c; }
     }
-    uint32_t tot;
-    uint32_t ri = chunk_in[blockIdx.x] + block_exclusive_scan<uint32_t>(si, &tot);
-    uint32_t ro = chunk_out[blockIdx.x] + block_exclusive_scan<uint32_t>(so, &tot);
-    uint32_t rs = chunk_sm[blockIdx.x] + block_exclusive_scan<uint32_t>(ss, &tot);
+    __syncthreads();
     const uint32_t n_units = *n_units_ptr;
+    uint32_t ri = chunk_in[blockIdx.x], ro = chunk_out[blockIdx.x], rs = chunk_sm[blockIdx.x];  // running offsets: pass, then wave
 #pragma unroll
     for (int i = 0; i < NEED_PER; i++) {
-        if (v0 + i >= n_nodes) break;
-        const uint32_t v = (uint32_t)(v0 + i), ci = nd[i].ci, co = nd[i].co;
-        cin[v] = ci; cout[v] = co; p_in[v] = ri; p_out[v] = ro;
-        for (uint32_t j = 0; j < ci; j++) b_node[ri + j] = v;
+        uint32_t bi = ri, bo = ro, bs = rs;
+        for (int w = 0; w < EB / 64; w++) {
+            if (w < wv) { bi += w_in[i][w]; bo += w_out[i][w]; bs += w_sm[i][w]; }
+            ri += w_in[i][w]; ro += w_out[i][w]; rs += w_sm[i][w];
+        }
+        const uint64_t v64 = (uint64_t)blockIdx.x * NEED_CHUNK + (uint64_t)i * EB + threadIdx.x;
+        if (v64 >= n_nodes) continue;
+        const uint32_t v = (uint32_t)v64, ci = nd[i].ci, co = nd[i].co;
+        const uint32_t pi = bi + xi[i], po = bo + xo[i];
+        cin[v] = ci; cout[v] = co; p_in[v] = pi; p_out[v] = po;
+        for (uint32_t j = 0; j < ci; j++) b_node[pi + j] = v;
         if (co) {
-            const uint32_t base = n_units - ro - co;
+            const uint32_t base = n_units - po - co;
             for (uint32_t j = 0; j < co; j++) a_node[base + j] = v;
         }
-        if (nd[i].sm) sm_list[rs] = v;
-        ri += ci; ro += co; rs += nd[i].sm;
+        if (nd[i].sm) sm_list[bs + xs[i]] = v;
     }
 }
 // first irregular step (see the header): min over s of "a cursor would have to skip at step s"

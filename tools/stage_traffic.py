@@ -24,7 +24,7 @@ MARKERS = [
     ("row_degree_kernel", "insert_eulerise"),
     ("pair_degree_kernel", "insert_eulerise"),
     ("degree_rank_offset_kernel", "buckets"),   # re-labelled below: decomposition (device mode) or records (reference order)
-    ("cycle_heads_kernel", "cut"),
+    ("rotation_kernel", "cut"),
 ]
 # once per graph, inside its first finish (before the degrees are read): the kept buckets of the original darts -- not a stage of a step
 ONE_OFF = ("degree_rank_kernel", "fill_kernel")
