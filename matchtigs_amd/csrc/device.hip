@@ -2285,10 +2285,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             w.cap_dense = n_dense;
         }
         hipLaunchKernelGGL(replay_dense_fill_kernel, dim3((unsigned)nb), dim3(DENSE_BLOCK), 0, st, d->d_out_nodes, d_cand_count,
-                           (const unsigned long long *)d_cand_start, (const unsigned long long *)d_pool, d->d_mirror, S, w.block_sums, w.dense, w.src_mirror);
+                           (const unsigned long long *)d_cand_start, (const unsigned long long *)d_pool, d->d_mirror, S, w.block_sums, w.dense, w.src_mirror, w.claims);
         HIP_CHECK(hipGetLastError());
     }
-    HIP_CHECK(hipMemsetAsync(w.claims, 0, S * 8, st));
     HIP_CHECK(hipMemsetAsync(w.ctl, 0, RC_COUNT * 8, st));
 
     ReplayArgs a{};
@@ -2387,9 +2386,12 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 
     // compaction in source order
     unsigned long long *cnt = &d->d_counters[C_OVF_LIST];
-    scan_values(st, w, ScanInClaims{w.claims}, S, w.final_off, cnt);
-    read_counters(d, st);
-    const uint64_t n_pairs = d->h_counters[C_OVF_LIST];
+    uint64_t n_pairs = 0;
+    if (n_dense) {  // (over the sources with candidates only: nobody else can claim)
+        scan_values(st, w, ScanInClaims{w.claims, w.dense}, n_dense, w.final_off, cnt);
+        read_counters(d, st);
+        n_pairs = d->h_counters[C_OVF_LIST];
+    }
     rt.lap("tail + scan");
     d->last_n_pairs = n_pairs;
     if (n_pairs > w.cap_out || !w.out) {
@@ -2398,7 +2400,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         w.cap_out = std::max<uint64_t>(n_pairs, 1);
     }
     if (n_pairs) {
-        hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
+        hipLaunchKernelGGL(replay_compact_kernel, dim3((unsigned)((n_dense + 255) / 256)), dim3(256), 0, st, a, w.final_off, w.out);
         HIP_CHECK(hipGetLastError());
     }
     HIP_CHECK(hipEventRecord(d->ev_r[3], st));
