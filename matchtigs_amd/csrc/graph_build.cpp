@@ -14,8 +14,12 @@ namespace mtg {
 void HostGraph::init_nodes(uint64_t n) {
     if (n >= NONE) MTG_DIE("graph has %llu nodes; node ids are 32-bit", (unsigned long long)n);
     mirror.assign(n, NONE);
-    head_out.assign(n, NONE);
-    out_deg.assign(n, 0);
+    // (head_out / out_deg: sized by the first ensure_linked() -- the device path never walks host adjacency, and 8 bytes per node
+    // of first-touch plus the linking itself were 0.4 of the 0.65 s a one-shot caller spent building the 2^27 graph)
+    head_out.clear();
+    out_deg.clear();
+    adjacency_ready = false;
+    linked_edges = 0;
 }
 
 void HostGraph::reserve_edges(uint64_t n) {
@@ -87,8 +91,14 @@ static void link_range(const HostGraph &g, uint64_t lo, uint64_t hi) {
 // call read-only functions on one graph meet at the lock; the fast path is one acquire load)
 void HostGraph::ensure_linked() const {
     const uint64_t total = e_from.size();
-    if (__atomic_load_n(&linked_edges, __ATOMIC_ACQUIRE) >= total) return;
+    if (__atomic_load_n(&adjacency_ready, __ATOMIC_ACQUIRE) && __atomic_load_n(&linked_edges, __ATOMIC_ACQUIRE) >= total) return;
     std::lock_guard<std::mutex> lock(*link_mutex);
+    if (!adjacency_ready) {  // first use of the host adjacency on this graph: the per-node heads come into being now
+        head_out.assign(node_count(), NONE);
+        out_deg.assign(node_count(), 0);
+        linked_edges = 0;
+        __atomic_store_n(&adjacency_ready, true, __ATOMIC_RELEASE);
+    }
     if (linked_edges >= total) return;
     link_range(*this, linked_edges, total);
     __atomic_store_n(&linked_edges, total, __ATOMIC_RELEASE);
@@ -163,10 +173,10 @@ void HostGraph::validate_pairing() const {
     });
 }
 
-// per-node adjacency lists over edges [0, n_edges) in insertion order (newest first, like petgraph's per-node edge list)
+// The per-node adjacency lists over the original edges (insertion order, newest first, like petgraph's per-node edge list) are
+// linked LAZILY, by the first host stage that walks them (ensure_linked): nothing on the device path does.
 static void link_adjacency(HostGraph &g, uint64_t n_edges) {
     g.linked_edges = 0;
-    g.ensure_linked();
     (void)n_edges;
 }
 

@@ -170,6 +170,7 @@ struct HostGraph {
     PodVec<uint32_t> e_from, e_to;              // [E]
     mutable PodVec<uint32_t> e_next_out;        // [E]
     mutable uint64_t linked_edges = 0;
+    mutable bool adjacency_ready = false;  // head_out / out_deg exist (sized by the first ensure_linked)
     mutable std::unique_ptr<std::mutex> link_mutex{new std::mutex};  // ensure_linked() (a pointer: the graph stays movable)
     PodVec<uint64_t> e_weight;                  // [E]
     PodVec<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)

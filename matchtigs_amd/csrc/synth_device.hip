@@ -176,8 +176,7 @@ HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint6
             g->e_fwd[e + 1] = 0;
         }
     });
-    g->ensure_linked();
-    g->n_original_edges = E;
+    g->n_original_edges = E;  // (host adjacency: linked on demand, like mtg_graph_from_edges)
     g->built = true;
     lap("host graph");
     b_from.release(); b_to.release(); b_w.release(); b_keep.release(); b_pos.release(); b_bsum.release(); b_tot.release(); b_T.release();
