@@ -1935,10 +1935,22 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     // The device graph is built ON the GPU from the ORIGINAL edges only (the search runs before any dummy edge exists, :678):
     // the host uploads from / to / clamped weight / mirror, the build kernels make the family blocks.
     const uint64_t V = d->V, E = g.n_original_edges;
+    struct {
+        const bool on = std::getenv("MTG_DEBUG") != nullptr;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(const char *what) {
+            if (!on) return;
+            (void)hipDeviceSynchronize();
+            const auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mtg] device_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+            t = n;
+        }
+    } dl;
     PodVec<uint16_t> wclamp(E);
     parallel_ranges(E, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t e = lo; e < hi; e++) wclamp[e] = (uint16_t)std::min<uint64_t>(g.e_weight[e], k);
     });
+    dl.lap("clamped weights (host)");
     hipStream_t st = nullptr;
     uint32_t *d_from = nullptr, *d_to = nullptr, *d_fill = nullptr, *d_need = nullptr;
     uint16_t *d_w = nullptr;
@@ -1962,14 +1974,17 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
     for (auto &e : d->ev_r) HIP_CHECK(hipEventCreate(&e));
+    dl.lap("allocations");
+    // (through the pinned ring: host threads fill the next slice while one crosses PCIe -- the runtime stages a pageable upload on one thread)
     if (E) {
-        HIP_CHECK(hipMemcpyAsync(d_from, g.e_from.data(), E * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_to, g.e_to.data(), E * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_w, wclamp.data(), E * 2, hipMemcpyHostToDevice, st));
+        hu::upload_sliced(d_from, g.e_from.data(), E * 4, st, device_id);
+        hu::upload_sliced(d_to, g.e_to.data(), E * 4, st, device_id);
+        hu::upload_sliced(d_w, wclamp.data(), E * 2, st, device_id);
     }
-    if (V) HIP_CHECK(hipMemcpyAsync(d->d_mirror, g.mirror.data(), V * 4, hipMemcpyHostToDevice, st));
+    if (V) hu::upload_sliced(d->d_mirror, g.mirror.data(), V * 4, st, device_id);
     HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, st));
     HIP_CHECK(hipMemsetAsync(d_fill, 0, std::max<uint64_t>(V, 1) * 4, st));
+    dl.lap("uploads + memsets");
     const unsigned eb = (unsigned)((E + 255) / 256), vb = (unsigned)((V + 255) / 256);
     uint64_t ext_total = 0;
     if (V) {
@@ -2009,6 +2024,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         }
         HIP_CHECK(hipGetLastError());
     }
+    dl.lap("build kernels (+ lower bounds)");
     // the finishing stages on this GPU start from the same two arrays: leave them with the graph instead of uploading them again
     uint32_t *d_mirror_copy = nullptr;
     hu::device_malloc(&d_mirror_copy, std::max<uint64_t>(V, 1) * 4);
@@ -2017,6 +2033,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
     for (void *p : {(void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
     d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13 + (d->w8 ? V : 0);
+    dl.lap("edge cache + frees");
     return d;
 }
 
