@@ -858,8 +858,34 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         g.breaking_weight = k;
         g.dummies_canonical = !long_pair;
     }
+    // The result arrays are known up to a bound once the Euleriser is through (kept edges <= original biedges + matched pairs; tigs
+    // <= dummy biedges + closed walks): they are reserved now and touched by a thread of their own while the GPU decomposes and
+    // cuts -- a one-shot caller's tigs land in memory that has never been touched (0.47 GB at 2^27: the cold step spent 50 ms of
+    // page faults inside the download), a caller that iterates gets recycled blocks and the touching costs nothing.
+    std::thread prefault_thread;
+    {
+        const uint64_t bound_edges = E0 / 2 + n_pairs, bound_tigs = n_dummy / 2 + 4096;
+        tigs.edges.reserve(bound_edges);
+        tigs.limits.reserve(bound_tigs);
+        if ((bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
+            char *pe = reinterpret_cast<char *>(tigs.edges.data()), *pl = reinterpret_cast<char *>(tigs.limits.data());
+            const uint64_t be = bound_edges * 4, bl = bound_tigs * 8;
+            prefault_thread = std::thread([pe, pl, be, bl]() {
+                parallel_ranges((be + bl + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t pg = lo; pg < hi; pg++) {
+                        const uint64_t off = pg * 4096;
+                        volatile char *p = off < be ? pe + off : pl + (off - be);
+                        if (off < be || off - be < bl) *p = 0;
+                    }
+                });
+            });
+        }
+    }
     if (times_out) times_out[1] = lap.lap("host graph: dummy edges");
-    if (E == 0) return tigs;
+    if (E == 0) {
+        if (prefault_thread.joinable()) prefault_thread.join();
+        return tigs;
+    }
 
     // ---- Euler bicycles ----
     Buf b_cyc, b_clen, b_cbase;
@@ -1013,6 +1039,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         cut_emit_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, d_clen, n_cycles, d_rotkey, ids, d_ck, d_ce, d_te, d_tl);
         HIP_CHECK(hipGetLastError());
         sev.mark(5, st);
+        if (prefault_thread.joinable()) prefault_thread.join();
         tigs.edges.resize(n_kept);
         tigs.limits.resize(n_tigs);
         download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
