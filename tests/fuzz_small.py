@@ -12,7 +12,9 @@ Three parties per graph: the C oracle, the independent Python 
 A graph on which the REFERENCE panics (e.g. an odd number of odd self-mirror nodes and no in-node to pair the last one with,
 implementation/mod.rs:496-498) is recognised by the Python restatement raising and is skipped -- the C parties abort() there, like
 the reference. Runs as a child process of tests/test_fuzz_small.py, so that an abort() names its seed instead of ending pytest:
-    python tests/fuzz_small.py cpu|gpu FIRST_SEED N_SEEDS
+    python tests/fuzz_small.py cpu|gpu|cpu_medium|gpu_medium FIRST_SEED N_SEEDS
+The *_medium modes run G-csr graphs of 50-3000 binodes with random parameters (k 3..300, degrees, unitig lengths, self-mirror share,
+scrambled numbering): the same parties on whole operators, candidate lists and counters.
 """
 from __future__ import annotations
 
@@ -162,6 +164,78 @@ def run_gpu(seed: int) -> str:
     return "ok:" + ("pairs" if pairs_o else "nopairs")
 
 
+def medium_bigraph(seed: int):
+    """G-csr graphs of 50 to 3000 binodes with every parameter drawn at random (k from 3 to 300: both weight formats of the device
+    graph; degrees, unitig lengths, self-mirror share), half of them with scrambled node numbering."""
+    from matchtigs_amd import synth
+
+    r = random.Random(0xD1B54A32D192ED03 ^ seed)
+    k = r.choice((3, 5, 9, 15, 31, 31, 63, 127, 255, 300))
+    bg = synth.g_csr(r.randint(50, 3000), seed=seed, k=k, mean_out_degree=r.uniform(0.6, 2.5), mean_weight=r.uniform(1.0, max(1.5, k / 2.0)),
+                     self_mirror_frac=r.choice((0.0, 0.0, 0.01, 0.05, 0.1)), max_degree=4)
+    if r.random() < 0.5:
+        rng = np.random.default_rng(seed)
+        perm = rng.permutation(bg.n_nodes).astype(np.uint32)  # old -> new
+        mirror = np.empty_like(bg.mirror)
+        mirror[perm] = perm[bg.mirror]
+        bg = synth.Bigraph(mirror, perm[bg.edge_from], perm[bg.edge_to], bg.edge_weight.copy(), k)
+    return bg
+
+
+def run_cpu_medium(seed: int) -> str:
+    import helpers
+    import pyref
+
+    bg = medium_bigraph(seed)
+    k, arrs = bg.k, (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    if reference_panics(arrs, k):
+        return "panic"
+    tigs_o, _ = helpers.oracle_graph(*arrs).compute_greedytigs(k)
+    tigs_p, _, _ = pyref.compute_greedytigs(helpers.py_graph(*arrs), k)
+    assert tigs_o == tigs_p, "greedy tigs"
+    assert helpers.oracle_graph(*arrs).compute_eulertigs(k) == pyref.compute_eulertigs(helpers.py_graph(*arrs), k), "eulertigs"
+    G = helpers.product_graph(*arrs)
+    pr = helpers.product_pairs_from_oracle_lists(G, helpers.oracle_graph(*arrs), k)
+    assert G.finish_greedytigs(pr, k) == tigs_o, "product host stages"
+    return "ok:" + ("pairs" if len(pr) else "nopairs")
+
+
+def run_gpu_medium(seed: int) -> str:
+    import helpers
+    from matchtigs_amd import api, torch_glue
+
+    bg = medium_bigraph(seed)
+    k, arrs = bg.k, (bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    if reference_panics(arrs, k):
+        return "panic"
+    og = helpers.oracle_graph(*arrs)
+    _, off, keys, st = og.candidate_lists(k)
+    tigs_o, _ = helpers.oracle_graph(*arrs).compute_greedytigs(k)
+    G = helpers.product_graph(*arrs)
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify()
+    dev.set_plan(seed % 4)  # 0 / 2 / 3: enumeration level (pruned when k <= 255), 1: the plain cascade
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    start, count, pool = torch_glue.candidates_to_numpy(bufs)
+    assert np.array_equal(count.astype(np.uint64), np.diff(off)), "list lengths"
+    got = np.concatenate([pool[int(s):int(s) + int(c)] for s, c in zip(start, count)]) if S else np.zeros(0, np.uint64)
+    assert np.array_equal(got, keys), "candidate lists"
+    cnt = dev.sssp_count(0, S)
+    assert (cnt["settled_nodes"], cnt["relaxed_edges"]) == (st["settled_nodes"], st["relaxed_edges"]), "full-ball counters"
+    n = dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr())
+    lim, ed = api.finish_greedytigs_resident_np(G, dev, k, finish_stage=api.FinishStage.Device)
+    assert [ed[(lim[i - 1] if i else 0):lim[i]].tolist() for i in range(len(lim))] == tigs_o, "device finish, reference order"
+    # device Euler mode: same number of tigs and cumulative length when no self-mirror node can put two breaking edges next to each other
+    G.reset()
+    lim_d, ed_d = api.finish_greedytigs_resident_np(G, dev, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    w = G.export()["edge_weight"].astype(np.int64)
+    if not (bg.mirror == np.arange(bg.n_nodes)).any():
+        assert len(lim_d) == len(tigs_o) and int(w[ed_d].sum()) == sum(int(w[np.asarray(t)].sum()) for t in tigs_o), "device Euler mode T3"
+    et_o = helpers.oracle_graph(*arrs).compute_eulertigs(k)
+    assert api.EulertigAlgorithm.compute_tigs(helpers.product_graph(*arrs), api.EulertigAlgorithmConfiguration(k)) == et_o, "eulertigs"
+    return "ok:" + ("pairs" if n else "nopairs")
+
+
 def reference_panics_links(weights, links, k) -> bool:
     import pyref
 
@@ -174,15 +248,18 @@ def reference_panics_links(weights, links, k) -> bool:
 
 def main():
     mode, first, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    fn = run_cpu if mode == "cpu" else run_gpu
+    fn = {"cpu": run_cpu, "gpu": run_gpu, "cpu_medium": run_cpu_medium, "gpu_medium": run_gpu_medium}[mode]
     tally = {}
     for seed in range(first, first + n):
         print(f"seed {seed}", flush=True)  # (the last line before an abort() names the graph)
         try:
             r = fn(seed)
         except AssertionError as e:
-            k, mirror, unitigs = tiny_bigraph(seed)
-            print(f"MISMATCH seed {seed}: {e}; k={k} mirror={mirror} unitigs={unitigs}", flush=True)
+            if mode.endswith("medium"):
+                print(f"MISMATCH seed {seed}: {e}", flush=True)
+            else:
+                k, mirror, unitigs = tiny_bigraph(seed)
+                print(f"MISMATCH seed {seed}: {e}; k={k} mirror={mirror} unitigs={unitigs}", flush=True)
             sys.exit(1)
         tally[r] = tally.get(r, 0) + 1
     print("TALLY " + " ".join(f"{kk}={v}" for kk, v in sorted(tally.items())), flush=True)

@@ -47,3 +47,26 @@ def test_fuzz_3000_tiny_bigraphs_through_the_hip_path(oracle, product_lib):
         pytest.fail("needs a GPU")
     tally, _ = _run("gpu", 20000, 3000, 800)  # (one child process on the GPU; other seeds than the CPU test's)
     assert sum(tally.values()) == 3000 and tally.get("ok:pairs", 0) >= 900 and tally.get("panic", 0) <= 150, tally
+
+
+def test_fuzz_200_medium_bigraphs_oracle_vs_restatement_vs_host_stages(oracle, product_lib):
+    """G-csr graphs of 50-3000 binodes with random parameters (k 3..300 ...): oracle == Python restatement == the product's host stages
+    on greedy tigs and eulertigs."""
+    chunks = [(i * 50, 50) for i in range(4)]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(lambda c: _run("cpu_medium", c[0], c[1], 900), chunks))
+    tally = {}
+    for t, _ in results:
+        for k, v in t.items():
+            tally[k] = tally.get(k, 0) + v
+    assert sum(tally.values()) == 200 and tally.get("ok:pairs", 0) >= 100 and tally.get("panic", 0) <= 20, tally
+
+
+@pytest.mark.gpu
+def test_fuzz_300_medium_bigraphs_through_the_hip_path(oracle, product_lib):
+    """The same family through the HIP path (plans 0-3 in turn): candidate lists, full-ball counters, device finish in reference
+    order == oracle; device Euler mode: equal tig count and cumulative length; eulertigs == oracle."""
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU")
+    tally, _ = _run("gpu_medium", 1000, 300, 800)
+    assert sum(tally.values()) == 300 and tally.get("ok:pairs", 0) >= 150 and tally.get("panic", 0) <= 30, tally
