@@ -324,9 +324,9 @@ mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t 
 mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id);
 double mtg_last_euler_kernel_ms(void); /* of the last device decomposition on this thread */
 /* The decomposition's segment walks recognise a splitter by a mark in bit 31 of its predecessor's successor word while dart ids
- * leave that bit free (fewer than 2^31 darts), else by a bitmap lookup per step. splitter_bitmap != 0 forces the bitmap form
- * (process-wide; tests run both on small graphs -- same walks). */
-void mtg_set_euler_device_tuning(int splitter_bitmap);
+ * leave that bit free (fewer than 2^31 darts), else by a bitmap lookup per step. Bit 0 of `flags` forces the bitmap form, bit 1 ranks
+ * the reduced list by pointer jumping over ALL splitters instead of two levels (process-wide; tests hold the forms to the same walks). */
+void mtg_set_euler_device_tuning(int flags);
 /* The whole finish on the GPU for a graph that holds only its original edges (finish_device.hip): matched-pair darts, the
  * Euleriser in the reference's sequence (implementation/mod.rs:392-649), Euler bicycles per cfg->euler_mode (device
  * decomposition, or the reference-order host walk over GPU-built records), rotate + cut (greedytigs/mod.rs:726-789). Appends the

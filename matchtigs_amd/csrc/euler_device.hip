@@ -328,6 +328,64 @@ __global__ __launch_bounds__(EB) void wyllie_kernel(const uint32_t *jump_in, con
     jump_out[i] = jump_in[j];
     dist_out[i] = dist_in[i] + dist_in[j];
 }
+// ---- two-level ranking of the reduced list (round 4) ----
+// Pointer jumping over all M splitters takes ceil(log2 2M) launches of a latency-bound kernel (23 x 0.09 ms at 2^27). Instead:
+// every 32nd splitter (by hash) and every root is a LEVEL-2 splitter; one walker per level-2 splitter sums the segment lengths
+// up to the next one (32 dependent steps over arrays that sit in L2), pointer jumping runs over the ~M/32 level-2 elements only,
+// and a second walk hands every splitter of a level-2 segment its terminal root and its distance to it.
+__device__ __forceinline__ bool hash_splitter2(uint32_t i) { return ((i * 0x85EBCA77u) >> 27) == 0; }
+__global__ __launch_bounds__(EB) void split2_flag_kernel(const uint32_t *rflag, uint32_t n_split, uint32_t *flag2) {
+    const uint64_t i = gid();
+    if (i < n_split) flag2[i] = (rflag[i] || hash_splitter2((uint32_t)i)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(EB) void split2_compact_kernel(const uint32_t *flag2, const uint32_t *idx2, uint32_t n_split, uint32_t *list2) {
+    const uint64_t i = gid();
+    if (i < n_split && flag2[i]) list2[idx2[i]] = (uint32_t)i;
+}
+// per level-2 splitter s (index a in list2): total length of its level-2 segment and the next level-2 splitter; a root is the
+// terminal of its list (jump to itself, distance 0) but still owns the segment that follows it
+__global__ __launch_bounds__(EB) void walk2_measure_kernel(const uint32_t *list2, uint32_t n2, const uint32_t *flag2, const uint32_t *idx2,
+                                                          const uint32_t *rflag, const uint32_t *next_split, const uint32_t *seg_len,
+                                                          uint32_t n_split, uint32_t *seg2_len, uint32_t *next2, uint32_t *jump2, uint32_t *dist2,
+                                                          uint32_t *error) {
+    const uint64_t a = gid();
+    if (a >= n2) return;
+    const uint32_t s = list2[a];
+    uint32_t x = s, total = 0, steps = 0;
+    do {
+        total += seg_len[x];
+        x = next_split[x];
+        if (++steps > n_split) { atomicOr(error, 2u); break; }  // (cannot happen: the reduced list is a permutation)
+    } while (!flag2[x]);
+    const uint32_t nx = idx2[x];
+    seg2_len[a] = total;
+    next2[a] = nx;
+    const bool root = rflag[s] != 0;
+    jump2[a] = root ? (uint32_t)a : nx;
+    dist2[a] = root ? 0u : total;
+}
+// every splitter of the level-2 segment of s: its terminal root (as a splitter index) and its distance to it
+__global__ __launch_bounds__(EB) void walk2_write_kernel(const uint32_t *list2, uint32_t n2, const uint32_t *flag2, const uint32_t *rflag,
+                                                        const uint32_t *next_split, const uint32_t *seg_len, const uint32_t *seg2_len,
+                                                        const uint32_t *next2, const uint32_t *jump2, const uint32_t *dist2, uint32_t *jump,
+                                                        uint32_t *dist) {
+    const uint64_t a = gid();
+    if (a >= n2) return;
+    const uint32_t s = list2[a];
+    const uint32_t t2 = next2[a];                        // the level-2 splitter that ends this segment
+    const uint32_t term = list2[jump2[t2]];              // ... its terminal (t2 itself when it is a root), as a splitter index
+    const uint32_t tail = dist2[t2];                     // ... and its distance to it (0 for a root)
+    uint32_t x = s, before = 0;
+    const uint32_t total = seg2_len[a];
+    do {
+        const bool root = rflag[x] != 0;                 // (only x == s can be a root: roots are level-2 splitters)
+        jump[x] = root ? x : term;
+        dist[x] = root ? 0u : total - before + tail;
+        before += seg_len[x];
+        x = next_split[x];
+    } while (!flag2[x]);
+}
+
 // per root splitter (ascending dart id): length of its trail
 __global__ __launch_bounds__(EB) void root_flag_kernel(const uint32_t *splitters, const uint32_t *root_bits, uint32_t n_split, uint32_t *rflag) {
     const uint64_t i = gid();
@@ -361,8 +419,8 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
 }  // namespace
 
 // (tests: the bitmap form of the splitter test, which graphs with 2^31 darts or more always use, on small graphs too)
-static std::atomic<int> g_force_bitmap{0};
-void device_euler_force_bitmap(int on) { g_force_bitmap.store(on ? 1 : 0); }
+static std::atomic<int> g_force_bitmap{0}, g_flat_ranking{0};
+void device_euler_force_bitmap(int on) { g_force_bitmap.store((on & 1) ? 1 : 0); g_flat_ranking.store((on & 2) ? 1 : 0); }
 
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
 // The buckets of darts [0, E) from the kept buckets of the original darts [0, E0) (row0 / adj0) and fresh ones of the dummy darts
@@ -447,7 +505,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     unsigned long long *d_best = b_best.alloc<unsigned long long>(st, n_b);
     uint8_t *d_active = b_active.alloc<uint8_t>(st, V);
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(E) + 2);
-    uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] a binode proposed in this round
+    uint32_t *d_small = b_small.alloc<uint32_t>(st, 8);  // [0] error, [1..3] scan totals, [4] a binode proposed in this round, [5] level-2 splitters
     uint32_t *d_error = d_small, *d_total = d_small + 1;
     HIP_CHECK(hipMemsetAsync(d_small, 0, 32, st));
     static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
@@ -526,12 +584,38 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
         walk_measure_kernel<false><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
     }
     int cur = 0;
-    for (uint64_t span = 1; span < (uint64_t)M * 2; span <<= 1) {  // after r rounds a pointer spans 2^r reduced elements
-        wyllie_kernel<<<grid_for(M), EB, 0, st>>>(d_jump[cur], d_dist[cur], M, d_jump[cur ^ 1], d_dist[cur ^ 1]);
-        cur ^= 1;
-    }
     root_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_split, d_rbits, M, d_rflag);
     scan_u32<uint32_t>(st, d_rflag, M, d_ridx, d_bsum, d_total + 1);
+    if (g_flat_ranking || M < (1u << 16)) {  // pointer jumping over all splitters (small inputs; tests hold the two forms to the same walks)
+        for (uint64_t span = 1; span < (uint64_t)M * 2; span <<= 1) {  // after r rounds a pointer spans 2^r reduced elements
+            wyllie_kernel<<<grid_for(M), EB, 0, st>>>(d_jump[cur], d_dist[cur], M, d_jump[cur ^ 1], d_dist[cur ^ 1]);
+            cur ^= 1;
+        }
+    } else {  // two levels (see split2_flag_kernel)
+        Buf b_flag2, b_idx2, b_list2, b_s2len, b_next2, b_j2a, b_j2b, b_d2a, b_d2b;
+        uint32_t *d_flag2 = b_flag2.alloc<uint32_t>(st, M), *d_idx2 = b_idx2.alloc<uint32_t>(st, M);
+        split2_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_rflag, M, d_flag2);
+        scan_u32<uint32_t>(st, d_flag2, M, d_idx2, d_bsum, d_small + 5);
+        HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        const uint32_t M2 = h_small[5];
+        uint32_t *d_list2 = b_list2.alloc<uint32_t>(st, M2), *d_s2len = b_s2len.alloc<uint32_t>(st, M2), *d_next2 = b_next2.alloc<uint32_t>(st, M2);
+        uint32_t *d_j2[2] = {b_j2a.alloc<uint32_t>(st, M2), b_j2b.alloc<uint32_t>(st, M2)};
+        uint32_t *d_d2[2] = {b_d2a.alloc<uint32_t>(st, M2), b_d2b.alloc<uint32_t>(st, M2)};
+        if (M2) {
+            split2_compact_kernel<<<grid_for(M), EB, 0, st>>>(d_flag2, d_idx2, M, d_list2);
+            walk2_measure_kernel<<<grid_for(M2), EB, 0, st>>>(d_list2, M2, d_flag2, d_idx2, d_rflag, d_next, d_seglen, M, d_s2len, d_next2, d_j2[0], d_d2[0], d_error);
+            int c2 = 0;
+            for (uint64_t span = 1; span < (uint64_t)M2 * 2; span <<= 1) {
+                wyllie_kernel<<<grid_for(M2), EB, 0, st>>>(d_j2[c2], d_d2[c2], M2, d_j2[c2 ^ 1], d_d2[c2 ^ 1]);
+                c2 ^= 1;
+            }
+            // splitters on trails without a level-2 splitter (short mirror trails) keep the values walk_measure gave them: never a root
+            walk2_write_kernel<<<grid_for(M2), EB, 0, st>>>(d_list2, M2, d_flag2, d_rflag, d_next, d_seglen, d_s2len, d_next2, d_j2[c2], d_d2[c2], d_jump[cur], d_dist[cur]);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));  // (the level-2 arrays go back to the block cache when this scope ends)
+    }
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: internal error (successor array is not a permutation)");

@@ -182,3 +182,24 @@ def test_device_euler_splitter_mark_and_bitmap_forms_agree(gpu):
             L.mtg_set_euler_device_tuning(0)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (seed, n)
         check_bicycles(G.export(), a[0], a[1])
+
+
+def test_device_euler_two_level_ranking_equals_flat_pointer_jumping(gpu):
+    """From 2^16 splitters on the reduced list is ranked in two levels (every 32nd splitter and every root; pointer jumping over
+    those only); mtg_set_euler_device_tuning(2) forces the flat form: identical walks on a graph of 9 M darts, Eulertigs and greedy."""
+    from matchtigs_amd import _lib, api, synth
+
+    L = _lib.load()
+    k = 31
+    G = synth.g_csr_device(1 << 21, seed=11, k=k, mean_out_degree=1.4)
+    G.make_eulerian(0, k)
+    a = G.euler_cycles_device_np()
+    assert len(a[1]) >= (1 << 21)  # biedges: twice as many darts, one splitter per 64 of them: >= 2^16 splitters
+    for flags in (2, 3):  # flat ranking; flat ranking + bitmap splitter test
+        L.mtg_set_euler_device_tuning(flags)
+        try:
+            b = G.euler_cycles_device_np()
+        finally:
+            L.mtg_set_euler_device_tuning(0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), flags
+    check_bicycles(G.export(), a[0], a[1])
