@@ -145,12 +145,27 @@ __global__ __launch_bounds__(EB) void iota_kernel(uint32_t *a, uint64_t n) {
 }
 
 // ---- step 3: labels of the trail pairs, over biedges ---------------------------------------------------------------
-// (the passage e -> f and its mirror f^1 -> e^1 name the same two biedges: the one with the smaller in-dart does the union)
-__global__ __launch_bounds__(EB) void union_succ_kernel(const uint32_t *succ, uint64_t n_darts, uint32_t *parent) {
-    const uint64_t e = gid();
-    if (e >= n_darts) return;
-    const uint32_t f = succ[e];
-    if ((uint32_t)e < (f ^ 1u)) uf_union(parent, (uint32_t)e >> 1, f >> 1);
+// A biedge b has exactly two neighbours in the graph whose components are the trail pairs: succ[2b] >> 1 and succ[2b + 1] >> 1
+// (the passage e -> f and its mirror f^1 -> e^1 name the same two biedges, so the predecessors are the same two). Components of
+// this 2-regular graph, ECL-CC style: the first pass links every biedge to its SMALLER neighbour without any atomic (one coalesced
+// 8-byte load per biedge, no random access: a forest in which every parent is smaller than its child); the second pass only has to
+// hook the edges the first could not express -- a biedge both of whose neighbours are smaller brings its second one (a third of
+// the biedges of a random order) -- through the lock-free union (roots hang below smaller roots, so the final root of a component
+// is its smallest biedge, whatever the thread timing).
+__global__ __launch_bounds__(EB) void label_init_kernel(const uint32_t *succ, uint64_t n_biedges, uint32_t *parent) {
+    const uint64_t b = gid();
+    if (b >= n_biedges) return;
+    const uint2 s2 = reinterpret_cast<const uint2 *>(succ)[b];
+    const uint32_t n1 = s2.x >> 1, n2 = s2.y >> 1, m = n1 < n2 ? n1 : n2;
+    parent[b] = m < (uint32_t)b ? m : (uint32_t)b;
+}
+__global__ __launch_bounds__(EB) void label_hook_kernel(const uint32_t *succ, uint64_t n_biedges, uint32_t *parent) {
+    const uint64_t b = gid();
+    if (b >= n_biedges) return;
+    const uint2 s2 = reinterpret_cast<const uint2 *>(succ)[b];
+    const uint32_t n1 = s2.x >> 1, n2 = s2.y >> 1;
+    const uint32_t hi = n1 < n2 ? n2 : n1;  // the neighbour the first pass did not link (when both are smaller than b)
+    if (hi < (uint32_t)b && hi != (n1 < n2 ? n1 : n2)) uf_union(parent, (uint32_t)b, hi);
 }
 // In place: parent[e] = root of e for EVERY e when the kernel ends. The find must not compress here: a path-halving store of
 // another thread (parent[e] = some ancestor it read earlier) could land after this thread's parent[e] = root and leave a
@@ -525,13 +540,13 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("buckets");
     // 2. pairing, 3. trail labels
     succ_node_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_succ, d_error);
-    iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b);
     uint32_t h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[0]) MTG_DIE("device_euler_cycles: the graph is not Eulerian (greedytigs/mod.rs:708)");
     lap("pairing");
-    union_succ_kernel<<<grid_for(E), EB, 0, st>>>(d_succ, E, d_comp);
+    label_init_kernel<<<grid_for(n_b), EB, 0, st>>>(d_succ, n_b, d_comp);
+    label_hook_kernel<<<grid_for(n_b), EB, 0, st>>>(d_succ, n_b, d_comp);
     flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b);
     uint32_t *d_parent2 = d_pos2;
     iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);

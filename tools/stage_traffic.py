@@ -30,12 +30,12 @@ MARKERS = [
 ONE_OFF = ("degree_rank_kernel", "fill_kernel")
 # kernels whose reads are dependent random accesses of 4 to 64 bytes (one request each, counted as issued); the others stream
 # coalesced 4-byte words, where gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
-GATHER = ("sssp_enum_kernel", "sssp_kernel", "replay_rounds_kernel", "walk_measure_kernel", "walk_write_kernel", "union_succ_kernel",
+GATHER = ("sssp_enum_kernel", "sssp_kernel", "replay_rounds_kernel", "walk_measure_kernel", "walk_write_kernel", "label_hook_kernel",
           "propose_kernel", "flatten_kernel", "rotate_kernel", "wyllie_kernel", "wide_build_kernel", "mid_build_slice_kernel", "lean_build_kernel",
           "zip_check_kernel", "sort_lists_kernel", "replay_compact_kernel", "replay_dense_fill_kernel", "root_len_kernel", "succ_node_kernel")
 ORDER = ["classify", "sssp", "replay", "insert_eulerise", "buckets", "cut"]
 # kernels that only occur in one kind of step tell which stage the buckets belong to
-DEVICE_ONLY = ("succ_node_kernel", "union_succ_kernel", "walk_measure_kernel")
+DEVICE_ONLY = ("succ_node_kernel", "label_hook_kernel", "walk_measure_kernel")
 HOST_ONLY = ("lean_ext_kernel", "lean_build_kernel", "wide_build_kernel", "mid_build_slice_kernel")
 
 
