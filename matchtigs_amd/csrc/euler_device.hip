@@ -207,10 +207,16 @@ __global__ __launch_bounds__(EB) void propose_kernel(const uint32_t *mirror, uin
     // components only ever merge: a binode whose passages were all in one component in an earlier round has nothing to propose in
     // any later one (the last round, which only finds out that nobody proposes, then reads one byte per node)
     if (!first_round && !active[v]) return;
+    {   // a binode with a single passage has nothing to merge (and its mirror node is handled by the lower node of the pair)
+        const uint32_t vm = mirror[v];
+        const uint32_t d = row[v + 1] - row[v];
+        if (vm < v || (vm == v ? d / 2 : d) < 2) { active[v] = 0; return; }
+    }
     bool mine = false;
     uint32_t r0 = 0;
     for_each_passage(mirror, row, adj, v, [&](uint32_t i, uint32_t, uint32_t b) {
-        const uint32_t r = uf_find(parent2, comp[b >> 1]);
+        // (first round: the second union-find is still the identity -- the label IS the root, one gather instead of two)
+        const uint32_t r = first_round ? comp[b >> 1] : uf_find(parent2, comp[b >> 1]);
         if (i == 0) {
             r0 = r;
             return;
@@ -240,6 +246,10 @@ __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint
                                                    const uint32_t *selected, uint32_t *succ) {
     const uint64_t vi = gid();
     if (vi >= n_nodes) return;
+    {   // (single-passage binodes: nothing can have been selected)
+        const uint32_t v = (uint32_t)vi, vm = mirror[v], d = row[v + 1] - row[v];
+        if (vm < v || (vm == v ? d / 2 : d) < 2) return;
+    }
     uint32_t a_prev = 0, b0 = 0;
     bool any = false;
     for_each_passage(mirror, row, adj, (uint32_t)vi, [&](uint32_t i, uint32_t a, uint32_t b) {
