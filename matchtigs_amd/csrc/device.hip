@@ -67,14 +67,16 @@ enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
 struct alignas(64) NodeBlock {
     uint32_t nbr[4];   // words 0-3: inline neighbours; if F_EXT: nbr[0]/nbr[1] = ext_begin lo/hi, nbr[2] = ext_count
     uint16_t w[4];     // words 4-5: weights clamped to min(w, k) (an edge with w >= k can never lie on a <= k-1 path); unused slots 0xFFFF.
-                       //            k <= 255 ("8:8 format"): low byte = that weight, high byte = min(255, weight + lb(child)), lb(v) = the
-                       //            distance from v to the nearest initial in-node (0 for an in-node): the goal-directed lower bound
+                       //            k <= 255 ("8:8 format"): low byte = that weight, high byte = min(255, weight + lb+(child)), lb+(v) = the
+                       //            distance from v to the nearest initial in-node BEYOND v: the goal-directed lower bound of what a
+                       //            search needs v's own block for (whether v is an in-node itself is told by cmeta)
     uint8_t deg;       // word 6: inline degree 0..4 (0 if F_EXT)
     uint8_t flags;     //         F_TARGET (initial in-node, greedytigs/mod.rs:231-240) | F_EXT
-    uint16_t cmeta;    //         bit j (0-3): child j is an in-node; bit 4+j: child j is NOT embedded below (it needs its own gather)
+    uint16_t cmeta;    //         bit j (0-3): child j is an in-node; bit 4+j: child j is NOT embedded below (it needs its own gather);
+                       //         8:8 format: bit 8+t: the neighbour in gnbr[t] is an in-node
     uint32_t gnbr[6];  // words 7-12: out-neighbours of the embedded children, children in order, each child's edges in order
     uint16_t gw[6];    // words 13-15: weight of the path node -> child -> that neighbour, saturated at 0xFFFF; unused slots 0xFFFF
-                       //            (8:8 format: low byte = path weight, high byte = path weight + lb(that neighbour), both saturated at 255)
+                       //            (8:8 format: low byte = path weight, high byte = path weight + lb+(that neighbour), both saturated at 255)
 };
 static_assert(sizeof(NodeBlock) == 64, "NodeBlock must be 64 bytes");
 constexpr int GSLOTS = 6;
@@ -98,10 +100,12 @@ constexpr int CLS_BLOCK = 256, CLS_PER = 8;  // nodes per workgroup = 2048 (the 
 constexpr int CLS_NODES = CLS_BLOCK * CLS_PER;
 
 __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *odeg, const uint32_t *mirror, uint32_t n_nodes, int32_t *mult,
-                                                             uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand) {
+                                                             uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand, const uint8_t *reach,
+                                                             uint32_t *block_active) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
     __shared__ uint32_t wave_dem[CLS_BLOCK / 64];
-    uint32_t cnt = 0, pos = 0;
+    __shared__ uint32_t wave_act[CLS_BLOCK / 64];
+    uint32_t cnt = 0, pos = 0, act = 0;
 #pragma unroll
     for (int p = 0; p < CLS_PER; p++) {
         const uint64_t n64 = (uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x;
@@ -110,75 +114,103 @@ __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *ode
         const uint32_t m = mirror[n];
         const NodeClass c = classify_node(odeg[n], m == n ? 0u : odeg[m], m == n);
         cnt += (c.cls & F_SOURCE) ? 1u : 0u;
+        // (8:8 format) a source that can reach an in-node within the bound at all: the only ones the SSSP stage searches
+        if (reach) act += ((c.cls & F_SOURCE) && reach[n]) ? 1u : 0u;
         mult[n] = c.diff;  // 0 for balanced nodes
         cls[n] = c.cls;
         pos += c.diff > 0 ? (uint32_t)c.diff : 0u;
     }
-    for (int dd = 32; dd >= 1; dd >>= 1) { pos += __shfl_down(pos, dd); cnt += __shfl_down(cnt, dd); }
-    if ((threadIdx.x & 63) == 0) { wave_cnt[threadIdx.x >> 6] = cnt; wave_dem[threadIdx.x >> 6] = pos; }
+    for (int dd = 32; dd >= 1; dd >>= 1) { pos += __shfl_down(pos, dd); cnt += __shfl_down(cnt, dd); act += __shfl_down(act, dd); }
+    if ((threadIdx.x & 63) == 0) { wave_cnt[threadIdx.x >> 6] = cnt; wave_dem[threadIdx.x >> 6] = pos; wave_act[threadIdx.x >> 6] = act; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t s = 0, dm = 0;
-        for (int i = 0; i < CLS_BLOCK / 64; i++) { s += wave_cnt[i]; dm += wave_dem[i]; }
+        uint32_t s = 0, dm = 0, ac = 0;
+        for (int i = 0; i < CLS_BLOCK / 64; i++) { s += wave_cnt[i]; dm += wave_dem[i]; ac += wave_act[i]; }
         block_counts[blockIdx.x] = s;
         block_demand[blockIdx.x] = dm;
+        if (reach) block_active[blockIdx.x] = ac;
     }
 }
 
-// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out; sum of block_demand in *demand_out
+// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out; sum of block_demand in *demand_out;
+// optionally the same scan of a second array (counts2 -> *total2_out)
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uint32_t n, unsigned long long *total_out,
-                                                           const uint32_t *block_demand, unsigned long long *demand_out) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry;
+                                                           const uint32_t *block_demand, unsigned long long *demand_out,
+                                                           uint32_t *counts2 = nullptr, unsigned long long *total2_out = nullptr) {
+    __shared__ uint32_t wave_tot[16], wave_tot2[16];
+    __shared__ uint32_t carry, carry2;
     __shared__ unsigned long long dem_sum;
-    if (threadIdx.x == 0) { carry = 0; dem_sum = 0; }
+    if (threadIdx.x == 0) { carry = 0; carry2 = 0; dem_sum = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long dem = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < n ? counts[i] : 0;
+        const uint32_t v2 = (counts2 && i < n) ? counts2[i] : 0;
         dem += (block_demand && i < n) ? block_demand[i] : 0u;
-        uint32_t incl = v;
+        uint32_t incl = v, incl2 = v2;
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
+            const uint32_t t = __shfl_up(incl, d), t2 = __shfl_up(incl2, d);
+            if (lane >= d) { incl += t; incl2 += t2; }
         }
-        if (lane == 63) wave_tot[wv] = incl;
+        if (lane == 63) { wave_tot[wv] = incl; wave_tot2[wv] = incl2; }
         __syncthreads();
-        uint32_t wave_off = 0;
-        for (int j = 0; j < wv; j++) wave_off += wave_tot[j];
-        const uint32_t c = carry;
-        if (i < n) counts[i] = c + wave_off + incl - v;
+        uint32_t wave_off = 0, wave_off2 = 0;
+        for (int j = 0; j < wv; j++) { wave_off += wave_tot[j]; wave_off2 += wave_tot2[j]; }
+        const uint32_t c = carry, c2 = carry2;
+        if (i < n) {
+            counts[i] = c + wave_off + incl - v;
+            if (counts2) counts2[i] = c2 + wave_off2 + incl2 - v2;
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c + wave_off + incl;
+        if (threadIdx.x == 1023) { carry = c + wave_off + incl; carry2 = c2 + wave_off2 + incl2; }
         __syncthreads();
     }
     for (int dd = 32; dd >= 1; dd >>= 1) dem += __shfl_down(dem, dd);
     if (lane == 0 && dem) atomicAdd(&dem_sum, dem);
     __syncthreads();
-    if (threadIdx.x == 0) { *total_out = carry; if (demand_out) *demand_out = dem_sum; }
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (demand_out) *demand_out = dem_sum;
+        if (total2_out) *total2_out = carry2;
+    }
 }
 
+// out_nodes = the sources, ascending; with `reach` (8:8 format) also the sources that can reach an in-node within the bound at all,
+// in order: act_index = their positions in out_nodes, act_node = their nodes -- the only sources the SSSP stage searches (the others
+// have an empty candidate list by construction). The flags are read in node order here: no gather, no pass of its own.
 __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_t *cls, uint32_t n_nodes,
-                                                                    const uint32_t *block_offsets, uint32_t *out_nodes) {
-    __shared__ uint32_t wave_cnt[CLS_PER][CLS_BLOCK / 64];
+                                                                    const uint32_t *block_offsets, uint32_t *out_nodes, const uint8_t *reach,
+                                                                    const uint32_t *block_act_offsets, uint32_t *act_index, uint32_t *act_node) {
+    __shared__ uint32_t wave_cnt[CLS_PER][CLS_BLOCK / 64], wave_act[CLS_PER][CLS_BLOCK / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long bal[CLS_PER];
+    unsigned long long bal[CLS_PER], abal[CLS_PER];
 #pragma unroll
     for (int p = 0; p < CLS_PER; p++) {
         const uint64_t n = (uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x;
-        bal[p] = __ballot(n < n_nodes && (cls[n] & F_SOURCE));
-        if (lane == 0) wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]);
+        const bool src = n < n_nodes && (cls[n] & F_SOURCE);
+        bal[p] = __ballot(src);
+        abal[p] = __ballot(src && reach && reach[n]);
+        if (lane == 0) { wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]); wave_act[p][wv] = (uint32_t)__popcll(abal[p]); }
     }
     __syncthreads();
-    uint32_t off = block_offsets[blockIdx.x];
+    uint32_t off = block_offsets[blockIdx.x], aoff = reach ? block_act_offsets[blockIdx.x] : 0u;
 #pragma unroll
     for (int p = 0; p < CLS_PER; p++) {  // ascending: lane order within a wave, wave order within a pass, pass order, block order
         for (int j = 0; j < CLS_BLOCK / 64; j++) {
-            if (j == wv && ((bal[p] >> lane) & 1ull))
-                out_nodes[off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull))] = (uint32_t)((uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x);
+            if (j == wv && ((bal[p] >> lane) & 1ull)) {
+                const uint32_t node = (uint32_t)((uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x);
+                const uint32_t idx = off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull));
+                out_nodes[idx] = node;
+                if ((abal[p] >> lane) & 1ull) {
+                    const uint32_t pos = aoff + (uint32_t)__popcll(abal[p] & ((1ull << lane) - 1ull));
+                    act_index[pos] = idx;
+                    act_node[pos] = node;
+                }
+            }
             off += wave_cnt[p][j];
+            aoff += wave_act[p][j];
         }
     }
 }
@@ -188,58 +220,31 @@ __global__ void export_live_kernel(const uint8_t *cls, uint32_t n_nodes, uint8_t
     if (n < n_nodes) live[n] = (cls[n] & F_TARGET) ? 1 : 0;
 }
 
-// The sources of [src_begin, src_begin + n) that can reach an in-node within the bound at all (reach[], build_lb_kernel), in
-// order: the only ones the enumeration level searches -- the others have an empty candidate list by construction. Two streaming
-// passes (count per workgroup, single-workgroup scan in between, ordered write); the second one also zeroes every candidate count
-// of the range (a search only stores the count of a non-empty list).
-constexpr int ACT_BLOCK = 256, ACT_PER = 8;  // sources per workgroup = 2048
-__global__ __launch_bounds__(ACT_BLOCK) void active_count_kernel(const uint32_t *sources, const uint8_t *reach, uint64_t src_begin, uint64_t n,
-                                                                 uint32_t *block_counts) {
-    __shared__ uint32_t s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * (ACT_BLOCK * ACT_PER);
-    uint32_t c = 0;
-#pragma unroll
-    for (int p = 0; p < ACT_PER; p++) {
-        const uint64_t i = base + (uint64_t)p * ACT_BLOCK + threadIdx.x;
-        c += (i < n && reach[sources[src_begin + i]]) ? 1u : 0u;
-    }
-    for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_down(c, dd);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
-}
-__global__ __launch_bounds__(ACT_BLOCK) void active_write_kernel(const uint32_t *sources, const uint8_t *reach, uint64_t src_begin, uint64_t n,
-                                                                 const uint32_t *block_offsets, uint32_t *act_index, uint32_t *act_node,
-                                                                 uint32_t *cand_count) {
-    __shared__ uint32_t wave_cnt[ACT_PER][ACT_BLOCK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * (ACT_BLOCK * ACT_PER);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t node[ACT_PER];
-    unsigned long long bal[ACT_PER];
-#pragma unroll
-    for (int p = 0; p < ACT_PER; p++) {
-        const uint64_t i = base + (uint64_t)p * ACT_BLOCK + threadIdx.x;
-        node[p] = i < n ? sources[src_begin + i] : 0u;
-        const bool act = i < n && reach[node[p]];
-        if (i < n) cand_count[i] = 0u;
-        bal[p] = __ballot(act);
-        if (lane == 0) wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]);
-    }
-    __syncthreads();
-    uint32_t off = block_offsets[blockIdx.x];
-#pragma unroll
-    for (int p = 0; p < ACT_PER; p++) {
-        for (int j = 0; j < ACT_BLOCK / 64; j++) {
-            if (j == wv && (bal[p] >> lane) & 1ull) {
-                const uint32_t pos = off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull));
-                act_index[pos] = (uint32_t)(src_begin + base + (uint64_t)p * ACT_BLOCK + threadIdx.x);
-                act_node[pos] = node[p];
-            }
-            off += wave_cnt[p][j];
+// The searched sources of a launch over the sources [src_begin, src_end): the part of the classification's list of sources that can
+// reach an in-node (act_index, ascending) inside that range -- first entry and number, by a wave-wide 64-ary search (one wave; each
+// round probes 64 evenly spaced entries: four rounds for ten million). *act_begin = first entry, *act_count = their number.
+__global__ __launch_bounds__(64) void active_range_kernel(const uint32_t *act_index, const unsigned long long *n_act_total, uint64_t src_begin,
+                                                          uint64_t src_end, unsigned long long *act_begin, unsigned long long *act_count) {
+    const int lane = threadIdx.x;
+    const unsigned long long n = *n_act_total;
+    auto lower_bound = [&](uint64_t key) -> unsigned long long {  // first i in [0, n] with act_index[i] >= key
+        unsigned long long lo = 0, hi = n;
+        while (lo < hi) {
+            const unsigned long long chunk = (hi - lo + 63) / 64;
+            const unsigned long long idx = lo + (unsigned long long)lane * chunk;
+            const bool ge = idx >= hi || (uint64_t)act_index[idx] >= key;  // (monotone over the lanes)
+            const unsigned long long m = __ballot(ge);
+            const int first = m ? __builtin_ctzll(m) : 64;
+            if (first == 0) break;  // act_index[lo] >= key
+            const unsigned long long new_lo = lo + (unsigned long long)(first - 1) * chunk + 1;
+            const unsigned long long at_first = lo + (unsigned long long)first * chunk;
+            hi = (first < 64 && at_first < hi) ? at_first : hi;
+            lo = new_lo;
         }
-    }
+        return lo;
+    };
+    const unsigned long long b = lower_bound(src_begin), e = lower_bound(src_end);
+    if (lane == 0) { *act_begin = b; *act_count = e - b; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,31 +363,52 @@ __global__ void lb_mirror_kernel(const uint32_t *mirror, const uint32_t *D, uint
     const uint32_t v = D[mirror[n]];
     lb8[n] = (uint8_t)(v < 255u ? v : 255u);
 }
-// first halves into the 8:8 format; reach[n] = 1 iff some successor of n can still lead to an in-node within the bound (a source
-// without one has an empty candidate list and is never searched)
-__global__ void build_lb_kernel(uint64_t n_nodes, NodeBlock *blocks, const uint32_t *ext_col, const uint16_t *ext_w, const uint8_t *lb8, uint32_t K1,
-                                uint8_t *reach) {
+// Pass 1: lbx[n] = lb(n) | lb+(n) << 8, where lb+(n) = min over the out-edges n -> c of weight + lb(c) is the distance from n to the
+// nearest in-node BEYOND n (for a node that is not an in-node itself lb+ = lb; for an in-node lb = 0 and lb+ says what a search that
+// has recorded n still needs n's block for). reach[n] = 1 iff lb+(n) <= k - 1: a source without that has an empty candidate list and
+// is never searched. (First halves still hold plain 16-bit weights here.)
+__global__ void build_lbx_kernel(uint64_t n_nodes, const NodeBlock *blocks, const uint32_t *ext_col, const uint16_t *ext_w, const uint8_t *lb8, uint32_t K1,
+                                 uint16_t *lbx, uint8_t *reach) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
-    uint32_t *me = reinterpret_cast<uint32_t *>(blocks + n);
+    const uint32_t *me = reinterpret_cast<const uint32_t *>(blocks + n);
     const uint32_t meta = me[6];
     uint32_t best = 255u;
-    if ((meta >> 8) & F_EXT) {  // spilled adjacency keeps plain weights (no pruning behind such a node)
+    if ((meta >> 8) & F_EXT) {
         const uint64_t b = (uint64_t)me[0] | ((uint64_t)me[1] << 32);
         for (uint32_t e = 0; e < me[2]; e++) best = min(best, (uint32_t)ext_w[b + e] + lb8[ext_col[b + e]]);
     } else {
         const uint32_t dg = meta & 0xFFu;
-        uint32_t slot[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
         for (uint32_t j = 0; j < dg; j++) {
             const uint32_t w = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;  // <= k <= 255
-            const uint32_t wl = min(255u, w + lb8[me[j]]);
-            slot[j] = (wl << 8) | w;
-            best = min(best, wl);
+            best = min(best, w + lb8[me[j]]);
         }
-        me[4] = slot[0] | (slot[1] << 16);
-        me[5] = slot[2] | (slot[3] << 16);
     }
+    lbx[n] = (uint16_t)(lb8[n] | (best << 8));
     reach[n] = best <= K1 ? 1 : 0;
+}
+// Pass 2: first halves into the 8:8 format -- low byte the weight, high byte weight + lb+(child): what a search needs the CHILD'S BLOCK
+// for. Whether the child is an in-node itself (lb = 0) travels in cmeta bit j, so the parent's step records that candidate and the
+// child's gather only happens when something lies beyond it ("leaf" in-nodes, a quarter of all visits on the bench graph, cost no
+// gather). A spilled adjacency keeps plain weights (no pruning behind such a node).
+__global__ void build_lb_kernel(uint64_t n_nodes, NodeBlock *blocks, const uint16_t *lbx) {
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    uint32_t *me = reinterpret_cast<uint32_t *>(blocks + n);
+    const uint32_t meta = me[6];
+    if ((meta >> 8) & F_EXT) return;
+    const uint32_t dg = meta & 0xFFu;
+    uint32_t slot[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+    uint32_t cm = 0;
+    for (uint32_t j = 0; j < dg; j++) {
+        const uint32_t w = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+        const uint32_t x = lbx[me[j]];
+        slot[j] = (min(255u, w + (x >> 8)) << 8) | w;
+        if ((x & 0xFFu) == 0) cm |= 1u << j;
+    }
+    me[4] = slot[0] | (slot[1] << 16);
+    me[5] = slot[2] | (slot[3] << 16);
+    me[6] = meta | (cm << 16);  // (bits 0-3 of cmeta: build_children_kernel reads them from the children's blocks for the grandchild flags)
 }
 
 // second half of every block: the children's in-node flags and, while they fit, the children's out-edges
@@ -412,8 +438,9 @@ __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
             for (uint32_t t = 0; t < cdeg; t++) {
                 gn[used + t] = ch[t];
                 const uint32_t st = (ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu;
-                if constexpr (W8) {  // path weight | path weight + lb(grandchild), each saturated at 255 (> any bound of this format)
+                if constexpr (W8) {  // path weight | path weight + lb+(grandchild), each saturated at 255 (> any bound of this format)
                     gwt[used + t] = min(255u, wj + (st & 0xFFu)) | (min(255u, wj + (st >> 8)) << 8);
+                    cmeta |= ((cmt >> (16 + t)) & 1u) << (8 + used + t);  // the grandchild is an in-node (the child's cmeta bit, build_lb_kernel)
                 } else {
                     const uint32_t sum = wj + st;
                     gwt[used + t] = sum < 0xFFFFu ? sum : 0xFFFFu;
@@ -459,6 +486,7 @@ enum Counter : int {
     C_FIX_CLASS0 = 13,  // enumeration level's post-pass: number of work-list entries per length class (13, 14, 15)
     C_FIX_CURSOR0 = 16, // ... and the cursors of its compaction (16, 17, 18)
     C_ACTIVE = 19,      // sources of the launch's range that can reach an in-node within the bound (the only ones searched)
+    C_ACT_BEGIN = 20,   // ... and where they start in the classification's list of such sources (active_range_kernel)
     C_COUNT = 24
 };
 
@@ -483,8 +511,9 @@ struct SsspArgs {
                                  // chunk's length class, then indices (relative to src_begin) of lists of that class, FIX_NONE = unused
     uint32_t wmask;              // inline weight slots: 0xFF in the 8:8 format (k <= 255: weight | weight + lower bound << 8), else 0xFFFF
     uint32_t prune;              // cooperative levels: 1 = skip a successor whose lower bound puts every in-node behind it beyond the bound
-    const uint32_t *act_index;   // enumeration level with pruning: the searched sources (absolute indices, ascending) ...
-    const uint32_t *act_node;    // ... and their nodes; their number is counters[C_ACTIVE] (it never travels to the host before the launch)
+    const uint32_t *act_index;   // enumeration level with pruning: the classification's list of sources that can reach an in-node (absolute
+    const uint32_t *act_node;    // indices, ascending) and their nodes; the launch's part of it is counters[C_ACT_BEGIN] .. + counters[C_ACTIVE]
+                                 // (neither number travels to the host before the launch)
 };
 
 template <bool GLOBAL_WS>
@@ -663,7 +692,9 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 if (!(flags & F_EXT)) {
                     const uint32_t deg = meta & 0xFFu;
                     const uint32_t wslot = (w_pair >> ((j & 1u) * 16)) & 0xFFFFu;
-                    if (j < deg) relax(nb_j, wslot & a.wmask, a.wmask == 0xFFu ? wslot >> 8 : wslot);
+                    // (8:8 format: the high byte is weight + lb+(child), what the child's block is needed for beyond the child itself -- an
+                    // in-node child, cmeta bit j, is needed for itself: this kernel emits a node from its own entry)
+                    if (j < deg) relax(nb_j, wslot & a.wmask, a.wmask == 0xFFu ? (((meta >> (16 + j)) & 1u) ? (wslot & 0xFFu) : wslot >> 8) : wslot);
                     if constexpr (COUNT) { if (j == 0) atomicAdd(&s.bt_attempts, (unsigned long long)deg); }
                 } else if (j == 0) {  // spilled adjacency (more than 4 out-edges): one lane walks the list
                     const uint64_t eb = ((uint64_t)rw[1] << 32) | nb_j;  // j == 0: nb_j is word 0
@@ -708,12 +739,23 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                 const uint32_t node = (uint32_t)(e >> ENT_NODE_SHIFT);
                 const uint32_t src = (uint32_t)(e >> ENT_SRC_SHIFT);
                 if constexpr (COUNT) {
-                    atomicAdd(&s.bt_settled, 1ull);
                     const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
                     const uint4 lo = rp[0];
                     const uint4 hi = rp[1];
                     const uint32_t flags = (hi.z >> 8) & 0xFFu;
-                    atomicAdd(&s.bt_relaxed, (unsigned long long)((flags & F_EXT) ? lo.z : (hi.z & 0xFFu)));
+                    // the units of the pruned search: every entry is a settled node (its distance is final and used), but an in-node
+                    // with nothing beyond it within the bound is not EXPANDED -- the enumeration level records it from its parent's
+                    // block and never gathers its own, so its out-edges are not relaxed (here it has an entry because this kernel
+                    // emits a node from its own entry). lb+(node) = the smallest "what the child is needed for" of its own slots.
+                    bool gathered = true;
+                    if (a.prune && !(flags & F_EXT) && node != s.srcnode[src]) {
+                        const uint32_t ws[4] = {hi.x & 0xFFFFu, hi.x >> 16, hi.y & 0xFFFFu, hi.y >> 16};
+                        uint32_t beyond = 255u;
+                        for (uint32_t j = 0; j < (hi.z & 0xFFu); j++) beyond = min(beyond, ((hi.z >> (16 + j)) & 1u) ? (ws[j] & 0xFFu) : (ws[j] >> 8));
+                        gathered = (uint32_t)((e >> 1) & ENT_DIST_MASK) + beyond <= a.K1;
+                    }
+                    atomicAdd(&s.bt_settled, 1ull);
+                    if (gathered) atomicAdd(&s.bt_relaxed, (unsigned long long)((flags & F_EXT) ? lo.z : (hi.z & 0xFFu)));
                 }
                 if (!(e & 1ull) && node != s.srcnode[src]) atomicAdd(&s.cnt[src], 1u);
             });
@@ -947,6 +989,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     // being handed out, `ahead` the wave's next one (loaded a whole chunk before it is needed). A lane that needs a source gets
     // the next unused one by a cross-lane permute: no atomic, no memory round trip, no LDS. ----
     const unsigned long long n_items = PRUNE ? a.counters[C_ACTIVE] : a.n_items;
+    const unsigned long long act_first = PRUNE ? a.counters[C_ACT_BEGIN] : 0ull;
     const unsigned long long n_waves = (unsigned long long)gridDim.x * WPB;
     unsigned long long next_chunk = (unsigned long long)blockIdx.x * WPB + wv;  // chunk that `ahead` will hold (wave-uniform)
     uint32_t cur_base = 0, cur_len = 0, cur_pos = 0, nxt_base = 0, nxt_len = 0;  // wave-uniform
@@ -959,8 +1002,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         nxt_base = (uint32_t)lo;
         nxt_len = lo >= n_items ? 0u : (n_items - lo < 64 ? (uint32_t)(n_items - lo) : 64u);
         if constexpr (PRUNE) {
-            ahead = (uint32_t)lane < nxt_len ? a.act_node[lo + lane] : 0u;
-            ahead_item = (uint32_t)lane < nxt_len ? (uint32_t)(a.act_index[lo + lane] - a.src_begin) : 0u;
+            ahead = (uint32_t)lane < nxt_len ? a.act_node[act_first + lo + lane] : 0u;
+            ahead_item = (uint32_t)lane < nxt_len ? (uint32_t)(a.act_index[act_first + lo + lane] - a.src_begin) : 0u;
         } else {
             ahead = (uint32_t)lane < nxt_len ? a.sources[a.src_begin + lo + lane] : 0u;
         }
@@ -1101,7 +1144,10 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             }
         }
         const bool is_ext = active && (meta & ((uint32_t)F_EXT << 8));
-        bool hv[5], pv[4 + GSLOTS];
+        // PRUNE: a grandchild that is an in-node (cmeta bit 8 + t) is recorded from THIS block, like the children, and pushed -- with its
+        // own flag done -- only if something lies beyond it (the high bytes carry weight + lb+): a quarter of the node visits of the
+        // bench graph are in-nodes with nothing behind them within the bound, and their blocks are never gathered.
+        bool hv[5], hg[GSLOTS], pv[4 + GSLOTS];
         hv[0] = active && !cur_chk && (meta & ((uint32_t)F_TARGET << 8)) && u != src_node;  // forbid_source_target, greedytigs/mod.rs:329
         uint32_t nh_f = nhit + (hv[0] ? 1u : 0u), sp_f = sp;
 #pragma unroll
@@ -1115,6 +1161,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         for (int t = 0; t < GSLOTS; t++) {
             pv[4 + t] = lg[t] <= K1;
             sp_f += pv[4 + t] ? 1u : 0u;
+            hg[t] = PRUNE && dg[t] <= K1 && (meta & (0x1000000u << t)) && gn[t] != src_node;
+            nh_f += hg[t] ? 1u : 0u;
         }
         if (__any(is_ext)) {  // spilled adjacency (more than 4 out-edges; never in a de Bruijn graph): count first
             if (is_ext) {
@@ -1148,13 +1196,24 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         // ---- hits and successors, straight into LDS (an overflowing lane scribbles into the scratch block instead) ----
         const uint32_t base = ovf ? SCRATCH : blk;
         uint32_t wsp = ovf ? 0u : sp, wnh = ovf ? 0u : nhit;
-        mem[hit_word(base, wnh)] = ((unsigned long long)d << 32) | u;
-        wnh += hv[0] ? 1u : 0u;
+        if (!PRUNE || __any(hv[0])) {  // (PRUNE: only the successors of a spilled adjacency arrive with their own flag still open)
+            mem[hit_word(base, wnh)] = ((unsigned long long)d << 32) | u;
+            wnh += hv[0] ? 1u : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < 2 || __any(hv[1 + j])) {
                 mem[hit_word(base, wnh)] = ((unsigned long long)dc[j] << 32) | nb[j];
                 wnh += hv[1 + j] ? 1u : 0u;
+            }
+        }
+        if constexpr (PRUNE) {
+#pragma unroll
+            for (int t = 0; t < GSLOTS; t++) {
+                if (__any(hg[t])) {
+                    mem[hit_word(base, wnh)] = ((unsigned long long)dg[t] << 32) | gn[t];
+                    wnh += hg[t] ? 1u : 0u;
+                }
             }
         }
         if (__any(is_ext)) {
@@ -1169,7 +1228,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 #pragma unroll
         for (int t = GSLOTS - 1; t >= 0; t--) {
             if (t < 4 || __any(pv[4 + t])) {
-                mem[stack_word(base, wsp)] = ((unsigned long long)dg[t] << 32) | gn[t];
+                mem[stack_word(base, wsp)] = ((unsigned long long)(dg[t] | (PRUNE ? 0x10000u : 0u)) << 32) | gn[t];  // (PRUNE: flag done above)
                 wsp += pv[4 + t] ? 1u : 0u;
             }
         }
@@ -1457,7 +1516,10 @@ struct Device {
                    // + 4 = without the goal-directed pruning (full balls, every source searched: A/B runs and tests)
     bool w8 = false;                 // blocks in the 8:8 format with lower bounds (k <= 255)
     uint8_t *d_reach = nullptr;      // [V] w8: 1 = some successor can still lead to an in-node within the bound
-    uint32_t *d_act_index = nullptr, *d_act_node = nullptr, *d_act_blocks = nullptr;  // the searched sources of the last launch (cap: act_cap)
+    // the sources that can reach an in-node (8:8 format), in order, written by the classification (cap: act_cap sources); per-block
+    // counts of them (d_act_blocks, n_cls_blocks words) and their number (d_act_total, on the device)
+    uint32_t *d_act_index = nullptr, *d_act_node = nullptr, *d_act_blocks = nullptr;
+    unsigned long long *d_act_total = nullptr;
     uint64_t act_cap = 0;
     uint64_t last_active_sources = 0;
     int n_cu = 256;
@@ -1502,7 +1564,7 @@ constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_N
 constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
 static std::string enum_level_name(bool quad, bool prune) {
     char b[160];
-    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_count/write_kernel + " : "",
+    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
                   ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
     return b;
 }
@@ -1539,21 +1601,12 @@ static bool enum_uses_quad_gathers(const Device *d) {
 }
 static bool enum_prunes(const Device *d) { return d->w8 && !(d->plan & 4) && (d->plan & 3) != 1; }  // (plan 1 = the plain cascade: full balls)
 
-// the searched sources of [src_begin, src_begin + n): d_act_index / d_act_node, their number in counters[C_ACTIVE]; zeroes cand_count
+// the searched sources of [src_begin, src_begin + n): the part of the classification's list (d_act_index / d_act_node) inside the range --
+// first entry and number in counters[C_ACT_BEGIN] / counters[C_ACTIVE]; zeroes cand_count (a search only stores the count of a non-empty list)
 static void launch_active_list(Device *d, hipStream_t st, const SsspArgs &args, uint64_t n) {
-    if (d->act_cap < n) {
-        for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node, (void *)d->d_act_blocks}) if (p) HIP_CHECK(hipFree(p));
-        hu::device_malloc(&d->d_act_index, n * 4);
-        hu::device_malloc(&d->d_act_node, n * 4);
-        hu::device_malloc(&d->d_act_blocks, ((n + ACT_BLOCK * ACT_PER - 1) / (ACT_BLOCK * ACT_PER)) * 4);
-        d->act_cap = n;
-    }
-    const unsigned nb = (unsigned)((n + ACT_BLOCK * ACT_PER - 1) / (ACT_BLOCK * ACT_PER));
-    hipLaunchKernelGGL(active_count_kernel, dim3(nb), dim3(ACT_BLOCK), 0, st, args.sources, d->d_reach, args.src_begin, n, d->d_act_blocks);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_act_blocks, nb, &args.counters[C_ACTIVE], (const uint32_t *)nullptr,
-                       (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(active_write_kernel, dim3(nb), dim3(ACT_BLOCK), 0, st, args.sources, d->d_reach, args.src_begin, n, d->d_act_blocks,
-                       d->d_act_index, d->d_act_node, args.cand_count);
+    hipLaunchKernelGGL(active_range_kernel, dim3(1), dim3(64), 0, st, d->d_act_index, d->d_act_total, args.src_begin, args.src_begin + n,
+                       &args.counters[C_ACT_BEGIN], &args.counters[C_ACTIVE]);
+    HIP_CHECK(hipMemsetAsync(args.cand_count, 0, n * sizeof(uint32_t), st));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1805,7 +1858,7 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
             read_counters(d, st);
             n_first = d->h_counters[C_ACTIVE];
             SsspArgs b = a;
-            b.src_index = d->d_act_index;
+            b.src_index = d->d_act_index + d->h_counters[C_ACT_BEGIN];
             b.n_items = n_first;
             launch_level(d, st, coop_level(first_coop, false), count, b);
         }
@@ -1969,6 +2022,8 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4);
     d->n_cls_blocks = (V + CLS_NODES - 1) / CLS_NODES;
     hu::device_malloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4);  // source counts | positive multiplicities per block
+    hu::device_malloc(&d->d_act_blocks, std::max<uint64_t>(d->n_cls_blocks, 1) * 4);
+    hu::device_malloc(&d->d_act_total, 8);
     hu::device_malloc(&d->d_counters, C_COUNT * sizeof(unsigned long long));
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
@@ -2006,19 +2061,23 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         if (d->w8) {  // goal-directed lower bounds: k - 1 rounds over a 32-bit distance array, then the 8:8 format of the weight slots
             uint32_t *d_D = nullptr;
             uint8_t *d_lb8 = nullptr;
+            uint16_t *d_lbx = nullptr;
             hu::device_malloc(&d_D, V * 4);
             hu::device_malloc(&d_lb8, V);
+            hu::device_malloc(&d_lbx, V * 2);
             hu::device_malloc(&d->d_reach, V);
             hipLaunchKernelGGL(lb_init_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, d->d_mirror, V, d_D);
             for (uint32_t r = 0; r < d->K1; r++)
                 hipLaunchKernelGGL(lb_round_kernel, dim3(vb), dim3(256), 0, st, d->d_recs, d->d_ext_col, d->d_ext_w, V, r, d->K1, d_D);
             hipLaunchKernelGGL(lb_mirror_kernel, dim3(vb), dim3(256), 0, st, d->d_mirror, d_D, V, d_lb8);
-            hipLaunchKernelGGL(build_lb_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d->d_reach);
+            hipLaunchKernelGGL(build_lbx_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d_lbx, d->d_reach);
+            hipLaunchKernelGGL(build_lb_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d_lbx);
             hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(st));
             HIP_CHECK(hipFree(d_D));
             HIP_CHECK(hipFree(d_lb8));
+            HIP_CHECK(hipFree(d_lbx));
         } else {
             hipLaunchKernelGGL(build_children_kernel<false>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
         }
@@ -2041,7 +2100,7 @@ void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
     void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters,
-                    d->d_reach, d->d_act_index, d->d_act_node, d->d_act_blocks};
+                    d->d_reach, d->d_act_index, d->d_act_node, d->d_act_blocks, d->d_act_total};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
@@ -2066,18 +2125,26 @@ uint64_t device_classify(Device *d, void *stream) {
     HIP_CHECK(hipSetDevice(d->dev));
     d->n_sources = 0;
     if (d->V) {
+        const uint8_t *reach = d->w8 ? d->d_reach : nullptr;
         hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_odeg, d->d_mirror, (uint32_t)d->V,
-                           d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks);
+                           d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks, reach, d->d_act_blocks);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
-                           &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND]);
+                           &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND],
+                           reach ? d->d_act_blocks : (uint32_t *)nullptr, reach ? d->d_act_total : (unsigned long long *)nullptr);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_cls,
-                           (uint32_t)d->V, d->d_block_counts, d->d_out_nodes);
-        HIP_CHECK(hipGetLastError());
-        read_counters(d, st);
+        read_counters(d, st);  // (the number of sources sizes the lists the compaction writes)
         d->n_sources = d->h_counters[C_OVF_LIST];
         d->total_demand = d->h_counters[C_DEMAND];
+        if (reach && d->act_cap < d->n_sources) {
+            for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node}) if (p) HIP_CHECK(hipFree(p));
+            hu::device_malloc(&d->d_act_index, d->n_sources * 4);
+            hu::device_malloc(&d->d_act_node, d->n_sources * 4);
+            d->act_cap = d->n_sources;
+        }
+        hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_cls,
+                           (uint32_t)d->V, d->d_block_counts, d->d_out_nodes, reach, d->d_act_blocks, d->d_act_index, d->d_act_node);
+        HIP_CHECK(hipGetLastError());
     }
     d->classified = true;
     return d->n_sources;

@@ -76,8 +76,10 @@ def test_classification_matches_oracle(gpu, oracle, idx):
 
 def _pruned_search_units(bg):
     """Independent count of what the goal-directed search visits (mtg_sssp_count_visited): lb(v) = distance to the nearest initial
-    in-node by a multi-source Dijkstra over the reversed edges; a source is searched iff some successor c has w + lb(c) <= k-1; a
-    search relaxes u -> v at distance d + w only if d + w + lb(v) <= k-1. Returns (searched sources, settled, relaxed edges)."""
+    in-node by a multi-source Dijkstra over the reversed edges, lb+(v) = min over v's out-edges of w + lb(head) = distance to the
+    nearest in-node BEYOND v; a source is searched iff lb+(source) <= k-1; a search settles v over u -> v at distance d + w only if
+    d + w + lb(v) <= k-1, and expands it (relaxes its out-edges) only if d + w + lb+(v) <= k-1: an in-node with nothing beyond it is
+    recorded from its parent's block and its own block is never read. Returns (searched sources, settled, relaxed edges)."""
     import heapq
 
     V, K1 = bg.n_nodes, bg.k - 1
@@ -111,9 +113,11 @@ def _pruned_search_units(bg):
             if nd <= K1 and nd < lb[rcol[i]]:
                 lb[rcol[i]] = nd
                 heapq.heappush(heap, (nd, int(rcol[i])))
+    lbp = np.full(V, INF, np.int64)
+    np.minimum.at(lbp, fr, w + lb[to])
     searched = settled = relaxed = 0
     for s in np.nonzero(source)[0]:
-        if not any(int(ww[i]) + lb[col[i]] <= K1 for i in range(row[s], row[s + 1])):
+        if lbp[s] > K1:
             continue
         searched += 1
         dist = {int(s): 0}
@@ -123,6 +127,8 @@ def _pruned_search_units(bg):
             if d > dist[u]:
                 continue
             settled += 1
+            if u != s and d + lbp[u] > K1:
+                continue
             relaxed += int(row[u + 1] - row[u])
             for i in range(row[u], row[u + 1]):
                 v, nd = int(col[i]), d + int(ww[i])

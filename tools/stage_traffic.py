@@ -18,7 +18,7 @@ from collections import defaultdict
 # first kernel of a stage -> stage (kernel names as rocprofv3 prints them, matched by substring)
 MARKERS = [
     ("classify_kernel", "classify"),
-    ("active_count_kernel", "sssp"),
+    ("active_range_kernel", "sssp"),
     ("sssp_enum_kernel", "sssp"),
     ("replay_state_init_kernel", "replay"),
     ("row_degree_kernel", "insert_eulerise"),
