@@ -71,7 +71,7 @@ def size_label(log2_edges: int) -> str:
     return "661k-pangenome-like (SURVEY 8d: 2^31)"
 
 
-def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, visits: int, kept: int, tigs: int) -> dict:
+def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, visits: int, kept: int, tigs: int, A: int = 0) -> dict:
     """Algorithmic bytes per stage of ONE step = the sum over the stage's kernels of the arrays each must read and write once
     (a gathered array counts once per gathering pass; DESIGN.md 3.9 derives every term). V nodes, E0 original darts, P matched
     pairs, N Euleriser units, E darts after the finish, D = E - E0 dummy darts, n = E / 2 biedges, M = E / 64 splitters."""
@@ -81,7 +81,8 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
     wy = max(1, math.ceil(math.log2(2 * M)))
     buckets = 32 * V + 44 * D + 4 * E0 + 4 * E  # dummy darts bucketed + one streaming merge with the kept buckets of the original darts
     return {
-        "classify": 18 * V + 4 * S,                                # classify (odeg, mirror -> mult, cls) + compaction (cls -> out_nodes)
+        # classify (odeg, mirror, reach -> mult, cls) + compaction (cls, reach -> out_nodes and the A sources the SSSP stage searches)
+        "classify": 20 * V + 4 * S + 8 * A,
         # state copy 17 V; dense list + claims words + pair-count scan 48 S; admission 187 B per listed source; 67.2 B per check
         # visit; compaction 32 B per pair
         "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
@@ -401,7 +402,9 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic, "traffic_note": traffic_note,
             "bytes_note": ("algorithmic bytes = 5 B x relaxed edges + 12 B x settled nodes + 12 B x candidates of the search the launch runs: "
-                           "the goal-directed (pruned) search when the device graph carries lower bounds (units in 'visited_per_step'), "
+                           "the goal-directed (pruned) search when the device graph carries lower bounds (units in 'visited_per_step': settled = "
+                           "nodes whose distance the search determines, relaxed = out-edges of the nodes it expands -- an in-node with nothing "
+                           "beyond it within the bound is settled from its parent's block and not expanded), "
                            "else full balls; 'full_ball_equivalent' prices the same time against the full-ball units of 'units_per_step'"),
             "gather_ceiling_note": "dependent random 64-B block gathers saturate at ~54 G/s below 3 GB of blocks and at ~44 G/s (one request "
                                    "per lane and line; 19 G/s with four) at 5.7 GB, tools/gather_bench_tlb.hip",
@@ -420,7 +423,7 @@ def main():
             n_dense = int((count_last > 0).sum().item()) if count_last is not None else 0
             models = stage_models(n_nodes, n_edges, result_info.get("pairs", 0), result_info.get("units", 0), result_info.get("darts", 0),
                                   result_info.get("S", 0), n_dense, result_info.get("replay_visits") or 0, result_info.get("tig_edges", 0),
-                                  result_info.get("tigs", 0))
+                                  result_info.get("tigs", 0), (total_visited or {}).get("searched_sources", 0))
             names = {"replay": "claim replay: replay_state_init + dense list + replay_rounds_kernel + pair-count scan + compaction",
                      "insert_eulerise": "matched-pair darts + Euleriser: degree / need / 3 scans / expand / zip_check / zip_emit / head kernels",
                      "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, splitter walks, ranking, write",

@@ -5,9 +5,9 @@ import argparse, json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
-from matchtigs_amd import api, synth
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None, help="another build of the library (A/B of a development variant)")
 ap.add_argument("--log2-edges", type=int, default=24)
 ap.add_argument("--k", type=int, default=31)
 ap.add_argument("--seed", type=int, default=1)
@@ -15,6 +15,10 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--stages", default="device,host")
 ap.add_argument("--eulers", default="device,exact")
 args = ap.parse_args()
+if args.lib:
+    from matchtigs_amd import _lib
+    _lib.LIB_PATH = type(_lib.LIB_PATH)(str(Path(args.lib).resolve()))
+from matchtigs_amd import api, synth
 k = args.k
 nb = int(round((1 << args.log2_edges) / 3.0))
 t0 = time.perf_counter()
