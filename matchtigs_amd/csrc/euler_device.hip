@@ -309,41 +309,106 @@ __global__ __launch_bounds__(EB) void mark_pred_kernel(uint32_t *succ, const uin
     const uint32_t p = (succ[x ^ 1u] & ~SUCC_MARK) ^ 1u;  // (the word of x ^ 1 may carry a mark of its own already)
     atomicOr(&succ[p], SUCC_MARK);
 }
-template <bool MARKED>
+// The measuring walk also RECORDS the darts it passes, so that no second chase through `succ` is needed to write the closed walks
+// (round 4; until then walk_write_kernel walked every emitted segment again: E / 2 more dependent random loads). The 64 walkers of
+// a wave advance in lockstep; in every step the darts of the lanes that are still walking are stored back to back (ballot rank) in
+// the wave's current chunk of the sequence buffer -- coalesced stores, exactly one word per dart. Chunks of SEQ_CHUNK words come
+// from a bump cursor (one atomic per chunk and wave), their numbers go to the wave's row of chunk_tab; seq_copy_kernel replays the
+// same arithmetic from the segment lengths alone (which lanes are active in step j, where the row starts) and moves every emitted
+// dart to its final place. Where a chunk lands depends on thread timing, the result does not.
+constexpr uint32_t SEQ_CHUNK = 1024;  // words
+constexpr int SEQ_MAXC = 48;          // chunks per wave (a wave's 64 segments are ~4096 darts on average: 4-5 chunks)
+__host__ __device__ inline uint64_t seq_capacity_chunks(uint64_t n_darts, uint64_t n_waves) { return n_darts / (SEQ_CHUNK - 64) + n_waves + 16; }
+template <bool MARKED, bool RECORD>
 __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, const uint32_t *splitters, const uint32_t *sidx,
                                                          const uint32_t *split_bits, const uint32_t *root_bits, uint32_t n_split,
                                                          uint64_t n_darts, uint32_t *seg_len, uint32_t *next_split, uint32_t *jump,
-                                                         uint32_t *dist, uint32_t *error) {
+                                                         uint32_t *dist, uint32_t *error, uint32_t *seq, unsigned long long *seq_cursor,
+                                                         uint64_t seq_chunks, uint32_t *chunk_tab) {
     const uint64_t i = gid();
-    if (i >= n_split) return;
-    const uint32_t s = splitters[i];
-    uint32_t x, len = 1;
-    if constexpr (MARKED) {
-        uint32_t w = succ[s];
-        while (!(w & SUCC_MARK)) {
-            w = succ[w];
+    const bool valid = i < n_split;
+    const uint32_t s = valid ? splitters[i] : 0u;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = i >> 6;
+    uint32_t cur = s, x = 0, len = 0;
+    bool act = valid;
+    uint32_t off = 0, end = 0, n_chunks = 0;  // wave-uniform: fill of the wave's current chunk
+    uint64_t base = 0;
+    for (;;) {
+        const unsigned long long m = __ballot(act);
+        if (!m) break;
+        if constexpr (RECORD) {
+            const uint32_t n_act = (uint32_t)__popcll(m);
+            if (off + n_act > end) {  // (wave-uniform) a new chunk
+                unsigned long long c = 0;
+                if (lane == 0) {
+                    c = atomicAdd(seq_cursor, 1ull);
+                    if (n_chunks >= (uint32_t)SEQ_MAXC || c >= seq_chunks) { atomicOr(error, 16u); c = 0; }  // (the caller falls back to the second walk)
+                    else chunk_tab[wave * SEQ_MAXC + n_chunks] = (uint32_t)c;
+                }
+                c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)c);
+                base = c * SEQ_CHUNK;
+                n_chunks++;
+                off = 0;
+                end = SEQ_CHUNK;
+            }
+            if (act) seq[base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cur;
+            off += n_act;
+        }
+        if (act) {
+            const uint32_t w = succ[cur];
+            const uint32_t nx = MARKED ? (w & ~SUCC_MARK) : w;
+            const bool stop = MARKED ? (w & SUCC_MARK) != 0u : bit_of(split_bits, w);
             if (++len == 0 || len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
                 atomicOr(error, 2u);
-                break;
+                act = false;
             }
-        }
-        x = w & ~SUCC_MARK;
-    } else {
-        x = succ[s];
-        while (!bit_of(split_bits, x)) {
-            x = succ[x];
-            if (++len == 0 || len > n_darts) {
-                atomicOr(error, 2u);
-                break;
-            }
+            if (stop) { x = nx; act = false; }
+            else cur = nx;
         }
     }
+    if (!valid) return;
     const uint32_t nxt = sidx[x];
     seg_len[i] = len;
     next_split[i] = nxt;
     const bool root = bit_of(root_bits, s);
     jump[i] = root ? (uint32_t)i : nxt;  // roots are the terminals of the reduced lists
     dist[i] = root ? 0u : len;
+}
+// every emitted segment from the recorded sequence to its place in the closed walk (see walk_measure_kernel)
+__global__ __launch_bounds__(EB) void seq_copy_kernel(const uint32_t *seq, const uint32_t *chunk_tab, const uint32_t *rflag, const uint32_t *ridx,
+                                                     const uint32_t *jump, const uint32_t *dist, const uint32_t *seg_len, const uint32_t *cyc_len,
+                                                     const uint32_t *cyc_base, uint32_t n_split, uint32_t *out) {
+    const uint64_t i = gid();
+    const bool valid = i < n_split;
+    const uint64_t wave = i >> 6;
+    const uint32_t len = valid ? seg_len[i] : 0u;
+    bool emit = false;
+    uint32_t p = 0;
+    if (valid) {
+        const uint32_t t = jump[i];
+        emit = rflag[t] != 0u;  // (a mirror trail has no root on it: not emitted)
+        if (emit) {
+            const uint32_t r = ridx[t];
+            p = cyc_base[r] + (i == t ? 0u : cyc_len[r] - dist[i]);
+        }
+    }
+    uint32_t off = 0, end = 0, n_chunks = 0;
+    uint64_t base = 0;
+    for (uint32_t j = 0;; j++) {
+        const bool act = len > j;
+        const unsigned long long m = __ballot(act);
+        if (!m) break;
+        const uint32_t n_act = (uint32_t)__popcll(m);
+        if (off + n_act > end) {
+            base = (uint64_t)chunk_tab[wave * SEQ_MAXC + n_chunks] * SEQ_CHUNK;
+            n_chunks++;
+            off = 0;
+            end = SEQ_CHUNK;
+        }
+        if (act && emit) out[p + j] = seq[base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))];
+        off += n_act;
+    }
 }
 __global__ __launch_bounds__(EB) void wyllie_kernel(const uint32_t *jump_in, const uint32_t *dist_in, uint32_t n, uint32_t *jump_out,
                                                    uint32_t *dist_out) {
@@ -444,8 +509,10 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
 }  // namespace
 
 // (tests: the bitmap form of the splitter test, which graphs with 2^31 darts or more always use, on small graphs too)
-static std::atomic<int> g_force_bitmap{0}, g_flat_ranking{0};
-void device_euler_force_bitmap(int on) { g_force_bitmap.store((on & 1) ? 1 : 0); g_flat_ranking.store((on & 2) ? 1 : 0); }
+static std::atomic<int> g_force_bitmap{0}, g_flat_ranking{0}, g_second_walk{0};
+// (bit 0: bitmap form of the splitter test; bit 1: pointer jumping over all splitters; bit 2: write the closed walks by a second
+// walk through the successor array instead of from the sequence the measuring walk recorded)
+void device_euler_force_bitmap(int on) { g_force_bitmap.store((on & 1) ? 1 : 0); g_flat_ranking.store((on & 2) ? 1 : 0); g_second_walk.store((on & 4) ? 1 : 0); }
 
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
 // The buckets of darts [0, E) from the kept buckets of the original darts [0, E0) (row0 / adj0) and fresh ones of the dummy darts
@@ -602,11 +669,20 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_ridx = b_ridx.alloc<uint32_t>(st, M);
     splitter_compact_kernel<<<grid_for(E), EB, 0, st>>>(d_flag, d_sidx, E, d_split);
     const bool marked = E < 0x80000000ull && !g_force_bitmap;  // bit 31 of a successor word is free: it marks "my successor is a splitter"
-    if (marked) {
-        mark_pred_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, M);
-        walk_measure_kernel<true><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
-    } else {
-        walk_measure_kernel<false><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error);
+    // the measuring walk records the darts it passes (see walk_measure_kernel): sequence buffer, its chunk cursor, the waves' chunk tables
+    const bool record = !g_second_walk;
+    const uint64_t n_waves = ((uint64_t)M + 63) / 64, seq_chunks = record ? seq_capacity_chunks(E, n_waves) : 0;
+    Buf b_seq, b_ctab, b_cursor;
+    uint32_t *d_seq = record ? b_seq.alloc<uint32_t>(st, seq_chunks * SEQ_CHUNK) : nullptr;
+    uint32_t *d_ctab = record ? b_ctab.alloc<uint32_t>(st, n_waves * SEQ_MAXC) : nullptr;
+    unsigned long long *d_cursor = b_cursor.alloc<unsigned long long>(st, 1);
+    HIP_CHECK(hipMemsetAsync(d_cursor, 0, 8, st));
+    if (marked) mark_pred_kernel<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, M);
+    {
+        auto fn = marked ? (record ? walk_measure_kernel<true, true> : walk_measure_kernel<true, false>)
+                         : (record ? walk_measure_kernel<false, true> : walk_measure_kernel<false, false>);
+        fn<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error, d_seq, d_cursor,
+                                       seq_chunks, d_ctab);
     }
     int cur = 0;
     root_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_split, d_rbits, M, d_rflag);
@@ -643,7 +719,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     }
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    if (h_small[0]) MTG_DIE("device_euler_cycles: internal error (successor array is not a permutation)");
+    if (h_small[0] & ~16u) MTG_DIE("device_euler_cycles: internal error (successor array is not a permutation)");
+    const bool from_sequence = record && !(h_small[0] & 16u);  // (16: a wave outgrew its chunk table -- the second walk writes instead)
     lap("segment walks + ranking");
     const uint32_t R = h_small[2];  // connected components = closed walks
     if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] euler decompose: E %llu V %llu hook rounds %d splitters %u components %u\n", (unsigned long long)E, (unsigned long long)V, hook_rounds, M, R);
@@ -658,7 +735,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipStreamSynchronize(st));
     if (h_small[3] != E / 2)
         MTG_DIE("device_euler_cycles: internal error (closed walks cover %u of %llu biedges)", h_small[3], (unsigned long long)(E / 2));
-    if (marked) walk_write_kernel<true><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
+    if (from_sequence) seq_copy_kernel<<<grid_for(M), EB, 0, st>>>(d_seq, d_ctab, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
+    else if (marked) walk_write_kernel<true><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
     else walk_write_kernel<false><<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_rflag, d_ridx, d_jump[cur], d_dist[cur], d_seglen, d_clen, d_cbase, M, d_out);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev1, st));

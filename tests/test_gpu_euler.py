@@ -184,6 +184,40 @@ def test_device_euler_splitter_mark_and_bitmap_forms_agree(gpu):
         check_bicycles(G.export(), a[0], a[1])
 
 
+def test_device_euler_walks_from_the_recorded_sequence_equal_the_second_walk(gpu):
+    """The measuring walk records the darts it passes (ballot-packed rows in chunks of a bump-allocated buffer) and the closed walks
+    are written from that record; mtg_set_euler_device_tuning(4) writes them by a second walk through the successor array, as until
+    round 4: identical walks -- small graphs (a few lanes per wave), both splitter tests, and a graph of 9 M darts."""
+    from matchtigs_amd import _lib, api, synth
+
+    L = _lib.load()
+    cases = [synth.g_csr(n, seed=seed, k=31, mean_out_degree=deg) for seed, n, deg in ((13, 200000, 1.2), (5, 60000, 2.0), (9, 300, 1.5), (2, 40, 1.0))]
+    graphs = []
+    for bg in cases:
+        G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+        G.make_eulerian(0, bg.k)
+        graphs.append(G)
+    big = synth.g_csr_device(1 << 21, seed=11, k=31, mean_out_degree=1.4)
+    big.make_eulerian(0, 31)
+    graphs.append(big)
+    for G in graphs:
+        a = G.euler_cycles_device_np()
+        for flags in (4, 5):  # second walk; second walk + bitmap splitter test
+            L.mtg_set_euler_device_tuning(flags)
+            try:
+                b = G.euler_cycles_device_np()
+            finally:
+                L.mtg_set_euler_device_tuning(0)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), flags
+        L.mtg_set_euler_device_tuning(1)  # recorded sequence + bitmap splitter test
+        try:
+            c = G.euler_cycles_device_np()
+        finally:
+            L.mtg_set_euler_device_tuning(0)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+        check_bicycles(G.export(), a[0], a[1])
+
+
 def test_device_euler_two_level_ranking_equals_flat_pointer_jumping(gpu):
     """From 2^16 splitters on the reduced list is ranked in two levels (every 32nd splitter and every root; pointer jumping over
     those only); mtg_set_euler_device_tuning(2) forces the flat form: identical walks on a graph of 9 M darts, Eulertigs and greedy."""
