@@ -395,19 +395,35 @@ __global__ __launch_bounds__(EB) void seq_copy_kernel(const uint32_t *seq, const
     }
     uint32_t off = 0, end = 0, n_chunks = 0;
     uint64_t base = 0;
-    for (uint32_t j = 0;; j++) {
-        const bool act = len > j;
-        const unsigned long long m = __ballot(act);
-        if (!m) break;
-        const uint32_t n_act = (uint32_t)__popcll(m);
-        if (off + n_act > end) {
-            base = (uint64_t)chunk_tab[wave * SEQ_MAXC + n_chunks] * SEQ_CHUNK;
-            n_chunks++;
-            off = 0;
-            end = SEQ_CHUNK;
+    // (a wave runs as many steps as its longest segment, ~300 for a mean of 64: the loop is bound by the latency of its loads, so four
+    // rows are requested before the first is stored)
+    constexpr int U = 4;
+    for (uint32_t j0 = 0;; j0 += U) {
+        uint32_t v[U];
+        bool wr[U];
+        bool done = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool act = len > j0 + u;
+            const unsigned long long m = __ballot(act);
+            wr[u] = false;
+            v[u] = 0;
+            if (!m) { done = true; continue; }  // (lengths only shrink the active set: once empty, empty for good)
+            const uint32_t n_act = (uint32_t)__popcll(m);
+            if (off + n_act > end) {
+                base = (uint64_t)chunk_tab[wave * SEQ_MAXC + n_chunks] * SEQ_CHUNK;
+                n_chunks++;
+                off = 0;
+                end = SEQ_CHUNK;
+            }
+            wr[u] = act && emit;
+            if (wr[u]) v[u] = seq[base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))];
+            off += n_act;
         }
-        if (act && emit) out[p + j] = seq[base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))];
-        off += n_act;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (wr[u]) out[p + j0 + u] = v[u];
+        if (done) break;
     }
 }
 __global__ __launch_bounds__(EB) void wyllie_kernel(const uint32_t *jump_in, const uint32_t *dist_in, uint32_t n, uint32_t *jump_out,
