@@ -25,9 +25,10 @@
 //      passages (and, mirrored, at the mirror node), which merges all their trails into one. Roots only hang below
 //      smaller ids, so the accepted proposals form a forest: every one joins two trails that are still distinct, and
 //      the result is exactly one trail pair per connected component.
-//   5. rank the final trails: random splitters (1/64 of the darts + the smallest dart of every component) walk to
-//      the next splitter, the reduced list is ranked by pointer jumping, and a second walk writes the darts at
-//      their final positions. Only the trail that contains the component's smallest dart is emitted.
+//   5. rank the final trails: splitters (every 64th dart id + the smallest dart of every component) walk to the next
+//      splitter and record the darts they pass, the reduced list is ranked by pointer jumping (two levels), and the
+//      recorded segments are copied to their final positions. Only the trail that contains the component's smallest
+//      dart is emitted.
 // No step depends on thread timing (atomics are only used for counts, minima and idempotent flags), so the same graph
 // always gives the same walks. Everything is integer gather/scatter work; no MFMA.
 #include <hip/hip_runtime.h>
@@ -271,33 +272,78 @@ __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint
 }
 
 // ---- step 5: ranking ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool hash_splitter(uint32_t e) { return ((e * 0x9E3779B1u) >> 26) == 0; }
 __device__ __forceinline__ bool bit_of(const uint32_t *bits, uint32_t e) { return (bits[e >> 5] >> (e & 31)) & 1u; }
 
-// flag[e] = 1 for splitters (1/64 of the darts by hash + the smallest dart of every connected component); the same flags as
-// a bitmap (one word per 32 darts, written whole by one thread) for the walks, and the roots as a second bitmap
-__global__ __launch_bounds__(EB) void splitter_flag_kernel(const uint32_t *comp, uint32_t *parent2, uint64_t n_darts, uint32_t *flag,
-                                                          uint32_t *split_bits, uint32_t *root_bits) {
+// Splitters (round 4, second form): every 64th dart id (dart ids are unrelated to the order of the trails, so these are as evenly
+// spread as a hash) and the smallest dart of every connected component ("root": the closed walk starts there, and only the trail
+// that carries it is emitted). Splitter i < M0 = ceil(E / 64) is dart 64 i; the roots that are not a multiple of 64 follow, in
+// ascending order (`extra`, X of them) -- no per-dart flag array, no scan and no compaction over the darts, and the index of a
+// splitter is arithmetic (extras: a binary search in their short list). Biedge b is a root iff it is the label of its own trail pair
+// and of its own component: comp[b] == b and parent2[b] == b (both arrays are flat here) -- two streaming passes over the biedges:
+//   root_count_kernel  extras per workgroup chunk (-> scan over the chunk counts) + the root bitmap (one bit per dart)
+//   root_write_kernel  the extras' darts, ranked inside the chunk
+constexpr int ROOT_PER = 8, ROOT_CHUNK = EB * ROOT_PER;
+__device__ __forceinline__ bool is_root_biedge(const uint32_t *comp, const uint32_t *parent2, uint64_t b) { return comp[b] == (uint32_t)b && parent2[b] == (uint32_t)b; }
+__global__ __launch_bounds__(EB) void root_count_kernel(const uint32_t *comp, const uint32_t *parent2, uint64_t n_biedges, uint32_t *chunk_extras,
+                                                       uint32_t *root_bits) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int p = 0; p < ROOT_PER; p++) {
+        const uint64_t b = (uint64_t)blockIdx.x * ROOT_CHUNK + (uint64_t)p * EB + threadIdx.x;
+        if (b < n_biedges && is_root_biedge(comp, parent2, b)) {
+            const uint64_t e = 2 * b;
+            atomicOr(&root_bits[e >> 5], 1u << (e & 31));  // (a handful per graph: one per connected component)
+            c += (e & 63u) ? 1u : 0u;
+        }
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) c += __shfl_down(c, dd);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_extras[blockIdx.x] = s_cnt;
+}
+__global__ __launch_bounds__(EB) void root_write_kernel(const uint32_t *comp, const uint32_t *parent2, uint64_t n_biedges, const uint32_t *chunk_offsets,
+                                                       uint32_t *extra) {
+    __shared__ uint32_t wave_cnt[ROOT_PER][EB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long bal[ROOT_PER];
+#pragma unroll
+    for (int p = 0; p < ROOT_PER; p++) {
+        const uint64_t b = (uint64_t)blockIdx.x * ROOT_CHUNK + (uint64_t)p * EB + threadIdx.x;
+        bal[p] = __ballot(b < n_biedges && ((2 * b) & 63u) && is_root_biedge(comp, parent2, b));
+        if (lane == 0) wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]);
+    }
+    __syncthreads();
+    uint32_t off = chunk_offsets[blockIdx.x];
+#pragma unroll
+    for (int p = 0; p < ROOT_PER; p++) {  // ascending: lane, wave, pass, chunk
+        for (int j = 0; j < EB / 64; j++) {
+            if (j == wv && ((bal[p] >> lane) & 1ull))
+                extra[off + (uint32_t)__popcll(bal[p] & ((1ull << lane) - 1ull))] = (uint32_t)(2 * ((uint64_t)blockIdx.x * ROOT_CHUNK + (uint64_t)p * EB + threadIdx.x));
+            off += wave_cnt[p][j];
+        }
+    }
+}
+// the splitters' darts, by index (M0 regular ones, then the extras)
+__global__ __launch_bounds__(EB) void split_list_kernel(uint32_t m0, const uint32_t *extra, uint32_t n_split, uint32_t *splitters) {
     const uint64_t i = gid();
-    const bool in = i < n_darts;
-    bool root = false, split = false;
-    if (in) {
-        const uint32_t e = (uint32_t)i;
-        root = !(e & 1u) && uf_find(parent2, comp[e >> 1]) == (e >> 1);  // smallest dart of its connected component
-        split = root || hash_splitter(e);
-        flag[e] = split ? 1u : 0u;
-    }
-    const unsigned long long ms = __ballot(split), mr = __ballot(root);
-    const int lane = threadIdx.x & 63;
-    if (in && (lane & 31) == 0) {
-        split_bits[i >> 5] = (uint32_t)(ms >> lane);
-        root_bits[i >> 5] = (uint32_t)(mr >> lane);
-    }
+    if (i < n_split) splitters[i] = i < m0 ? (uint32_t)(i * 64) : extra[i - m0];
 }
-__global__ __launch_bounds__(EB) void splitter_compact_kernel(const uint32_t *flag, const uint32_t *sidx, uint64_t n_darts, uint32_t *splitters) {
-    const uint64_t e = gid();
-    if (e < n_darts && flag[e]) splitters[sidx[e]] = (uint32_t)e;
-}
+struct SplitIndex {  // dart -> index of the splitter it is
+    uint32_t m0, n_extra;
+    const uint32_t *extra;
+    __device__ __forceinline__ uint32_t operator()(uint32_t x) const {
+        if (!(x & 63u)) return x >> 6;
+        uint32_t lo = 0, hi = n_extra;  // (x is an extra root: present)
+        while (lo + 1 < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (extra[mid] <= x) lo = mid; else hi = mid;
+        }
+        return m0 + lo;
+    }
+};
 // While dart ids leave bit 31 free (fewer than 2^31 darts) the walks do not look the splitter bitmap up at every step: the
 // PREDECESSOR of every splitter carries the mark in bit 31 of its successor word -- pred(x) = succ[x ^ 1] ^ 1, by the mirror symmetry
 // of the pairing -- set by one thread per splitter. One random load per step instead of two (walk_measure 6.8 -> see DESIGN 3.6).
@@ -320,8 +366,8 @@ constexpr uint32_t SEQ_CHUNK = 1024;  // words
 constexpr int SEQ_MAXC = 48;          // chunks per wave (a wave's 64 segments are ~4096 darts on average: 4-5 chunks)
 __host__ __device__ inline uint64_t seq_capacity_chunks(uint64_t n_darts, uint64_t n_waves) { return n_darts / (SEQ_CHUNK - 64) + n_waves + 16; }
 template <bool MARKED, bool RECORD>
-__global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, const uint32_t *splitters, const uint32_t *sidx,
-                                                         const uint32_t *split_bits, const uint32_t *root_bits, uint32_t n_split,
+__global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, const uint32_t *splitters, SplitIndex sidx,
+                                                         const uint32_t *root_bits, uint32_t n_split,
                                                          uint64_t n_darts, uint32_t *seg_len, uint32_t *next_split, uint32_t *jump,
                                                          uint32_t *dist, uint32_t *error, uint32_t *seq, unsigned long long *seq_cursor,
                                                          uint64_t seq_chunks, uint32_t *chunk_tab) {
@@ -358,7 +404,7 @@ __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, 
         if (act) {
             const uint32_t w = succ[cur];
             const uint32_t nx = MARKED ? (w & ~SUCC_MARK) : w;
-            const bool stop = MARKED ? (w & SUCC_MARK) != 0u : bit_of(split_bits, w);
+            const bool stop = MARKED ? (w & SUCC_MARK) != 0u : (!(w & 63u) || bit_of(root_bits, w));
             if (++len == 0 || len > n_darts) {  // cannot happen for a permutation; guards against a corrupted successor array
                 atomicOr(error, 2u);
                 act = false;
@@ -368,7 +414,7 @@ __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, 
         }
     }
     if (!valid) return;
-    const uint32_t nxt = sidx[x];
+    const uint32_t nxt = sidx(x);
     seg_len[i] = len;
     next_split[i] = nxt;
     const bool root = bit_of(root_bits, s);
@@ -597,7 +643,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
 
-    Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_sidx, b_sbits, b_rbits, b_best, b_bsum, b_small, b_active;
+    Buf b_row, b_adj, b_pos2, b_succ, b_comp, b_flag, b_rbits, b_best, b_bsum, b_small, b_active;
     uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1);
     uint32_t *d_adj = b_adj.alloc<uint32_t>(st, E);
     const uint64_t n_b = E / 2;  // biedges
@@ -606,9 +652,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_succ = b_succ.alloc<uint32_t>(st, E);
     uint32_t *d_comp = b_comp.alloc<uint32_t>(st, n_b);  // union-find over biedges -> labels of the trail pairs, in place
     uint32_t *d_flag = b_flag.alloc<uint32_t>(st, E);
-    uint32_t *d_sidx = b_sidx.alloc<uint32_t>(st, E);
     const uint64_t n_words = (E + 31) / 32;
-    uint32_t *d_sbits = b_sbits.alloc<uint32_t>(st, n_words);
     uint32_t *d_rbits = b_rbits.alloc<uint32_t>(st, n_words);
     unsigned long long *d_best = b_best.alloc<unsigned long long>(st, n_b);
     uint8_t *d_active = b_active.alloc<uint8_t>(st, V);
@@ -645,7 +689,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
     lap("trail labels");
     // 4. merge the trails of every connected component
-    HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`, reused as the splitter flags afterwards
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`
     HIP_CHECK(hipMemsetAsync(d_best, 0xFF, n_b * 8, st));
     int hook_rounds = 0;
     for (;; hook_rounds++) {  // (a round in which no binode sees two components is the last: nothing to hook, nothing to flatten)
@@ -662,18 +706,28 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     b_best.release();
     b_active.release();
     rotate_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_flag, d_succ);
-    // 5. ranking
-    splitter_flag_kernel<<<grid_for(E), EB, 0, st>>>(d_comp, d_parent2, E, d_flag, d_sbits, d_rbits);
-    scan_u32<uint32_t>(st, d_flag, E, d_sidx, d_bsum, d_total);
+    // 5. ranking: splitters = every 64th dart + the components' roots (see root_count_kernel)
+    const uint64_t n_root_chunks = (n_b + ROOT_CHUNK - 1) / ROOT_CHUNK;
+    Buf b_xcnt, b_extra;
+    uint32_t *d_xcnt = b_xcnt.alloc<uint32_t>(st, n_root_chunks);
+    HIP_CHECK(hipMemsetAsync(d_rbits, 0, n_words * 4, st));
+    root_count_kernel<<<(unsigned)n_root_chunks, EB, 0, st>>>(d_comp, d_parent2, n_b, d_xcnt, d_rbits);
+    scan_u32<uint32_t>(st, d_xcnt, n_root_chunks, d_xcnt, d_bsum, d_total);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    lap("rotate + splitter flags");
-    const uint32_t M = h_small[1];  // splitters
-    if (M == 0) MTG_DIE("device_euler_cycles: internal error (no splitters)");
+    const uint64_t M0 = (E + 63) / 64, X = h_small[1];  // regular splitters, extra roots
+    if (M0 + X >= 0xFFFFFFFFull) MTG_DIE("device_euler_cycles: too many splitters");
+    const uint32_t M = (uint32_t)(M0 + X);
+    uint32_t *d_extra = b_extra.alloc<uint32_t>(st, std::max<uint64_t>(X, 1));
+    if (X) root_write_kernel<<<(unsigned)n_root_chunks, EB, 0, st>>>(d_comp, d_parent2, n_b, d_xcnt, d_extra);
+    HIP_CHECK(hipGetLastError());
+    lap("rotate + roots");
     b_row.release();
     b_adj.release();
+    b_flag.release();
     b_comp.release();
     b_pos2.release();
+    b_xcnt.release();
 
     Buf b_split, b_seglen, b_next, b_jump0, b_dist0, b_jump1, b_dist1, b_rflag, b_ridx;
     uint32_t *d_split = b_split.alloc<uint32_t>(st, M);
@@ -683,7 +737,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_dist[2] = {b_dist0.alloc<uint32_t>(st, M), b_dist1.alloc<uint32_t>(st, M)};
     uint32_t *d_rflag = b_rflag.alloc<uint32_t>(st, M);
     uint32_t *d_ridx = b_ridx.alloc<uint32_t>(st, M);
-    splitter_compact_kernel<<<grid_for(E), EB, 0, st>>>(d_flag, d_sidx, E, d_split);
+    split_list_kernel<<<grid_for(M), EB, 0, st>>>((uint32_t)M0, d_extra, M, d_split);
+    const SplitIndex sidx{(uint32_t)M0, (uint32_t)X, d_extra};
     const bool marked = E < 0x80000000ull && !g_force_bitmap;  // bit 31 of a successor word is free: it marks "my successor is a splitter"
     // the measuring walk records the darts it passes (see walk_measure_kernel): sequence buffer, its chunk cursor, the waves' chunk tables
     const bool record = !g_second_walk;
@@ -697,7 +752,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     {
         auto fn = marked ? (record ? walk_measure_kernel<true, true> : walk_measure_kernel<true, false>)
                          : (record ? walk_measure_kernel<false, true> : walk_measure_kernel<false, false>);
-        fn<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, d_sidx, d_sbits, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error, d_seq, d_cursor,
+        fn<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, sidx, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error, d_seq, d_cursor,
                                        seq_chunks, d_ctab);
     }
     int cur = 0;
@@ -740,8 +795,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("segment walks + ranking");
     const uint32_t R = h_small[2];  // connected components = closed walks
     if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] euler decompose: E %llu V %llu hook rounds %d splitters %u components %u\n", (unsigned long long)E, (unsigned long long)V, hook_rounds, M, R);
-    b_flag.release();
-    b_sidx.release();
+    b_extra.release();
     uint32_t *d_clen = b_clen.alloc<uint32_t>(st, R);
     uint32_t *d_cbase = b_cbase.alloc<uint32_t>(st, R);
     uint32_t *d_out = b_out.alloc<uint32_t>(st, E / 2);
