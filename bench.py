@@ -87,7 +87,9 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
         # visit; compaction 32 B per pair
         "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
         "insert_eulerise": 48 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
-        "decomposition": buckets + 48 * V + int(104.4 * E) + (100 + 16 * wy) * M,
+        # (since the arithmetic splitters and the recorded sequence: root pass 4 E + bitmap E / 8, measuring walk 4 E gathered + 4 E
+        # recorded, copy 2 E + 2 E -- 16.1 E where flags, scan, compaction and the two walks were 32.4 E)
+        "decomposition": buckets + 48 * V + int(88.2 * E) + (100 + 16 * wy) * M,
         "records": buckets + 732 * V + 12 * E,
         "cut": 12 * n + 4 * P + 4 * kept + 4 * tigs,                 # three passes over the closed walks (rotation, count, emit) + the tigs
     }
@@ -426,7 +428,7 @@ def main():
                                   result_info.get("tigs", 0), (total_visited or {}).get("searched_sources", 0))
             names = {"replay": "claim replay: replay_state_init + dense list + replay_rounds_kernel + pair-count scan + compaction",
                      "insert_eulerise": "matched-pair darts + Euleriser: degree / need / 3 scans / expand / zip_check / zip_emit / head kernels",
-                     "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, splitter walks, ranking, write",
+                     "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, recording splitter walks, ranking, copy",
                      "records": "walk records (reference-order mode): bucket merge + lean_build + wide_build kernels (the records' download is not in it)",
                      "cut": "rotate + cut: cycle heads / rotation / rotate_cycles / cut_flags / 3 scans / cut_write (the tig download is not in it)"}
             roofline_stages = []
