@@ -55,7 +55,8 @@ namespace mtg {
 // ------------------------------------------------------------------------------------------------
 // Node records
 // ------------------------------------------------------------------------------------------------
-enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8 };
+enum : uint8_t { F_TARGET = 1, F_EXT = 2, F_SOURCE = 4, F_SELF_MIRROR = 8, F_REACH = 16 };  // (F_REACH: class bytes only -- a source that can reach an in-node within the bound)
+constexpr uint32_t ODEG_REACH = 0x80000000u;  // bit 31 of odeg[n] (8:8 format): lb+(n) <= k - 1, set once with the device graph (build_lbx_kernel)
 
 // One 64-byte "family" block per node: the node's own <= 4 out-edges (first 32 bytes: what the cooperative levels read) AND, for as
 // many of its children as fit, the child's in-node flag and the child's out-edges (grandchildren of the node). A path enumeration
@@ -100,7 +101,7 @@ constexpr int CLS_BLOCK = 256, CLS_PER = 8;  // nodes per workgroup = 2048 (the 
 constexpr int CLS_NODES = CLS_BLOCK * CLS_PER;
 
 __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *odeg, const uint32_t *mirror, uint32_t n_nodes, int32_t *mult,
-                                                             uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand, const uint8_t *reach,
+                                                             uint8_t *cls, uint32_t *block_counts, uint32_t *block_demand,
                                                              uint32_t *block_active) {
     __shared__ uint32_t wave_cnt[CLS_BLOCK / 64];
     __shared__ uint32_t wave_dem[CLS_BLOCK / 64];
@@ -112,12 +113,15 @@ __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *ode
         if (n64 >= n_nodes) continue;
         const uint32_t n = (uint32_t)n64;
         const uint32_t m = mirror[n];
-        const NodeClass c = classify_node(odeg[n], m == n ? 0u : odeg[m], m == n);
+        const uint32_t on = odeg[n];
+        const NodeClass c = classify_node(on & ~ODEG_REACH, m == n ? 0u : odeg[m] & ~ODEG_REACH, m == n);
         cnt += (c.cls & F_SOURCE) ? 1u : 0u;
-        // (8:8 format) a source that can reach an in-node within the bound at all: the only ones the SSSP stage searches
-        if (reach) act += ((c.cls & F_SOURCE) && reach[n]) ? 1u : 0u;
+        // (8:8 format) a source that can reach an in-node within the bound at all: the only ones the SSSP stage searches. The flag
+        // is a function of the graph and rides in bit 31 of the out-degree word this kernel reads anyway.
+        const bool reaches = (c.cls & F_SOURCE) && (on & ODEG_REACH);
+        act += reaches ? 1u : 0u;
         mult[n] = c.diff;  // 0 for balanced nodes
-        cls[n] = c.cls;
+        cls[n] = c.cls | (reaches ? F_REACH : 0);
         pos += c.diff > 0 ? (uint32_t)c.diff : 0u;
     }
     for (int dd = 32; dd >= 1; dd >>= 1) { pos += __shfl_down(pos, dd); cnt += __shfl_down(cnt, dd); act += __shfl_down(act, dd); }
@@ -128,60 +132,54 @@ __global__ __launch_bounds__(CLS_BLOCK) void classify_kernel(const uint32_t *ode
         for (int i = 0; i < CLS_BLOCK / 64; i++) { s += wave_cnt[i]; dm += wave_dem[i]; ac += wave_act[i]; }
         block_counts[blockIdx.x] = s;
         block_demand[blockIdx.x] = dm;
-        if (reach) block_active[blockIdx.x] = ac;
+        block_active[blockIdx.x] = ac;
     }
 }
 
-// single-block exclusive scan of block_counts -> block_offsets (in place), total in *total_out; sum of block_demand in *demand_out;
-// optionally the same scan of a second array (counts2 -> *total2_out)
+// single-workgroup exclusive scan of block_counts -> block_offsets (in place), total in *total_out; sum of block_demand in *demand_out.
+// Launched with two workgroups, the second one scans a second array the same way (counts2 -> *total2_out).
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *counts, uint32_t n, unsigned long long *total_out,
                                                            const uint32_t *block_demand, unsigned long long *demand_out,
                                                            uint32_t *counts2 = nullptr, unsigned long long *total2_out = nullptr) {
-    __shared__ uint32_t wave_tot[16], wave_tot2[16];
-    __shared__ uint32_t carry, carry2;
+    if (blockIdx.x == 1) { counts = counts2; total_out = total2_out; block_demand = nullptr; demand_out = nullptr; }
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
     __shared__ unsigned long long dem_sum;
-    if (threadIdx.x == 0) { carry = 0; carry2 = 0; dem_sum = 0; }
+    if (threadIdx.x == 0) { carry = 0; dem_sum = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long dem = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < n ? counts[i] : 0;
-        const uint32_t v2 = (counts2 && i < n) ? counts2[i] : 0;
         dem += (block_demand && i < n) ? block_demand[i] : 0u;
-        uint32_t incl = v, incl2 = v2;
+        uint32_t incl = v;
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d), t2 = __shfl_up(incl2, d);
-            if (lane >= d) { incl += t; incl2 += t2; }
+            uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
         }
-        if (lane == 63) { wave_tot[wv] = incl; wave_tot2[wv] = incl2; }
+        if (lane == 63) wave_tot[wv] = incl;
         __syncthreads();
-        uint32_t wave_off = 0, wave_off2 = 0;
-        for (int j = 0; j < wv; j++) { wave_off += wave_tot[j]; wave_off2 += wave_tot2[j]; }
-        const uint32_t c = carry, c2 = carry2;
-        if (i < n) {
-            counts[i] = c + wave_off + incl - v;
-            if (counts2) counts2[i] = c2 + wave_off2 + incl2 - v2;
-        }
+        uint32_t wave_off = 0;
+        for (int j = 0; j < wv; j++) wave_off += wave_tot[j];
+        const uint32_t c = carry;
+        if (i < n) counts[i] = c + wave_off + incl - v;
         __syncthreads();
-        if (threadIdx.x == 1023) { carry = c + wave_off + incl; carry2 = c2 + wave_off2 + incl2; }
+        if (threadIdx.x == 1023) carry = c + wave_off + incl;
         __syncthreads();
     }
     for (int dd = 32; dd >= 1; dd >>= 1) dem += __shfl_down(dem, dd);
     if (lane == 0 && dem) atomicAdd(&dem_sum, dem);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        *total_out = carry;
-        if (demand_out) *demand_out = dem_sum;
-        if (total2_out) *total2_out = carry2;
-    }
+    if (threadIdx.x == 0) { *total_out = carry; if (demand_out) *demand_out = dem_sum; }
 }
 
-// out_nodes = the sources, ascending; with `reach` (8:8 format) also the sources that can reach an in-node within the bound at all,
-// in order: act_index = their positions in out_nodes, act_node = their nodes -- the only sources the SSSP stage searches (the others
-// have an empty candidate list by construction). The flags are read in node order here: no gather, no pass of its own.
+// out_nodes = the sources, ascending; and the sources that can reach an in-node within the bound at all (F_REACH in their class
+// byte; 8:8 format), in order: act_index = their positions in out_nodes, act_node = their nodes -- the only sources the SSSP stage
+// searches (the others have an empty candidate list by construction). No gather and no pass of its own: the flag arrives with the
+// class byte this pass reads anyway.
 __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_t *cls, uint32_t n_nodes,
-                                                                    const uint32_t *block_offsets, uint32_t *out_nodes, const uint8_t *reach,
+                                                                    const uint32_t *block_offsets, uint32_t *out_nodes,
                                                                     const uint32_t *block_act_offsets, uint32_t *act_index, uint32_t *act_node) {
     __shared__ uint32_t wave_cnt[CLS_PER][CLS_BLOCK / 64], wave_act[CLS_PER][CLS_BLOCK / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -189,13 +187,13 @@ __global__ __launch_bounds__(CLS_BLOCK) void compact_sources_kernel(const uint8_
 #pragma unroll
     for (int p = 0; p < CLS_PER; p++) {
         const uint64_t n = (uint64_t)blockIdx.x * CLS_NODES + (uint64_t)p * CLS_BLOCK + threadIdx.x;
-        const bool src = n < n_nodes && (cls[n] & F_SOURCE);
-        bal[p] = __ballot(src);
-        abal[p] = __ballot(src && reach && reach[n]);
+        const uint8_t c = n < n_nodes ? cls[n] : (uint8_t)0;
+        bal[p] = __ballot((c & F_SOURCE) != 0);
+        abal[p] = __ballot((c & F_REACH) != 0);
         if (lane == 0) { wave_cnt[p][wv] = (uint32_t)__popcll(bal[p]); wave_act[p][wv] = (uint32_t)__popcll(abal[p]); }
     }
     __syncthreads();
-    uint32_t off = block_offsets[blockIdx.x], aoff = reach ? block_act_offsets[blockIdx.x] : 0u;
+    uint32_t off = block_offsets[blockIdx.x], aoff = block_act_offsets[blockIdx.x];
 #pragma unroll
     for (int p = 0; p < CLS_PER; p++) {  // ascending: lane order within a wave, wave order within a pass, pass order, block order
         for (int j = 0; j < CLS_BLOCK / 64; j++) {
@@ -365,10 +363,10 @@ __global__ void lb_mirror_kernel(const uint32_t *mirror, const uint32_t *D, uint
 }
 // Pass 1: lbx[n] = lb(n) | lb+(n) << 8, where lb+(n) = min over the out-edges n -> c of weight + lb(c) is the distance from n to the
 // nearest in-node BEYOND n (for a node that is not an in-node itself lb+ = lb; for an in-node lb = 0 and lb+ says what a search that
-// has recorded n still needs n's block for). reach[n] = 1 iff lb+(n) <= k - 1: a source without that has an empty candidate list and
+// has recorded n still needs n's block for). bit 31 of odeg[n] (ODEG_REACH) is set iff lb+(n) <= k - 1: a source without that has an empty candidate list and
 // is never searched. (First halves still hold plain 16-bit weights here.)
 __global__ void build_lbx_kernel(uint64_t n_nodes, const NodeBlock *blocks, const uint32_t *ext_col, const uint16_t *ext_w, const uint8_t *lb8, uint32_t K1,
-                                 uint16_t *lbx, uint8_t *reach) {
+                                 uint16_t *lbx, uint32_t *odeg) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
     const uint32_t *me = reinterpret_cast<const uint32_t *>(blocks + n);
@@ -385,7 +383,7 @@ __global__ void build_lbx_kernel(uint64_t n_nodes, const NodeBlock *blocks, cons
         }
     }
     lbx[n] = (uint16_t)(lb8[n] | (best << 8));
-    reach[n] = best <= K1 ? 1 : 0;
+    if (best <= K1) odeg[n] |= ODEG_REACH;  // (read by the classification with the degree; every other reader of odeg runs before this kernel or masks)
 }
 // Pass 2: first halves into the 8:8 format -- low byte the weight, high byte weight + lb+(child): what a search needs the CHILD'S BLOCK
 // for. Whether the child is an in-node itself (lb = 0) travels in cmeta bit j, so the parent's step records that candidate and the
@@ -1411,14 +1409,15 @@ __global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_li
 // Lane-parallel form: G lanes per list, one key per lane -- coalesced reads and writes (a list is one or two memory requests instead
 // of one per key or key pair), bitonic sort across the lanes, then each key looks at the keys before it for its node.
 template <int G, int CLS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
-                                                           uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters) {
+__device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
+                                                 uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters, uint32_t block,
+                                                 uint32_t n_blocks) {
     constexpr uint32_t LPB = BLOCK / G;  // lists per workgroup pass
     unsigned long long begin = 0;
     for (int k = 0; k < CLS; k++) begin += counters[C_FIX_CLASS0 + k];
     const unsigned long long n = counters[C_FIX_CLASS0 + CLS];
     const uint32_t g = threadIdx.x % G;
-    for (unsigned long long l0 = (unsigned long long)blockIdx.x * LPB; l0 < n; l0 += (unsigned long long)gridDim.x * LPB) {
+    for (unsigned long long l0 = (unsigned long long)block * LPB; l0 < n; l0 += (unsigned long long)n_blocks * LPB) {
         const unsigned long long l = l0 + threadIdx.x / G;
         const uint32_t i = l < n ? dense[begin + l] : FIX_NONE;
         uint32_t c = i != FIX_NONE ? cand_count[i] : 0u;
@@ -1451,6 +1450,16 @@ __global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *p
             if (g == 0 && (dm & group)) cand_count[i] = c - (uint32_t)__popcll(dm & group);
         } else if (g < c) pool[st + g] = key;
     }
+}
+// the three length classes in ONE launch (a third of the grid each: their lists are disjoint, and three launches in a row spent more
+// on their gaps and tails than on sorting)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
+                                                           uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters) {
+    const uint32_t per = gridDim.x / 3u, cls = blockIdx.x / per, block = blockIdx.x % per;
+    if (cls == 0) sort_lists_class<8, 0, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
+    else if (cls == 1) sort_lists_class<16, 1, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
+    else if (cls == 2) sort_lists_class<32, 2, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
 }
 
 #include "replay_kernels.inc"
@@ -1515,7 +1524,6 @@ struct Device {
                    // chosen by the size of the graph); 1 = cascade only; 2 / 3 = plan 0 with quad-cooperative / per-lane gathers regardless of size;
                    // + 4 = without the goal-directed pruning (full balls, every source searched: A/B runs and tests)
     bool w8 = false;                 // blocks in the 8:8 format with lower bounds (k <= 255)
-    uint8_t *d_reach = nullptr;      // [V] w8: 1 = some successor can still lead to an in-node within the bound
     // the sources that can reach an in-node (8:8 format), in order, written by the classification (cap: act_cap sources); per-block
     // counts of them (d_act_blocks, n_cls_blocks words) and their number (d_act_total, on the device)
     uint32_t *d_act_index = nullptr, *d_act_node = nullptr, *d_act_blocks = nullptr;
@@ -1640,11 +1648,7 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
     static_assert(ENUM_MAX_HITS <= 32, "the post-pass sorts up to 32 keys");
     hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.counters, d->d_fix_dense);
-    hipLaunchKernelGGL((sort_lists_kernel<8, 0, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
-                       args.cand_count, d->d_fix_dense, args.counters);
-    hipLaunchKernelGGL((sort_lists_kernel<16, 1, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
-                       args.cand_count, d->d_fix_dense, args.counters);
-    hipLaunchKernelGGL((sort_lists_kernel<32, 2, 256>), dim3(post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
+    hipLaunchKernelGGL((sort_lists_kernel<256>), dim3(3 * post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
                        args.cand_count, d->d_fix_dense, args.counters);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(d->ev1, st));
@@ -2065,12 +2069,11 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
             hu::device_malloc(&d_D, V * 4);
             hu::device_malloc(&d_lb8, V);
             hu::device_malloc(&d_lbx, V * 2);
-            hu::device_malloc(&d->d_reach, V);
             hipLaunchKernelGGL(lb_init_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, d->d_mirror, V, d_D);
             for (uint32_t r = 0; r < d->K1; r++)
                 hipLaunchKernelGGL(lb_round_kernel, dim3(vb), dim3(256), 0, st, d->d_recs, d->d_ext_col, d->d_ext_w, V, r, d->K1, d_D);
             hipLaunchKernelGGL(lb_mirror_kernel, dim3(vb), dim3(256), 0, st, d->d_mirror, d_D, V, d_lb8);
-            hipLaunchKernelGGL(build_lbx_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d_lbx, d->d_reach);
+            hipLaunchKernelGGL(build_lbx_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d_lbx, d->d_odeg);
             hipLaunchKernelGGL(build_lb_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d_lbx);
             hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
             HIP_CHECK(hipGetLastError());
@@ -2091,7 +2094,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     HIP_CHECK(hipStreamSynchronize(st));
     hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
     for (void *p : {(void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
-    d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13 + (d->w8 ? V : 0);
+    d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13;
     dl.lap("edge cache + frees");
     return d;
 }
@@ -2100,7 +2103,7 @@ void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
     void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters,
-                    d->d_reach, d->d_act_index, d->d_act_node, d->d_act_blocks, d->d_act_total};
+                    d->d_act_index, d->d_act_node, d->d_act_blocks, d->d_act_total};
     for (void *b : bufs) (void)hipFree(b);
     for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
     (void)hipFree(d->d_fix);
@@ -2125,25 +2128,24 @@ uint64_t device_classify(Device *d, void *stream) {
     HIP_CHECK(hipSetDevice(d->dev));
     d->n_sources = 0;
     if (d->V) {
-        const uint8_t *reach = d->w8 ? d->d_reach : nullptr;
         hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_odeg, d->d_mirror, (uint32_t)d->V,
-                           d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks, reach, d->d_act_blocks);
+                           d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks, d->d_act_blocks);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(2), dim3(1024), 0, st, d->d_block_counts, (uint32_t)d->n_cls_blocks,
                            &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND],
-                           reach ? d->d_act_blocks : (uint32_t *)nullptr, reach ? d->d_act_total : (unsigned long long *)nullptr);
+                           d->d_act_blocks, d->d_act_total);
         HIP_CHECK(hipGetLastError());
         read_counters(d, st);  // (the number of sources sizes the lists the compaction writes)
         d->n_sources = d->h_counters[C_OVF_LIST];
         d->total_demand = d->h_counters[C_DEMAND];
-        if (reach && d->act_cap < d->n_sources) {
+        if (d->act_cap < d->n_sources || !d->d_act_index) {
             for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node}) if (p) HIP_CHECK(hipFree(p));
-            hu::device_malloc(&d->d_act_index, d->n_sources * 4);
-            hu::device_malloc(&d->d_act_node, d->n_sources * 4);
+            hu::device_malloc(&d->d_act_index, std::max<uint64_t>(d->n_sources, 1) * 4);
+            hu::device_malloc(&d->d_act_node, std::max<uint64_t>(d->n_sources, 1) * 4);
             d->act_cap = d->n_sources;
         }
         hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_cls,
-                           (uint32_t)d->V, d->d_block_counts, d->d_out_nodes, reach, d->d_act_blocks, d->d_act_index, d->d_act_node);
+                           (uint32_t)d->V, d->d_block_counts, d->d_out_nodes, d->d_act_blocks, d->d_act_index, d->d_act_node);
         HIP_CHECK(hipGetLastError());
     }
     d->classified = true;
@@ -2637,7 +2639,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
 // ------------------------------------------------------------------------------------------------
 __global__ void source_work_kernel(const uint32_t *out_nodes, const uint32_t *odeg, uint64_t n, uint32_t *work) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) work[i] = 1u + odeg[out_nodes[i]];
+    if (i < n) work[i] = 1u + (odeg[out_nodes[i]] & ~ODEG_REACH);
 }
 // cut[r] = first source whose exclusive work prefix reaches total * r / parts (r = 1 .. parts-1)
 __global__ void work_cuts_kernel(const unsigned long long *prefix, const uint32_t *work, uint64_t n, const unsigned long long *total, int parts,
