@@ -188,13 +188,15 @@ const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
 /* Goal-directed pruning (k <= 255): with the device graph the engine computes lb(v) = distance from v to the nearest
- * initial in-node and keeps it beside every edge weight. A search then skips a successor v reached at distance d when d + lb(v)
- * exceeds k-1 -- no in-node behind v can be within the bound, so the candidate lists are unchanged (the reference truncates its
- * searches as well, by target_amount, greedytigs/mod.rs:323-335) -- and sources that cannot reach any in-node within the bound
+ * initial in-node and lb+(v) = distance to the nearest one BEYOND v, and keeps weight + lb+(head) beside every edge weight and the
+ * in-node flags of a node's children and grandchildren in its block. A search records an in-node it reaches at distance d <= k-1
+ * from the block of its parent, and expands a node v -- reads its block, relaxes its out-edges -- only when d + lb+(v) <= k-1:
+ * no in-node behind v can be within the bound otherwise, so the candidate lists are unchanged (the reference truncates its
+ * searches as well, by target_amount, greedytigs/mod.rs:323-335); sources that cannot reach any in-node within the bound
  * are not searched at all. mtg_sssp_count keeps counting FULL balls (the unit of work of SURVEY 8d, equal to a full-ball
- * Dijkstra's counters); mtg_sssp_count_visited counts what the pruned search visits: stats->sources = sources searched,
- * settled_nodes / relaxed_edges = distinct (source, node) pairs it settles and their out-edges, emitted = the same candidates.
- * Aborts when the device graph / plan does not prune (mtg_sssp_prunes() == 0). */
+ * Dijkstra's counters); mtg_sssp_count_visited counts what the pruned search does: stats->sources = sources searched,
+ * settled_nodes = distinct (source, node) pairs whose distance it determines, relaxed_edges = the out-edges of the pairs it
+ * expands, emitted = the same candidates. Aborts when the device graph / plan does not prune (mtg_sssp_prunes() == 0). */
 void mtg_sssp_count_visited(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
 int mtg_sssp_prunes(const mtg_device *d);
 /* Sources the enumeration level of the last mtg_sssp_candidates call searched (0 when it does not prune). */
