@@ -342,7 +342,7 @@ mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg
 /* Device memory the library keeps BETWEEN calls, and how to get it back:
  *  - the finishing stages keep the work arrays of the last call on a GPU for the next one (a caller that finishes graph after graph
  *    pays no allocation); a call frees what it did not touch itself, so at most one call's arrays are held, and calls that worked
- *    on more than 32 GB keep nothing. mtg_device_memory_held tells how much that is right now, mtg_release_device_memory gives
+ *    on more than a third of the device's memory keep nothing. mtg_device_memory_held tells how much that is right now, mtg_release_device_memory gives
  *    all of it back to the driver (e.g. before another allocator of the process needs the HBM);
  *  - a graph keeps the device copy of its original edges, its mirror array and the buckets of its original darts on the GPU of
  *    its first device stage (<= 8 B per edge + 8 B per node) until mtg_graph_free / mtg_graph_release_device_cache.

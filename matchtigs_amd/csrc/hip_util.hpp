@@ -433,10 +433,18 @@ inline void upload_sliced(void *d_dst, const void *src, size_t bytes, hipStream_
     HIP_CHECK(hipStreamSynchronize(st));
 }
 
-// Gives the finish's kept device blocks back to the driver when a call worked on more than `threshold` bytes (small calls keep
-// their arrays for the next one).
-inline void finish_trim(int device_id, uint64_t bytes_used, uint64_t threshold = 32ull << 30) {
-    if (bytes_used < threshold) device_block_cache(device_id).end_call();  // (keeps this call's arrays, frees what it did not touch)
+// End of a finishing call: its work arrays stay with the library for the next call (what the call did not touch goes back to the
+// driver) while the call worked on less than a third of the device's memory -- BASELINE configs[3] at its nominal size (2^30: ~80 GB
+// by this estimate) iterates without asking the driver for tens of gigabytes per call, which costs between 0.2 and 5 s there --;
+// beyond that everything goes back. mtg_release_device_memory returns what is held at any time.
+inline void finish_trim(int device_id, uint64_t bytes_used) {
+    static uint64_t threshold[64] = {0};
+    if (device_id >= 0 && device_id < 64 && !threshold[device_id]) {
+        size_t free_b = 0, total_b = 0;
+        threshold[device_id] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? (uint64_t)total_b / 3 : (32ull << 30);
+    }
+    const uint64_t limit = device_id >= 0 && device_id < 64 ? threshold[device_id] : (32ull << 30);
+    if (bytes_used < limit) device_block_cache(device_id).end_call();  // (keeps this call's arrays, frees what it did not touch)
     else device_block_cache(device_id).trim();
 }
 

@@ -71,6 +71,9 @@ def _free_memory_gb(torch):
     """(free HBM, host memory this process may still use) in GB; the host side honours a cgroup limit if there is one."""
     gc.collect()
     torch.cuda.empty_cache()
+    from matchtigs_amd import api
+
+    api.release_device_memory(0)  # (what the library kept of an earlier test's finish: it would come back on demand, but it is not "free")
     free_hbm = torch.cuda.mem_get_info()[0] / 1e9
     avail = None
     for line in open("/proc/meminfo"):
