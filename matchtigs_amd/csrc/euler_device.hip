@@ -603,18 +603,90 @@ __global__ __launch_bounds__(EB) void merge_buckets_kernel(uint64_t n_nodes, con
     for (uint32_t j = 0; j < dd; j++) adj[o++] = adj_d[lod + j];
 }
 }  // namespace
-void device_build_buckets_merged(hipStream_t st, const uint32_t *d_from, uint64_t E0, uint64_t E, uint64_t V, const uint32_t *d_row0,
-                                 const uint32_t *d_adj0, uint32_t *d_row, uint32_t *d_adj) {
-    const uint64_t n_d = E - E0;
-    Buf b_rowd, b_adjd, b_rank, b_bsum, b_tot;
-    uint32_t *d_rowd = b_rowd.alloc<uint32_t>(st, V + 1), *d_adjd = b_adjd.alloc<uint32_t>(st, n_d), *d_rank = b_rank.alloc<uint32_t>(st, n_d);
+// ---- the arithmetic part of the dummy buckets (ZipBuckets, finish_device.hpp) ----
+namespace {
+struct ZipRange { uint32_t a_lo, a_hi, b_lo, b_hi; };  // steps whose even (a) / odd (b) dart leaves the node
+__device__ __forceinline__ ZipRange zip_range(const ZipBuckets &z, const uint32_t *mirror, uint32_t v) {
+    ZipRange r{0u, 0u, 0u, 0u};
+    const uint32_t co = z.cout[v];
+    if (co) {  // a_node holds v at [N - p_out[v] - cout[v], + cout[v]) (out-nodes descending)
+        const int64_t a0 = (int64_t)z.n_units - (int64_t)z.p_out[v] - (int64_t)co;
+        const int64_t lo = a0 > 0 ? a0 : 0, hi = a0 + co < (int64_t)z.n_steps ? a0 + co : (int64_t)z.n_steps;
+        if (hi > lo) { r.a_lo = (uint32_t)lo; r.a_hi = (uint32_t)hi; }
+    }
+    const uint32_t t = mirror[v], ci = z.cin[t];
+    if (ci) {  // b_node holds t at [p_in[t], + cin[t]) (in-nodes ascending); step s reads b_node[s + delta]
+        const int64_t b0 = (int64_t)z.p_in[t] - (int64_t)z.delta;
+        const int64_t lo = b0 > 0 ? b0 : 0, hi = b0 + ci < (int64_t)z.n_steps ? b0 + ci : (int64_t)z.n_steps;
+        if (hi > lo) { r.b_lo = (uint32_t)lo; r.b_hi = (uint32_t)hi; }
+    }
+    return r;
+}
+__global__ __launch_bounds__(EB) void zip_degree_kernel(uint64_t n_nodes, ZipBuckets z, const uint32_t *mirror, uint32_t *zdeg) {
+    const uint64_t v = gid();
+    if (v > n_nodes) return;
+    uint32_t d = 0;
+    if (v < n_nodes) {
+        const ZipRange r = zip_range(z, mirror, (uint32_t)v);
+        d = (r.a_hi - r.a_lo) + (r.b_hi - r.b_lo);
+    }
+    zdeg[v] = d;
+}
+// bucket of v = its original darts, its bucketed dummy darts below the zip region (matched pairs, self-mirror phase), its zip darts
+// (two arithmetic runs merged by id), its bucketed dummy darts above it (the sequential tail): ascending dart id throughout
+__global__ __launch_bounds__(EB) void merge_zip_buckets_kernel(uint64_t n_nodes, const uint32_t *row0, const uint32_t *adj0, const uint32_t *row_g,
+                                                              const uint32_t *adj_g, const uint32_t *row_z, ZipBuckets z, const uint32_t *mirror,
+                                                              uint32_t *row, uint32_t *adj) {
+    const uint64_t v = gid();
+    if (v > n_nodes) return;
+    const uint32_t lo0 = row0[v], log_ = row_g[v];
+    uint32_t o = lo0 + log_ + row_z[v];
+    row[v] = o;
+    if (v == n_nodes) return;
+    const uint32_t d0 = row0[v + 1] - lo0, dg = row_g[v + 1] - log_;
+    for (uint32_t j = 0; j < d0; j++) adj[o++] = adj0[lo0 + j];
+    uint32_t j = 0;
+    for (; j < dg; j++) {
+        const uint32_t e = adj_g[log_ + j];
+        if ((uint64_t)e >= z.zip_first) break;
+        adj[o++] = e;
+    }
+    const ZipRange r = zip_range(z, mirror, (uint32_t)v);
+    uint32_t ia = r.a_lo, ib = r.b_lo;
+    while (ia < r.a_hi || ib < r.b_hi) {
+        // even dart of step ia against odd dart of step ib: 2 ia < 2 ib + 1  <=>  ia <= ib
+        const bool take_a = ia < r.a_hi && (ib >= r.b_hi || ia <= ib);
+        adj[o++] = (uint32_t)(z.zip_first + 2ull * (take_a ? ia : ib) + (take_a ? 0u : 1u));
+        if (take_a) ia++; else ib++;
+    }
+    for (; j < dg; j++) adj[o++] = adj_g[log_ + j];
+}
+}  // namespace
+void device_build_buckets_merged(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E0, uint64_t E, uint64_t V,
+                                 const uint32_t *d_row0, const uint32_t *d_adj0, uint32_t *d_row, uint32_t *d_adj, const ZipBuckets *zip) {
+    const bool use_zip = zip && zip->n_steps > 0;
+    // the dummy darts that are bucketed with atomics: all of them, or -- beside the arithmetic zip region -- those below and above it
+    const uint64_t zip_lo = use_zip ? zip->zip_first : E, zip_hi = use_zip ? zip->zip_first + 2ull * zip->n_steps : E;
+    const uint64_t n1 = zip_lo - E0, n2 = E - zip_hi, n_d = n1 + n2;
+    Buf b_rowd, b_adjd, b_rank, b_bsum, b_tot, b_rowz;
+    uint32_t *d_rowd = b_rowd.alloc<uint32_t>(st, V + 1), *d_adjd = b_adjd.alloc<uint32_t>(st, std::max<uint64_t>(n_d, 1)),
+             *d_rank = b_rank.alloc<uint32_t>(st, std::max<uint64_t>(n_d, 1));
     uint32_t *d_bsum = b_bsum.alloc<uint32_t>(st, scan_blocks(V + 1) + 1), *d_tot = b_tot.alloc<uint32_t>(st, 1);
     HIP_CHECK(hipMemsetAsync(d_rowd, 0, (V + 1) * 4, st));
-    if (n_d) degree_rank_offset_kernel<<<grid_for(n_d), EB, 0, st>>>(d_from, E0, n_d, d_rowd, d_rank);
+    if (n1) degree_rank_offset_kernel<<<grid_for(n1), EB, 0, st>>>(d_from, E0, n1, d_rowd, d_rank);
+    if (n2) degree_rank_offset_kernel<<<grid_for(n2), EB, 0, st>>>(d_from, zip_hi, n2, d_rowd, d_rank + n1);
     scan_u32<uint32_t>(st, d_rowd, V + 1, d_rowd, d_bsum, d_tot);
-    if (n_d) fill_offset_kernel<<<grid_for(n_d), EB, 0, st>>>(d_from, E0, n_d, d_rowd, d_rank, d_adjd);
+    if (n1) fill_offset_kernel<<<grid_for(n1), EB, 0, st>>>(d_from, E0, n1, d_rowd, d_rank, d_adjd);
+    if (n2) fill_offset_kernel<<<grid_for(n2), EB, 0, st>>>(d_from, zip_hi, n2, d_rowd, d_rank + n1, d_adjd);
     sort_buckets_kernel<<<grid_for(V), EB, 0, st>>>(V, d_rowd, d_adjd, nullptr);
-    merge_buckets_kernel<<<grid_for(V + 1), EB, 0, st>>>(V, d_row0, d_adj0, d_rowd, d_adjd, d_row, d_adj);
+    if (use_zip) {
+        uint32_t *d_rowz = b_rowz.alloc<uint32_t>(st, V + 1);
+        zip_degree_kernel<<<grid_for(V + 1), EB, 0, st>>>(V, *zip, d_mirror, d_rowz);
+        scan_u32<uint32_t>(st, d_rowz, V + 1, d_rowz, d_bsum, d_tot);
+        merge_zip_buckets_kernel<<<grid_for(V + 1), EB, 0, st>>>(V, d_row0, d_adj0, d_rowd, d_adjd, d_rowz, *zip, d_mirror, d_row, d_adj);
+    } else {
+        merge_buckets_kernel<<<grid_for(V + 1), EB, 0, st>>>(V, d_row0, d_adj0, d_rowd, d_adjd, d_row, d_adj);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
@@ -636,7 +708,8 @@ void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, ui
 // The decomposition over device arrays: from[E] (dart e leaves from[e]; its mirror is e ^ 1) and mirror[V]. Results: the closed
 // walks back to back in b_out (u32[E / 2], dart ids), their lengths in b_clen and start offsets in b_cbase (u32[*n_cycles]).
 void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E, uint64_t V, Buf &b_out, Buf &b_clen,
-                            Buf &b_cbase, uint32_t *n_cycles, double *kernel_ms_out, const uint32_t *d_row0, const uint32_t *d_adj0, uint64_t E0) {
+                            Buf &b_cbase, uint32_t *n_cycles, double *kernel_ms_out, const uint32_t *d_row0, const uint32_t *d_adj0, uint64_t E0,
+                            const ZipBuckets *zip) {
     if (E == 0 || (E & 1) || E >= 0xFFFFFFFFull) MTG_DIE("device_euler_decompose: %llu darts (must be even and fit 32-bit ids)", (unsigned long long)E);
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));
@@ -672,7 +745,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("allocations");
 
     // 1. buckets
-    if (d_row0) device_build_buckets_merged(st, d_from, E0, E, V, d_row0, d_adj0, d_row, d_adj);
+    if (d_row0) device_build_buckets_merged(st, d_from, d_mirror, E0, E, V, d_row0, d_adj0, d_row, d_adj, zip);
     else device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr, d_pos2);  // (d_pos2 is free until the trail labels)
     lap("buckets");
     // 2. pairing, 3. trail labels

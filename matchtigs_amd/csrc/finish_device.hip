@@ -793,7 +793,10 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         std::fprintf(stderr, "[mtg] device_finish:   Euleriser: %u units, %u self-mirror nodes, %u of %u steps by the parallel prefix, %llu by the sequential tail\n",
                      N, n_sm, s_star, n_steps, (unsigned long long)(n_brk - n_sm_edges - s_star));
     const uint64_t E = first_brk + 2 * n_brk, n_dummy = E - E0;
-    b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release(); b_deg.release(); b_chunks.release();
+    // (the counters and their prefixes stay until the buckets are built: the breaking darts of the regular steps are bucketed
+    // arithmetically from them, finish_device.hpp)
+    const ZipBuckets zip{first_brk + 2 * (uint64_t)n_sm_edges, s_star, delta, N, d_cin, d_cout, d_pin, d_pout};
+    b_deg.release(); b_chunks.release();
     b_sm.release(); b_anode.release(); b_bnode.release(); b_pairs.release();
     HIP_CHECK(hipStreamSynchronize(st));
     acc0 += lap.lap("upload + insertion + Euleriser");
@@ -843,11 +846,19 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             // device's side stream and writes the 33 bytes per dart while the GPU decomposes and cuts (joined at the end)
             HIP_CHECK(hipEventCreateWithFlags(&ev_heads, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(ev_heads, st));  // (behind the dart, weight and head kernels)
-            append_thread = std::thread([download, fill, ev_heads, device_id]() {
+            // (through the pinned ring, whose slices host threads copy out: 0.3 ms better than the runtime's own staging of a copy
+            // into pageable memory. Either way the copies are wide KERNELS on this platform -- __amd_rocclr_copyBuffer in the traces --
+            // and the decomposition's first kernels run two to six times longer beside them, `tools/kernel_timeline.py`; a copy
+            // kernel of our own with 16 to 256 workgroups was measured and is worse at every width: 29.5-34 ms for the
+            // decomposition against 26.5.)
+            uint32_t *h_from = g.e_from.data() + E0, *h_to = g.e_to.data() + E0;
+            append_thread = std::thread([fill, ev_heads, device_id, h_from, h_to, h_pw_p, d_from, d_to, d_pw, pairs, n_pairs, E0, n_dummy]() {
                 HIP_CHECK(hipSetDevice(device_id));
                 hipStream_t side = finish_side_stream(device_id);
                 HIP_CHECK(hipStreamWaitEvent(side, ev_heads, 0));
-                download(side);
+                if (!pairs && n_pairs) download_sliced(h_pw_p, d_pw, n_pairs * 4, side, device_id);
+                download_sliced(h_from, d_from + E0, n_dummy * 4, side, device_id);
+                download_sliced(h_to, d_to, n_dummy * 4, side, device_id);
                 fill();
             });
         } else {
@@ -892,15 +903,17 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     uint32_t n_cycles = 0;
     double kernel_ms = 0, acc2 = 0;
     if (euler_mode == MTG_EULER_DEVICE) {
-        device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms, d_row0, d_adj0, E0);
+        device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms, d_row0, d_adj0, E0, &zip);
+        b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release();
     } else {
         Walks cycles;
         {
             Buf b_row, b_adj, b_need, b_off, b_tot, b_nodes, b_xe, b_xt;
             uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1), *d_adj = b_adj.alloc<uint32_t>(st, E);
             sev.mark(2, st);
-            if (d_row0) device_build_buckets_merged(st, d_from, E0, E, V, d_row0, d_adj0, d_row, d_adj);
+            if (d_row0) device_build_buckets_merged(st, d_from, d_mirror, E0, E, V, d_row0, d_adj0, d_row, d_adj, &zip);
             else device_build_buckets(st, d_from, E, V, d_row, d_adj, nullptr);
+            b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release();
             uint32_t *d_need = b_need.alloc<uint32_t>(st, V), *d_off = b_off.alloc<uint32_t>(st, V), *d_tot = b_tot.alloc<uint32_t>(st, 1);
             lean_ext_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_need, d_small);
             scan_u32<uint32_t>(st, d_need, V, d_off, d_bsum, d_tot);
