@@ -79,7 +79,11 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
     M = E // 64 + 1
     import math
     wy = max(1, math.ceil(math.log2(2 * M)))
-    buckets = 32 * V + 44 * D + 4 * E0 + 4 * E  # dummy darts bucketed + one streaming merge with the kept buckets of the original darts
+    # the dummy darts that are bucketed with atomics (pairs, self-mirror phase, tail: D - N) + the arithmetic buckets of the Euleriser's
+    # regular steps (N darts: per node the counters, their prefixes and the mirror's, 24 V read + 4 V written + a scan of 12 V, read
+    # again by the merge) + one streaming merge with the kept buckets of the original darts
+    Dg = max(D - N, 0)
+    buckets = 88 * V + 44 * Dg + 4 * N + 4 * E0 + 4 * E  # (32 V + 44 D + 4 E0 + 4 E while all dummy darts were bucketed with atomics)
     return {
         # classify (odeg, mirror, reach -> mult, cls) + compaction (cls, reach -> out_nodes and the A sources the SSSP stage searches)
         "classify": 20 * V + 4 * S + 8 * A,
