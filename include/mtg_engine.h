@@ -328,7 +328,8 @@ double mtg_last_euler_kernel_ms(void); /* of the last device decomposition on th
 /* The decomposition's segment walks recognise a splitter by a mark in bit 31 of its predecessor's successor word while dart ids
  * leave that bit free (fewer than 2^31 darts), else by a bitmap lookup per step. Bit 0 of `flags` forces the bitmap form, bit 1 ranks
  * the reduced list by pointer jumping over ALL splitters instead of two levels, bit 2 writes the closed walks by a second walk through
- * the successor array instead of from the sequence the measuring walk recorded (process-wide; tests hold the forms to the same walks). */
+ * the successor array instead of from the sequence the measuring walk recorded, bit 3 shrinks the per-wave chunk tables of that
+ * record to one entry, so that large graphs take the fallback to the second walk (process-wide; tests hold the forms to the same walks). */
 void mtg_set_euler_device_tuning(int flags);
 /* The whole finish on the GPU for a graph that holds only its original edges (finish_device.hip): matched-pair darts, the
  * Euleriser in the reference's sequence (implementation/mod.rs:392-649), Euler bicycles per cfg->euler_mode (device

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, 
                                                          const uint32_t *root_bits, uint32_t n_split,
                                                          uint64_t n_darts, uint32_t *seg_len, uint32_t *next_split, uint32_t *jump,
                                                          uint32_t *dist, uint32_t *error, uint32_t *seq, unsigned long long *seq_cursor,
-                                                         uint64_t seq_chunks, uint32_t *chunk_tab) {
+                                                         uint64_t seq_chunks, uint32_t *chunk_tab, uint32_t max_chunks) {
     const uint64_t i = gid();
     const bool valid = i < n_split;
     const uint32_t s = valid ? splitters[i] : 0u;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(EB) void walk_measure_kernel(const uint32_t *succ, 
                 unsigned long long c = 0;
                 if (lane == 0) {
                     c = atomicAdd(seq_cursor, 1ull);
-                    if (n_chunks >= (uint32_t)SEQ_MAXC || c >= seq_chunks) { atomicOr(error, 16u); c = 0; }  // (the caller falls back to the second walk)
+                    if (n_chunks >= max_chunks || c >= seq_chunks) { atomicOr(error, 16u); c = 0; }  // (the caller falls back to the second walk)
                     else chunk_tab[wave * SEQ_MAXC + n_chunks] = (uint32_t)c;
                 }
                 c = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)c);
@@ -571,10 +571,14 @@ __global__ __launch_bounds__(EB) void walk_write_kernel(const uint32_t *succ, co
 }  // namespace
 
 // (tests: the bitmap form of the splitter test, which graphs with 2^31 darts or more always use, on small graphs too)
-static std::atomic<int> g_force_bitmap{0}, g_flat_ranking{0}, g_second_walk{0};
+static std::atomic<int> g_force_bitmap{0}, g_flat_ranking{0}, g_second_walk{0}, g_small_tables{0};
 // (bit 0: bitmap form of the splitter test; bit 1: pointer jumping over all splitters; bit 2: write the closed walks by a second
-// walk through the successor array instead of from the sequence the measuring walk recorded)
-void device_euler_force_bitmap(int on) { g_force_bitmap.store((on & 1) ? 1 : 0); g_flat_ranking.store((on & 2) ? 1 : 0); g_second_walk.store((on & 4) ? 1 : 0); }
+// walk through the successor array instead of from the sequence the measuring walk recorded; bit 3: one-entry chunk tables, so
+// that every wave of a large graph outgrows its table and the fallback to the second walk runs)
+void device_euler_force_bitmap(int on) {
+    g_force_bitmap.store((on & 1) ? 1 : 0); g_flat_ranking.store((on & 2) ? 1 : 0); g_second_walk.store((on & 4) ? 1 : 0);
+    g_small_tables.store((on & 8) ? 1 : 0);
+}
 
 // adj[row[v] + i] = i-th out-dart of v in ascending dart id; pos[e] = slot of e in its bucket (pos may be null)
 // The buckets of darts [0, E) from the kept buckets of the original darts [0, E0) (row0 / adj0) and fresh ones of the dummy darts
@@ -826,7 +830,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
         auto fn = marked ? (record ? walk_measure_kernel<true, true> : walk_measure_kernel<true, false>)
                          : (record ? walk_measure_kernel<false, true> : walk_measure_kernel<false, false>);
         fn<<<grid_for(M), EB, 0, st>>>(d_succ, d_split, sidx, d_rbits, M, E, d_seglen, d_next, d_jump[0], d_dist[0], d_error, d_seq, d_cursor,
-                                       seq_chunks, d_ctab);
+                                       seq_chunks, d_ctab, g_small_tables ? 1u : (uint32_t)SEQ_MAXC);
     }
     int cur = 0;
     root_flag_kernel<<<grid_for(M), EB, 0, st>>>(d_split, d_rbits, M, d_rflag);

@@ -202,7 +202,7 @@ def test_device_euler_walks_from_the_recorded_sequence_equal_the_second_walk(gpu
     graphs.append(big)
     for G in graphs:
         a = G.euler_cycles_device_np()
-        for flags in (4, 5):  # second walk; second walk + bitmap splitter test
+        for flags in (4, 5, 8):  # second walk; second walk + bitmap splitter test; chunk tables of one entry (the overflow fallback)
             L.mtg_set_euler_device_tuning(flags)
             try:
                 b = G.euler_cycles_device_np()
