@@ -2138,11 +2138,12 @@ uint64_t device_classify(Device *d, void *stream) {
         read_counters(d, st);  // (the number of sources sizes the lists the compaction writes)
         d->n_sources = d->h_counters[C_OVF_LIST];
         d->total_demand = d->h_counters[C_DEMAND];
-        if (d->act_cap < d->n_sources || !d->d_act_index) {
+        const uint64_t act_need = d->w8 ? d->n_sources : 0;  // (without the 8:8 format no source carries the flag: the lists stay empty)
+        if (d->act_cap < act_need || !d->d_act_index) {
             for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node}) if (p) HIP_CHECK(hipFree(p));
-            hu::device_malloc(&d->d_act_index, std::max<uint64_t>(d->n_sources, 1) * 4);
-            hu::device_malloc(&d->d_act_node, std::max<uint64_t>(d->n_sources, 1) * 4);
-            d->act_cap = d->n_sources;
+            hu::device_malloc(&d->d_act_index, std::max<uint64_t>(act_need, 1) * 4);
+            hu::device_malloc(&d->d_act_node, std::max<uint64_t>(act_need, 1) * 4);
+            d->act_cap = act_need;
         }
         hipLaunchKernelGGL(compact_sources_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_cls,
                            (uint32_t)d->V, d->d_block_counts, d->d_out_nodes, d->d_act_blocks, d->d_act_index, d->d_act_node);
