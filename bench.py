@@ -86,7 +86,7 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
     buckets = 88 * V + 44 * Dg + 4 * N + 4 * E0 + 4 * E  # (32 V + 44 D + 4 E0 + 4 E while all dummy darts were bucketed with atomics)
     return {
         # classify (odeg, mirror, reach -> mult, cls) + compaction (cls, reach -> out_nodes and the A sources the SSSP stage searches)
-        "classify": 20 * V + 4 * S + 8 * A,
+        "classify": 19 * V + 4 * S + 8 * A,
         # state copy 17 V; dense list + claims words + pair-count scan 48 S; admission 187 B per listed source; 67.2 B per check
         # visit; compaction 32 B per pair
         "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
