@@ -36,7 +36,8 @@ Walks euler_cycles_generic(const HostGraph &g);
 template <typename Rec>
 static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
-                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels);
+                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels, LeanNode *lean = nullptr,
+                                const std::atomic<uint64_t> *arrived = nullptr);
 template <typename Rec>
 static void seed_from_lean(const LeanNode *lean, Rec *nodes, uint64_t V);
 
@@ -105,6 +106,14 @@ Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_
     return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true);
 }
 
+Walks euler_cycles_from_wide_arriving(EulerNode3 *nodes, LeanNode *lean, const std::atomic<uint64_t> *arrived, uint64_t V, const uint32_t *ext_eid,
+                                      const uint32_t *ext_to, const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true, lean, arrived);
+}
+
 // seeds phase A of the records (own adjacency) from the 32-byte ones
 template <typename Rec>
 static void seed_from_lean(const LeanNode *lean, Rec *nodes, uint64_t V) {
@@ -140,10 +149,14 @@ Walks euler_cycles_from_mid(EulerNode2 *nodes, uint64_t V, const uint32_t *ext_e
     return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true);
 }
 
+// (lean / arrived: the records of nodes >= *arrived are still on their way from the GPU, in node order -- a step that needs one
+// takes the node's 32-byte record instead: own adjacency only, one step per record, the same sequences. *arrived only grows and
+// reaches V; a node's record is complete and visible once its index lies below it.)
 template <typename Rec>
 static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                 const uint32_t *e_from, const uint32_t *e_to, const uint64_t E, HugeArena *arena_ptr,
-                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels) {
+                                std::chrono::steady_clock::time_point t_begin, bool have_sub_levels, LeanNode *lean,
+                                const std::atomic<uint64_t> *arrived) {
     constexpr bool L3 = Rec::LEVELS == 3;  // records with the heads' heads
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
@@ -242,7 +255,14 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
     Walks out;
     out.edges.reserve(E / 2);
     constexpr size_t PF = 12;  // FIFO prefetch distance
-    uint64_t n_walks = 0, n_hinted = 0, n_full = 0, n_pred_hit = 0;
+    uint64_t n_walks = 0, n_hinted = 0, n_full = 0, n_pred_hit = 0, n_lean = 0;
+    uint64_t arrived_seen = arrived ? 0 : V;  // nodes below it have their record (a cached lower bound of *arrived)
+    auto wait_for_all_records = [&]() {
+        while (arrived_seen < V) {
+            arrived_seen = arrived->load(std::memory_order_acquire);
+            if (arrived_seen < V) std::this_thread::yield();
+        }
+    };
     uint32_t last_pf = NONE;
     double t_walk = 0, t_scan = 0, t_emit = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -302,7 +322,23 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                     }
                     level = 0;
                 }
-                if (full) {
+                if (full && from >= arrived_seen && from >= (arrived_seen = arrived->load(std::memory_order_acquire))) {
+                    // the node's 256-byte record has not arrived yet: its 32-byte record (own adjacency) decides this step
+                    level = 0;
+                    n_lean++;
+                    LeanNode &l = lean[from];
+                    e = NONE;
+                    while (l.pos < l.deg) {
+                        const uint32_t cand = l.pos < 3 ? l.eid[l.pos] : ext_eid[l.ext_begin + l.pos - 3];
+                        if (!is_used(cand)) {
+                            e = cand;
+                            to = l.pos < 3 ? l.to[l.pos] : ext_to[l.ext_begin + l.pos - 3];
+                            break;
+                        }
+                        l.pos++;
+                    }
+                    if (e != NONE) { __builtin_prefetch(&lean[to]); prefetch_record(to); last_pf = to; }
+                } else if (full) {
                     level = 0;
                     n_full++;
                     n_pred_hit += (from == last_pf);
@@ -373,6 +409,7 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                 }
             }
             const size_t w_end = n_ent;
+            wait_for_all_records();  // (the splice scans below read the records of arbitrary nodes)
             const auto tw1 = now();
             t_walk += secs(tw0, tw1);
             if (splice_at == NONE) {
@@ -459,6 +496,7 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
         const auto t_end = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[mtg] euler_cycles: walk %.3f s, scan for splice points %.3f s, emit %.3f s; %llu record reads, %.0f%% of them at the predicted node\n",
                      t_walk, t_scan, t_emit, (unsigned long long)n_full, n_full ? 100.0 * n_pred_hit / n_full : 0.0);
+        if (arrived) std::fprintf(stderr, "[mtg] euler_cycles: %llu steps took the 32-byte record of a node whose 256-byte record was still on its way\n", (unsigned long long)n_lean);
         std::fprintf(stderr, "[mtg] euler_cycles: records %.3f s, walk+splice+emit %.3f s (%llu closed walks, %zu biedges, %.0f%% of steps hinted)\n",
                      std::chrono::duration<double>(t_built - t_begin).count(), std::chrono::duration<double>(t_end - t_built).count(),
                      (unsigned long long)n_walks, out.edges.size(), out.edges.empty() ? 0.0 : 100.0 * n_hinted / out.edges.size());

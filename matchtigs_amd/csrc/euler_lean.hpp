@@ -2,6 +2,7 @@
 // finish_device.hip. No HIP types here: the walk is host C++.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 
 #include "host_graph.hpp"
@@ -77,6 +78,13 @@ Walks euler_cycles_from_lean(const LeanNode *lean, EulerNode3 *nodes, uint64_t V
 // The same walk over complete 256-byte records (all three levels filled, e.g. by the GPU: finish_device.hip); nodes[V] is consumed.
 Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to, const uint32_t *e_from,
                              const uint32_t *e_to, uint64_t E, HugeArena *arena);
+
+// The same walk started while the 256-byte records still arrive from the GPU, in node order: the records of nodes >= *arrived are
+// not there yet (the caller's transfer raises *arrived with release order after every completed slice, up to V) -- a step that
+// needs one takes the node's 32-byte record in `lean` instead (own adjacency, one step per record). Same sequences; lean[V] is
+// consumed as well (its cursors move).
+Walks euler_cycles_from_wide_arriving(EulerNode3 *nodes, LeanNode *lean, const std::atomic<uint64_t> *arrived, uint64_t V, const uint32_t *ext_eid,
+                                      const uint32_t *ext_to, const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);
 
 // The walk over 128-byte records: seeded from the 32-byte ones (level two filled by host threads) / complete (e.g. from the GPU).
 Walks euler_cycles_from_lean_mid(const LeanNode *lean, EulerNode2 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,

@@ -262,6 +262,38 @@ def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(g
         assert np.array_equal(eh[key], e2[key]), key
 
 
+@pytest.mark.parametrize("log2_edges, delay_us", [(22, 0), (22, 300), (20, 3000), (17, 20000)])
+def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monkeypatch, log2_edges, delay_us):
+    """From the second reference-order finish of a graph on, its record arena is page-locked and the host walk starts while the
+    256-byte records still cross PCIe: they arrive in node order, a watcher thread publishes how far they have come, and a step that
+    needs a record beyond that mark takes the node's 32-byte record instead. MTG_TEST_RECORD_DELAY_US slows the arrival so that small
+    graphs take that path for most of their steps. Same tigs as the first call (records complete before the walk), and -- on the
+    smallest graph -- as the oracle."""
+    from matchtigs_amd import api, synth
+
+    k = 31
+    G = synth.g_csr_device(int((1 << log2_edges) / 3), seed=5 + log2_edges, k=k)
+    dev = api.DeviceGraph(G, k)
+    dev.classify()
+    pairs = api.compute_pairs([dev])
+    del dev
+    monkeypatch.setenv("MTG_TEST_RECORD_DELAY_US", str(delay_us))
+    results = []
+    for _ in range(3):  # call 1: plain path; calls 2, 3: the arena is page-locked, the walk overlaps the download
+        lim, ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Device)
+        results.append((lim.copy(), ed.copy()))
+        G.reset()
+    for lim, ed in results[1:]:
+        assert np.array_equal(results[0][0], lim) and np.array_equal(results[0][1], ed)
+    if log2_edges <= 17:
+        ex = G.export()
+        og = oracle.OracleGraph.from_arrays(ex["mirror"], ex["edge_from"], ex["edge_to"], ex["edge_weight"])
+        want, _ = og.compute_greedytigs(k)
+        lim, ed = results[-1]
+        got = [ed[int(a):int(b)].tolist() for a, b in zip(np.concatenate([[0], lim[:-1]]), lim)]
+        assert got == want
+
+
 def test_kept_device_memory_is_bounded_and_can_be_released(gpu):
     """The finish keeps the work arrays of its LAST call only (a smaller call after a larger one frees what it did not touch), and
     mtg_release_device_memory / mtg_graph_release_device_cache return everything; results do not change."""
