@@ -997,41 +997,60 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         HIP_CHECK(hipGetLastError());
                         sev.mark(3, st);
                         static const bool overlap_ok = std::getenv("MTG_NO_RECORD_OVERLAP") == nullptr;
-                        if (pinned && overlap_ok && V >= (1u << 16)) {
-                            // The walk starts while the records still cross PCIe (23 GB = 0.4 s at 2^27, a twentieth of the step): they
-                            // arrive in node order, slice by slice, a watcher thread publishes how far they have come, and a step that
-                            // needs a record beyond that mark takes the node's 32-byte record instead (euler_fast.cpp) -- those came down
-                            // first, on the side stream, while wide_build_kernel ran.
+                        if (overlap_ok && V >= (1u << 16)) {
+                            // The walk starts while the records still cross PCIe (23 GB = 0.4-0.5 s at 2^27, a twentieth of the step): they
+                            // arrive in node order, slice by slice, `arrived` says how far they have come, and a step that needs a record
+                            // beyond that mark takes the node's 32-byte record instead (euler_fast.cpp) -- those came down first, on the
+                            // side stream, while wide_build_kernel ran. Into a page-locked arena (a graph's second call and later) the
+                            // slices are plain copies and a watcher thread follows their events; into a fresh one they go through the
+                            // pinned ring on a thread of their own, whose copying threads report every slice they have moved out.
                             HugeBuf<LeanNode> lbuf(V, &g.arena);
                             hipStream_t side = finish_side_stream(device_id);
                             download_sliced(lbuf.p, d_nodes, V * sizeof(LeanNode), side, device_id);  // (d_nodes was complete before the spill sizes were read back)
                             HIP_CHECK(hipStreamSynchronize(st));  // (the spill arrays' copies and wide_build_kernel: done by now, the 32-byte records took longer)
-                            constexpr int N_SLICES = 64;
-                            const uint64_t per = (V + N_SLICES - 1) / N_SLICES;
-                            std::vector<hipEvent_t> evs;
-                            std::vector<uint64_t> upto;
-                            for (uint64_t lo = 0; lo < V; lo += per) {
-                                const uint64_t n = std::min<uint64_t>(per, V - lo);
-                                HIP_CHECK(hipMemcpyAsync(wbuf.p + lo, d_wide + lo, n * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
-                                hipEvent_t e;
-                                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem));
-                                HIP_CHECK(hipEventRecord(e, st));
-                                evs.push_back(e);
-                                upto.push_back(lo + n);
-                            }
                             std::atomic<uint64_t> arrived{0};
                             const char *delay_env = std::getenv("MTG_TEST_RECORD_DELAY_US");  // (tests: slow arrival, so that small graphs take the 32-byte path too)
                             const long delay_us = delay_env ? std::atol(delay_env) : 0;
-                            std::thread watcher([&evs, &upto, &arrived, delay_us]() {
-                                for (size_t i = 0; i < evs.size(); i++) {
-                                    HIP_CHECK(hipEventSynchronize(evs[i]));
-                                    if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
-                                    arrived.store(upto[i], std::memory_order_release);
+                            std::vector<hipEvent_t> evs;
+                            std::vector<uint64_t> upto;
+                            std::thread mover;
+                            if (pinned) {
+                                constexpr int N_SLICES = 64;
+                                const uint64_t per = (V + N_SLICES - 1) / N_SLICES;
+                                for (uint64_t lo = 0; lo < V; lo += per) {
+                                    const uint64_t n = std::min<uint64_t>(per, V - lo);
+                                    HIP_CHECK(hipMemcpyAsync(wbuf.p + lo, d_wide + lo, n * sizeof(EulerNode3), hipMemcpyDeviceToHost, st));
+                                    hipEvent_t e;
+                                    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem));
+                                    HIP_CHECK(hipEventRecord(e, st));
+                                    evs.push_back(e);
+                                    upto.push_back(lo + n);
                                 }
-                            });
+                                mover = std::thread([&evs, &upto, &arrived, delay_us]() {
+                                    for (size_t i = 0; i < evs.size(); i++) {
+                                        HIP_CHECK(hipEventSynchronize(evs[i]));
+                                        if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+                                        arrived.store(upto[i], std::memory_order_release);
+                                    }
+                                });
+                            } else {
+                                EulerNode3 *dst = wbuf.p;
+                                const uint64_t n_nodes = V;
+                                mover = std::thread([dst, d_wide, n_nodes, st, device_id, &arrived, delay_us]() {
+                                    HIP_CHECK(hipSetDevice(device_id));
+                                    const std::function<void(size_t)> progress = [&arrived, n_nodes, delay_us](size_t bytes_done) {
+                                        if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+                                        const uint64_t whole = bytes_done / sizeof(EulerNode3);  // (a record cut by a slice boundary counts with the next slice)
+                                        arrived.store(whole < n_nodes ? whole : n_nodes, std::memory_order_release);
+                                    };
+                                    download_sliced_with(d_wide, n_nodes * sizeof(EulerNode3), st, device_id,
+                                                         [dst](size_t off, const char *src, size_t n) { std::memcpy((char *)dst + off, src, n); }, &progress);
+                                    arrived.store(n_nodes, std::memory_order_release);
+                                });
+                            }
                             acc2 += lap.lap("walk records, all levels (GPU); 32-byte records down");
                             cycles = euler_cycles_from_wide_arriving(wbuf.p, lbuf.p, &arrived, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
-                            watcher.join();
+                            mover.join();
                             HIP_CHECK(hipStreamSynchronize(st));
                             for (hipEvent_t e : evs) HIP_CHECK(hipEventDestroy(e));
                             b_wide.release();

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -330,8 +331,11 @@ inline TransferRing &transfer_ring(int device_id) {
     if (device_id < 0 || device_id >= MAX_FINISH_DEVICES) MTG_DIE("sliced transfer: device id %d out of range", device_id);
     return rings[device_id];
 }
+// (progress, optional: called with the number of leading bytes that have reached their place, after every slice -- by one of the
+// copying threads; slices complete in order)
 template <typename Put>
-inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st, int device_id, Put &&put) {
+inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st, int device_id, Put &&put,
+                                 const std::function<void(size_t)> *progress = nullptr) {
     constexpr size_t SLICE = RING_SLICE;
     constexpr int NS = RING_SLOTS;
     TransferRing &r = transfer_ring(device_id);
@@ -349,7 +353,8 @@ inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st
             const size_t off = i * SLICE, n = std::min(SLICE, bytes - off);
             const size_t a0 = (n / 8 * t / T) * 8, a1 = t + 1 == T ? n : (n / 8 * (t + 1) / T) * 8;  // (8-byte aligned shares)
             put(off + a0, r.slot[i % NS] + a0, a1 - a0);
-            done[i].fetch_add(1, std::memory_order_release);
+            const uint32_t before = done[i].fetch_add(1, std::memory_order_acq_rel);
+            if (progress && before + 1 == T) (*progress)(off + n);  // (the last share of slice i: every thread takes the slices in order)
         }
     };
     std::vector<std::thread> th;

@@ -264,11 +264,11 @@ def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(g
 
 @pytest.mark.parametrize("log2_edges, delay_us", [(22, 0), (22, 300), (20, 3000), (17, 20000)])
 def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monkeypatch, log2_edges, delay_us):
-    """From the second reference-order finish of a graph on, its record arena is page-locked and the host walk starts while the
-    256-byte records still cross PCIe: they arrive in node order, a watcher thread publishes how far they have come, and a step that
-    needs a record beyond that mark takes the node's 32-byte record instead. MTG_TEST_RECORD_DELAY_US slows the arrival so that small
-    graphs take that path for most of their steps. Same tigs as the first call (records complete before the walk), and -- on the
-    smallest graph -- as the oracle."""
+    """The reference-order host walk starts while its 256-byte records still cross PCIe: they arrive in node order (first call on a
+    graph: through the pinned ring on a thread of its own; later calls: plain copies into the page-locked arena, followed by a watcher
+    thread), a counter says how far they have come, and a step that needs a record beyond that mark takes the node's 32-byte record
+    instead. MTG_TEST_RECORD_DELAY_US slows the arrival so that small graphs take that path for most of their steps. Same tigs as the
+    host stages' finish (no GPU records at all), and -- on the smallest graph -- as the oracle."""
     from matchtigs_amd import api, synth
 
     k = 31
@@ -277,9 +277,12 @@ def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monke
     dev.classify()
     pairs = api.compute_pairs([dev])
     del dev
+    ref_lim, ref_ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Host)
+    ref_lim, ref_ed = ref_lim.copy(), ref_ed.copy()
+    G.reset()
     monkeypatch.setenv("MTG_TEST_RECORD_DELAY_US", str(delay_us))
-    results = []
-    for _ in range(3):  # call 1: plain path; calls 2, 3: the arena is page-locked, the walk overlaps the download
+    results = [(ref_lim, ref_ed)]
+    for _ in range(3):  # call 1: records through the pinned ring; calls 2, 3: the arena is page-locked
         lim, ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Device)
         results.append((lim.copy(), ed.copy()))
         G.reset()
