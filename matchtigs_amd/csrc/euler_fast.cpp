@@ -114,6 +114,14 @@ Walks euler_cycles_from_wide_arriving(EulerNode3 *nodes, LeanNode *lean, const s
     return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true, lean, arrived);
 }
 
+Walks euler_cycles_from_mid_arriving(EulerNode2 *nodes, LeanNode *lean, const std::atomic<uint64_t> *arrived, uint64_t V, const uint32_t *ext_eid,
+                                     const uint32_t *ext_to, const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena) {
+    if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
+    const auto t_begin = std::chrono::steady_clock::now();
+    NumaPin pin(arena ? arena->node : -1);
+    return euler_walk_records(nodes, V, ext_eid, ext_to, e_from, e_to, E, arena, t_begin, true, lean, arrived);
+}
+
 // seeds phase A of the records (own adjacency) from the 32-byte ones
 template <typename Rec>
 static void seed_from_lean(const LeanNode *lean, Rec *nodes, uint64_t V) {
@@ -496,7 +504,7 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
         const auto t_end = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[mtg] euler_cycles: walk %.3f s, scan for splice points %.3f s, emit %.3f s; %llu record reads, %.0f%% of them at the predicted node\n",
                      t_walk, t_scan, t_emit, (unsigned long long)n_full, n_full ? 100.0 * n_pred_hit / n_full : 0.0);
-        if (arrived) std::fprintf(stderr, "[mtg] euler_cycles: %llu steps took the 32-byte record of a node whose 256-byte record was still on its way\n", (unsigned long long)n_lean);
+        if (arrived) std::fprintf(stderr, "[mtg] euler_cycles: %llu steps took the 32-byte record of a node whose larger record was still on its way\n", (unsigned long long)n_lean);
         std::fprintf(stderr, "[mtg] euler_cycles: records %.3f s, walk+splice+emit %.3f s (%llu closed walks, %zu biedges, %.0f%% of steps hinted)\n",
                      std::chrono::duration<double>(t_built - t_begin).count(), std::chrono::duration<double>(t_end - t_built).count(),
                      (unsigned long long)n_walks, out.edges.size(), out.edges.empty() ? 0.0 : 100.0 * n_hinted / out.edges.size());

@@ -86,6 +86,10 @@ Walks euler_cycles_from_wide(EulerNode3 *nodes, uint64_t V, const uint32_t *ext_
 Walks euler_cycles_from_wide_arriving(EulerNode3 *nodes, LeanNode *lean, const std::atomic<uint64_t> *arrived, uint64_t V, const uint32_t *ext_eid,
                                       const uint32_t *ext_to, const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);
 
+// (the same for the 128-byte records)
+Walks euler_cycles_from_mid_arriving(EulerNode2 *nodes, LeanNode *lean, const std::atomic<uint64_t> *arrived, uint64_t V, const uint32_t *ext_eid,
+                                     const uint32_t *ext_to, const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);
+
 // The walk over 128-byte records: seeded from the 32-byte ones (level two filled by host threads) / complete (e.g. from the GPU).
 Walks euler_cycles_from_lean_mid(const LeanNode *lean, EulerNode2 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                                  const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);

@@ -944,27 +944,53 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 const char *rec = std::getenv("MTG_EULER_RECORDS");
                 const uint64_t room = host_available_bytes(), walk_arrays = E * 16;
                 const bool wide = rec ? std::strcmp(rec, "wide") == 0 : (V * 256 <= (48ull << 30) && V * 256 + walk_arrays <= room / 4 * 3);
-                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30) && V * 128 + walk_arrays <= room / 4 * 3);
+                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30) && V * (128 + 32) + walk_arrays <= room / 4 * 3);
                 if (mid) {
                     // built on the GPU (one gather level) and brought down in slices through pageable memory: these are the
                     // graphs of a hundred gigabytes, where page-locking the arena would cost more than the copy
                     HugeBuf<EulerNode2> mbuf(V, &g.arena);
                     b_row.release(); b_adj.release(); b_need.release(); b_off.release();
-                    {
+                    static const bool overlap_mid = std::getenv("MTG_NO_RECORD_OVERLAP") == nullptr;
+                    const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / sizeof(EulerNode2));  // 1 GB of records at a time
+                    auto build_and_download = [&](std::atomic<uint64_t> *arrived, long delay_us) {
                         Buf b_mid;
-                        const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / sizeof(EulerNode2));  // 1 GB of records at a time
                         EulerNode2 *d_mid = b_mid.alloc<EulerNode2>(st, std::min<uint64_t>(V, slice));
                         for (uint64_t lo = 0; lo < V; lo += slice) {
                             const uint64_t n = std::min(slice, V - lo);
                             mid_build_slice_kernel<<<grid_for(n), EB, 0, st>>>(lo, n, V, d_nodes, d_mid);
                             HIP_CHECK(hipGetLastError());
                             HIP_CHECK(hipMemcpyAsync(mbuf.p + lo, d_mid, n * sizeof(EulerNode2), hipMemcpyDeviceToHost, st));
+                            if (arrived) {
+                                HIP_CHECK(hipStreamSynchronize(st));
+                                if (delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+                                arrived->store(lo + n, std::memory_order_release);
+                            }
                         }
                         HIP_CHECK(hipStreamSynchronize(st));
+                    };
+                    if (overlap_mid && V >= (1u << 16) && host_available_bytes() >= V * sizeof(LeanNode) + (4ull << 30)) {  // (room for the 32-byte records beside everything else)
+                        // as for the 256-byte records below: the walk starts on the 32-byte records (23 GB at 2^30, down first) while
+                        // the 128-byte ones (92 GB there: 6 s of a 100-s finish) are built and brought down slice by slice on a
+                        // thread of their own
+                        HugeBuf<LeanNode> lbuf(V, &g.arena);
+                        download_sliced(lbuf.p, d_nodes, V * sizeof(LeanNode), st, device_id);
+                        std::atomic<uint64_t> arrived{0};
+                        const char *delay_env = std::getenv("MTG_TEST_RECORD_DELAY_US");
+                        const long delay_us = delay_env ? std::atol(delay_env) : 0;
+                        std::thread mover([&build_and_download, &arrived, delay_us, device_id]() {
+                            HIP_CHECK(hipSetDevice(device_id));
+                            build_and_download(&arrived, delay_us);
+                        });
+                        acc2 += lap.lap("32-byte records down (the 128-byte ones follow beside the walk)");
+                        cycles = euler_cycles_from_mid_arriving(mbuf.p, lbuf.p, &arrived, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
+                        mover.join();
+                        b_nodes.release(); b_xe.release(); b_xt.release();
+                    } else {
+                        build_and_download(nullptr, 0);
+                        b_nodes.release(); b_xe.release(); b_xt.release();
+                        acc2 += lap.lap("walk records, two levels (GPU) + download");
+                        cycles = euler_cycles_from_mid(mbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                     }
-                    b_nodes.release(); b_xe.release(); b_xt.release();
-                    acc2 += lap.lap("walk records, two levels (GPU) + download");
-                    cycles = euler_cycles_from_mid(mbuf.p, V, ext_eid.data(), ext_to.data(), g.e_from.data(), g.e_to.data(), E, &g.arena);
                 } else if (!wide) {
                     HugeBuf<LeanNode> nodes(V, &g.arena);
                     download_sliced(nodes.p, d_nodes, V * sizeof(LeanNode), st, device_id);
@@ -997,7 +1023,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         HIP_CHECK(hipGetLastError());
                         sev.mark(3, st);
                         static const bool overlap_ok = std::getenv("MTG_NO_RECORD_OVERLAP") == nullptr;
-                        if (overlap_ok && V >= (1u << 16)) {
+                        if (overlap_ok && V >= (1u << 16) && host_available_bytes() >= V * sizeof(LeanNode) + (4ull << 30)) {  // (room for the 32-byte records beside everything else)
                             // The walk starts while the records still cross PCIe (23 GB = 0.4-0.5 s at 2^27, a twentieth of the step): they
                             // arrive in node order, slice by slice, `arrived` says how far they have come, and a step that needs a record
                             // beyond that mark takes the node's 32-byte record instead (euler_fast.cpp) -- those came down first, on the

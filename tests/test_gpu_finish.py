@@ -262,13 +262,15 @@ def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(g
         assert np.array_equal(eh[key], e2[key]), key
 
 
-@pytest.mark.parametrize("log2_edges, delay_us", [(22, 0), (22, 300), (20, 3000), (17, 20000)])
-def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monkeypatch, log2_edges, delay_us):
+@pytest.mark.parametrize("log2_edges, delay_us, records", [(22, 0, None), (22, 300, None), (20, 3000, None), (17, 20000, None),
+                                                          (22, 300, "mid"), (17, 20000, "mid")])
+def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monkeypatch, log2_edges, delay_us, records):
     """The reference-order host walk starts while its 256-byte records still cross PCIe: they arrive in node order (first call on a
     graph: through the pinned ring on a thread of its own; later calls: plain copies into the page-locked arena, followed by a watcher
     thread), a counter says how far they have come, and a step that needs a record beyond that mark takes the node's 32-byte record
     instead. MTG_TEST_RECORD_DELAY_US slows the arrival so that small graphs take that path for most of their steps. Same tigs as the
-    host stages' finish (no GPU records at all), and -- on the smallest graph -- as the oracle."""
+    host stages' finish (no GPU records at all), and -- on the smallest graph -- as the oracle. `records` = "mid": the 128-byte
+    records of the graphs whose 256-byte ones would not fit the host (built and brought down slice by slice beside the walk)."""
     from matchtigs_amd import api, synth
 
     k = 31
@@ -281,6 +283,8 @@ def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monke
     ref_lim, ref_ed = ref_lim.copy(), ref_ed.copy()
     G.reset()
     monkeypatch.setenv("MTG_TEST_RECORD_DELAY_US", str(delay_us))
+    if records:
+        monkeypatch.setenv("MTG_EULER_RECORDS", records)
     results = [(ref_lim, ref_ed)]
     for _ in range(3):  # call 1: records through the pinned ring; calls 2, 3: the arena is page-locked
         lim, ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Device)
