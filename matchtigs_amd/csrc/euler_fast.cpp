@@ -272,10 +272,11 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
         }
     };
     uint32_t last_pf = NONE;
-    double t_walk = 0, t_scan = 0, t_emit = 0;
+    double t_walk = 0, t_scan = 0, t_emit = 0, t_fill = 0, t_jump = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
+    std::vector<uint64_t> maybe_unused;  // (built by the first long splice scan) bit per node: it may still have an unused out-edge
     std::vector<uint32_t> breaks;  // entries whose successor is not the next entry (a handful per splice): the cycle is a few long runs
     for (uint64_t e0 = 0; e0 < E; e0++) {
         if (is_used((uint32_t)e0)) continue;
@@ -426,7 +427,12 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                 head = (uint32_t)w_begin;
                 ent_next[w_end - 1] = head;
                 breaks.push_back((uint32_t)(w_end - 1));
-                for (size_t i = w_begin; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
+                {   // (93 M consecutive numbers at the bench size: by several threads)
+                    uint32_t *dst = fifo.p + fifo_tail;
+                    const size_t first = w_begin;
+                    parallel_ranges(w_end - w_begin, [dst, first](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) dst[i] = (uint32_t)(first + i); }, 16);
+                    fifo_tail += w_end - w_begin;
+                }
             } else {
                 // insert W before x = splice_at: x's edge moves to a fresh entry y behind W, x receives W's first edge
                 const uint32_t x = splice_at;
@@ -441,24 +447,65 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                 head = y;
                 fifo[fifo_head] = y;
                 fifo[fifo_tail++] = x;
-                for (size_t i = w_begin + 1; i < w_end; i++) fifo[fifo_tail++] = (uint32_t)i;
+                {
+                    uint32_t *dst = fifo.p + fifo_tail;
+                    const size_t first = w_begin + 1;
+                    parallel_ranges(w_end - first, [dst, first](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) dst[i] = (uint32_t)(first + i); }, 16);
+                    fifo_tail += w_end - first;
+                }
             }
             // next start edge: first entry in cycle order whose from-node still has an unused out-edge. A long backlog is
             // first narrowed down by host threads (read-only: each finds the first such entry of its chunk).
+            const auto tq0 = now();
+            t_fill += secs(tw1, tq0);
             start_edge = NONE;
-            auto has_unused = [&](uint32_t node) -> bool {  // like next_unused, without moving the node's cursor
-                const Rec &r = nodes[node];
-                for (uint32_t p = r.pos; p < r.deg; p++)
-                    if (!is_used(p < 3 ? r.eid[p] : ext_eid[r.ext_begin + p - 3])) return true;
-                return false;
-            };
-            // (the first entries are checked in place: when splice points are frequent the next one is close, and
-            // spawning threads per splice would cost more than the scan)
-            for (size_t probe = 0; probe < 4096 && fifo_head < fifo_tail; probe++) {
-                if (has_unused(ent_node[fifo[fifo_head]])) break;
-                fifo_head++;
-            }
-            while (fifo_tail - fifo_head >= (1u << 18) && !has_unused(ent_node[fifo[fifo_head]])) {
+            auto maybe = [&](uint32_t node) -> bool { return (maybe_unused[node >> 6] >> (node & 63)) & 1ull; };
+            // The next start edge, in turns: a sequential stretch checks entries exactly (when splice points are frequent the next one
+            // is close, and spawning threads per splice would cost more than the scan); when it has run through its budget without a
+            // find and a long rest of the FIFO lies ahead, threads jump over the part of it in which no node can have an unused
+            // out-edge.
+            for (;;) {
+                const bool filtered = !maybe_unused.empty();
+                size_t budget = filtered ? ((size_t)1 << 17) : 4096;  // (filtered: a stream over the entries and one bit each; else a record read each)
+                bool found = false;
+                while (fifo_head < fifo_tail && budget--) {
+                    const uint32_t ent = fifo[fifo_head];
+                    const uint32_t node = ent_node[ent];
+                    if (filtered) {
+                        if (!maybe(node)) { fifo_head++; continue; }
+                    } else if (fifo_head + PF < fifo_tail) __builtin_prefetch(&nodes[ent_node[fifo[fifo_head + PF]]]);
+                    uint32_t to2 = NONE, j = 0;
+                    const uint32_t cand = next_unused(node, to2, j);
+                    if (cand != NONE) { start_edge = cand; start_to = to2; start_node = node; splice_at = ent; found = true; break; }
+                    if (filtered) maybe_unused[node >> 6] &= ~(1ull << (node & 63));  // exhausted for good: edges are only ever used up
+                    fifo_head++;
+                }
+                if (found || fifo_head >= fifo_tail) break;
+                if (fifo_tail - fifo_head < (1u << 18)) continue;  // (a short rest: sequentially to its end)
+                // Which nodes can still have an unused out-edge at all: the from-nodes of the biedges that are unused NOW (a few per
+                // thousand once the first closed sub-walk is through). Edges are only ever used up, so the set stays a superset for
+                // the scans that follow: the threads below test one bit per entry (an 11-MB bitmap) instead of reading the entry's node
+                // record (23 GB, random), and the sequential stretch after them checks exactly.
+                {   // (rebuilt before every jump: a bit left over from an earlier scan whose node has been exhausted since costs a
+                    // sequential stretch and another jump -- a hundred of them were most of the scan time at the bench size)
+                    maybe_unused.assign((V + 63) / 64, 0);
+                    const uint64_t n_b = E / 2, n_words = (n_b + 63) / 64;
+                    parallel_ranges(n_words, [&](uint64_t lo, uint64_t hi) {
+                        for (uint64_t w = lo; w < hi; w++) {
+                            uint64_t free_bits = ~used[w];
+                            if (w == n_words - 1 && (n_b & 63)) free_bits &= (1ull << (n_b & 63)) - 1ull;
+                            while (free_bits) {
+                                const uint64_t b = w * 64 + (uint64_t)__builtin_ctzll(free_bits);
+                                free_bits &= free_bits - 1;
+                                for (uint64_t e = 2 * b; e < 2 * b + 2; e++) {
+                                    const uint32_t node = e_from[e];
+                                    __atomic_fetch_or(&maybe_unused[node >> 6], 1ull << (node & 63), __ATOMIC_RELAXED);
+                                }
+                            }
+                        }
+                    }, 16);
+                }
+                const auto tj0 = now();
                 std::atomic<size_t> first_hit{fifo_tail};
                 const size_t base = fifo_head;
                 // tasks of 64 K entries handed out in FIFO order: all threads work on the earliest unfinished stretch, so the
@@ -469,25 +516,15 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                     const uint64_t lo = base + task * TASK, hi = std::min<uint64_t>(base + n_scan, lo + TASK);
                     if (first_hit.load(std::memory_order_relaxed) < lo) return;
                     for (uint64_t i = lo; i < hi; i++) {
-                        if (i + PF < hi) __builtin_prefetch(&nodes[ent_node[fifo[i + PF]]]);
-                        if (has_unused(ent_node[fifo[i]])) {
+                        if (maybe(ent_node[fifo[i]])) {
                             size_t cur = first_hit.load(std::memory_order_relaxed);
                             while (i < cur && !first_hit.compare_exchange_weak(cur, (size_t)i)) {}
                             return;
                         }
                     }
-                }, 64);
-                fifo_head = first_hit.load();  // everything before it is exhausted; the sequential loop takes it from here
-                break;
-            }
-            while (fifo_head < fifo_tail) {
-                if (fifo_head + PF < fifo_tail) __builtin_prefetch(&nodes[ent_node[fifo[fifo_head + PF]]]);
-                const uint32_t ent = fifo[fifo_head];
-                const uint32_t node = ent_node[ent];
-                uint32_t to2 = NONE, j = 0;
-                const uint32_t cand = next_unused(node, to2, j);
-                if (cand != NONE) { start_edge = cand; start_to = to2; start_node = node; splice_at = ent; break; }
-                fifo_head++;
+                }, 32);
+                fifo_head = first_hit.load();  // everything before it is exhausted; the next sequential stretch takes it from here
+                t_jump += secs(tj0, now());
             }
             t_scan += secs(tw1, now());
         }
@@ -519,6 +556,8 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
         const auto t_end = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[mtg] euler_cycles: walk %.3f s, scan for splice points %.3f s, emit %.3f s; %llu record reads, %.0f%% of them at the predicted node\n",
                      t_walk, t_scan, t_emit, (unsigned long long)n_full, n_full ? 100.0 * n_pred_hit / n_full : 0.0);
+        std::fprintf(stderr, "[mtg] euler_cycles: of the scan time: splices + FIFO fill %.3f s, parallel jumps %.3f s, sequential stretches %.3f s\n", t_fill, t_jump,
+                     t_scan - t_fill - t_jump);
         if (arrived) std::fprintf(stderr, "[mtg] euler_cycles: %llu steps took the 32-byte record of a node whose larger record was still on its way\n", (unsigned long long)n_lean);
         std::fprintf(stderr, "[mtg] euler_cycles: records %.3f s, walk+splice+emit %.3f s (%llu closed walks, %zu biedges, %.0f%% of steps hinted)\n",
                      std::chrono::duration<double>(t_built - t_begin).count(), std::chrono::duration<double>(t_end - t_built).count(),

@@ -214,3 +214,18 @@ def test_euler_walk_high_degree_nodes_equal_oracle(oracle, product_lib, seed, de
     G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     og2 = oracle.OracleGraph.from_arrays(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
     assert api.EulertigAlgorithm.compute_tigs(G2, api.EulertigAlgorithmConfiguration(15)) == og2.compute_eulertigs(15)
+
+
+@pytest.mark.parametrize("seed, deg", [(3, 1.5), (4, 1.15)])
+def test_walk_forms_agree_beyond_the_long_splice_scans(seed, deg, product_lib):
+    """From 2^18 entries on, the 256- / 128-byte-record walk (euler_fast.cpp) narrows a splice scan down with a bitmap of the nodes that
+    can still have an unused out-edge, and it emits every cycle run by run; the 32-byte-record walk (euler_lean.cpp) does neither.
+    Same closed walks on Eulerised graphs of ~1.5 M darts (the sparser one falls into many components and splices)."""
+    k = 31
+    bg = synth.g_csr(360000, seed=seed, k=k, mean_out_degree=deg)
+    G = helpers.product_graph(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    G.make_eulerian(0, k)
+    lean = G.euler_cycles_records(1)
+    assert sum(len(c) for c in lean) == G.edge_count() // 2 >= (1 << 18)
+    assert lean == G.euler_cycles()
+    assert lean == G.euler_cycles_records(3)
