@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--full-size-log2", type=int, default=30,
                     help="after the timed regions: ONE device-mode step at this G-csr size (SURVEY 8d's nominal human size) when the box "
                          "has the memory (>= 170 GB of HBM and >= 140 GB of host memory free); 0 = skip")
+    ap.add_argument("--no-one-shot", dest="one_shot", action="store_false",
+                    help="skip the one_shot block (the consuming one-shot call, host arrays in -> clib.rs arrays out, in a child process of its own per Euler mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
@@ -176,7 +178,11 @@ def main():
     from matchtigs_amd import api, synth, torch_glue
     from matchtigs_amd import distributed as mdist
 
+    api.set_default_device(local_rank)  # (the GPU whose memory a graph's construction reserves ahead of the call that follows)
     k = args.k
+    # ---- the consuming one-shot call (clib.rs:280-291: every real call of the reference is a first call), each Euler mode in a
+    # process of its own, before this process takes any device memory ----
+    one_shot = run_one_shot(args) if (world == 1 and args.one_shot and args.workload == "g_csr") else None
     # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned.
     # G-csr is generated ON each rank's GPU (csrc/synth_device.hip, the twin of synth.g_csr): seconds, no numpy argsort.
     t_gen = time.perf_counter()
@@ -324,7 +330,6 @@ def main():
         for name, mode in (("device", api.EulerMode.Device), ("host", euler_mode)):
             if name == "host" and args.euler == "device":
                 continue
-            api.release_device_memory(local_rank)
             t0c = time.perf_counter()
             g2 = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k, device_id=local_rank)
             t1c = time.perf_counter()
@@ -343,9 +348,11 @@ def main():
             graph, dev, bufs = keep
             del g2, d2
             torch.cuda.empty_cache()
-        api.release_device_memory(local_rank)
-        cold["note"] = ("first step on a fresh graph after mtg_release_device_memory: device work arrays allocated, buckets of the original "
-                        "darts built, host result arrays and the walk's arena mapped for the first time")
+        cold["note"] = ("first step on a fresh graph and a fresh device graph (beside the main one): its device arrays are new ranges of the "
+                        "library's arena (new chunks from the driver where the arena has no room), host result arrays and the walk's arena are mapped "
+                        "for the first time. The arena is NOT released first: memory given back with hipFree is wiped by the driver at ~28 GB/s and "
+                        "allocations that arrive during the wipe wait for it (tools/alloc_probe.hip) -- a release right before the step would put "
+                        "that wait into it; the one_shot block is the consuming call in a process of its own")
 
     # ---- second mode, first class: the same step with the parallel Euler decomposition on the GPU, in its own timed region.
     # It runs BEFORE the headline region: the two modes use different sets of device work arrays, and the runtime's stream-ordered
@@ -475,7 +482,9 @@ def main():
             dev = graph = bufs = None
             count_ref[0] = None
             torch.cuda.empty_cache()
+            held = api.device_memory_held(local_rank)
             api.release_device_memory(local_rank)
+            time.sleep(1.0 + held / 20e9)  # (the driver wipes what was just given back, and allocations wait for that: tools/alloc_probe.hip)
             full_size = full_size_step(args, k, local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {
@@ -500,6 +509,7 @@ def main():
             "device_graph_bytes": device_graph_bytes,
             "roofline": roofline,
             "roofline_stages": roofline_stages,
+            "one_shot": one_shot,
             "cold_step_ms": cold,
             "full_size": full_size,
             # claim replay (one cooperative kernel): cost model = source visits x (32-B touch record + 8-B state and 8-B reservation
@@ -515,6 +525,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_one_shot(args) -> dict:
+    """tools/one_shot.py as a child process per Euler mode: host edge arrays -> mtg_graph_from_edges -> mtg_compute_tigs_clib (what
+    matchtigs_compute_tigs runs) -> clib.rs output arrays, twice per process. `first_call_of_the_process` pays for the HIP runtime's
+    queues, the transfer ring and the kernels' code objects on top; `later_call` is a first call on a fresh graph in a process that has
+    called before. The library's device memory is released before each call; the generator that makes the input arrays is not timed."""
+    import subprocess
+
+    out = {"note": "host edge arrays -> mtg_graph_from_edges -> mtg_compute_tigs_clib (= matchtigs_compute_tigs after its configuration) -> "
+                   "clib.rs output arrays; total_s = graph_build_s + compute_tigs_clib_s (graph_free_s, the consumed handle's memory going back, beside it); "
+                   "phases_s of the compute call: device_build = upload + device graph + lower bounds, sssp = search + claim replay, eulerise = "
+                   "matched-pair darts + Euleriser, euler = Euler bicycles, cut = rotate + cut + flattened tigs into the caller's arrays"}
+    for mode in ("device", "host"):
+        if mode == "host" and args.euler == "device":
+            continue
+        cmd = [sys.executable, str(ROOT / "tools" / "one_shot.py"), "--log2-edges", str(args.log2_edges), "--k", str(args.k),
+               "--seed", str(args.seed), "--euler", mode, "--calls", "2"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+            if r.returncode != 0 or len(lines) < 2:
+                out[mode] = {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+                continue
+            keep = ("graph_build_s", "compute_tigs_clib_s", "graph_free_s", "total_s", "tigs", "phases_s")
+            out[mode] = {"first_call_of_the_process": {kk: lines[0][kk] for kk in keep},
+                         "later_call": {kk: lines[1][kk] for kk in keep}, "total_s": lines[1]["total_s"],
+                         "same_result_both_calls": lines[0]["checksum"] == lines[1]["checksum"] and lines[0]["tigs"] == lines[1]["tigs"]}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+            out[mode] = {"error": repr(e)[:300]}
+    return out
 
 
 def host_free_bytes() -> int:

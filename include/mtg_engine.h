@@ -73,9 +73,12 @@ enum { MTG_EULER_HOST_REFERENCE_ORDER = 0, MTG_EULER_DEVICE = 1 };
 enum { MTG_FINISH_AUTO = 0, MTG_FINISH_HOST = 1, MTG_FINISH_DEVICE = 2 };
 #define MTG_MAX_DEVICES 8
 typedef struct {
-    uint64_t struct_size;              /* sizeof(mtg_config) of the header the caller was built against: set by mtg_config_init, checked by
-                                          every function that takes a configuration (a mismatch aborts with a message instead of reading
-                                          shifted fields). ALWAYS fill a configuration through mtg_config_init. New fields are appended. */
+    uint64_t struct_size;              /* sizeof(mtg_config) of the header the caller was built against: set by mtg_config_init and checked by
+                                          every function that takes a configuration. ALWAYS fill a configuration through mtg_config_init.
+                                          New fields are only ever APPENDED: a caller built against an older header (struct_size smaller,
+                                          down to MTG_CONFIG_MIN_SIZE = the layout of round 4) keeps working -- the fields it does not
+                                          know take the values mtg_config_init gives them --, a struct_size LARGER than this library's
+                                          (a caller newer than the library) or below the minimum aborts with a message. */
     uint64_t threads;                  /* greedytigs/mod.rs:42 */
     uint64_t k;                        /* :44 */
     double staged_parallelism_divisor; /* :47, 0 = None */
@@ -93,6 +96,7 @@ typedef struct {
     int32_t finish_stage;              /* MTG_FINISH_AUTO / _HOST / _DEVICE (appended in round 3) */
     int32_t reserved0;
 } mtg_config;
+#define MTG_CONFIG_MIN_SIZE 120 /* sizeof(mtg_config) of round 4, the oldest layout with struct_size in front */
 /* GreedytigAlgorithmConfiguration::new(threads, k) (greedytigs/mod.rs:62-72): staged None, factor 0, HashbrownHashMap,
  * StdBinaryHeap, performance data None; engine fields: host Euler walk, one device (id 0). */
 void mtg_config_init(mtg_config *cfg, uint64_t threads, uint64_t k);
@@ -351,6 +355,20 @@ mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg
 void mtg_release_device_memory(int device_id);
 uint64_t mtg_device_memory_held(int device_id);
 void mtg_graph_release_device_cache(mtg_graph *g);
+/* The GPU whose memory a graph's construction reserves ahead of the call that will follow (default 0): building a graph of more
+ * than a few million edges (mtg_graph_from_edges, matchtigs_initialise_graph, mtg_synth_g_csr on its own device) starts a helper
+ * thread that brings up the HIP runtime, loads the kernels and takes ONE chunk of device memory sized for the whole call from
+ * (nodes, edges) -- every device array of the call is then a range of it (hip_util.hpp: DeviceArena), so no stage waits for the
+ * driver. A process that runs one rank per GPU names its GPU here before it builds graphs. Never changes a result; without a GPU
+ * nothing happens. */
+void mtg_set_default_device(int device_id);
+/* Tuning of the finishing stages for measurements and tests (process-wide, read at the start of a call; the library reads no
+ * environment variable for any of it, and none changes a result). records: walk-record format of the reference-order mode, 0 = the
+ * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records. flags: bit 0 = the walk
+ * waits until all of its records have arrived (instead of starting on the 32-byte ones), bit 1 = never page-lock the record arena,
+ * bit 2 = keep nothing of a graph on the device between calls (edges, mirror, buckets). record_delay_us: slows the arrival of the
+ * records by that much per slice (tests: small graphs then take the 32-byte path for most of their steps). */
+void mtg_set_finish_tuning(int records, int flags, int64_t record_delay_us);
 /* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,
  * [2] Euler bicycles, [3] rotate + cut + tig download; [4] kernel ms of the device decomposition; [5] breaking biedges added. */
 void mtg_last_finish_device_times(double out[6]);
@@ -434,6 +452,12 @@ mtg_graph *mtg_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint64_t
 /* Whole path: algorithm 1, 3 or 5 (clib.rs ids). Mutates g. matchtigs_compute_tigs builds the configuration from
  * clib.rs:378-389's constants and calls this. */
 mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg);
+/* The whole path into a caller's clib.rs output arrays (clib.rs:332-348: 2 E, 2 E and E entries for E original edges; layout as
+ * mtg_flatten_clib / clib.rs:393-407): mtg_compute_tigs_cfg + mtg_flatten_clib in one call -- what matchtigs_compute_tigs runs.
+ * With a finish on the GPU (the default) the tigs never exist as walks on the host: the threads that empty the download ring write
+ * the flattened form straight into the caller's arrays. Mutates g like mtg_compute_tigs_cfg. Returns the number of tigs. */
+uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg, int64_t *tigs_edge_out,
+                               uint64_t *tigs_insert_out, uint64_t *tigs_out_limits);
 /* The same with mtg_config_init(threads = 1, k) on GPU `device_id`. */
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id);
 /* Counters of the last mtg_compute_tigs_cfg(5) on this thread run with MTG_PERFORMANCE_DATA_COMPLETE (zeros otherwise). */

@@ -185,6 +185,7 @@ def load():
         "mtg_finish_matchtigs_cfg": (vp, [vp, vp, u64, P(MtgConfig)]),
         "mtg_compute_matchtigs_cfg": (vp, [vp, P(MtgConfig)]),
         "mtg_compute_tigs_cfg": (vp, [vp, u64, P(MtgConfig)]),
+        "mtg_compute_tigs_clib": (u64, [vp, u64, P(MtgConfig), vp, vp, vp]),
         "mtg_last_performance_data": (None, [P(MtgDijkstraPerformanceData)]),
         "mtg_last_euler_kernel_ms": (C.c_double, []),
         "mtg_set_euler_device_tuning": (None, [C.c_int]),
@@ -216,6 +217,8 @@ def load():
         "mtg_release_device_memory": (None, [C.c_int]),
         "mtg_device_memory_held": (u64, [C.c_int]),
         "mtg_graph_release_device_cache": (None, [vp]),
+        "mtg_set_default_device": (None, [C.c_int]),
+        "mtg_set_finish_tuning": (None, [C.c_int, C.c_int, i64]),
         "mtg_replay_claims_resident": (u64, [vp, vp, u64, vp, vp, vp]),
         "mtg_last_replay_ms": (None, [vp, P(C.c_double)]),
         "mtg_set_replay_tuning": (None, [vp, u64, C.c_int, C.c_int, C.c_int, C.c_int]),

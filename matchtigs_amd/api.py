@@ -665,6 +665,23 @@ def finish_greedytigs_resident_np(graph: Bigraph, device: "DeviceGraph", k: int,
     return _take_walks_np(L, L.mtg_finish_greedytigs_resident(graph.handle, device.handle, C.byref(c)))
 
 
+RECORD_FORMATS = {None: 0, "auto": 0, "lean": 1, "mid": 2, "wide": 3}
+
+
+def set_finish_tuning(records=None, wait_for_records: bool = False, no_pin: bool = False, no_edge_cache: bool = False,
+                      record_delay_us: int = 0) -> None:
+    """mtg_set_finish_tuning: walk-record format of the reference-order mode ("lean" 32-byte / "mid" 128-byte / "wide" 256-byte
+    records, None = the engine's choice), whether the walk waits for all of its records, page-locking, the graph's device cache, and
+    a delay per arriving slice of records (tests). Process-wide; never changes a result."""
+    flags = (1 if wait_for_records else 0) | (2 if no_pin else 0) | (4 if no_edge_cache else 0)
+    _lib.load().mtg_set_finish_tuning(RECORD_FORMATS[records], flags, int(record_delay_us))
+
+
+def set_default_device(device_id: int) -> None:
+    """mtg_set_default_device: the GPU whose memory a graph's construction reserves ahead of the call that follows."""
+    _lib.load().mtg_set_default_device(device_id)
+
+
 def release_device_memory(device_id: int = 0) -> None:
     """mtg_release_device_memory: the work arrays the finishing stages keep on that GPU between calls."""
     _lib.load().mtg_release_device_memory(device_id)

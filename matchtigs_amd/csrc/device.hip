@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <future>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -268,9 +269,13 @@ __global__ void build_fill_kernel(const uint32_t *e_from, uint64_t n_edges, cons
     if (odeg[f] > 4) ext_col[ext_off[f] + slot] = (uint32_t)e;
     else blocks[f].nbr[slot] = (uint32_t)e;
 }
-// per node: edge ids ascending -> (neighbour, clamped weight); degree, own class flag
+// per node: edge ids ascending -> (neighbour, clamped weight); degree, own class flag. The head of edge e is mirror(from(e ^ 1)) (the
+// mirror edge runs mirror(to) -> mirror(from), clib.rs:244-248) and both edges of unitig u = e >> 1 weigh w_unitig[u], so neither a
+// head array nor per-edge weights are uploaded. adj0 (optional): the node's out-edges in ascending id at row0[n] -- the buckets of
+// the original darts the finishing stages keep with the graph (finish_device.hip), a by-product of the sort here.
 __global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const uint32_t *mirror, const unsigned long long *ext_off,
-                                   const uint32_t *e_to, const uint16_t *e_w, NodeBlock *blocks, uint32_t *ext_col, uint16_t *ext_w) {
+                                   const uint32_t *e_from, const uint16_t *w_unitig, NodeBlock *blocks, uint32_t *ext_col, uint16_t *ext_w,
+                                   const uint32_t *row0, uint32_t *adj0) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
     const uint32_t dg = odeg[n];
@@ -289,7 +294,9 @@ __global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const
         for (uint32_t j = 0; j < dg; j++) ids[j] = blocks[n].nbr[j];
         auto cswap = [&](int x, int y) { if (ids[x] > ids[y]) { const uint32_t t = ids[x]; ids[x] = ids[y]; ids[y] = t; } };
         cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
-        for (uint32_t j = 0; j < dg; j++) { b.nbr[j] = e_to[ids[j]]; b.w[j] = e_w[ids[j]]; }
+        for (uint32_t j = 0; j < dg; j++) { b.nbr[j] = mirror[e_from[ids[j] ^ 1u]]; b.w[j] = w_unitig[ids[j] >> 1]; }
+        if (adj0)
+            for (uint32_t j = 0; j < dg; j++) adj0[row0[n] + j] = ids[j];
         b.deg = (uint8_t)dg;
     } else {
         const unsigned long long off = ext_off[n];
@@ -301,8 +308,9 @@ __global__ void build_nodes_kernel(uint64_t n_nodes, const uint32_t *odeg, const
         }
         for (uint32_t i = 0; i < dg; i++) {
             const uint32_t e = ext_col[off + i];
-            ext_col[off + i] = e_to[e];
-            ext_w[off + i] = e_w[e];
+            if (adj0) adj0[row0[n] + i] = e;
+            ext_col[off + i] = mirror[e_from[e ^ 1u]];
+            ext_w[off + i] = w_unitig[e >> 1];
         }
         b.flags |= F_EXT;
         b.nbr[0] = (uint32_t)(off & 0xFFFFFFFFull);
@@ -1493,6 +1501,8 @@ struct Device {
     uint64_t k = 0;
     uint32_t K1 = 0;
     uint64_t V = 0;
+    uint64_t E0 = 0;  // original edges of the graph the device copy was built from
+    bool single_use = false;  // the caller searches once (mtg_compute_tigs_cfg): what only the search needs goes back before the claim replay takes its arrays
     NodeBlock *d_recs = nullptr;              // [V] family blocks
     uint32_t *d_odeg = nullptr;               // [V] out-degree (classification)
     uint8_t *d_cls = nullptr;                 // [V] class byte of the last classification (F_TARGET | F_SOURCE | F_SELF_MIRROR)
@@ -1681,7 +1691,7 @@ static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool co
     HIP_CHECK(hipEventRecord(d->ev1, st));
     if (ws) {
         HIP_CHECK(hipStreamSynchronize(st));
-        HIP_CHECK(hipFree(ws));
+        hu::device_free(ws);
     }
 }
 
@@ -1787,7 +1797,7 @@ static void run_dense_level(Device *d, hipStream_t st, const SsspArgs &a, const 
     }
     HIP_CHECK(hipMemcpyAsync(&d->d_counters[C_POOL], &d->h_counters[C_POOL], 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    for (void *p : {(void *)d_dist, (void *)d_stamp, (void *)d_front[0], (void *)d_front[1], (void *)d_keys, (void *)d_n}) HIP_CHECK(hipFree(p));
+    for (void *p : {(void *)d_dist, (void *)d_stamp, (void *)d_front[0], (void *)d_front[1], (void *)d_keys, (void *)d_n}) hu::device_free(p);
 }
 
 static void read_counters(Device *d, hipStream_t st) {
@@ -1799,6 +1809,7 @@ static void read_counters(Device *d, hipStream_t st) {
 static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, uint64_t src_end, unsigned long long *d_pool,
                       uint64_t pool_cap, unsigned long long *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed,
                       mtg_sssp_stats *stats) {
+    if (!d->d_recs) MTG_DIE("this device copy was built for one search (mtg_compute_tigs_cfg) and has given its search arrays back");
     if (!d->classified) MTG_DIE("mtg_sssp_candidates: call mtg_classify first");
     if (src_end > d->n_sources || src_begin > src_end) MTG_DIE("mtg_sssp_candidates: source range out of bounds");
     const uint64_t n = src_end - src_begin;
@@ -1817,15 +1828,15 @@ static int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_be
     if (prune_count && !enum_prunes(d)) MTG_DIE("mtg_sssp_count_visited: this device graph / plan does not prune (k > 255 or plan + 4)");
     if (d->ovf_cap < n) {  // two overflow lists of up to n source indices each + the post-pass work list
         for (int i = 0; i < 2; i++) {
-            if (d->d_ovf[i]) HIP_CHECK(hipFree(d->d_ovf[i]));
+            if (d->d_ovf[i]) hu::device_free(d->d_ovf[i]);
             hu::device_malloc(&d->d_ovf[i], std::max<uint64_t>(n, 1) * sizeof(uint32_t));
         }
-        if (d->d_fix) HIP_CHECK(hipFree(d->d_fix));
+        if (d->d_fix) hu::device_free(d->d_fix);
 
         // (a wave abandons a work-list chunk with fewer than 64 free slots: < 1/7 of every chunk incl. its tag) + three open chunks per wave
         const uint64_t fix_slots = std::max<uint64_t>(n, 1) * 5 / 4 + (uint64_t)d->n_cu * 32 * 3 * ENUM_FIX_CHUNK;
         hu::device_malloc(&d->d_fix, fix_slots * sizeof(uint32_t));
-        if (d->d_fix_dense) HIP_CHECK(hipFree(d->d_fix_dense));
+        if (d->d_fix_dense) hu::device_free(d->d_fix_dense);
         hu::device_malloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
         d->ovf_cap = n;
     }
@@ -1966,6 +1977,61 @@ int device_count() {
     return n;
 }
 
+// Bytes of device memory a whole call on a graph of V nodes and E original edges has in use at its peak (device graph with the build's
+// scratch, or the device graph beside the search and replay arrays, or the finish's dart arrays): the size of the arena chunk a
+// first call reserves. Calibrated on G-csr graphs from 2^20 to 2^30 edges (MTG_DEBUG prints the arena's peak at the end of a call); an
+// estimate that is too small costs a second chunk, one that is too large memory the driver has to map for nothing.
+size_t device_call_bytes_estimate(uint64_t V, uint64_t E, uint64_t k) {
+    (void)k;
+    return (size_t)(V * 106 + E * 12) + (64u << 20);
+}
+
+// Kernel code objects load lazily, at the first launch of a kernel of their translation unit (3-10 ms each on a cold process); asking
+// for a kernel's attributes loads them without launching anything.
+void device_warm_device_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(classify_kernel));
+}
+void device_warm_finish_kernels();  // finish_device.hip
+void device_warm_euler_kernels();   // euler_device.hip
+
+void device_arena_stats(int device_id, uint64_t out[4]) {
+    hu::DeviceArena &a = hu::device_arena(device_id);
+    std::lock_guard<std::mutex> lock(a.m);
+    out[0] = a.chunk_bytes; out[1] = a.live_bytes; out[2] = a.peak_bytes; out[3] = a.n_chunk_allocs;
+}
+static std::atomic<int> g_default_device{0};
+void device_set_default(int device_id) { g_default_device.store(device_id); }
+int device_get_default() { return g_default_device.load(); }
+
+// Called when a host graph of V nodes and E edges comes into being (graph_build.cpp): on a helper thread, beside the host's own work,
+// the HIP runtime starts, the code objects load, and the arena of the default device gets its chunk for the call that will follow --
+// ONE hipMalloc, whose cost (nothing to 60 ms per GB depending on the box) no stage then waits for. Small graphs reserve nothing.
+void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
+    const size_t bytes = device_call_bytes_estimate(V, E, 31);
+    if (bytes < (256u << 20)) return;
+    const int dev = device_id >= 0 ? device_id : device_get_default();
+    std::promise<void> done;
+    std::shared_future<void> fut = done.get_future().share();
+    {
+        hu::DeviceArena &arena = hu::device_arena(dev);
+        std::lock_guard<std::mutex> lock(arena.m);
+        if (arena.pending.valid()) return;  // (one at a time)
+        arena.pending = fut;
+    }
+    std::thread([dev, bytes](std::promise<void> p) {
+        if (device_count() > dev && hipSetDevice(dev) == hipSuccess) {
+            hu::device_arena(dev).reserve(bytes);
+            (void)hu::finish_stream(dev);
+            device_warm_device_kernels();
+            device_warm_finish_kernels();
+            device_warm_euler_kernels();
+        }
+        (void)hipGetLastError();
+        p.set_value();
+    }, std::move(done)).detach();
+}
+
 Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     if (k < 1) MTG_DIE("k must be >= 1");
     if (k > 0xFFFFFFFFull) MTG_DIE("k = %llu is not supported by the device stage (32-bit distances)", (unsigned long long)k);
@@ -1973,11 +2039,27 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         // Edge weights live in 16 bits, clamped to min(w, k) (an edge of weight >= k can never lie on a path within k - 1). With
         // k beyond 16 bits the clamp no longer fits, so every weight itself has to: true for any unitig set (a weight is a
         // number of k-mers of a unitig). Distances beyond 15 / 21 bits skip the enumeration / cooperative levels (run_levels).
-        for (uint64_t e = 0; e < g.n_original_edges; e++)
-            if (g.e_weight[e] > 65534)
-                MTG_DIE("k = %llu with a unitig of %llu k-mers: beyond k = 65535 the device stage needs every weight below 65535",
-                        (unsigned long long)k, (unsigned long long)g.e_weight[e]);
+        parallel_ranges(g.n_original_edges / 2, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t u = lo; u < hi; u++)
+                if (g.w_biedge[u] > 65534)
+                    MTG_DIE("k = %llu with a unitig of %llu k-mers: beyond k = 65535 the device stage needs every weight below 65535",
+                            (unsigned long long)k, (unsigned long long)g.w_biedge[u]);
+        });
     }
+    // weights: 16 bits per UNITIG, clamped to min(w, k) (both edges of a unitig weigh the same, host_graph.hpp); a unitig without
+    // k-mers aborts here -- the bounded search, its lower bounds and the (distance, node) pop order of the reference's heap all need
+    // weights >= 1 (the reference computes weight = len + 1 - k >= 1, bin.rs:369-376)
+    const uint64_t U = g.n_original_edges / 2;
+    PodVec<uint16_t> wclamp(U);
+    parallel_ranges(U, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t u = lo; u < hi; u++) {
+            const uint64_t w = g.w_biedge[u];
+            if (w == 0)
+                MTG_DIE("unitig %llu has weight 0: the bounded search needs weights >= 1 (the reference computes "
+                        "weight = len + 1 - k >= 1, bin.rs:369-376)", (unsigned long long)u);
+            wclamp[u] = (uint16_t)std::min<uint64_t>(w, k);
+        }
+    });
     if (device_count() <= device_id) MTG_DIE("no MI355X/HIP device %d available; libmatchtigs has no CPU path", device_id);
     HIP_CHECK(hipSetDevice(device_id));
     Device *d = new Device();
@@ -1985,6 +2067,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     d->k = k;
     d->K1 = (uint32_t)(k - 1);
     d->V = g.node_count();
+    d->E0 = g.n_original_edges;
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
     d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -2003,42 +2086,46 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
             t = n;
         }
     } dl;
-    PodVec<uint16_t> wclamp(E);
-    parallel_ranges(E, [&](uint64_t lo, uint64_t hi) {
-        for (uint64_t e = lo; e < hi; e++) wclamp[e] = (uint16_t)std::min<uint64_t>(g.e_weight[e], k);
-    });
     dl.lap("clamped weights (host)");
     hipStream_t st = nullptr;
-    uint32_t *d_from = nullptr, *d_to = nullptr, *d_fill = nullptr, *d_need = nullptr;
+    // One chunk of the device's arena for the whole call unless an earlier call (or the reservation the graph's construction started
+    // on a helper thread, device_reserve_async) left one: every allocation below and in the stages that follow is a range of it.
+    const size_t call_bytes = device_call_bytes_estimate(V, E, k);
+    uint32_t *d_from = nullptr, *d_fill = nullptr, *d_need = nullptr, *d_row0 = nullptr, *d_adj0 = nullptr;
     uint16_t *d_w = nullptr;
     unsigned long long *d_ext_off = nullptr;
-    hu::device_malloc(&d_from, std::max<uint64_t>(E, 1) * 4);
-    hu::device_malloc(&d_to, std::max<uint64_t>(E, 1) * 4);
-    hu::device_malloc(&d_w, std::max<uint64_t>(E, 1) * 2);
-    hu::device_malloc(&d_fill, std::max<uint64_t>(V, 1) * 4);
-    hu::device_malloc(&d_need, std::max<uint64_t>(V, 1) * 4);
-    hu::device_malloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8);
-    hu::device_malloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeBlock));
+    // the long-lived arrays first (they collect at the front of the chunk), the build's scratch after them
+    hu::device_malloc(&d->d_recs, std::max<uint64_t>(V, 1) * sizeof(NodeBlock), call_bytes);
     hu::device_malloc(&d->d_odeg, std::max<uint64_t>(V, 1) * 4);
-    hu::device_malloc(&d->d_cls, std::max<uint64_t>(V, 1));
-    hu::device_malloc(&d->d_mult, std::max<uint64_t>(V, 1) * 4);
     hu::device_malloc(&d->d_mirror, std::max<uint64_t>(V, 1) * 4);
-    hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(V, 1) * 4);
+    // (class bytes, multiplicities, out-node list: taken by the first classification, once the build's scratch arrays are back)
     d->n_cls_blocks = (V + CLS_NODES - 1) / CLS_NODES;
     hu::device_malloc(&d->d_block_counts, std::max<uint64_t>(d->n_cls_blocks, 1) * 2 * 4);  // source counts | positive multiplicities per block
     hu::device_malloc(&d->d_act_blocks, std::max<uint64_t>(d->n_cls_blocks, 1) * 4);
     hu::device_malloc(&d->d_act_total, 8);
     hu::device_malloc(&d->d_counters, C_COUNT * sizeof(unsigned long long));
+    hu::device_malloc(&d_from, std::max<uint64_t>(E, 1) * 4);
+    // the buckets of the original darts by from-node (row0[V + 1], adj0[E]: what the finishing stages keep with the graph) fall out
+    // of build_nodes_kernel's sort; kept while they are small next to the stand-ins of BASELINE configs[4] (finish_device.hip)
+    const bool want_buckets = E && (V + 1 + E) * 4 <= (8ull << 30) && !g.device_cache && !(hu::finish_tuning().flags.load() & hu::FT_NO_EDGE_CACHE);
+    if (want_buckets) {
+        hu::device_malloc(&d_row0, (V + 1) * 4);
+        hu::device_malloc(&d_adj0, E * 4);
+    }
+    hu::device_malloc(&d_w, std::max<uint64_t>(U, 1) * 2);
+    hu::device_malloc(&d_fill, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d_need, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8);
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
     for (auto &e : d->ev_r) HIP_CHECK(hipEventCreate(&e));
     dl.lap("allocations");
-    // (through the pinned ring: host threads fill the next slice while one crosses PCIe -- the runtime stages a pageable upload on one thread)
+    // (through the pinned ring: host threads fill the next slice while one crosses PCIe -- the runtime stages a pageable upload on one
+    // thread. from + mirror + 2 bytes per unitig: the heads are mirror(from(e ^ 1)), 6.3 B per edge + 4 B per node in all)
     if (E) {
         hu::upload_sliced(d_from, g.e_from.data(), E * 4, st, device_id);
-        hu::upload_sliced(d_to, g.e_to.data(), E * 4, st, device_id);
-        hu::upload_sliced(d_w, wclamp.data(), E * 2, st, device_id);
+        hu::upload_sliced(d_w, wclamp.data(), U * 2, st, device_id);
     }
     if (V) hu::upload_sliced(d->d_mirror, g.mirror.data(), V * 4, st, device_id);
     HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, st));
@@ -2051,6 +2138,13 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         hipLaunchKernelGGL(build_ext_need_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, V, d_need);
         HIP_CHECK(hipGetLastError());
         scan_u32(d, st, d->replay, d_need, V, d_ext_off, &d->d_counters[C_OVF_LIST]);
+        if (want_buckets) {  // row0 = exclusive scan of the out-degrees (d_fill's memory serves as the scan's block sums until build_fill_kernel runs)
+            uint32_t *d_bs = nullptr;
+            hu::device_malloc(&d_bs, (hu::scan_blocks(V) + 2) * 4);
+            hu::scan_u32<uint32_t>(st, d->d_odeg, V, d_row0, d_bs, d_row0 + V);
+            HIP_CHECK(hipStreamSynchronize(st));
+            hu::device_free(d_bs);
+        }
         read_counters(d, st);
         ext_total = d->h_counters[C_OVF_LIST];
     }
@@ -2059,8 +2153,8 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
     hu::device_malloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2);
     if (V) {
         if (E) hipLaunchKernelGGL(build_fill_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_ext_off, d_fill, d->d_recs, d->d_ext_col);
-        hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_to, d_w, d->d_recs,
-                           d->d_ext_col, d->d_ext_w);
+        hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_from, d_w, d->d_recs,
+                           d->d_ext_col, d->d_ext_w, d_row0, d_adj0);
         d->w8 = k <= 255;
         if (d->w8) {  // goal-directed lower bounds: k - 1 rounds over a 32-bit distance array, then the 8:8 format of the weight slots
             uint32_t *d_D = nullptr;
@@ -2078,22 +2172,23 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
             hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(st));
-            HIP_CHECK(hipFree(d_D));
-            HIP_CHECK(hipFree(d_lb8));
-            HIP_CHECK(hipFree(d_lbx));
+            hu::device_free(d_D);
+            hu::device_free(d_lb8);
+            hu::device_free(d_lbx);
         } else {
             hipLaunchKernelGGL(build_children_kernel<false>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
         }
         HIP_CHECK(hipGetLastError());
     }
     dl.lap("build kernels (+ lower bounds)");
-    // the finishing stages on this GPU start from the same two arrays: leave them with the graph instead of uploading them again
+    // the finishing stages on this GPU start from the same arrays: from, mirror and the buckets stay with the graph
     uint32_t *d_mirror_copy = nullptr;
     hu::device_malloc(&d_mirror_copy, std::max<uint64_t>(V, 1) * 4);
     if (V) HIP_CHECK(hipMemcpyAsync(d_mirror_copy, d->d_mirror, V * 4, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
     hu::edge_cache_put(g, device_id, d_from, d_mirror_copy);
-    for (void *p : {(void *)d_to, (void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) HIP_CHECK(hipFree(p));
+    if (want_buckets) hu::edge_cache_set_buckets(g, device_id, d_row0, d_adj0);
+    for (void *p : {(void *)d_w, (void *)d_fill, (void *)d_need, (void *)d_ext_off}) hu::device_free(p);
     d->graph_bytes = V * sizeof(NodeBlock) + ext_total * 6 + V * 13;
     dl.lap("edge cache + frees");
     return d;
@@ -2104,14 +2199,14 @@ void device_free(Device *d) {
     (void)hipSetDevice(d->dev);
     void *bufs[] = {d->d_recs, d->d_odeg, d->d_cls, d->d_ext_col, d->d_ext_w, d->d_mult, d->d_mirror, d->d_out_nodes, d->d_block_counts, d->d_counters,
                     d->d_act_index, d->d_act_node, d->d_act_blocks, d->d_act_total};
-    for (void *b : bufs) (void)hipFree(b);
-    for (int i = 0; i < 2; i++) (void)hipFree(d->d_ovf[i]);
-    (void)hipFree(d->d_fix);
-    (void)hipFree(d->d_fix_dense);
+    for (void *b : bufs) hu::device_free(b);
+    for (int i = 0; i < 2; i++) hu::device_free(d->d_ovf[i]);
+    hu::device_free(d->d_fix);
+    hu::device_free(d->d_fix_dense);
     ReplayWork &w = d->replay;
     void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.src_mirror, w.dense, w.claims, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};
-    for (void *b : rb) (void)hipFree(b);
+    for (void *b : rb) hu::device_free(b);
     (void)hipHostFree(w.h_ctl);
     (void)hipHostFree(w.h_out);
     (void)hipHostFree(d->h_counters);
@@ -2127,6 +2222,11 @@ uint64_t device_classify(Device *d, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(d->dev));
     d->n_sources = 0;
+    if (!d->d_cls) {
+        hu::device_malloc(&d->d_cls, std::max<uint64_t>(d->V, 1));
+        hu::device_malloc(&d->d_mult, std::max<uint64_t>(d->V, 1) * 4);
+        hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(d->V, 1) * 4);
+    }
     if (d->V) {
         hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_odeg, d->d_mirror, (uint32_t)d->V,
                            d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks, d->d_act_blocks);
@@ -2140,7 +2240,7 @@ uint64_t device_classify(Device *d, void *stream) {
         d->total_demand = d->h_counters[C_DEMAND];
         const uint64_t act_need = d->w8 ? d->n_sources : 0;  // (without the 8:8 format no source carries the flag: the lists stay empty)
         if (d->act_cap < act_need || !d->d_act_index) {
-            for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node}) if (p) HIP_CHECK(hipFree(p));
+            for (void *p : {(void *)d->d_act_index, (void *)d->d_act_node}) if (p) hu::device_free(p);
             hu::device_malloc(&d->d_act_index, std::max<uint64_t>(act_need, 1) * 4);
             hu::device_malloc(&d->d_act_node, std::max<uint64_t>(act_need, 1) * 4);
             d->act_cap = act_need;
@@ -2167,7 +2267,7 @@ void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int3
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(live, d_live, d->V, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        HIP_CHECK(hipFree(d_live));
+        hu::device_free(d_live);
     }
     HIP_CHECK(hipStreamSynchronize(st));
 }
@@ -2192,8 +2292,8 @@ void device_sssp_count(Device *d, void *stream, uint64_t src_begin, uint64_t src
     const double keep_ms = d->last_kernel_ms;
     run_levels(d, (hipStream_t)stream, 1, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
     d->last_kernel_ms = keep_ms;
-    HIP_CHECK(hipFree(d_start));
-    HIP_CHECK(hipFree(d_count));
+    hu::device_free(d_start);
+    hu::device_free(d_count);
 }
 
 // the same counters for the search the default plan really runs: only the sources that can reach an in-node, successors pruned by
@@ -2209,8 +2309,8 @@ void device_sssp_count_visited(Device *d, void *stream, uint64_t src_begin, uint
     run_levels(d, (hipStream_t)stream, 3, src_begin, src_end, nullptr, 0, d_start, d_count, nullptr, stats);
     if (stats) stats->sources = d->h_counters[C_ACTIVE];
     d->last_kernel_ms = keep_ms;
-    HIP_CHECK(hipFree(d_start));
-    HIP_CHECK(hipFree(d_count));
+    hu::device_free(d_start);
+    hu::device_free(d_count);
 }
 bool device_prunes(const Device *d) { return enum_prunes(d); }
 uint64_t device_last_active_sources(const Device *d) { return d->last_active_sources; }
@@ -2225,8 +2325,8 @@ void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_d
     hu::device_malloc(&d_count, std::max<uint64_t>(n, 1) * 4);
     mtg_sssp_stats st{};
     run_levels(d, (hipStream_t)stream, 2, 0, n, nullptr, 0, d_start, d_count, nullptr, &st);
-    HIP_CHECK(hipFree(d_start));
-    HIP_CHECK(hipFree(d_count));
+    hu::device_free(d_start);
+    hu::device_free(d_count);
     out->dijkstras = n;
     out->iterations = st.settled_nodes;
     out->heap_pushes = d->h_counters[C_PUSHES];
@@ -2254,7 +2354,7 @@ template <typename In>
 static void scan_values(hipStream_t st, ReplayWork &w, In in, uint64_t n, unsigned long long *out, unsigned long long *d_total) {
     const uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (nb > w.cap_blocks) {
-        if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
+        if (w.block_sums) hu::device_free(w.block_sums);
         hu::device_malloc(&w.block_sums, nb * 8);
         w.cap_blocks = nb;
     }
@@ -2296,8 +2396,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         return 0;
     }
     if (V > w.cap_v) {
-        if (w.state) HIP_CHECK(hipFree(w.state));
-        for (int i = 0; i < 2; i++) if (w.resv[i]) { HIP_CHECK(hipFree(w.resv[i])); w.resv[i] = nullptr; }
+        if (w.state) hu::device_free(w.state);
+        for (int i = 0; i < 2; i++) if (w.resv[i]) { hu::device_free(w.resv[i]); w.resv[i] = nullptr; }
 #if MTG_REPLAY_RECORDS
         hu::device_malloc(&w.state, ((V + 1) / 2) * 64);  // one 64-byte record per pair of numeric neighbours: states + both reservation words
 #else
@@ -2310,8 +2410,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     if (S > w.cap_s) {
         if (w.touch) {
-            HIP_CHECK(hipFree(w.touch)); HIP_CHECK(hipFree(w.src_mirror)); HIP_CHECK(hipFree(w.claims));
-            HIP_CHECK(hipFree(w.pending[0])); HIP_CHECK(hipFree(w.pending[1])); HIP_CHECK(hipFree(w.final_off));
+            hu::device_free(w.touch); hu::device_free(w.src_mirror); hu::device_free(w.claims);
+            hu::device_free(w.pending[0]); hu::device_free(w.pending[1]); hu::device_free(w.final_off);
         }
         hu::device_malloc(&w.touch, S * sizeof(Touch));
         hu::device_malloc(&w.src_mirror, S * 4);
@@ -2323,7 +2423,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     const uint64_t spill_need = std::max<uint64_t>(d->total_demand, 1);  // a source emits at most its demand (classification)
     if (spill_need > w.cap_spill) {
-        if (w.spill) HIP_CHECK(hipFree(w.spill));
+        if (w.spill) hu::device_free(w.spill);
         hu::device_malloc(&w.spill, spill_need * 4);
         w.cap_spill = spill_need;
     }
@@ -2356,7 +2456,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         static_assert(DENSE_BLOCK == SCAN_BLOCK, "the dense fill uses the scan's block offsets");
         const uint64_t nb = (S + SCAN_BLOCK - 1) / SCAN_BLOCK;
         if (nb > w.cap_blocks) {
-            if (w.block_sums) HIP_CHECK(hipFree(w.block_sums));
+            if (w.block_sums) hu::device_free(w.block_sums);
             hu::device_malloc(&w.block_sums, nb * 8);
             w.cap_blocks = nb;
         }
@@ -2367,7 +2467,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         read_counters(d, st);
         n_dense = d->h_counters[C_OVF_LIST];
         if (n_dense > w.cap_dense) {
-            if (w.dense) HIP_CHECK(hipFree(w.dense));
+            if (w.dense) hu::device_free(w.dense);
             hu::device_malloc(&w.dense, n_dense * sizeof(Dense));
             w.cap_dense = n_dense;
         }
@@ -2482,7 +2582,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     rt.lap("tail + scan");
     d->last_n_pairs = n_pairs;
     if (n_pairs > w.cap_out || !w.out) {
-        if (w.out) HIP_CHECK(hipFree(w.out));
+        if (w.out) hu::device_free(w.out);
         hu::device_malloc(&w.out, std::max<uint64_t>(n_pairs, 1) * sizeof(mtg_pair));
         w.cap_out = std::max<uint64_t>(n_pairs, 1);
     }
@@ -2568,12 +2668,14 @@ void device_set_replay_tuning(Device *d, uint64_t windows, int block, int grid, 
 }
 void device_last_replay_ms(const Device *d, double out[2]) { out[0] = d->last_replay_kernel_ms; out[1] = d->last_replay_gpu_ms; }
 int device_id_of(const Device *d) { return d->dev; }
+// was d built from g (same node and edge counts) for bound k - 1? What the resident pairs of d may be finished on.
+bool device_matches(const Device *d, const HostGraph &g, uint64_t k) { return d->V == g.node_count() && d->E0 == g.n_original_edges && d->k == k; }
 // the pairs of the last claim replay as they lie in HBM (valid until the next replay on this device)
 const mtg_pair *device_resident_pairs(const Device *d, uint64_t *n_out) {
     if (n_out) *n_out = d->last_n_pairs;
     return d->last_n_pairs ? d->replay.out : nullptr;
 }
-// the same, handed over: the caller owns the device array now (hipFree) -- lets the device graph go before the finish starts
+// the same, handed over: the caller owns the device array now (device_free_array) -- lets the device graph go before the finish starts
 mtg_pair *device_take_pairs(Device *d, uint64_t *n_out) {
     if (n_out) *n_out = d->last_n_pairs;
     mtg_pair *p = d->replay.out;
@@ -2583,9 +2685,7 @@ mtg_pair *device_take_pairs(Device *d, uint64_t *n_out) {
     return p;
 }
 void device_free_array(int device_id, void *p) {
-    if (!p) return;
-    (void)hipSetDevice(device_id);
-    (void)hipFree(p);
+    hu::device_free_on(device_id, p);
 }
 // host copy of the resident pairs (malloc'd)
 uint64_t device_download_pairs(Device *d, mtg_pair **pairs_out) {
@@ -2601,6 +2701,21 @@ uint64_t device_last_replay_visits(const Device *d) { return d->last_replay_visi
 
 // one-shot path: SSSP candidates for all sources into engine-owned device buffers (pool grown on demand), then the
 // claim replay on the GPU; only the matched pairs travel to the host.
+// A device copy that is searched once (the consuming call, clib.rs:291): the family blocks (64 of the ~100 bytes per node a call holds
+// at its peak) and the search's lists are dead once the candidates exist, and the claim replay's arrays take their place in the arena
+// instead of new memory beside them.
+void device_set_single_use(Device *d) { d->single_use = true; }
+static void device_drop_search_arrays(Device *d) {
+    HIP_CHECK(hipDeviceSynchronize());
+    for (void **p : {(void **)&d->d_recs, (void **)&d->d_ext_col, (void **)&d->d_ext_w, (void **)&d->d_act_index, (void **)&d->d_act_node,
+                     (void **)&d->d_ovf[0], (void **)&d->d_ovf[1], (void **)&d->d_fix, (void **)&d->d_fix_dense}) {
+        if (*p) hu::device_arena(d->dev).free(*p, false);
+        *p = nullptr;
+    }
+    d->ovf_cap = 0;
+    d->act_cap = 0;
+}
+
 uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out) {
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(d->dev));
@@ -2620,14 +2735,15 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
         hu::device_malloc(&d_pool, cap * 8);
         uint64_t needed = 0;
         if (run_levels(d, st, 0, 0, S, d_pool, cap, d_start, d_count, &needed, nullptr) == 0) break;
-        HIP_CHECK(hipFree(d_pool));
+        hu::device_free(d_pool);
         d_pool = nullptr;
         cap = needed + needed / 8 + 1024;
     }
+    if (d->single_use) device_drop_search_arrays(d);
     const uint64_t n = device_replay(d, stream, S, (const uint64_t *)d_start, d_count, (const uint64_t *)d_pool, pairs_out, rounds_out);
-    HIP_CHECK(hipFree(d_pool));
-    HIP_CHECK(hipFree(d_start));
-    HIP_CHECK(hipFree(d_count));
+    hu::device_free(d_pool);
+    hu::device_free(d_start);
+    hu::device_free(d_count);
     return n;
 }
 
@@ -2682,7 +2798,7 @@ std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int part
     HIP_CHECK(hipMemcpyAsync(h.data(), d_cut, (size_t)parts * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     for (int r = 1; r < parts; r++) cuts[(size_t)r] = std::max<uint64_t>(cuts[(size_t)r - 1], h[(size_t)r]);
-    HIP_CHECK(hipFree(d_work)); HIP_CHECK(hipFree(d_prefix)); HIP_CHECK(hipFree(d_cut));
+    hu::device_free(d_work); hu::device_free(d_prefix); hu::device_free(d_cut);
     return cuts;
 }
 
@@ -2718,7 +2834,7 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
                 hu::device_malloc(&p.pool, cap * 8);
                 uint64_t needed = 0;
                 if (run_levels(d, nullptr, 0, lo, hi, p.pool, cap, p.start, p.count, &needed, nullptr) == 0) { p.used = needed; break; }
-                HIP_CHECK(hipFree(p.pool));
+                hu::device_free(p.pool);
                 p.pool = nullptr;
                 cap = needed + needed / 8 + 1024;
             }
@@ -2756,11 +2872,12 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
     if (gather_ms_out) *gather_ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < n_dev; i++) {
         HIP_CHECK(hipSetDevice(devs[i]->dev));
-        if (parts[(size_t)i].start) { HIP_CHECK(hipFree(parts[(size_t)i].start)); HIP_CHECK(hipFree(parts[(size_t)i].count)); HIP_CHECK(hipFree(parts[(size_t)i].pool)); }
+        if (parts[(size_t)i].start) { hu::device_free(parts[(size_t)i].start); hu::device_free(parts[(size_t)i].count); hu::device_free(parts[(size_t)i].pool); }
     }
     HIP_CHECK(hipSetDevice(d0->dev));
+    if (d0->single_use) device_drop_search_arrays(d0);
     const uint64_t n = device_replay(d0, nullptr, S, (const uint64_t *)g_start, g_count, (const uint64_t *)g_pool, pairs_out, rounds_out);
-    HIP_CHECK(hipFree(g_pool)); HIP_CHECK(hipFree(g_start)); HIP_CHECK(hipFree(g_count));
+    hu::device_free(g_pool); hu::device_free(g_start); hu::device_free(g_count);
     return n;
 }
 
@@ -2788,16 +2905,16 @@ void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &c
             if (needed) HIP_CHECK(hipMemcpyAsync(pool.data(), d_pool, needed * 8, hipMemcpyDeviceToHost, st));
             break;
         }
-        HIP_CHECK(hipFree(d_pool));
+        hu::device_free(d_pool);
         d_pool = nullptr;
         cap = needed + needed / 8 + 1024;
     }
     HIP_CHECK(hipMemcpyAsync(cand_start.data(), d_start, S * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(cand_count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipFree(d_pool));
-    HIP_CHECK(hipFree(d_start));
-    HIP_CHECK(hipFree(d_count));
+    hu::device_free(d_pool);
+    hu::device_free(d_start);
+    hu::device_free(d_count);
 }
 
 }  // namespace mtg

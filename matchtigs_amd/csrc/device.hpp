@@ -12,8 +12,15 @@ namespace mtg {
 struct Device;
 
 int device_count();
+// device memory of a call, reserved ahead of it (device.hip)
+size_t device_call_bytes_estimate(uint64_t V, uint64_t E, uint64_t k);
+void device_reserve_async(uint64_t V, uint64_t E, int device_id = -1);  // helper thread: HIP runtime, code objects, one arena chunk (-1: on the default device)
+void device_arena_stats(int device_id, uint64_t out[4]);  // bytes in chunks, live bytes, peak of live bytes, chunks taken from the driver so far
+void device_set_default(int device_id);
+int device_get_default();
 Device *device_create(const HostGraph &g, uint64_t k, int device_id);
 void device_free(Device *d);
+void device_set_single_use(Device *d);  // the caller searches once: the search's arrays go back before the claim replay (device.hip)
 uint64_t device_graph_bytes(const Device *d);
 uint64_t device_classify(Device *d, void *stream);
 void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int32_t *mult, uint8_t *live);
@@ -40,6 +47,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 // (first) device for a finish there)
 uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds_out);
 int device_id_of(const Device *d);
+bool device_matches(const Device *d, const HostGraph &g, uint64_t k);
 const mtg_pair *device_resident_pairs(const Device *d, uint64_t *n_out);
 mtg_pair *device_take_pairs(Device *d, uint64_t *n_out);
 void device_free_array(int device_id, void *p);
@@ -54,8 +62,17 @@ void device_euler_force_bitmap(int on);
 // (d_pairs_resident: the n_pairs pairs as they lie in the HBM of `device_id`, e.g. left there by the claim replay -- `pairs` may then be null:
 // nothing is uploaded, and the host graph gets its dummy weights from a download that runs beside the GPU stages)
 // (times_out: 12 values, see mtg_last_finish_device_times / mtg_last_finish_device_stage_ms)
+// (sink: the tigs go straight into a caller's clib.rs output arrays instead of a Walks object -- the host threads that empty the
+// download ring write the flattened form, clib.rs:393-407 -- and the returned Walks is empty)
+struct TigSink {
+    int64_t *edge_out = nullptr;    // [>= kept edges]  +/- unitig id, 0 for a dummy edge (clib.rs:397-398)
+    uint64_t *insert_out = nullptr; // [>= kept edges]  0 for an original edge, else the dummy's weight (clib.rs:399-403)
+    uint64_t *limits_out = nullptr; // [>= tigs]        exclusive end of tig i (clib.rs:405-406)
+    uint64_t n_tigs = 0, n_edges = 0;  // filled by the finish
+};
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
-                    const mtg_pair *d_pairs_resident = nullptr);
+                    const mtg_pair *d_pairs_resident = nullptr, TigSink *sink = nullptr);
+void device_set_finish_tuning(int records, int flags, long record_delay_us);
 void device_release_memory(int device_id);
 uint64_t device_memory_held(int device_id);
 void device_release_graph_cache(const HostGraph &g);

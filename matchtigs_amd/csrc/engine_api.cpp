@@ -3,6 +3,7 @@
 // matchtigs_* are the drop-in replacements of /root/reference/src/clib.rs:87-410; mtg_* is the
 // engine layer underneath (see the header for which reference lines each stage replaces).
 #include <spawn.h>
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -21,6 +22,7 @@
 #include "euler_lean.hpp"
 #include "host_graph.hpp"
 #include "hugebuf.hpp"
+#include "parallel.hpp"
 
 using namespace mtg;
 
@@ -38,12 +40,17 @@ static thread_local double g_last_euler_kernel_ms = 0;
 static thread_local double g_last_gather_ms = 0;
 static thread_local mtg_dijkstra_performance_data g_last_perf = {};
 static thread_local double g_last_finish_times[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// mtg_compute_tigs_clib: where a device finish on this thread delivers its tigs (the caller's clib.rs arrays) instead of a Walks object
+static thread_local TigSink *g_clib_sink = nullptr;
+static thread_local bool g_clib_sink_used = false;
 
 static void check_config(const mtg_config *cfg, const char *who) {
     if (!cfg) MTG_DIE("%s: null configuration", who);
-    if (cfg->struct_size != sizeof(mtg_config))
-        MTG_DIE("%s: mtg_config.struct_size = %llu, this library's mtg_config has %zu bytes: fill the configuration with mtg_config_init, and "
-                "build against the mtg_engine.h of this library", who, (unsigned long long)cfg->struct_size, sizeof(mtg_config));
+    // fields are only ever appended: an older caller's (shorter) struct is valid, a newer or a garbage one is not
+    static_assert(sizeof(mtg_config) == MTG_CONFIG_MIN_SIZE, "a field was appended to mtg_config: read it only when cfg->struct_size covers it, and default it otherwise");
+    if (cfg->struct_size < MTG_CONFIG_MIN_SIZE || cfg->struct_size > sizeof(mtg_config))
+        MTG_DIE("%s: mtg_config.struct_size = %llu, this library understands %d to %zu bytes: fill the configuration with mtg_config_init, and "
+                "build against an mtg_engine.h no newer than this library", who, (unsigned long long)cfg->struct_size, MTG_CONFIG_MIN_SIZE, sizeof(mtg_config));
     if (cfg->k < 1) MTG_DIE("%s: k must be >= 1", who);
     if (cfg->n_devices < 1 || cfg->n_devices > MTG_MAX_DEVICES) MTG_DIE("%s: n_devices = %d is out of range [1, %d]", who, cfg->n_devices, MTG_MAX_DEVICES);
     if (cfg->euler_mode != MTG_EULER_HOST_REFERENCE_ORDER && cfg->euler_mode != MTG_EULER_DEVICE) MTG_DIE("%s: unknown euler_mode %d", who, cfg->euler_mode);
@@ -61,6 +68,9 @@ static Walks euler_cycles_by_mode(const HostGraph &g, const mtg_config &cfg) {
     return euler_cycles(g);
 }
 
+static size_t tig_count(const mtg_walks *tigs) {  // (a device finish with a sink delivers no walks)
+    return g_clib_sink && g_clib_sink_used ? (size_t)g_clib_sink->n_tigs : tigs->w.limits.size();
+}
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -116,6 +126,20 @@ void mtg_graph_reset(mtg_graph *g) {
 }
 uint64_t mtg_graph_node_count(const mtg_graph *g) { return g->g.node_count(); }
 uint64_t mtg_graph_edge_count(const mtg_graph *g) { return g->g.edge_count(); }
+// (the payload of an edge is kept per biedge, and only what is not arithmetic: host_graph.hpp)
+static void export_payload(const HostGraph &h, uint64_t first, uint64_t n, uint64_t *edge_weight, uint64_t *edge_dummy_id, uint64_t *edge_unitig,
+                           uint8_t *edge_forwards) {
+    if (!edge_weight && !edge_dummy_id && !edge_unitig && !edge_forwards) return;
+    parallel_ranges(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint64_t e = first + i;
+            if (edge_weight) edge_weight[i] = h.weight(e);
+            if (edge_dummy_id) edge_dummy_id[i] = h.dummy_id(e);
+            if (edge_unitig) edge_unitig[i] = h.unitig(e);
+            if (edge_forwards) edge_forwards[i] = h.forwards(e) ? 1 : 0;
+        }
+    });
+}
 void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from, uint32_t *edge_to, uint64_t *edge_weight,
                       uint64_t *edge_dummy_id, uint64_t *edge_unitig, uint8_t *edge_forwards) {
     const HostGraph &h = g->g;
@@ -123,10 +147,7 @@ void mtg_graph_export(const mtg_graph *g, uint32_t *mirror, uint32_t *edge_from,
     if (mirror && V) std::memcpy(mirror, h.mirror.data(), V * 4);
     if (edge_from && E) std::memcpy(edge_from, h.e_from.data(), E * 4);
     if (edge_to && E) std::memcpy(edge_to, h.e_to.data(), E * 4);
-    if (edge_weight && E) std::memcpy(edge_weight, h.e_weight.data(), E * 8);
-    if (edge_dummy_id && E) std::memcpy(edge_dummy_id, h.e_dummy.data(), E * 8);
-    if (edge_unitig && E) std::memcpy(edge_unitig, h.e_unitig.data(), E * 8);
-    if (edge_forwards && E) std::memcpy(edge_forwards, h.e_fwd.data(), E);
+    export_payload(h, 0, E, edge_weight, edge_dummy_id, edge_unitig, edge_forwards);
 }
 
 void mtg_graph_export_range(const mtg_graph *g, uint64_t first_edge, uint64_t n_edges, uint32_t *edge_from, uint32_t *edge_to,
@@ -137,20 +158,15 @@ void mtg_graph_export_range(const mtg_graph *g, uint64_t first_edge, uint64_t n_
     const size_t o = first_edge, n = n_edges;
     if (edge_from) std::memcpy(edge_from, h.e_from.data() + o, n * 4);
     if (edge_to) std::memcpy(edge_to, h.e_to.data() + o, n * 4);
-    if (edge_weight) std::memcpy(edge_weight, h.e_weight.data() + o, n * 8);
-    if (edge_dummy_id) std::memcpy(edge_dummy_id, h.e_dummy.data() + o, n * 8);
-    if (edge_unitig) std::memcpy(edge_unitig, h.e_unitig.data() + o, n * 8);
-    if (edge_forwards) std::memcpy(edge_forwards, h.e_fwd.data() + o, n);
+    export_payload(h, o, n, edge_weight, edge_dummy_id, edge_unitig, edge_forwards);
 }
 uint64_t mtg_graph_original_edge_count(const mtg_graph *g) { return g->g.n_original_edges; }
 
 // ---- device stage ----
 mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id) {
     if (!g || !g->g.built) MTG_DIE("mtg_device_create: graph is not built");
-    for (uint64_t e = 0; e < g->g.n_original_edges; e++)
-        if (g->g.e_weight[e] == 0)
-            MTG_DIE("unitig %llu has weight 0: the bounded search needs weights >= 1 (the reference computes "
-                    "weight = len + 1 - k >= 1, bin.rs:369-376)", (unsigned long long)(e / 2));
+    // (a unitig of weight 0 aborts inside device_create, in the pass that clamps the weights: the bounded search and its lower
+    // bounds need weights >= 1 -- the reference computes weight = len + 1 - k >= 1, bin.rs:369-376)
     return new mtg_device{device_create(g->g, k, device_id)};
 }
 void mtg_device_free(mtg_device *d) {
@@ -299,7 +315,8 @@ static mtg_walks *finish_on_device(HostGraph &g, const mtg_pair *pairs, uint64_t
     log_info("Making graph Eulerian by adding breaking dummy edges");
     log_info("Finding Eulerian bicycle");
     double *t = g_last_finish_times;
-    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t, d_pairs_resident)};
+    if (g_clib_sink) g_clib_sink_used = true;
+    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t, d_pairs_resident, g_clib_sink)};
     g_phase[5] = t[0] + t[1];
     g_phase[6] = t[2];
     g_phase[7] = t[3];
@@ -348,14 +365,14 @@ mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64
     if (n_pairs && !pairs) MTG_DIE("mtg_finish_greedytigs_cfg: null pairs");
     if (use_device_finish(g->g, pairs, n_pairs, *cfg)) {
         mtg_walks *tigs = finish_on_device(g->g, pairs, n_pairs, *cfg);
-        log_info("Found %zu greedytigs", tigs->w.limits.size());
+        log_info("Found %zu greedytigs", tig_count(tigs));
         return tigs;
     }
     double t0 = now_s();
     const uint64_t dummy_edge_id = insert_pair_edges(g->g, reinterpret_cast<const Pair *>(pairs), n_pairs);
     g_phase[5] = now_s() - t0;
     mtg_walks *tigs = eulerise_and_cut(g->g, dummy_edge_id, *cfg);
-    log_info("Found %zu greedytigs", tigs->w.limits.size());
+    log_info("Found %zu greedytigs", tig_count(tigs));
     return tigs;
 }
 mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg) {
@@ -370,11 +387,16 @@ mtg_walks *mtg_finish_device(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pai
 mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg_config *cfg) {
     check_config(cfg, "mtg_finish_greedytigs_resident");
     if (!g || !g->g.built || !d) MTG_DIE("mtg_finish_greedytigs_resident: graph is not built / null device");
+    // (the resident pairs index the graph d was built from, and their distances are below d's k: the host path checks every pair
+    // it is handed, here the identity of the graph stands for that)
+    if (!device_matches(d->d, g->g, cfg->k))
+        MTG_DIE("mtg_finish_greedytigs_resident: the device copy was built from another graph (node / edge counts differ) or for another k than cfg->k = %llu",
+                (unsigned long long)cfg->k);
     uint64_t n_pairs = 0;
     const mtg_pair *d_pairs = device_resident_pairs(d->d, &n_pairs);
     if (use_device_finish(g->g, nullptr, 0, *cfg) && device_id_of(d->d) == cfg->device_ids[0]) {
         mtg_walks *tigs = finish_on_device(g->g, nullptr, n_pairs, *cfg, d_pairs);
-        log_info("Found %zu greedytigs", tigs->w.limits.size());
+        log_info("Found %zu greedytigs", tig_count(tigs));
         return tigs;
     }
     // host finish, or a finish on another GPU: through the host, like mtg_finish_greedytigs_cfg
@@ -385,6 +407,14 @@ mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg
     return tigs;
 }
 void mtg_release_device_memory(int device_id) { device_release_memory(device_id); }
+void mtg_set_default_device(int device_id) {
+    if (device_id < 0 || device_id >= 64) MTG_DIE("mtg_set_default_device: device id %d out of range", device_id);
+    device_set_default(device_id);
+}
+void mtg_set_finish_tuning(int records, int flags, int64_t record_delay_us) {
+    if (records < 0 || records > 3) MTG_DIE("mtg_set_finish_tuning: unknown record format %d", records);
+    device_set_finish_tuning(records, flags, (long)record_delay_us);
+}
 uint64_t mtg_device_memory_held(int device_id) { return device_memory_held(device_id); }
 void mtg_graph_release_device_cache(mtg_graph *g) {
     if (g) device_release_graph_cache(g->g);
@@ -415,7 +445,7 @@ mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg) {
     g_phase[5] = 0;
     mtg_walks *tigs = use_device_finish(g->g, nullptr, 0, *cfg) ? finish_on_device(g->g, nullptr, 0, *cfg)
                                                                 : eulerise_and_cut(g->g, 0, *cfg);  // eulertigs/mod.rs:101-102
-    log_info("Found %zu eulertigs", tigs->w.limits.size());
+    log_info("Found %zu eulertigs", tig_count(tigs));
     return tigs;
 }
 mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k) {
@@ -623,7 +653,7 @@ mtg_walks *mtg_finish_matchtigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_
     for (uint64_t c = 0; c < cycles.limits.size(); c++) {  // :870-886
         uint64_t longest = 0;
         for (uint64_t i = begin; i < cycles.limits[c]; i++)
-            if (g->g.is_dummy(cycles.edges[i])) longest = std::max<uint64_t>(longest, g->g.e_weight[cycles.edges[i]]);
+            if (g->g.is_dummy(cycles.edges[i])) longest = std::max<uint64_t>(longest, g->g.weight(cycles.edges[i]));
         if (longest > 0 && longest < k) MTG_DIE("Eulerian bicycle contains at least one dummy edge, but no breaking edge (matchtigs/mod.rs:883)");
         begin = cycles.limits[c];
     }
@@ -694,6 +724,8 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
                 for (auto &t : th) t.join();
             }
             mtg_device *dev = devs[0];
+            if (cfg->performance_data_type != MTG_PERFORMANCE_DATA_COMPLETE)  // (the counters are a second search)
+                for (mtg_device *x : devs) device_set_single_use(x->d);
             double t1 = now_s();
             g_phase[0] = t1 - t0;
             log_info("Collecting nodes with missing incoming or outgoing edges");
@@ -740,8 +772,14 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
             mtg_walks *tigs;
             if (resident) {
                 tigs = finish_on_device(g->g, nullptr, n_pairs, *cfg, d_pairs);
-                log_info("Found %zu greedytigs", tigs->w.limits.size());
+                log_info("Found %zu greedytigs", tig_count(tigs));
                 device_free_array(cfg->device_ids[0], d_pairs);
+                if (std::getenv("MTG_DEBUG")) {
+                    uint64_t a[4];
+                    device_arena_stats(cfg->device_ids[0], a);
+                    std::fprintf(stderr, "[mtg] device arena: %.2f GB in chunks (%llu taken from the driver so far), peak of live arrays %.2f GB, estimate for this graph %.2f GB\n",
+                                 a[0] / 1e9, (unsigned long long)a[3], a[2] / 1e9, device_call_bytes_estimate(g->g.node_count(), g->g.n_original_edges, k) / 1e9);
+                }
             } else {
                 tigs = mtg_finish_greedytigs_cfg(g, pairs, n_pairs, cfg);
                 std::free(pairs);
@@ -756,6 +794,52 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
             MTG_DIE("Unknown tigs algorithm identifier %llu", (unsigned long long)tig_algorithm);  // clib.rs:390
     }
     return nullptr;
+}
+
+// The whole path into a caller's clib.rs output arrays (sized as clib.rs:332-348: 2 E, 2 E and E entries for E original edges):
+// what matchtigs_compute_tigs does after it has built its configuration. With a finish on the GPU the tigs never exist as walks on
+// the host: the host threads that empty the download ring write the flattened form (clib.rs:393-407) straight into the caller's
+// arrays, whose pages a helper thread touches while the GPU stages run.
+uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg, int64_t *tigs_edge_out, uint64_t *tigs_insert_out,
+                               uint64_t *tigs_out_limits) {
+    check_config(cfg, "mtg_compute_tigs_clib");
+    if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs_clib: graph is not built");
+    if (!tigs_edge_out || !tigs_insert_out || !tigs_out_limits) MTG_DIE("mtg_compute_tigs_clib: null output array");
+    TigSink sink;
+    sink.edge_out = tigs_edge_out;
+    sink.insert_out = tigs_insert_out;
+    sink.limits_out = tigs_out_limits;
+    const uint64_t E0 = g->g.n_original_edges;
+    std::thread toucher;
+    if ((tig_algorithm == 5 || tig_algorithm == 3) && E0 >= (1u << 22) && use_device_finish(g->g, nullptr, 0, *cfg)) {
+        // fresh output arrays cost a page fault per 4 KB when they are first written: a few threads take those faults now, beside the
+        // device-graph build and the search (tigs hold one edge per unitig and a few matched dummies; a tig per four unitigs is plenty)
+        const uint64_t n_e = E0 / 2 + E0 / 8, n_l = E0 / 4;
+        // (advice only: where the caller's arrays are anonymous memory and the system hands out huge pages on request, a fault brings 2 MB)
+        for (auto r : {std::make_pair((char *)tigs_edge_out, n_e * 8), std::make_pair((char *)tigs_insert_out, n_e * 8), std::make_pair((char *)tigs_out_limits, n_l * 8)}) {
+            const uintptr_t lo = ((uintptr_t)r.first + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), hi = ((uintptr_t)r.first + r.second) & ~(uintptr_t)((2u << 20) - 1);
+            if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+        }
+        toucher = std::thread([=]() {
+            parallel_ranges((n_e * 8 + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t pg = lo; pg < hi; pg++) {
+                    *((volatile char *)tigs_edge_out + pg * 4096) = 0;
+                    *((volatile char *)tigs_insert_out + pg * 4096) = 0;
+                }
+            }, 6);
+            parallel_ranges((n_l * 8 + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t pg = lo; pg < hi; pg++) *((volatile char *)tigs_out_limits + pg * 4096) = 0;
+            }, 6);
+        });
+    }
+    g_clib_sink = &sink;
+    g_clib_sink_used = false;
+    mtg_walks *tigs = mtg_compute_tigs_cfg(g, tig_algorithm, cfg);
+    g_clib_sink = nullptr;
+    if (toucher.joinable()) toucher.join();
+    const uint64_t n = g_clib_sink_used ? sink.n_tigs : flatten_clib(g->g, tigs->w, tigs_edge_out, tigs_insert_out, tigs_out_limits);
+    delete tigs;
+    return n;
 }
 
 mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, int device_id) {
@@ -820,11 +904,8 @@ size_t matchtigs_compute_tigs(MatchtigsData *data, size_t tig_algorithm, size_t 
     cfg.node_weight_array_type = MTG_NODE_WEIGHT_EPOCH_ARRAY;
     cfg.matching_file_prefix = matching_file_prefix;  // clib.rs:362-376
     cfg.matcher_path = matcher_path;
-    mtg_walks *tigs = mtg_compute_tigs_cfg(&data->graph, tig_algorithm, &cfg);
-    const uint64_t n = flatten_clib(data->graph.g, tigs->w, reinterpret_cast<int64_t *>(tigs_edge_out),
-                                    reinterpret_cast<uint64_t *>(tigs_insert_out),
-                                    reinterpret_cast<uint64_t *>(tigs_out_limits));
-    delete tigs;
+    const uint64_t n = mtg_compute_tigs_clib(&data->graph, tig_algorithm, &cfg, reinterpret_cast<int64_t *>(tigs_edge_out),
+                                             reinterpret_cast<uint64_t *>(tigs_insert_out), reinterpret_cast<uint64_t *>(tigs_out_limits));
     delete data;  // Box::from_raw at clib.rs:291: the handle is consumed
     return n;
 }

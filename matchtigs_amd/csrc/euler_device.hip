@@ -933,4 +933,9 @@ Walks device_euler_cycles(const HostGraph &g, int device_id, double *kernel_ms_o
     return result;
 }
 
+void device_warm_euler_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(degree_rank_kernel));
+}
+
 }  // namespace mtg

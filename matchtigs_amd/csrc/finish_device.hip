@@ -583,16 +583,25 @@ static uint64_t host_available_bytes() {
 }
 
 // What the library keeps between calls on a GPU, given back on request (mtg_release_device_memory / mtg_graph_release_device_cache):
-// the finish's block cache, and a graph's device copy of its original edges with their buckets.
+// the chunks of the device's arena that no live array sits in, and a graph's device copy of its original edges with their buckets.
 void device_release_memory(int device_id) {
     if (device_id < 0 || device_id >= device_count()) return;
     HIP_CHECK(hipSetDevice(device_id));
     HIP_CHECK(hipStreamSynchronize(finish_stream(device_id)));
-    device_block_cache(device_id).trim();
+    device_arena(device_id).release_free_chunks(true);
 }
 uint64_t device_memory_held(int device_id) {
     if (device_id < 0 || device_id >= 64) return 0;
-    return device_block_cache(device_id).held_bytes();
+    return device_arena(device_id).reclaimable_bytes();
+}
+void device_set_finish_tuning(int records, int flags, long record_delay_us) {
+    finish_tuning().records.store(records);
+    finish_tuning().flags.store(flags);
+    finish_tuning().record_delay_us.store(record_delay_us < 0 ? 0 : record_delay_us);
+}
+void device_warm_finish_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(head_kernel));
 }
 void device_release_graph_cache(const HostGraph &g) {
     std::lock_guard<std::mutex> l(edge_cache_mutex());
@@ -613,7 +622,7 @@ static hipStream_t finish_side_stream(int device_id) {
 }
 
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
-                    const mtg_pair *d_pairs_resident) {
+                    const mtg_pair *d_pairs_resident, TigSink *sink) {
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
     if (n_pairs && !pairs && !d_pairs_resident) MTG_DIE("device_finish: null pairs");
     if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
@@ -626,6 +635,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     hipStream_t st = finish_stream(device_id);
     Lap lap;
     static_assert(sizeof(Pair) == sizeof(mtg_pair), "pair layout");
+    // (the stage's arrays are ranges of the device's arena: what an earlier stage of the call gave back, else one more chunk now)
+    device_arena(device_id).ensure_free((E0 + 2 * n_pairs + E0 / 3) * 24 + V * 28);
     // GPU time of the stages (HIP events on the finish stream; read at the end): [0,1] insertion + Euleriser kernels, [2,3] buckets +
     // walk records (reference-order mode), [4,5] rotate + cut kernels; the decomposition has its own pair (device_euler_decompose)
     struct StageEvents {
@@ -681,7 +692,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     // configs[4]: the out-degrees come from their row array, and the buckets of the Eulerised darts from a merge (euler_device.hip).
     const uint32_t *d_row0 = nullptr, *d_adj0 = nullptr;
     if (const DeviceEdgeCache *cache = edge_cache_get(g, device_id)) {
-        if (!cache->d_row0 && (V + 1 + E0) * 4 <= (8ull << 30) && E0 && !std::getenv("MTG_NO_EDGE_CACHE")) {
+        if (!cache->d_row0 && (V + 1 + E0) * 4 <= (8ull << 30) && E0 && !(finish_tuning().flags.load() & FT_NO_EDGE_CACHE)) {
             uint32_t *row0 = nullptr, *adj0 = nullptr;
             device_malloc(&row0, (V + 1) * 4);
             device_malloc(&adj0, E0 * 4);
@@ -807,6 +818,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     // by a thread of their own while the GPU decomposes and cuts (joined at the end). ----
     Buf b_to;
     std::thread append_thread;
+    std::atomic<bool> pw_ready{false};  // the host copy of the resident pairs' weights is complete (a sink flattens with it)
     hipEvent_t ev_heads = nullptr;
     std::unique_ptr<uint32_t[]> h_pw;  // resident pairs: their weights for the host graph (4 of the 16 bytes of a pair); not zero-filled
     {
@@ -822,13 +834,9 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         auto fill = [&g, pairs, h_pw_p, n_pairs, k, E0, n_dummy]() {  // weights, dummy ids (1-based, :681 / mod.rs:573)
             parallel_ranges(n_dummy / 2, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t i = lo; i < hi; i++) {
-                    const uint64_t e = E0 + 2 * i;
                     const uint64_t w = i < n_pairs ? (pairs ? pairs[i].distance : (uint64_t)h_pw_p[i]) : k;
-                    g.e_weight[e] = g.e_weight[e + 1] = w;
-                    g.e_dummy[e] = g.e_dummy[e + 1] = i + 1;
-                    g.e_unitig[e] = g.e_unitig[e + 1] = 0;
-                    g.e_fwd[e] = 1;
-                    g.e_fwd[e + 1] = 0;
+                    g.w_biedge[E0 / 2 + i] = w;  // (the payload is per biedge: host_graph.hpp)
+                    g.dummy_tail[i] = i + 1;
                 }
             });
         };
@@ -852,17 +860,19 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             // kernel of our own with 16 to 256 workgroups was measured and is worse at every width: 29.5-34 ms for the
             // decomposition against 26.5.)
             uint32_t *h_from = g.e_from.data() + E0, *h_to = g.e_to.data() + E0;
-            append_thread = std::thread([fill, ev_heads, device_id, h_from, h_to, h_pw_p, d_from, d_to, d_pw, pairs, n_pairs, E0, n_dummy]() {
+            append_thread = std::thread([fill, ev_heads, device_id, h_from, h_to, h_pw_p, d_from, d_to, d_pw, pairs, n_pairs, E0, n_dummy, &pw_ready]() {
                 HIP_CHECK(hipSetDevice(device_id));
                 hipStream_t side = finish_side_stream(device_id);
                 HIP_CHECK(hipStreamWaitEvent(side, ev_heads, 0));
                 if (!pairs && n_pairs) download_sliced(h_pw_p, d_pw, n_pairs * 4, side, device_id);
+                pw_ready.store(true, std::memory_order_release);
                 download_sliced(h_from, d_from + E0, n_dummy * 4, side, device_id);
                 download_sliced(h_to, d_to, n_dummy * 4, side, device_id);
                 fill();
             });
         } else {
             download(st);
+            pw_ready.store(true, std::memory_order_release);
             fill();
         }
         g.first_breaking_edge = first_brk;
@@ -876,12 +886,21 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     std::thread prefault_thread;
     {
         const uint64_t bound_edges = E0 / 2 + n_pairs, bound_tigs = n_dummy / 2 + 4096;
-        tigs.edges.reserve(bound_edges);
-        tigs.limits.reserve(bound_tigs);
+        if (!sink) {
+            tigs.edges.resize(bound_edges);  // (PodVec: no element is written; shrunk to the real sizes after the cut)
+            tigs.limits.resize(bound_tigs);
+        }
+        // (a sink's arrays are sized as clib.rs:332-348: 2 E0 / 2 E0 / E0 entries. Its first array is touched here, the second by the
+        // same threads through the offset below; a caller that passes touched memory loses nothing)
         if ((bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
-            char *pe = reinterpret_cast<char *>(tigs.edges.data()), *pl = reinterpret_cast<char *>(tigs.limits.data());
-            const uint64_t be = bound_edges * 4, bl = bound_tigs * 8;
-            prefault_thread = std::thread([pe, pl, be, bl]() {
+            char *pe = sink ? reinterpret_cast<char *>(sink->edge_out) : reinterpret_cast<char *>(tigs.edges.data());
+            char *pl = sink ? reinterpret_cast<char *>(sink->limits_out) : reinterpret_cast<char *>(tigs.limits.data());
+            char *pi = sink ? reinterpret_cast<char *>(sink->insert_out) : nullptr;
+            const uint64_t be = sink ? bound_edges * 8 : bound_edges * 4, bl = std::min<uint64_t>(bound_tigs, std::max<uint64_t>(E0, 1)) * 8;
+            prefault_thread = std::thread([pe, pl, pi, be, bl]() {
+                if (pi) parallel_ranges((be + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t pg = lo; pg < hi; pg++) *(volatile char *)(pi + pg * 4096) = 0;
+                });
                 parallel_ranges((be + bl + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
                     for (uint64_t pg = lo; pg < hi; pg++) {
                         const uint64_t off = pg * 4096;
@@ -895,6 +914,8 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     if (times_out) times_out[1] = lap.lap("host graph: dummy edges");
     if (E == 0) {
         if (prefault_thread.joinable()) prefault_thread.join();
+        tigs.edges.resize(0);
+        tigs.limits.resize(0);
         return tigs;
     }
 
@@ -925,11 +946,19 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 b_row.release(); b_adj.release(); b_need.release(); b_off.release();
                 cycles = euler_cycles_generic(g);
             } else {
+                struct EventHolder {
+                    hipEvent_t e = nullptr;
+                    EventHolder() { HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+                    ~EventHolder() { if (e) (void)hipEventDestroy(e); }
+                    hipEvent_t get() const { return e; }
+                } ev_lean;
                 LeanNode *d_nodes = b_nodes.alloc<LeanNode>(st, V);
                 uint32_t *d_xe = b_xe.alloc<uint32_t>(st, ext_total), *d_xt = b_xt.alloc<uint32_t>(st, ext_total);
                 lean_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_row, d_adj, d_from, d_mirror, d_off, d_nodes, d_xe, d_xt);
                 HIP_CHECK(hipGetLastError());
                 sev.mark(3, st);
+                // (a download of the 32-byte records on the side stream waits for this: nothing else orders the two streams)
+                HIP_CHECK(hipEventRecord(ev_lean.get(), st));
                 std::vector<uint32_t> ext_eid(ext_total), ext_to(ext_total);
                 if (ext_total) {
                     HIP_CHECK(hipMemcpyAsync(ext_eid.data(), d_xe, (uint64_t)ext_total * 4, hipMemcpyDeviceToHost, st));
@@ -941,16 +970,18 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 // (speed / memory only).
                 // The larger formats are only chosen when the host has room for them next to the walk's entry arrays (16 bytes
                 // per dart) -- free memory as the kernel and the cgroup report it.
-                const char *rec = std::getenv("MTG_EULER_RECORDS");
+                const int rec = finish_tuning().records.load();  // (mtg_set_finish_tuning: 1 lean, 2 mid, 3 wide)
+                const int tuning_flags = finish_tuning().flags.load();
+                const long delay_us = finish_tuning().record_delay_us.load();  // (tests: slow arrival, so that small graphs take the 32-byte path too)
                 const uint64_t room = host_available_bytes(), walk_arrays = E * 16;
-                const bool wide = rec ? std::strcmp(rec, "wide") == 0 : (V * 256 <= (48ull << 30) && V * 256 + walk_arrays <= room / 4 * 3);
-                const bool mid = rec ? std::strcmp(rec, "mid") == 0 : (!wide && V * 128 <= (100ull << 30) && V * (128 + 32) + walk_arrays <= room / 4 * 3);
+                const bool wide = rec ? rec == 3 : (V * 256 <= (48ull << 30) && V * 256 + walk_arrays <= room / 4 * 3);
+                const bool mid = rec ? rec == 2 : (!wide && V * 128 <= (100ull << 30) && V * (128 + 32) + walk_arrays <= room / 4 * 3);
                 if (mid) {
                     // built on the GPU (one gather level) and brought down in slices through pageable memory: these are the
                     // graphs of a hundred gigabytes, where page-locking the arena would cost more than the copy
                     HugeBuf<EulerNode2> mbuf(V, &g.arena);
                     b_row.release(); b_adj.release(); b_need.release(); b_off.release();
-                    static const bool overlap_mid = std::getenv("MTG_NO_RECORD_OVERLAP") == nullptr;
+                    const bool overlap_mid = !(tuning_flags & FT_NO_RECORD_OVERLAP);
                     const uint64_t slice = std::max<uint64_t>(1, (1ull << 30) / sizeof(EulerNode2));  // 1 GB of records at a time
                     auto build_and_download = [&](std::atomic<uint64_t> *arrived, long delay_us) {
                         Buf b_mid;
@@ -975,8 +1006,6 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         HugeBuf<LeanNode> lbuf(V, &g.arena);
                         download_sliced(lbuf.p, d_nodes, V * sizeof(LeanNode), st, device_id);
                         std::atomic<uint64_t> arrived{0};
-                        const char *delay_env = std::getenv("MTG_TEST_RECORD_DELAY_US");
-                        const long delay_us = delay_env ? std::atol(delay_env) : 0;
                         std::thread mover([&build_and_download, &arrived, delay_us, device_id]() {
                             HIP_CHECK(hipSetDevice(device_id));
                             build_and_download(&arrived, delay_us);
@@ -1005,7 +1034,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                     HugeBuf<EulerNode3> wbuf(V, &g.arena);
                     bool pinned = false;
                     const unsigned uses = g.arena.uses_of(wbuf.p, &pinned);
-                    static const bool pin_ok = std::getenv("MTG_NO_PIN") == nullptr;
+                    const bool pin_ok = !(tuning_flags & FT_NO_PIN);
                     if (!pinned && uses >= 2 && pin_ok) {
                         HugeArena::unpin_hook() = [](void *p) { (void)hipHostUnregister(p); };
                         if (hipHostRegister(wbuf.p, wbuf.bytes, hipHostRegisterDefault) == hipSuccess) {
@@ -1022,7 +1051,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                         wide_build_kernel<<<grid_for(V), EB, 0, st>>>(V, d_nodes, d_wide);
                         HIP_CHECK(hipGetLastError());
                         sev.mark(3, st);
-                        static const bool overlap_ok = std::getenv("MTG_NO_RECORD_OVERLAP") == nullptr;
+                        const bool overlap_ok = !(tuning_flags & FT_NO_RECORD_OVERLAP);
                         if (overlap_ok && V >= (1u << 16) && host_available_bytes() >= V * sizeof(LeanNode) + (4ull << 30)) {  // (room for the 32-byte records beside everything else)
                             // The walk starts while the records still cross PCIe (23 GB = 0.4-0.5 s at 2^27, a twentieth of the step): they
                             // arrive in node order, slice by slice, `arrived` says how far they have come, and a step that needs a record
@@ -1032,11 +1061,10 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                             // pinned ring on a thread of their own, whose copying threads report every slice they have moved out.
                             HugeBuf<LeanNode> lbuf(V, &g.arena);
                             hipStream_t side = finish_side_stream(device_id);
-                            download_sliced(lbuf.p, d_nodes, V * sizeof(LeanNode), side, device_id);  // (d_nodes was complete before the spill sizes were read back)
+                            HIP_CHECK(hipStreamWaitEvent(side, ev_lean.get(), 0));  // (lean_build_kernel, which writes d_nodes, runs on `st`)
+                            download_sliced(lbuf.p, d_nodes, V * sizeof(LeanNode), side, device_id);
                             HIP_CHECK(hipStreamSynchronize(st));  // (the spill arrays' copies and wide_build_kernel: done by now, the 32-byte records took longer)
                             std::atomic<uint64_t> arrived{0};
-                            const char *delay_env = std::getenv("MTG_TEST_RECORD_DELAY_US");  // (tests: slow arrival, so that small graphs take the 32-byte path too)
-                            const long delay_us = delay_env ? std::atol(delay_env) : 0;
                             std::vector<hipEvent_t> evs;
                             std::vector<uint64_t> upto;
                             std::thread mover;
@@ -1140,11 +1168,45 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipGetLastError());
         sev.mark(5, st);
         if (prefault_thread.joinable()) prefault_thread.join();
-        tigs.edges.resize(n_kept);
-        tigs.limits.resize(n_tigs);
-        download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
-        // (the limits cross PCIe as 32-bit words and are widened by the host threads that empty the download ring)
-        download_sliced_widen(tigs.limits.data(), d_tl, n_tigs, st, device_id);
+        if (sink) {
+            // clib.rs:393-407 on the way out of the download ring: an original edge e is unitig e >> 1, forwards iff e is even
+            // (host_graph.hpp); a dummy edge inside a tig is a matched pair, whose weight is its distance
+            while (!pw_ready.load(std::memory_order_acquire)) std::this_thread::yield();  // (resident pairs: their weights came down first, on the side stream)
+            const uint32_t E0u = (uint32_t)E0;
+            const uint32_t *pw = h_pw.get();
+            int64_t *eo = sink->edge_out;
+            uint64_t *io = sink->insert_out;
+            auto expand = [=](size_t first, const uint32_t *e, size_t n) {
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t x = e[i];
+                    if (x < E0u) {
+                        eo[first + i] = (x & 1u) ? -(int64_t)(x >> 1) : (int64_t)(x >> 1);
+                        io[first + i] = 0;
+                    } else {
+                        const uint64_t b = (x - E0u) >> 1;
+                        eo[first + i] = 0;
+                        io[first + i] = b < n_pairs ? (pairs ? pairs[b].distance : (uint64_t)pw[b]) : k;
+                    }
+                }
+            };
+            if (n_kept * 4 < (64u << 20)) {
+                std::vector<uint32_t> tmp(n_kept);
+                if (n_kept) HIP_CHECK(hipMemcpyAsync(tmp.data(), d_te, n_kept * 4, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                expand(0, tmp.data(), n_kept);
+            } else
+                download_sliced_with(d_te, n_kept * 4, st, device_id,
+                                     [&expand](size_t off, const char *src, size_t n) { expand(off / 4, reinterpret_cast<const uint32_t *>(src), n / 4); });
+            download_sliced_widen(sink->limits_out, d_tl, n_tigs, st, device_id);
+            sink->n_tigs = n_tigs;
+            sink->n_edges = n_kept;
+        } else {
+            tigs.edges.resize(n_kept);
+            tigs.limits.resize(n_tigs);
+            download_sliced(tigs.edges.data(), d_te, n_kept * 4, st, device_id);
+            // (the limits cross PCIe as 32-bit words and are widened by the host threads that empty the download ring)
+            download_sliced_widen(tigs.limits.data(), d_tl, n_tigs, st, device_id);
+        }
     }
     if (times_out) times_out[3] = lap.lap("rotate + cut + download");
     if (append_thread.joinable()) {

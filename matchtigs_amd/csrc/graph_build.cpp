@@ -7,13 +7,14 @@
 #include <algorithm>
 #include <thread>
 
+#include "device.hpp"
 #include "parallel.hpp"
 
 namespace mtg {
 
 void HostGraph::init_nodes(uint64_t n) {
     if (n >= NONE) MTG_DIE("graph has %llu nodes; node ids are 32-bit", (unsigned long long)n);
-    mirror.assign(n, NONE);
+    mirror.resize(n);  // (uninitialised: graph_from_edges copies into it from host threads, builder_build fills it with NONE first)
     // (head_out / out_deg: sized by the first ensure_linked() -- the device path never walks host adjacency, and 8 bytes per node
     // of first-touch plus the linking itself were 0.4 of the 0.65 s a one-shot caller spent building the 2^27 graph)
     head_out.clear();
@@ -24,27 +25,7 @@ void HostGraph::init_nodes(uint64_t n) {
 
 void HostGraph::reserve_edges(uint64_t n) {
     e_from.reserve(n); e_to.reserve(n); e_next_out.reserve(n);
-    e_weight.reserve(n); e_dummy.reserve(n); e_unitig.reserve(n); e_fwd.reserve(n);
-}
-
-static inline void push_edge(HostGraph &g, uint32_t from, uint32_t to, uint64_t w, uint64_t dummy, uint64_t unitig,
-                             bool fwd) {
-    if (g.e_from.size() >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
-    uint32_t e = (uint32_t)g.e_from.size();
-    g.e_from.push_back(from); g.e_to.push_back(to);
-    g.e_weight.push_back(w); g.e_dummy.push_back(dummy); g.e_unitig.push_back(unitig); g.e_fwd.push_back(fwd ? 1 : 0);
-    g.e_next_out.push_back(g.head_out[from]);  // newest first, like petgraph's per-node edge list
-    g.head_out[from] = e;
-    g.out_deg[from]++;
-}
-
-uint32_t HostGraph::add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig) {
-    ensure_linked();
-    uint32_t e = (uint32_t)e_from.size();
-    push_edge(*this, from, to, weight, dummy_id, unitig, true);
-    push_edge(*this, mirror[to], mirror[from], weight, dummy_id, unitig, false);
-    linked_edges = e_from.size();
-    return e;
+    w_biedge.reserve(n / 2 + 1);
 }
 
 // Links the edges [lo, hi) into the per-node adjacency lists in ascending id, i.e. exactly as one-by-one insertion would
@@ -107,8 +88,10 @@ void HostGraph::ensure_linked() const {
 void HostGraph::append_unlinked(uint64_t n_new) {
     const uint64_t total = e_from.size() + n_new;
     if (total >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
+    if ((e_from.size() | n_new) & 1) MTG_DIE("internal error: edges come in (edge, mirror edge) pairs");
     e_from.resize(total); e_to.resize(total); e_next_out.resize(total);
-    e_weight.resize(total); e_dummy.resize(total); e_unitig.resize(total); e_fwd.resize(total);
+    w_biedge.resize(total / 2);
+    if (built) dummy_tail.resize((total - n_original_edges) / 2);
 }
 
 // Appends n dummy biedges (out[i] -> in[i] with weight[i] and dummy id first_dummy_id + 1 + i, each followed by its
@@ -124,10 +107,8 @@ void HostGraph::add_biedges_bulk(const uint32_t *out, const uint32_t *in, const 
             const uint64_t e = base + 2 * i;
             e_from[e] = out[i]; e_to[e] = in[i];
             e_from[e + 1] = mirror[in[i]]; e_to[e + 1] = mirror[out[i]];
-            e_weight[e] = e_weight[e + 1] = weight[i];
-            e_dummy[e] = e_dummy[e + 1] = first_dummy_id + 1 + i;
-            e_unitig[e] = e_unitig[e + 1] = 0;
-            e_fwd[e] = 1; e_fwd[e + 1] = 0;
+            w_biedge[e >> 1] = weight[i];
+            dummy_tail[(e - n_original_edges) >> 1] = first_dummy_id + 1 + i;
         }
     });
     if (link) ensure_linked();
@@ -158,7 +139,8 @@ void HostGraph::reset_to_original() {
         });
     linked_edges = std::min(linked_edges, keep);
     e_from.resize(keep); e_to.resize(keep); e_next_out.resize(keep);
-    e_weight.resize(keep); e_dummy.resize(keep); e_unitig.resize(keep); e_fwd.resize(keep);
+    w_biedge.resize(keep / 2);
+    dummy_tail.resize(0);
 }
 
 void HostGraph::validate_pairing() const {
@@ -185,6 +167,8 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
     if ((n_nodes && !mirror) || (n_edges && (!from || !to || !weight))) MTG_DIE("mtg_graph_from_edges: null array");
     if (n_edges % 2) MTG_DIE("mtg_graph_from_edges: edges must come in (forward, mirror) pairs");
     if (n_edges >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
+    // (a helper thread starts the HIP runtime and reserves the device memory of the call that will follow, beside the work below)
+    device_reserve_async(n_nodes, n_edges);
     HostGraph *g = new HostGraph();
     static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -207,7 +191,7 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
     // now -- address space only, untouched pages cost nothing --, so that the first insertion does not copy 5 GB of edge arrays.
     g->reserve_edges(n_edges + n_edges / 2 + 1024);
     g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
-    g->e_weight.resize(n_edges); g->e_dummy.resize(n_edges); g->e_unitig.resize(n_edges); g->e_fwd.resize(n_edges);
+    g->w_biedge.resize(n_edges / 2);
     parallel_ranges(n_edges / 2, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t u = lo; u < hi; u++) {
             const uint64_t e = 2 * u;
@@ -218,10 +202,7 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
                 MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (edge %llu)", (unsigned long long)e);
             g->e_from[e] = f; g->e_to[e] = t;
             g->e_from[e + 1] = from[e + 1]; g->e_to[e + 1] = to[e + 1];
-            g->e_weight[e] = g->e_weight[e + 1] = weight[e];
-            g->e_dummy[e] = g->e_dummy[e + 1] = 0;
-            g->e_unitig[e] = g->e_unitig[e + 1] = u;
-            g->e_fwd[e] = 1; g->e_fwd[e + 1] = 0;
+            g->w_biedge[u] = weight[e];  // (edge 2u = unitig u forwards, edge 2u + 1 its mirror: host_graph.hpp)
         }
     });
     lap("edge arrays");
@@ -249,6 +230,9 @@ static inline uint64_t uf_root(HostGraph *g, uint64_t x) {
 }
 
 HostGraph *builder_new(uint64_t unitig_amount) {
+    // (a helper thread starts the HIP runtime and reserves the device memory of the call that will follow, while the caller reports
+    // its links: a compacted de Bruijn graph has about 1.4 nodes per unitig)
+    device_reserve_async(unitig_amount + unitig_amount / 2, 2 * unitig_amount);
     HostGraph *g = new HostGraph();
     g->has_builder = true;
     g->unitig_amount = unitig_amount;
@@ -296,7 +280,10 @@ void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
     for (uint64_t i = 0; i < slots; i++) (void)uf_root(g, i);  // full compression once: the parallel fill below only reads parents
     g->reserve_edges(n_edges + n_edges / 2 + 1024);  // (room for the dummy edges: see graph_from_edges)
     g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
-    g->e_weight.resize(n_edges); g->e_dummy.resize(n_edges); g->e_unitig.resize(n_edges); g->e_fwd.resize(n_edges);
+    g->w_biedge.resize(n_edges / 2);
+    parallel_ranges(n_nodes, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) g->mirror[i] = NONE;
+    });
     auto node_of = [&](uint64_t slot) { return node_of_root[g->uf_parent[slot]]; };
     // set_mirror_nodes (clib.rs:236-237) is an assignment in unitig order: a later unitig re-pairs a node an earlier one
     // paired differently (then verify_node_pairing fails below, as in the reference); kept sequential for that order
@@ -310,10 +297,7 @@ void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
             const uint64_t e = 2 * u;
             g->e_from[e] = node_of(u * 4); g->e_to[e] = node_of(u * 4 + 2);              // clib.rs:239-243
             g->e_from[e + 1] = node_of(u * 4 + 3); g->e_to[e + 1] = node_of(u * 4 + 1);  // clib.rs:244-248
-            g->e_weight[e] = g->e_weight[e + 1] = unitig_weights[u];
-            g->e_dummy[e] = g->e_dummy[e + 1] = 0;
-            g->e_unitig[e] = g->e_unitig[e + 1] = u;
-            g->e_fwd[e] = 1; g->e_fwd[e + 1] = 0;
+            g->w_biedge[u] = unitig_weights[u];
         }
     });
     link_adjacency(*g, n_edges);

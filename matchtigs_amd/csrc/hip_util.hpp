@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <future>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -27,6 +28,20 @@
 
 namespace mtg {
 namespace hu {
+
+// Tuning of the finishing stages for measurements and tests (mtg_set_finish_tuning, include/mtg_engine.h): process-wide, read at
+// the start of a call, never changes a result. The library reads no environment variable for any of it.
+struct FinishTuning {
+    std::atomic<int> records{0};           // walk records of the reference-order mode: 0 = the engine's choice, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte
+    std::atomic<int> flags{0};             // bit 0: the walk waits for all of its records; bit 1: never page-lock the record arena;
+                                           // bit 2: keep nothing of the graph on the device between calls (edges, mirror, buckets)
+    std::atomic<long> record_delay_us{0};  // tests: slows the arrival of the walk's records
+};
+enum : int { FT_NO_RECORD_OVERLAP = 1, FT_NO_PIN = 2, FT_NO_EDGE_CACHE = 4 };
+inline FinishTuning &finish_tuning() {
+    static FinishTuning t;
+    return t;
+}
 
 constexpr int EB = 256;  // threads per block of the element-wise kernels
 inline unsigned grid_for(uint64_t n, int block = EB) { return (unsigned)((n + (uint64_t)block - 1) / (uint64_t)block); }
@@ -112,105 +127,269 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
     HIP_CHECK(hipGetLastError());
 }
 
-// Stream-ordered allocation from the device's default memory pool (which the callers tell to keep freed memory: the work
-// arrays of a call cost milliseconds to map afresh, and a driver that finishes graph after graph reuses them).
-// Device work arrays of the finishing stages. Every call asks for the same sizes again, so released blocks are kept per device and
-// handed back by size (the smallest that fits, at most twice the request); what is not there comes from hipMalloc. (The runtime's
-// stream-ordered pool -- hipMallocAsync with the release threshold at its maximum -- was used until the end of round 3: on some
-// boxes the twelve allocations at the head of the Euler decomposition then took 0.5 to 4.7 s on some steps, nothing on the others.)
-// All users run on the one finish stream of their device, so a block released earlier on that stream is free when it is used again.
-struct DeviceBlockCache {
-    struct Kept { void *p; uint64_t gen; };
+// ---- device memory: one arena per device ----------------------------------------------------------------------------------
+// Every device array of the library -- device graph, search and replay work arrays, the finishing stages' arrays, the graph's kept
+// edge arrays -- is a range of a few large hipMalloc'd CHUNKS, handed out by a best-fit free list with coalescing. Why: what a
+// hipMalloc costs differs by two orders of magnitude between the boxes of one pool (0.1 ms to 30-60 ms per GB: the driver's cold
+// step of round 4 paid 0.44 s for the ~24 GB its stages allocated one after the other, most of it memory an earlier stage had just
+// given back), and a one-shot caller -- the only kind the reference has, clib.rs:291 -- pays all of it. With the arena a call's
+// stages reuse each other's memory (the device graph's blocks become the finish's dart arrays), the first chunk is sized for the
+// whole call from (V, E) and reserved by ONE hipMalloc on a helper thread while the host still builds the graph
+// (arena_reserve_async), and a caller that iterates allocates nothing after its first call.
+// Ordering: a range released by a hu::Buf may still be in use by work queued on the device's finish stream ("dirty"); a Buf
+// allocation takes it as it is (same stream: ordered), any other allocation synchronises that stream first. device_free() keeps
+// hipFree's meaning (the device is idle when it returns).
+hipStream_t finish_stream(int device_id);
+struct DeviceArena {
+    struct Chunk { char *base; size_t bytes; size_t live = 0, peak_live = 0; };
+    struct Range { size_t bytes; bool dirty; };
     std::mutex m;
-    std::multimap<size_t, Kept> free_blocks;
-    size_t held = 0;
-    uint64_t gen = 1;  // number of the running call: a block given back carries it
-    static constexpr size_t GRAIN = 1u << 20, HOLD_LIMIT = 192ull << 30;
-    static size_t rounded(size_t bytes) { return (std::max<size_t>(bytes, 1) + GRAIN - 1) / GRAIN * GRAIN; }
-    // the smallest kept block that holds `bytes` and is at most twice as large (a stage's arrays fit the blocks an earlier stage of
-    // the same call gave back: the first call on a large graph allocates less from the driver, where a gigabyte costs ~50 ms on some
-    // boxes); *block_bytes = the block's real size, to be handed to give()
-    void *take(size_t bytes, size_t *block_bytes) {
-        const size_t want = rounded(bytes);
-        {
-            std::lock_guard<std::mutex> lock(m);
-            auto it = free_blocks.lower_bound(want);
-            if (it != free_blocks.end() && it->first <= 2 * want) {
-                void *p = it->second.p;
-                *block_bytes = it->first;
-                held -= it->first;
-                free_blocks.erase(it);
-                return p;
+    std::vector<Chunk> chunks;
+    std::map<char *, Range> free_ranges;                  // by address (coalescing)
+    std::multimap<size_t, char *> free_by_size;           // best fit
+    std::map<char *, size_t> live;                        // allocated ranges
+    size_t live_bytes = 0, peak_bytes = 0, chunk_bytes = 0;
+    uint64_t n_chunk_allocs = 0;
+    int device = 0;
+    size_t device_total = 0;           // bytes of HBM on the device (first use)
+    std::shared_future<void> pending;  // a reservation under way on a helper thread (device_reserve_async): allocations wait for it instead of growing
+    static constexpr size_t SMALL = 4096, BIG = 2u << 20;
+    static size_t rounded(size_t bytes) {
+        bytes = std::max<size_t>(bytes, 1);
+        const size_t g = bytes >= BIG ? BIG : SMALL;  // (large arrays start and end on 2-MB boundaries: whole translation fragments)
+        return (bytes + g - 1) / g * g;
+    }
+    void erase_size_entry(size_t bytes, char *p) {
+        auto r = free_by_size.equal_range(bytes);
+        for (auto it = r.first; it != r.second; ++it)
+            if (it->second == p) { free_by_size.erase(it); return; }
+    }
+    void insert_free(char *p, size_t bytes, bool dirty) {  // (under the lock) with coalescing inside the chunk
+        Chunk *c = chunk_of(p);
+        auto next = free_ranges.lower_bound(p);
+        if (next != free_ranges.end() && p + bytes == next->first && chunk_of(next->first) == c) {
+            bytes += next->second.bytes;
+            dirty = dirty || next->second.dirty;
+            erase_size_entry(next->second.bytes, next->first);
+            next = free_ranges.erase(next);
+        }
+        if (next != free_ranges.begin()) {
+            auto prev = std::prev(next);
+            if (prev->first + prev->second.bytes == p && chunk_of(prev->first) == c) {
+                p = prev->first;
+                bytes += prev->second.bytes;
+                dirty = dirty || prev->second.dirty;
+                erase_size_entry(prev->second.bytes, prev->first);
+                free_ranges.erase(prev);
             }
         }
-        *block_bytes = want;
+        free_ranges[p] = Range{bytes, dirty};
+        free_by_size.emplace(bytes, p);
+    }
+    Chunk *chunk_of(const void *p) {
+        for (Chunk &c : chunks)
+            if ((const char *)p >= c.base && (const char *)p < c.base + c.bytes) return &c;
+        return nullptr;
+    }
+    // A chunk for a whole call is only taken while it is small next to the device (a quarter of its memory): the stand-ins of BASELINE
+    // configs[3] and [4] (2^30, 2^31 edges) fill most of the HBM, and a chunk sized for the call's peak would sit half empty beside the
+    // other allocators of the process. Beyond that size every array gets a chunk of its own, exactly as large as it is.
+    size_t whole_call_limit() {
+        if (!device_total) {
+            size_t free_b = 0, total_b = 0;
+            device_total = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b : (size_t)(64ull << 30);
+        }
+        return device_total / 4;
+    }
+    bool add_chunk(size_t bytes) {  // (under the lock)
+        bytes = (bytes + BIG - 1) / BIG * BIG;
         void *p = nullptr;
-        if (hipMalloc(&p, want) != hipSuccess) {  // out of memory with blocks of other sizes held back: give them up and try again
+        if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
-            trim();
-            HIP_CHECK(hipMalloc(&p, want));
+            return false;
         }
-        return p;
+        Chunk c;
+        c.base = (char *)p;
+        c.bytes = bytes;
+        chunks.push_back(c);
+        chunk_bytes += bytes;
+        n_chunk_allocs++;
+        free_ranges[(char *)p] = Range{bytes, false};
+        free_by_size.emplace(bytes, (char *)p);
+        return true;
     }
-    void give(void *p, size_t block_bytes) {
-        {
-            std::lock_guard<std::mutex> lock(m);
-            if (held + block_bytes <= HOLD_LIMIT) {
-                free_blocks.emplace(block_bytes, Kept{p, gen});
-                held += block_bytes;
-                return;
-            }
-        }
-        (void)hipFree(p);  // (more than HOLD_LIMIT kept already: calls of that size are trimmed at their end anyway)
-    }
-    // End of a call: what it did not touch goes back to the driver, so the cache never holds more than the last call's own arrays
-    // (a driver that finishes graphs of different sizes would otherwise collect blocks of every size it has ever seen, out of
-    // reach of the other allocators of the process).
-    void end_call() {
+    // entirely free chunks go back to the driver (all == false: only those the calls since the last end_call() used less than a
+    // quarter of, so that a caller that moves on to smaller graphs does not sit on the largest one's memory)
+    void release_free_chunks(bool all) {
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lock(m);
-            for (auto it = free_blocks.begin(); it != free_blocks.end();) {
-                if (it->second.gen < gen) {
-                    drop.push_back(it->second.p);
-                    held -= it->first;
-                    it = free_blocks.erase(it);
-                } else ++it;
+            for (size_t i = 0; i < chunks.size();) {
+                Chunk &c = chunks[i];
+                auto it = free_ranges.find(c.base);
+                const bool empty = c.live == 0 && it != free_ranges.end() && it->second.bytes == c.bytes;
+                if (empty && (all || c.peak_live < c.bytes / 4)) {
+                    erase_size_entry(c.bytes, c.base);
+                    free_ranges.erase(it);
+                    drop.push_back(c.base);
+                    chunk_bytes -= c.bytes;
+                    chunks.erase(chunks.begin() + (long)i);
+                } else i++;
             }
-            gen++;
+            if (!all) for (Chunk &c : chunks) c.peak_live = c.live;
         }
+        if (all) { std::lock_guard<std::mutex> lock(m); peak_bytes = live_bytes; }
+        if (!drop.empty()) (void)hipDeviceSynchronize();
         for (void *p : drop) (void)hipFree(p);
     }
-    void trim() {
-        std::multimap<size_t, Kept> drop;
-        {
-            std::lock_guard<std::mutex> lock(m);
-            drop.swap(free_blocks);
-            held = 0;
+    // `for_finish_stream`: the caller works on the device's finish stream only (hu::Buf)
+    void *alloc(size_t bytes, bool for_finish_stream, size_t grow_hint = 0) {
+        const size_t want = rounded(bytes);
+        bool sync_finish = false;
+        void *out = nullptr;
+        for (int attempt = 0; attempt < 3 && !out; attempt++) {
+            {
+                std::unique_lock<std::mutex> lock(m);
+                auto it = free_by_size.lower_bound(want);
+                if (it != free_by_size.end()) {
+                    char *p = it->second;
+                    const size_t have = it->first;
+                    const Range r = free_ranges[p];
+                    free_by_size.erase(it);
+                    free_ranges.erase(p);
+                    // a large request takes the END of the range when the range is much larger (long-lived small arrays collect at the
+                    // front of a chunk, the big work arrays at its back)
+                    char *mine = p;
+                    if (have > want) {
+                        const bool at_end = want >= BIG && ((size_t)(p + have - want) % BIG) == 0;
+                        if (at_end) {
+                            mine = p + have - want;
+                            free_ranges[p] = Range{have - want, r.dirty};
+                            free_by_size.emplace(have - want, p);
+                        } else {
+                            free_ranges[p + want] = Range{have - want, r.dirty};
+                            free_by_size.emplace(have - want, p + want);
+                        }
+                    }
+                    live[mine] = want;
+                    live_bytes += want;
+                    peak_bytes = std::max(peak_bytes, live_bytes);
+                    Chunk *c = chunk_of(mine);
+                    c->live += want;
+                    c->peak_live = std::max(c->peak_live, c->live);
+                    if (r.dirty && !for_finish_stream) sync_finish = true;
+                    out = mine;
+                    break;
+                }
+                if (pending.valid()) {  // a chunk is on its way
+                    std::shared_future<void> f = pending;
+                    pending = std::shared_future<void>();
+                    lock.unlock();
+                    f.wait();
+                    lock.lock();
+                    attempt--;
+                    continue;
+                }
+                if (grow_hint > whole_call_limit()) grow_hint = 0;
+                if (attempt == 0 && add_chunk(std::max(want, grow_hint))) continue;
+                if (attempt == 0 && grow_hint > want && add_chunk(want)) continue;
+            }
+            if (attempt == 0) { release_free_chunks(true); continue; }  // the device is full: give up what is held and try once more
+            if (attempt == 1) {
+                std::lock_guard<std::mutex> lock(m);
+                if (!add_chunk(want)) MTG_DIE("out of device memory: %zu bytes on device %d (the library holds %zu in %zu chunks)", want, device, chunk_bytes, chunks.size());
+            }
         }
-        for (auto &kv : drop) (void)hipFree(kv.second.p);
+        if (!out) MTG_DIE("out of device memory: %zu bytes on device %d", want, device);
+        if (sync_finish) {
+            HIP_CHECK(hipStreamSynchronize(finish_stream(device)));
+            std::lock_guard<std::mutex> lock(m);  // everything released before this point is idle now
+            for (auto &kv : free_ranges) kv.second.dirty = false;
+        }
+        return out;
     }
-    size_t held_bytes() {
+    bool owns(const void *p) {
         std::lock_guard<std::mutex> lock(m);
-        return held;
+        return live.count((char *)p) != 0;
+    }
+    void free(void *p, bool dirty) {
+        std::lock_guard<std::mutex> lock(m);
+        auto it = live.find((char *)p);
+        if (it == live.end()) MTG_DIE("internal error: device range %p is not an allocation of the arena of device %d", p, device);
+        const size_t bytes = it->second;
+        live.erase(it);
+        live_bytes -= bytes;
+        chunk_of(p)->live -= bytes;
+        insert_free((char *)p, bytes, dirty);
+    }
+    // one chunk of `bytes` unless that much is free in one piece already
+    void reserve(size_t bytes) {
+        bytes = (bytes + BIG - 1) / BIG * BIG;
+        std::lock_guard<std::mutex> lock(m);
+        if (bytes > whole_call_limit()) return;
+        if (!free_by_size.empty() && std::prev(free_by_size.end())->first >= bytes) return;
+        (void)add_chunk(bytes);  // (failure is not an error here: the allocations themselves will ask again, in smaller pieces)
+    }
+    // at least `bytes` free in all (not necessarily in one piece), else one more chunk for what is missing: the head of a stage that
+    // is about to take many arrays (instead of one small chunk per array)
+    void ensure_free(size_t bytes) {
+        std::unique_lock<std::mutex> lock(m);
+        if (pending.valid()) {
+            std::shared_future<void> f = pending;
+            pending = std::shared_future<void>();
+            lock.unlock();
+            f.wait();
+            lock.lock();
+        }
+        size_t have = 0;
+        for (auto &kv : free_ranges) have += kv.second.bytes;
+        if (have >= bytes || bytes > whole_call_limit()) return;
+        (void)add_chunk(bytes - have + (bytes - have) / 8);
+    }
+    size_t reclaimable_bytes() {  // what release_free_chunks(true) would give back right now
+        std::lock_guard<std::mutex> lock(m);
+        size_t n = 0;
+        for (Chunk &c : chunks) {
+            auto it = free_ranges.find(c.base);
+            if (c.live == 0 && it != free_ranges.end() && it->second.bytes == c.bytes) n += c.bytes;
+        }
+        return n;
     }
 };
-inline DeviceBlockCache &device_block_cache(int device_id) {
-    static DeviceBlockCache *caches = new DeviceBlockCache[64];  // (never destroyed: buffers may be released during static destruction)
+inline DeviceArena &device_arena(int device_id) {
+    static DeviceArena *arenas = [] {  // (never destroyed: buffers may be released during static destruction)
+        DeviceArena *a = new DeviceArena[64];
+        for (int i = 0; i < 64; i++) a[i].device = i;
+        return a;
+    }();
     if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
-    return caches[device_id];
+    return arenas[device_id];
 }
 
-// hipMalloc for the engine's long-lived device arrays: when the device is full, the blocks the finish keeps for its next call are
-// given up before the allocation is tried again.
+// the library's hipMalloc / hipFree: ranges of the current device's arena (grow_hint: size of the chunk to add if none has room)
 template <typename T>
-inline void device_malloc(T **p, size_t bytes) {
-    if (hipMalloc((void **)p, bytes) == hipSuccess) return;
-    (void)hipGetLastError();
+inline void device_malloc(T **p, size_t bytes, size_t grow_hint = 0) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    device_block_cache(dev).trim();
-    HIP_CHECK(hipMalloc((void **)p, bytes));
+    *p = (T *)device_arena(dev).alloc(bytes, false, grow_hint);
+}
+// like hipFree: the device is idle when the range goes back (callers free right after a stage, when it is idle anyway)
+inline void device_free(const void *p) {
+    if (!p) return;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceSynchronize());
+    device_arena(dev).free(const_cast<void *>(p), false);
+}
+// ... on a named device (destructors that may run on any thread)
+inline void device_free_on(int device_id, const void *p) {
+    if (!p) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device_id);
+    (void)hipDeviceSynchronize();
+    device_arena(device_id).free(const_cast<void *>(p), false);
+    (void)hipSetDevice(cur);
 }
 
 // One stream per device for the finishing stages, created on first use.
@@ -220,32 +399,36 @@ inline hipStream_t finish_stream(int device_id) {
     if (device_id < 0 || device_id >= 64) MTG_DIE("device id %d out of range", device_id);
     std::lock_guard<std::mutex> l(mu);
     if (!streams[device_id]) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
         HIP_CHECK(hipSetDevice(device_id));
         HIP_CHECK(hipStreamCreate(&streams[device_id]));
+        (void)hipSetDevice(cur);
     }
     return streams[device_id];
 }
 
+// Work arrays of the finishing stages: every user runs on the device's one finish stream, so a range released earlier on that
+// stream is free when it is used again -- no synchronisation between release and reuse.
 struct Buf {
     void *p = nullptr;
-    size_t bytes = 0, block_bytes = 0;
+    size_t bytes = 0;
     int device = 0;
     Buf() = default;
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
     ~Buf() { release(); }
     void release() {
-        if (p) device_block_cache(device).give(p, block_bytes);
+        if (p) device_arena(device).free(p, true);
         p = nullptr;
     }
     template <typename T>
     T *alloc(hipStream_t st, uint64_t n) {
         release();
         HIP_CHECK(hipGetDevice(&device));
-        // a kept block is reused without an event in between: that is only ordered if every user works on the device's one finish stream
         if (st != finish_stream(device)) MTG_DIE("hu::Buf: work arrays of the finishing stages belong on the finish stream of device %d", device);
         bytes = (n ? n : 1) * sizeof(T);
-        p = device_block_cache(device).take(bytes, &block_bytes);
+        p = device_arena(device).alloc(bytes, true);
         return (T *)p;
     }
     template <typename T>
@@ -257,10 +440,9 @@ inline void edge_cache_free(DeviceEdgeCache *c) {
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(c->device);
-    (void)hipFree(c->d_from);
-    (void)hipFree(c->d_mirror);
-    if (c->d_row0) (void)hipFree(c->d_row0);
-    if (c->d_adj0) (void)hipFree(c->d_adj0);
+    (void)hipDeviceSynchronize();
+    for (void *p : {c->d_from, c->d_mirror, c->d_row0, c->d_adj0})
+        if (p) device_arena(c->device).free(p, false);
     (void)hipSetDevice(cur);
 }
 // the cache of g on `device`, or null (another device, or a graph whose sizes changed: never the case after build)
@@ -273,13 +455,13 @@ inline const DeviceEdgeCache *edge_cache_get(const HostGraph &g, int device) {
     const DeviceEdgeCache *c = g.device_cache.get();
     return (c && c->device == device && c->n_edges == g.n_original_edges && c->n_nodes == g.node_count()) ? c : nullptr;
 }
-// Takes ownership of two plain hipMalloc'd arrays on `device` (from-nodes of the original edges, mirror); keeps an existing
+// Takes ownership of two arrays from hu::device_malloc on `device` (from-nodes of the original edges, mirror); keeps an existing
 // cache of the same device and frees the offered arrays instead.
 inline void edge_cache_put(const HostGraph &g, int device, uint32_t *d_from, uint32_t *d_mirror) {
     std::lock_guard<std::mutex> l(edge_cache_mutex());
-    if (g.device_cache || std::getenv("MTG_NO_EDGE_CACHE")) {  // first come, first kept (one cache per graph)
-        (void)hipFree(d_from);
-        (void)hipFree(d_mirror);
+    if (g.device_cache || (finish_tuning().flags.load() & FT_NO_EDGE_CACHE)) {  // first come, first kept (one cache per graph)
+        device_free_on(device, d_from);
+        device_free_on(device, d_mirror);
         return;
     }
     auto *c = new DeviceEdgeCache();
@@ -302,8 +484,8 @@ inline void edge_cache_set_buckets(const HostGraph &g, int device, uint32_t *d_r
         c->d_adj0 = d_adj0;
         return;
     }
-    (void)hipFree(d_row0);
-    (void)hipFree(d_adj0);
+    device_free_on(device, d_row0);
+    device_free_on(device, d_adj0);
 }
 
 // Device -> pageable host memory through a pinned ring: while slice i + 1 crosses PCIe at full rate, host threads copy slice i out
@@ -438,10 +620,11 @@ inline void upload_sliced(void *d_dst, const void *src, size_t bytes, hipStream_
     HIP_CHECK(hipStreamSynchronize(st));
 }
 
-// End of a finishing call: its work arrays stay with the library for the next call (what the call did not touch goes back to the
-// driver) while the call worked on less than a third of the device's memory -- BASELINE configs[3] at its nominal size (2^30: ~80 GB
-// by this estimate) iterates without asking the driver for tens of gigabytes per call, which costs between 0.2 and 5 s there --;
-// beyond that everything goes back. mtg_release_device_memory returns what is held at any time.
+// End of a finishing call: the arena's chunks stay with the library for the next call (a caller that finishes graph after graph
+// allocates nothing) while the call worked on less than a third of the device's memory -- BASELINE configs[3] at its nominal size
+// (2^30: ~80 GB by this estimate) iterates without asking the driver for tens of gigabytes per call, which costs between 0.2 and 5 s
+// there --; chunks the call hardly used (a caller that moved on to smaller graphs) and, beyond that size, every chunk that is free
+// go back. mtg_release_device_memory returns what is free at any time.
 inline void finish_trim(int device_id, uint64_t bytes_used) {
     static uint64_t threshold[64] = {0};
     if (device_id >= 0 && device_id < 64 && !threshold[device_id]) {
@@ -449,8 +632,7 @@ inline void finish_trim(int device_id, uint64_t bytes_used) {
         threshold[device_id] = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? (uint64_t)total_b / 3 : (32ull << 30);
     }
     const uint64_t limit = device_id >= 0 && device_id < 64 ? threshold[device_id] : (32ull << 30);
-    if (bytes_used < limit) device_block_cache(device_id).end_call();  // (keeps this call's arrays, frees what it did not touch)
-    else device_block_cache(device_id).trim();
+    device_arena(device_id).release_free_chunks(bytes_used >= limit);
 }
 
 }  // namespace hu

@@ -162,7 +162,7 @@ struct HostGraph {
     std::vector<uint8_t> uf_rank;
 
     // ---- graph ----
-    std::vector<uint32_t> mirror;    // [V]
+    PodVec<uint32_t> mirror;         // [V] (filled by host threads)
     // Per-node adjacency lists (newest edge first, the petgraph iteration order) cover the edges [0, linked_edges): the device
     // finish appends its dummy edges to the edge arrays only, and a host stage that walks adjacency calls ensure_linked() first.
     mutable std::vector<uint32_t> head_out;  // [V] newest outgoing edge among the linked ones
@@ -172,11 +172,18 @@ struct HostGraph {
     mutable uint64_t linked_edges = 0;
     mutable bool adjacency_ready = false;  // head_out / out_deg exist (sized by the first ensure_linked)
     mutable std::unique_ptr<std::mutex> link_mutex{new std::mutex};  // ensure_linked() (a pointer: the graph stays movable)
-    PodVec<uint64_t> e_weight;                  // [E]
-    PodVec<uint64_t> e_dummy;                   // [E] 0 = original (implementation/mod.rs:291-293)
-    PodVec<uint64_t> e_unitig;                  // [E] unitig id / sequence handle (0 for dummies)
-    PodVec<uint8_t> e_fwd;                      // [E]
+    // Edge payload (MatchtigEdgeData, implementation/mod.rs:287-317: sequence handle, forwards, weight, dummy id). Edges only ever
+    // come as (edge, mirror edge) pairs 2b, 2b + 1 -- "biedge" b -- that share weight and dummy id; edge 2b is the forwards one;
+    // original biedge b IS unitig b (clib.rs:239-248); a dummy has no unitig. So the payload is kept per BIEDGE, and only the part
+    // that is not arithmetic: 8 bytes per biedge instead of the 25 bytes per EDGE of four arrays (4.3 -> 0.5 GB of first-touch
+    // writes for the 2^27 graph: 0.14 of the 0.24 s a one-shot caller spent in mtg_graph_from_edges).
+    PodVec<uint64_t> w_biedge;                  // [E / 2] weight (k-mers of the unitig; length of a dummy)
+    PodVec<uint64_t> dummy_tail;                // [(E - n_original_edges) / 2] dummy id of the dummy biedges, in edge order
     uint64_t n_original_edges = 0;
+    uint64_t weight(uint64_t e) const { return w_biedge[e >> 1]; }
+    uint64_t dummy_id(uint64_t e) const { return e < n_original_edges ? 0 : dummy_tail[(e - n_original_edges) >> 1]; }  // 0 = original (implementation/mod.rs:291-293)
+    uint64_t unitig(uint64_t e) const { return e < n_original_edges ? e >> 1 : 0; }
+    bool forwards(uint64_t e) const { return !(e & 1); }
     // bookkeeping for the streaming cutter: ids >= first_breaking_edge are breaking dummies of weight breaking_weight
     uint64_t first_breaking_edge = UINT64_MAX;
     uint64_t breaking_weight = 0;
@@ -186,17 +193,17 @@ struct HostGraph {
 
     uint64_t node_count() const { return mirror.size(); }
     uint64_t edge_count() const { return e_from.size(); }
-    bool is_dummy(uint32_t e) const { return e_dummy[e] != 0; }
+    bool is_dummy(uint32_t e) const { return e >= n_original_edges; }  // (dummy ids are >= 1: greedytigs/mod.rs:681, implementation/mod.rs:573)
     bool self_mirror(uint32_t n) const { return mirror[n] == n; }
     uint32_t in_deg(uint32_t n) const { return out_deg[mirror[n]]; }
 
     void reserve_edges(uint64_t n);
-    // Appends edge `from -> to` and its mirror `mirror(to) -> mirror(from)` (ids e, e+1).
-    uint32_t add_biedge(uint32_t from, uint32_t to, uint64_t weight, uint64_t dummy_id, uint64_t unitig);
-    // n dummy biedges at once (same result as n add_biedge calls; adjacency linked in parallel by node range unless !link)
+    // n dummy biedges at once -- `out[i] -> in[i]` and its mirror `mirror(in[i]) -> mirror(out[i])`, ids e, e + 1 -- with the adjacency
+    // lists as n one-by-one insertions would leave them (linked in parallel by node range unless !link)
     void add_biedges_bulk(const uint32_t *out, const uint32_t *in, const uint64_t *weight, uint64_t first_dummy_id, uint64_t n,
                           bool link = true);
-    // Grows the edge arrays by n_new (uninitialised) entries WITHOUT linking them; the caller fills e_from .. e_fwd.
+    // Grows the edge arrays by n_new (uninitialised) entries WITHOUT linking them; the caller fills e_from, e_to, w_biedge and --
+    // for dummy edges -- dummy_tail.
     void append_unlinked(uint64_t n_new);
     // Links the edges [linked_edges, E) into the adjacency lists, in ascending id (== one-by-one insertion order).
     void ensure_linked() const;

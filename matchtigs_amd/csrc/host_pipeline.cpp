@@ -196,7 +196,7 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
         g.first_breaking_edge = g.edge_count();
         g.breaking_weight = k;
         for (uint64_t e = g.n_original_edges; e < g.edge_count(); e++)
-            if (g.e_weight[e] >= k) g.dummies_canonical = false;  // a matched dummy as long as a breaking edge
+            if (g.weight(e) >= k) g.dummies_canonical = false;  // a matched dummy as long as a breaking edge
     } else g.dummies_canonical = false;  // Eulerised twice
     // the pairing below only needs `need[]`; the breaking biedges are collected and appended in one bulk call
     std::vector<uint32_t> brk_out, brk_in;
@@ -388,7 +388,7 @@ static Walks cut_cycles_generic(const HostGraph &g, const Walks &cycles, uint64_
         uint64_t longest_w = 0, rot = 0;                         // :737-745
         for (uint64_t i = 0; i < len; i++) {
             const uint32_t e = cyc[i];
-            if (e >= n_orig && g.e_weight[e] > longest_w) { longest_w = g.e_weight[e]; rot = i; }
+            if (e >= n_orig && g.weight(e) > longest_w) { longest_w = g.weight(e); rot = i; }
         }
         if (longest_w == 0) rot = 0;                             // :746-748
         auto at = [&](uint64_t i) -> uint32_t { uint64_t j = i + rot; return cyc[j >= len ? j - len : j]; };
@@ -400,7 +400,7 @@ static Walks cut_cycles_generic(const HostGraph &g, const Walks &cycles, uint64_
         for (uint64_t i = 0; i < len; i++) {                     // :752
             const uint32_t e = at(i);
             const bool dummy = e >= n_orig;
-            if (dummy && (g.e_weight[e] >= k || i == 0)) {       // :767-769
+            if (dummy && (g.weight(e) >= k || i == 0)) {       // :767-769
                 if (offset < i) emit(offset, i);                 // :770-771
                 offset = i + 1;                                  // :775
             }
@@ -437,7 +437,7 @@ Walks cut_cycles(const HostGraph &g, const Walks &cycles, uint64_t k) {
             uint64_t longest_w = 0;
             rot = 0;
             for (uint64_t i = 0; i < len; i++)
-                if (cyc[i] >= n_orig && g.e_weight[cyc[i]] > longest_w) { longest_w = g.e_weight[cyc[i]]; rot = i; }
+                if (cyc[i] >= n_orig && g.weight(cyc[i]) > longest_w) { longest_w = g.weight(cyc[i]); rot = i; }
         }
         if (len >= (1u << 20)) {
             // long cycle: the same cut, by host threads over chunks of the rotated index j (edge = cyc[(rot + j) % len]):
@@ -532,8 +532,8 @@ uint64_t flatten_clib(const HostGraph &g, const Walks &tigs, int64_t *edge_out, 
     parallel_ranges(n_edges, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t j = lo; j < hi; j++) {
             const uint32_t e = tigs.edges[j];
-            edge_out[j] = (int64_t)g.e_unitig[e] * (g.e_fwd[e] ? 1 : -1);
-            insert_out[j] = g.is_dummy(e) ? g.e_weight[e] : 0;
+            edge_out[j] = (int64_t)g.unitig(e) * (g.forwards(e) ? 1 : -1);
+            insert_out[j] = g.is_dummy(e) ? g.weight(e) : 0;
         }
     });
     parallel_ranges(tigs.limits.size(), [&](uint64_t lo, uint64_t hi) {

@@ -46,7 +46,7 @@ uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *
     if (gfa) head = (gfa_header ? std::string(gfa_header) : "H\tKL:Z:" + std::to_string(k)) + "\n";
     const uint64_t prefix_len = gfa ? 2 : 1, after_number = 1;  // "S\t" / ">", then the number, then "\t" / "\n"
     const uint64_t n_orig = g.n_original_edges;
-    auto seq_len = [&](uint32_t e) -> uint64_t { return seq_off[g.e_unitig[e] + 1] - seq_off[g.e_unitig[e]]; };
+    auto seq_len = [&](uint32_t e) -> uint64_t { return seq_off[g.unitig(e) + 1] - seq_off[g.unitig(e)]; };
     // pass 1: record offsets
     std::vector<uint64_t> rec_off(n_walks + 1, 0);
     rec_off[0] = head.size();
@@ -61,9 +61,9 @@ uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *
         for (uint64_t j = begin + 1; j < end; j++) {
             const uint32_t cur = edges[j];
             if (cur >= n_orig) { prev = cur; continue; }
-            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.e_weight[prev];
+            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.weight(prev);
             const uint64_t sl = seq_len(cur);
-            if (offset > sl) MTG_DIE("overlap %llu longer than unitig %llu", (unsigned long long)offset, (unsigned long long)g.e_unitig[cur]);
+            if (offset > sl) MTG_DIE("overlap %llu longer than unitig %llu", (unsigned long long)offset, (unsigned long long)g.unitig(cur));
             len += sl - offset;
             prev = cur;
         }
@@ -77,10 +77,10 @@ uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *
     std::memcpy(out, head.data(), head.size());
     // pass 2: spell
     auto put_edge = [&](char *dst, uint32_t e, uint64_t offset) -> char * {
-        const char *s = seqs + seq_off[g.e_unitig[e]];
+        const char *s = seqs + seq_off[g.unitig(e)];
         const uint64_t sl = seq_len(e);
         const uint64_t n = sl - offset;
-        if (g.e_fwd[e]) {
+        if (g.forwards(e)) {
             std::memcpy(dst, s + offset, n);
         } else {
             for (uint64_t i = 0; i < n; i++) dst[i] = complement(s[n - 1 - i]);
@@ -107,7 +107,7 @@ uint64_t write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *
         for (uint64_t j = begin + 1; j < end; j++) {
             const uint32_t cur = edges[j];
             if (cur >= n_orig) { prev = cur; continue; }
-            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.e_weight[prev];
+            const uint64_t offset = prev < n_orig ? k - 1 : k - 1 - g.weight(prev);
             p = put_edge(p, cur, offset);
             prev = cur;
         }
@@ -130,7 +130,7 @@ uint64_t write_duplication_bitvector(const HostGraph &g, uint64_t n_walks, const
         const uint64_t end = limits[i];
         if (end <= begin) MTG_DIE("Found empty walk when writing duplication bitvector (implementation/mod.rs:686)");
         uint64_t len = 1;  // "\n"
-        for (uint64_t j = begin; j < end; j++) len += g.e_weight[edges[j]];
+        for (uint64_t j = begin; j < end; j++) len += g.weight(edges[j]);
         rec_off[i + 1] = rec_off[i] + len;
         begin = end;
     }
@@ -142,8 +142,8 @@ uint64_t write_duplication_bitvector(const HostGraph &g, uint64_t n_walks, const
         char *p = out + rec_off[i];
         for (uint64_t j = begin; j < limits[i]; j++) {
             const uint32_t e = edges[j];
-            std::memset(p, g.is_dummy(e) ? '0' : '1', g.e_weight[e]);
-            p += g.e_weight[e];
+            std::memset(p, g.is_dummy(e) ? '0' : '1', g.weight(e));
+            p += g.weight(e);
         }
         *p = '\n';
         begin = limits[i];

@@ -65,9 +65,8 @@ __device__ __forceinline__ uint32_t digits_of(uint64_t v) {
 struct SpellArgs {
     const uint32_t *edges;        // [P] walk edges
     const uint32_t *walk_start;   // [P + 1] walk index + 1 at the first position of a walk (and n_walks + 1 at position P), else 0
-    const uint32_t *e_unitig;     // [n_orig] unitig of an original edge
-    const uint8_t *e_fwd;         // [n_orig]
-    const uint32_t *dummy_w;      // [n_dummy] weight of dummy edge n_orig + i
+    // (original edge e is unitig e >> 1, forwards iff e is even: host_graph.hpp)
+    const uint32_t *dummy_w;      // [n_dummy / 2] weight of the dummy biedge (n_orig + 2 i, n_orig + 2 i + 1)
     const unsigned long long *seq_off;  // [U + 1] base offsets
     const uint32_t *packed;
     uint64_t n_pos;               // P
@@ -86,11 +85,11 @@ __device__ __forceinline__ void position_extent(const SpellArgs &a, uint64_t p, 
     if (p >= a.n_pos) return;
     const uint32_t e = a.edges[p];
     if (e >= a.n_orig) return;  // dummy edges emit nothing
-    const uint32_t u = a.e_unitig[e];
+    const uint32_t u = e >> 1;
     const uint64_t sl = a.seq_off[u + 1] - a.seq_off[u];
     if (!ws) {
         const uint32_t prev = a.edges[p - 1];
-        offset = prev < a.n_orig ? a.k - 1 : a.k - 1 - a.dummy_w[prev - a.n_orig];
+        offset = prev < a.n_orig ? a.k - 1 : a.k - 1 - a.dummy_w[(prev - a.n_orig) >> 1];
     }
     chars = sl > offset ? sl - offset : 0;
 }
@@ -202,8 +201,8 @@ __global__ __launch_bounds__(SP_BLOCK) void spell_kernel(SpellArgs a, const unsi
         } else {
             const uint64_t ci = r - hdr;
             const uint32_t e = a.edges[p];
-            const uint32_t u = a.e_unitig[e];
-            const bool fwd = a.e_fwd[e] != 0;
+            const uint32_t u = e >> 1;
+            const bool fwd = !(e & 1u);
             const uint64_t bi = a.seq_off[u] + (fwd ? off + ci : chars - 1 - ci);
             uint32_t code = (a.packed[bi >> 4] >> (2 * (bi & 15))) & 3u;
             if (!fwd) code = 3u - code;
@@ -258,12 +257,9 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     if (n_words) hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_ascii, n_bases, d_packed, d_tot + 1);
     HIP_CHECK(hipGetLastError());
     // per-edge tables the positions index (u32 / u8 instead of the host graph's 64-bit fields)
-    PodVec<uint32_t> h_unitig(n_orig), h_dw(std::max<uint64_t>(n_dummy, 1));
-    for (uint64_t e = 0; e < n_orig; e++) h_unitig[e] = (uint32_t)g.e_unitig[e];
-    for (uint64_t e = 0; e < n_dummy; e++) h_dw[e] = (uint32_t)std::min<uint64_t>(g.e_weight[n_orig + e], 0xFFFFFFFFull);
-    hu::device_malloc(&d_unitig, std::max<uint64_t>(n_orig, 1) * 4);
-    hu::device_malloc(&d_fwd, std::max<uint64_t>(n_orig, 1));
-    hu::device_malloc(&d_dw, std::max<uint64_t>(n_dummy, 1) * 4);
+    PodVec<uint32_t> h_dw(std::max<uint64_t>(n_dummy / 2, 1));
+    for (uint64_t i = 0; i < n_dummy / 2; i++) h_dw[i] = (uint32_t)std::min<uint64_t>(g.w_biedge[n_orig / 2 + i], 0xFFFFFFFFull);
+    hu::device_malloc(&d_dw, std::max<uint64_t>(n_dummy / 2, 1) * 4);
     hu::device_malloc(&d_seq_off, (U + 1) * 8);
     hu::device_malloc(&d_edges, std::max<uint64_t>(P, 1) * 4);
     hu::device_malloc(&d_limits, std::max<uint64_t>(n_walks, 1) * 8);
@@ -273,18 +269,14 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     hu::device_malloc(&d_start, (P + 2) * 8);
     const uint64_t nb = (P + 1 + 1023) / 1024;
     hu::device_malloc(&d_bsum, nb * 8);
-    if (n_orig) {
-        HIP_CHECK(hipMemcpyAsync(d_unitig, h_unitig.data(), n_orig * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_fwd, g.e_fwd.data(), n_orig, hipMemcpyHostToDevice, st));
-    }
-    if (n_dummy) HIP_CHECK(hipMemcpyAsync(d_dw, h_dw.data(), n_dummy * 4, hipMemcpyHostToDevice, st));
+    if (n_dummy) HIP_CHECK(hipMemcpyAsync(d_dw, h_dw.data(), n_dummy / 2 * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(d_seq_off, seq_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (P) HIP_CHECK(hipMemcpyAsync(d_edges, edges, P * 4, hipMemcpyHostToDevice, st));
     if (n_walks) HIP_CHECK(hipMemcpyAsync(d_limits, limits, n_walks * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(d_ws, 0, (P + 1) * 4, st));
     hipLaunchKernelGGL(mark_starts_kernel, dim3((unsigned)((n_walks + 1 + 255) / 256)), dim3(256), 0, st, d_limits, n_walks, P, d_ws);
     SpellArgs a{};
-    a.edges = d_edges; a.walk_start = d_ws; a.e_unitig = d_unitig; a.e_fwd = d_fwd; a.dummy_w = d_dw; a.seq_off = d_seq_off; a.packed = d_packed;
+    a.edges = d_edges; a.walk_start = d_ws; a.dummy_w = d_dw; a.seq_off = d_seq_off; a.packed = d_packed;
     a.n_pos = P; a.n_orig = n_orig; a.k = (uint32_t)k; a.rec_prefix = gfa ? 2 : 1; a.sep = gfa ? '\t' : '\n'; a.head_bytes = head.size();
     hipLaunchKernelGGL(extent_kernel, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, a, d_lo, d_hi);
     hipLaunchKernelGGL(scan64_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, st, d_lo, d_hi, P + 1, d_bsum);
@@ -298,7 +290,7 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     const uint64_t total = n_walks ? h_tot[0] : head.size();
     char *out = static_cast<char *>(std::malloc(total + 1));
     if (!out) MTG_DIE("out of memory (%llu bytes)", (unsigned long long)total);
-    HIP_CHECK(hipFree(d_ascii));
+    hu::device_free(d_ascii);
     d_ascii = nullptr;
     double ms = 0.0;
     if (n_walks) {
@@ -324,7 +316,7 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     if (bytes_out) *bytes_out = total + n_bases / 4 + (P + 1) * (8 + 4 + 4);
     for (void *p : {(void *)d_out, (void *)d_packed, (void *)d_edges, (void *)d_ws, (void *)d_unitig, (void *)d_dw, (void *)d_lo, (void *)d_hi,
                     (void *)d_fwd, (void *)d_seq_off, (void *)d_limits, (void *)d_start, (void *)d_bsum, (void *)d_tot})
-        (void)hipFree(p);
+        hu::device_free(p);
     *out_buf = out;
     return total;
 }

@@ -95,6 +95,7 @@ HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint6
     if (max_degree < 1 || max_degree > 64) MTG_DIE("mtg_synth_g_csr: max_degree out of range");
     if (device_count() <= device_id) MTG_DIE("mtg_synth_g_csr: no MI355X/HIP device %d (the generator has no CPU form in the library; numpy twin: synth.g_csr)", device_id);
     HIP_CHECK(hipSetDevice(device_id));
+    device_reserve_async(V, 2 * n_unitigs, device_id);  // (the device memory of the call that will follow on this graph; the generator's own arrays are ranges of it)
     hipStream_t st = finish_stream(device_id);
     static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -168,12 +169,7 @@ HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint6
     lap("emit + download");
     parallel_ranges(kept, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t u = lo; u < hi; u++) {
-            const uint64_t e = 2 * u;
-            g->e_weight[e] = g->e_weight[e + 1] = w16[u];
-            g->e_dummy[e] = g->e_dummy[e + 1] = 0;
-            g->e_unitig[e] = g->e_unitig[e + 1] = u;
-            g->e_fwd[e] = 1;
-            g->e_fwd[e + 1] = 0;
+            g->w_biedge[u] = w16[u];  // (edge 2u = unitig u forwards, 2u + 1 its mirror: host_graph.hpp)
         }
     });
     g->n_original_edges = E;  // (host adjacency: linked on demand, like mtg_graph_from_edges)
@@ -181,7 +177,6 @@ HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint6
     lap("host graph");
     b_from.release(); b_to.release(); b_w.release(); b_keep.release(); b_pos.release(); b_bsum.release(); b_tot.release(); b_T.release();
     HIP_CHECK(hipStreamSynchronize(st));
-    finish_trim(device_id, V * 8 + n_unitigs * 8 + E * 10);
     return g;
 }
 

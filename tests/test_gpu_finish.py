@@ -111,7 +111,7 @@ def _same_graph(a, b):
 
 
 @pytest.mark.parametrize("idx", range(N_CASES))
-def test_device_finish_equals_host_finish_reference_order(gpu, idx, monkeypatch):
+def test_device_finish_equals_host_finish_reference_order(gpu, idx):
     """Greedy finish: same graph afterwards (every dummy edge: id, endpoints, weight, dummy id) and the same tigs."""
     from matchtigs_amd import api
 
@@ -120,15 +120,17 @@ def test_device_finish_equals_host_finish_reference_order(gpu, idx, monkeypatch)
     pairs = _pairs_of(bg, k)
     H, D = _graphs(bg)
     lim_h, ed_h = api.finish_greedytigs_np(H, pairs, k, finish_stage=api.FinishStage.Host)
-    for records in ("lean", "mid", "wide"):  # the record formats of the reference-order walk (a speed / memory choice only)
-        monkeypatch.setenv("MTG_EULER_RECORDS", records)
-        lim_d, ed_d = api.finish_greedytigs_np(D, pairs, k, finish_stage=api.FinishStage.Device)
-        _same_graph(H, D)
-        assert np.array_equal(lim_h, lim_d), (name, records)
-        assert np.array_equal(ed_h, ed_d), (name, records)
-        if records != "wide":
-            D.reset()
-    monkeypatch.delenv("MTG_EULER_RECORDS")
+    try:
+        for records in ("lean", "mid", "wide"):  # the record formats of the reference-order walk (a speed / memory choice only)
+            api.set_finish_tuning(records=records)
+            lim_d, ed_d = api.finish_greedytigs_np(D, pairs, k, finish_stage=api.FinishStage.Device)
+            _same_graph(H, D)
+            assert np.array_equal(lim_h, lim_d), (name, records)
+            assert np.array_equal(ed_h, ed_d), (name, records)
+            if records != "wide":
+                D.reset()
+    finally:
+        api.set_finish_tuning()
     t = api.last_finish_device_times()
     assert t["breaking_biedges"] == (D.edge_count() - bg.n_edges) // 2 - len(pairs)
     # and the graph can be reset and finished again (the dummy edges were appended unlinked)
@@ -262,19 +264,23 @@ def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(g
         assert np.array_equal(eh[key], e2[key]), key
 
 
-@pytest.mark.parametrize("log2_edges, delay_us, records", [(22, 0, None), (22, 300, None), (20, 3000, None), (17, 20000, None),
-                                                          (22, 300, "mid"), (17, 20000, "mid")])
-def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monkeypatch, log2_edges, delay_us, records):
+@pytest.mark.parametrize("log2_edges, delay_us, records, max_degree", [(22, 0, None, 4), (22, 300, None, 4), (20, 3000, None, 4), (17, 20000, None, 4),
+                                                                      (22, 300, "mid", 4), (17, 20000, "mid", 4),
+                                                                      # no node with more than three out-edges: no spill arrays, so nothing but the
+                                                                      # event behind lean_build_kernel orders the side stream's download of the
+                                                                      # 32-byte records after the kernel that writes them
+                                                                      (18, 2000, None, 3), (22, 0, None, 3)])
+def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, log2_edges, delay_us, records, max_degree):
     """The reference-order host walk starts while its 256-byte records still cross PCIe: they arrive in node order (first call on a
     graph: through the pinned ring on a thread of its own; later calls: plain copies into the page-locked arena, followed by a watcher
     thread), a counter says how far they have come, and a step that needs a record beyond that mark takes the node's 32-byte record
-    instead. MTG_TEST_RECORD_DELAY_US slows the arrival so that small graphs take that path for most of their steps. Same tigs as the
+    instead. mtg_set_finish_tuning's record_delay_us slows the arrival so that small graphs take that path for most of their steps. Same tigs as the
     host stages' finish (no GPU records at all), and -- on the smallest graph -- as the oracle. `records` = "mid": the 128-byte
     records of the graphs whose 256-byte ones would not fit the host (built and brought down slice by slice beside the walk)."""
     from matchtigs_amd import api, synth
 
     k = 31
-    G = synth.g_csr_device(int((1 << log2_edges) / 3), seed=5 + log2_edges, k=k)
+    G = synth.g_csr_device(int((1 << log2_edges) / 3), seed=5 + log2_edges, k=k, max_degree=max_degree)
     dev = api.DeviceGraph(G, k)
     dev.classify()
     pairs = api.compute_pairs([dev])
@@ -282,14 +288,15 @@ def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monke
     ref_lim, ref_ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Host)
     ref_lim, ref_ed = ref_lim.copy(), ref_ed.copy()
     G.reset()
-    monkeypatch.setenv("MTG_TEST_RECORD_DELAY_US", str(delay_us))
-    if records:
-        monkeypatch.setenv("MTG_EULER_RECORDS", records)
+    api.set_finish_tuning(records=records, record_delay_us=delay_us)
     results = [(ref_lim, ref_ed)]
-    for _ in range(3):  # call 1: records through the pinned ring; calls 2, 3: the arena is page-locked
-        lim, ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Device)
-        results.append((lim.copy(), ed.copy()))
-        G.reset()
+    try:
+        for _ in range(3):  # call 1: records through the pinned ring; calls 2, 3: the arena is page-locked
+            lim, ed = api.finish_greedytigs_np(G, pairs, k, euler_mode=api.EulerMode.HostReferenceOrder, finish_stage=api.FinishStage.Device)
+            results.append((lim.copy(), ed.copy()))
+            G.reset()
+    finally:
+        api.set_finish_tuning()
     for lim, ed in results[1:]:
         assert np.array_equal(results[0][0], lim) and np.array_equal(results[0][1], ed)
     if log2_edges <= 17:
@@ -299,6 +306,44 @@ def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, monke
         lim, ed = results[-1]
         got = [ed[int(a):int(b)].tolist() for a, b in zip(np.concatenate([[0], lim[:-1]]), lim)]
         assert got == want
+
+
+@pytest.mark.parametrize("log2_edges, algorithm, euler", [(12, 5, "host"), (12, 3, "device"), (18, 5, "host"), (18, 5, "device"), (18, 3, "host"),
+                                                         (25, 5, "device"), (25, 3, "device")])
+def test_compute_tigs_clib_equals_compute_plus_flatten(gpu, oracle, log2_edges, algorithm, euler):
+    """mtg_compute_tigs_clib (what matchtigs_compute_tigs runs, clib.rs:280-410): with a finish on the GPU the tigs go from the
+    download ring straight into the caller's clib.rs arrays (flattened by the host threads that empty the ring; the 2^25 cases take
+    the ring, the others the plain copy). Same arrays as mtg_compute_tigs_cfg + mtg_flatten_clib (clib.rs:393-407), and -- in the
+    reference's walk order, on the sizes the oracle finishes -- as the oracle's tigs flattened by the same rule."""
+    import ctypes as C
+
+    from matchtigs_amd import api, synth
+
+    k = 31
+    L = gpu
+    G = synth.g_csr_device(int((1 << log2_edges) / 3), seed=40 + log2_edges, k=k)
+    E0 = G.edge_count()
+    mode = api.EulerMode.Device if euler == "device" else api.EulerMode.HostReferenceOrder
+    cfg = api.GreedytigAlgorithmConfiguration(1, k, euler_mode=mode).to_c()
+    w = L.mtg_compute_tigs_cfg(G.handle, algorithm, C.byref(cfg))
+    e1, i1, l1 = np.full(2 * E0, -7, np.int64), np.full(2 * E0, 7, np.uint64), np.full(E0, 7, np.uint64)
+    n1 = L.mtg_flatten_clib(G.handle, w, e1.ctypes.data, i1.ctypes.data, l1.ctypes.data)
+    L.mtg_walks_free(w)
+    ex = G.export() if log2_edges <= 18 and euler == "host" else None
+    G.reset()
+    e2, i2, l2 = np.full(2 * E0, -7, np.int64), np.full(2 * E0, 7, np.uint64), np.full(E0, 7, np.uint64)
+    n2 = L.mtg_compute_tigs_clib(G.handle, algorithm, C.byref(cfg), e2.ctypes.data, i2.ctypes.data, l2.ctypes.data)
+    assert n1 == n2 and n1 > 0
+    m = int(l1[n1 - 1])
+    assert np.array_equal(l1[:n1], l2[:n2])
+    assert np.array_equal(e1[:m], e2[:m])
+    assert np.array_equal(i1[:m], i2[:m])
+    if ex is not None:
+        n_orig = E0
+        og = oracle.OracleGraph.from_arrays(ex["mirror"], ex["edge_from"][:n_orig], ex["edge_to"][:n_orig], ex["edge_weight"][:n_orig])
+        n_o, eo, io, lo = og.clib_compute_tigs(algorithm, k)  # the oracle's own flattening (clib.rs:393-407)
+        assert n_o == n2 and np.array_equal(lo[:n_o], l2[:n2])
+        assert np.array_equal(eo[:m], e2[:m]) and np.array_equal(io[:m], i2[:m])
 
 
 def test_kept_device_memory_is_bounded_and_can_be_released(gpu):

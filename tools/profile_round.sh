@@ -19,7 +19,7 @@ T="timeout -k 10 420"
 mkdir -p "$OUT"
 LG=$(echo "$SIZE" | sed -n 's/.*--log2-edges \([0-9]*\).*/\1/p'); LG=${LG:-27}
 for MODE in $MODES; do
-  COMMON="--euler $MODE --device-mode-steps 0 --no-cpu-baseline --extra-seeds= --full-size-log2 0 $SIZE"
+  COMMON="--euler $MODE --device-mode-steps 0 --no-cpu-baseline --no-one-shot --extra-seeds= --full-size-log2 0 $SIZE"
   BENCH="python3 bench.py --steps 3 --warmup 1 $COMMON"
   PMCBENCH="python3 bench.py --steps 1 --warmup 1 --no-cold-steps $COMMON"
   has stats && $T rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$MODE" -- $BENCH > "$OUT/bench_$MODE.json" 2> "$OUT/stats_$MODE.err"; echo "$MODE stats rc=$?"
