@@ -333,7 +333,8 @@ def main():
             t0c = time.perf_counter()
             g2 = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k, device_id=local_rank)
             t1c = time.perf_counter()
-            d2 = api.DeviceGraph(g2, k, local_rank)
+            # (a caller's first and only search: the device graph without the goal-directed lower bounds, as mtg_compute_tigs_cfg builds it)
+            d2 = api.DeviceGraph(g2, k, local_rank, lower_bounds=False)
             d2.set_plan(args.plan)
             torch.cuda.synchronize()
             t2c = time.perf_counter()
@@ -344,7 +345,9 @@ def main():
             torch.cuda.synchronize()
             t3c = time.perf_counter()
             cold[name] = {"step_ms": round((t3c - t2c) * 1e3, 2), "device_graph_build_ms": round((t2c - t1c) * 1e3, 2),
-                          "generate_ms": round((t1c - t0c) * 1e3, 2), "phases_ms": {kk: round(v * 1e3, 2) for kk, v in phc.items()}}
+                          "generate_ms": round((t1c - t0c) * 1e3, 2), "phases_ms": {kk: round(v * 1e3, 2) for kk, v in phc.items()},
+                          "sssp_stage_ms": round(d2.last_sssp_kernel_ms(), 4),
+                          "sssp_levels": [{"kernel": x["kernel"], "ms": round(x["ms"], 4), "sources": x["sources"]} for x in d2.last_sssp_levels()]}
             graph, dev, bufs = keep
             del g2, d2
             torch.cuda.empty_cache()
@@ -428,6 +431,20 @@ def main():
             "kernel_sssp_edges_per_s": round(stats["relaxed_edges"] / (local_kernel_ms * 1e-3), 1) if local_kernel_ms > 0 else 0.0,
             "work_efficiency_attempts_per_edge": round(stats["relax_attempts"] / max(stats["relaxed_edges"], 1), 4),
         }
+        # what the pruning costs: the lower bounds are computed once per device graph (HIP events inside the engine); a caller that
+        # searches a graph ONCE (the reference's only calling convention) runs the full-ball search without them instead -- the stage
+        # time of the cold step's device graph, built the way mtg_compute_tigs_cfg builds it
+        pre_ms = dev.lower_bounds_ms()
+        roofline["precompute_ms"] = round(pre_ms, 4)
+        cold_dev = (cold or {}).get("device") or (cold or {}).get("host")
+        if cold_dev:
+            os_ms = cold_dev["sssp_stage_ms"]
+            roofline["one_shot"] = {"stage_ms": os_ms, "precompute_ms": 0.0, "kernels": cold_dev["sssp_levels"],
+                                    "algorithmic_bytes_per_launch": alg_bytes_full,
+                                    "frac": round(alg_bytes_full / (os_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if os_ms > 0 else None,
+                                    "note": "first search on a fresh device graph without lower bounds (full balls, cold caches): what one call pays"}
+            gain = os_ms - local_kernel_ms
+            roofline["pruned_search_pays_off_after_steps"] = (int(np.ceil(pre_ms / gain)) if gain > 0 and pre_ms > 0 else None)
         # ---- the other GPU stages of the step, each against the HBM roofline: GPU time from HIP events inside the engine (on the
         # stream the kernels run on), algorithmic bytes from stage_models(), counter traffic from profiles/stage_traffic.json ----
         roofline_stages = None
@@ -488,7 +505,8 @@ def main():
             full_size = full_size_step(args, k, local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {
-            "metric": "greedy-matchtigs SSSP edges/s (whole hot-path step: classify+SSSP+claim+Euler+cut)",
+            "metric": "greedy-matchtigs SSSP edges/s, full-ball-equivalent edges (the edges a full-ball Dijkstra of every source examines -- the "
+                      "pruned search examines fewer for the same lists, 'visited_per_step') / whole hot-path step: classify+SSSP+claim+Euler+cut",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "wall_clock_s": round(ms_per_step / 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",

@@ -156,6 +156,16 @@ uint64_t mtg_graph_original_edge_count(const mtg_graph *g); /* edges before any 
  * Aborts if no GPU is present (there is no CPU path). Weights must be >= 1 for algorithm 5
  * (checked here; the reference's (distance, node) pop order needs it). */
 mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id);
+/* The same with options. MTG_DEVICE_NO_LOWER_BOUNDS: the goal-directed lower bounds (k <= 255, see mtg_sssp_count_visited) are NOT
+ * computed with the graph -- they cost k - 1 passes over the nodes and a rewrite of the blocks, several times what they save ONE search;
+ * the search then explores full balls (identical candidate lists). mtg_compute_tigs_cfg, whose device graph is searched once (the
+ * reference's calling convention, clib.rs:291), builds it this way; a caller that holds an mtg_device and iterates keeps the default,
+ * or adds the bounds later with mtg_device_build_lower_bounds (which repeats the classification if there was one).
+ * mtg_device_lower_bounds_ms: GPU time (HIP events) of that precompute, 0 while the device graph has none. */
+enum { MTG_DEVICE_DEFAULT = 0, MTG_DEVICE_NO_LOWER_BOUNDS = 1 };
+mtg_device *mtg_device_create_opts(const mtg_graph *g, uint64_t k, int device_id, int flags);
+void mtg_device_build_lower_bounds(mtg_device *d, void *stream);
+double mtg_device_lower_bounds_ms(const mtg_device *d);
 void mtg_device_free(mtg_device *d);
 /* Bytes of HBM held by the device graph. */
 uint64_t mtg_device_graph_bytes(const mtg_device *d);

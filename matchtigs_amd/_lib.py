@@ -218,6 +218,9 @@ def load():
         "mtg_device_memory_held": (u64, [C.c_int]),
         "mtg_graph_release_device_cache": (None, [vp]),
         "mtg_set_default_device": (None, [C.c_int]),
+        "mtg_device_create_opts": (vp, [vp, u64, C.c_int, C.c_int]),
+        "mtg_device_build_lower_bounds": (None, [vp, vp]),
+        "mtg_device_lower_bounds_ms": (C.c_double, [vp]),
         "mtg_set_finish_tuning": (None, [C.c_int, C.c_int, i64]),
         "mtg_replay_claims_resident": (u64, [vp, vp, u64, vp, vp, vp]),
         "mtg_last_replay_ms": (None, [vp, P(C.c_double)]),

@@ -397,14 +397,24 @@ def _take_walks_np(L, wp):
 class DeviceGraph:
     """One GPU's resident copy of a Bigraph (mtg_device). Raises/aborts without a GPU: no CPU path."""
 
-    def __init__(self, graph: Bigraph, k: int, device_id: int = 0):
+    def __init__(self, graph: Bigraph, k: int, device_id: int = 0, lower_bounds: bool = True):
+        """lower_bounds=False: mtg_device_create_opts(MTG_DEVICE_NO_LOWER_BOUNDS) -- the device graph of a caller that searches once
+        (what mtg_compute_tigs_cfg builds); build_lower_bounds() adds them later."""
         self._L = _lib.load()
         if self._L.mtg_device_count() <= device_id:
             raise RuntimeError(f"no HIP device {device_id}: the matchtigs_amd device stage has no CPU fallback")
         self.graph = graph
         self.k = k
-        self._d = self._L.mtg_device_create(graph.handle, k, device_id)
+        self._d = self._L.mtg_device_create_opts(graph.handle, k, device_id, 0 if lower_bounds else 1)
         self.n_sources = None
+
+    def build_lower_bounds(self, stream: int = 0) -> float:
+        """mtg_device_build_lower_bounds; returns the GPU milliseconds of the precompute (mtg_device_lower_bounds_ms)."""
+        self._L.mtg_device_build_lower_bounds(self._d, stream)
+        return self.lower_bounds_ms()
+
+    def lower_bounds_ms(self) -> float:
+        return float(self._L.mtg_device_lower_bounds_ms(self._d))
 
     def __del__(self):
         d, self._d = getattr(self, "_d", None), None

@@ -393,60 +393,53 @@ __global__ void build_lbx_kernel(uint64_t n_nodes, const NodeBlock *blocks, cons
     lbx[n] = (uint16_t)(lb8[n] | (best << 8));
     if (best <= K1) odeg[n] |= ODEG_REACH;  // (read by the classification with the degree; every other reader of odeg runs before this kernel or masks)
 }
-// Pass 2: first halves into the 8:8 format -- low byte the weight, high byte weight + lb+(child): what a search needs the CHILD'S BLOCK
-// for. Whether the child is an in-node itself (lb = 0) travels in cmeta bit j, so the parent's step records that candidate and the
-// child's gather only happens when something lies beyond it ("leaf" in-nodes, a quarter of all visits on the bench graph, cost no
-// gather). A spilled adjacency keeps plain weights (no pruning behind such a node).
-__global__ void build_lb_kernel(uint64_t n_nodes, NodeBlock *blocks, const uint16_t *lbx) {
-    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_nodes) return;
-    uint32_t *me = reinterpret_cast<uint32_t *>(blocks + n);
-    const uint32_t meta = me[6];
-    if ((meta >> 8) & F_EXT) return;
-    const uint32_t dg = meta & 0xFFu;
-    uint32_t slot[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-    uint32_t cm = 0;
-    for (uint32_t j = 0; j < dg; j++) {
-        const uint32_t w = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
-        const uint32_t x = lbx[me[j]];
-        slot[j] = (min(255u, w + (x >> 8)) << 8) | w;
-        if ((x & 0xFFu) == 0) cm |= 1u << j;
-    }
-    me[4] = slot[0] | (slot[1] << 16);
-    me[5] = slot[2] | (slot[3] << 16);
-    me[6] = meta | (cm << 16);  // (bits 0-3 of cmeta: build_children_kernel reads them from the children's blocks for the grandchild flags)
-}
-
-// second half of every block: the children's in-node flags and, while they fit, the children's out-edges
+// second half of every block: the children's in-node flags and, while they fit, the children's out-edges.
+// W8 = false: plain 16-bit weights (k > 255, or a device graph built without lower bounds).
+// W8 = true: the 8:8 format, written in the same pass (round 5: one kernel where build_lb_kernel rewrote the first halves and this
+// kernel then read the children's rewritten halves). Own first half: low byte the weight, high byte weight + lb+(child) -- what a
+// search needs the CHILD'S BLOCK for; whether the child is an in-node itself (lb = 0) travels in cmeta bit j, so the parent's step
+// records that candidate and the child's gather only happens when something lies beyond it ("leaf" in-nodes, a quarter of all
+// visits on the bench graph, cost no gather). Second half: path weight | path weight + lb+(grandchild), both saturated at 255 (> any
+// bound of this format), and the grandchild's in-node flag in cmeta bit 8 + t. lb and lb+ of children and grandchildren come from
+// lbx[] (build_lbx_kernel), never from another node's block: while this kernel runs a node's first half is read by its parents'
+// threads and rewritten by its own, and either version decodes to the same neighbours, degree, flags and LOW bytes (a plain
+// 16-bit weight is <= k <= 255, an unused slot is 0xFFFF in both formats; the three words are written whole). A spilled adjacency
+// keeps plain weights (no pruning behind such a node).
 template <bool W8>
-__global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
+__global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks, const uint16_t *lbx) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
     const uint32_t *me = reinterpret_cast<const uint32_t *>(blocks + n);
     const uint32_t meta = me[6];
     if ((meta >> 8) & F_EXT) return;
     const uint32_t dg = meta & 0xFFu;
+    const uint32_t nb[4] = {me[0], me[1], me[2], me[3]};
+    const uint32_t w45[2] = {me[4], me[5]};
     uint32_t cmeta = 0, used = 0;
     uint32_t gn[GSLOTS];
     uint32_t gwt[GSLOTS];
+    uint32_t slot[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
 #pragma unroll
     for (int i = 0; i < GSLOTS; i++) { gn[i] = 0; gwt[i] = 0xFFFFu; }
     bool open = true;  // children are embedded in order while they fit
     for (uint32_t j = 0; j < 4; j++) {
         if (j >= dg) continue;
-        const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + me[j]);  // first half only: never written by this kernel
+        const uint32_t *ch = reinterpret_cast<const uint32_t *>(blocks + nb[j]);  // first half only
         const uint32_t cmt = ch[6];
         const uint32_t cflags = (cmt >> 8) & 0xFFu, cdeg = cmt & 0xFFu;
-        const uint32_t sj = (me[4 + (j >> 1)] >> ((j & 1u) * 16)) & 0xFFFFu;
+        const uint32_t sj = (w45[j >> 1] >> ((j & 1u) * 16)) & 0xFFFFu;
         const uint32_t wj = W8 ? (sj & 0xFFu) : sj;
         if (cflags & F_TARGET) cmeta |= 1u << j;
+        if constexpr (W8) slot[j] = (min(255u, wj + ((uint32_t)lbx[nb[j]] >> 8)) << 8) | wj;
         if (open && !(cflags & F_EXT) && used + cdeg <= (uint32_t)GSLOTS) {
             for (uint32_t t = 0; t < cdeg; t++) {
-                gn[used + t] = ch[t];
+                const uint32_t gc = ch[t];
+                gn[used + t] = gc;
                 const uint32_t st = (ch[4 + (t >> 1)] >> ((t & 1u) * 16)) & 0xFFFFu;
-                if constexpr (W8) {  // path weight | path weight + lb+(grandchild), each saturated at 255 (> any bound of this format)
-                    gwt[used + t] = min(255u, wj + (st & 0xFFu)) | (min(255u, wj + (st >> 8)) << 8);
-                    cmeta |= ((cmt >> (16 + t)) & 1u) << (8 + used + t);  // the grandchild is an in-node (the child's cmeta bit, build_lb_kernel)
+                if constexpr (W8) {
+                    const uint32_t x = lbx[gc], wt = st & 0xFFu;
+                    gwt[used + t] = min(255u, wj + wt) | (min(255u, wj + wt + (x >> 8)) << 8);
+                    if ((x & 0xFFu) == 0) cmeta |= 1u << (8 + used + t);  // the grandchild is an in-node
                 } else {
                     const uint32_t sum = wj + st;
                     gwt[used + t] = sum < 0xFFFFu ? sum : 0xFFFFu;
@@ -459,6 +452,10 @@ __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks) {
         }
     }
     uint32_t *out = reinterpret_cast<uint32_t *>(blocks + n);
+    if constexpr (W8) {
+        out[4] = slot[0] | (slot[1] << 16);
+        out[5] = slot[2] | (slot[3] << 16);
+    }
     out[6] = (meta & 0xFFFFu) | (cmeta << 16);
 #pragma unroll
     for (int i = 0; i < GSLOTS; i++) out[7 + i] = gn[i];
@@ -1502,6 +1499,7 @@ struct Device {
     uint32_t K1 = 0;
     uint64_t V = 0;
     uint64_t E0 = 0;  // original edges of the graph the device copy was built from
+    double lower_bounds_ms = 0.0;  // GPU time of the lower-bound precompute (0 without)
     bool single_use = false;  // the caller searches once (mtg_compute_tigs_cfg): what only the search needs goes back before the claim replay takes its arrays
     NodeBlock *d_recs = nullptr;              // [V] family blocks
     uint32_t *d_odeg = nullptr;               // [V] out-degree (classification)
@@ -2032,7 +2030,49 @@ void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
     }, std::move(done)).detach();
 }
 
-Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
+// The goal-directed lower bounds of a device graph whose blocks hold plain weights (k <= 255): k - 1 rounds over a 32-bit distance
+// array (lb), one pass for lb+ and the reach flags, and the blocks rewritten into the 8:8 format. A function of the graph alone;
+// what it costs (HIP events: device_lower_bounds_ms) is the price of the pruned search, paid once per device graph -- a caller that
+// searches once is better off without (mtg_compute_tigs_cfg builds none: 4.5 ms of full-ball search against 2 + 12 ms).
+static void build_lower_bounds(Device *d, hipStream_t st) {
+    const uint64_t V = d->V;
+    if (!V || d->w8) return;
+    const unsigned vb = (unsigned)((V + 255) / 256);
+    uint32_t *d_D = nullptr;
+    uint8_t *d_lb8 = nullptr;
+    uint16_t *d_lbx = nullptr;
+    hu::device_malloc(&d_D, V * 4);
+    hu::device_malloc(&d_lb8, V);
+    hu::device_malloc(&d_lbx, V * 2);
+    HIP_CHECK(hipEventRecord(d->ev0, st));
+    hipLaunchKernelGGL(lb_init_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, d->d_mirror, V, d_D);
+    for (uint32_t r = 0; r < d->K1; r++)
+        hipLaunchKernelGGL(lb_round_kernel, dim3(vb), dim3(256), 0, st, d->d_recs, d->d_ext_col, d->d_ext_w, V, r, d->K1, d_D);
+    hipLaunchKernelGGL(lb_mirror_kernel, dim3(vb), dim3(256), 0, st, d->d_mirror, d_D, V, d_lb8);
+    hipLaunchKernelGGL(build_lbx_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d_lbx, d->d_odeg);
+    hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs, (const uint16_t *)d_lbx);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(d->ev1, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    d->lower_bounds_ms = elapsed_ms(d);
+    d->w8 = true;
+    hu::device_free(d_D);
+    hu::device_free(d_lb8);
+    hu::device_free(d_lbx);
+}
+// ... for a device graph that was built without them (a caller that turns out to iterate): the searchable-source list of the
+// classification changes with the reach flags, so a classification that was there is repeated.
+void device_build_lower_bounds(Device *d, void *stream) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    if (d->k > 255 || d->w8) return;
+    if (!d->d_recs) MTG_DIE("mtg_device_build_lower_bounds: this device copy has given its search arrays back");
+    build_lower_bounds(d, (hipStream_t)stream);
+    if (d->classified) (void)device_classify(d, stream);
+}
+double device_lower_bounds_ms(const Device *d) { return d->lower_bounds_ms; }
+bool device_has_lower_bounds(const Device *d) { return d->w8; }
+
+Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_bounds) {
     if (k < 1) MTG_DIE("k must be >= 1");
     if (k > 0xFFFFFFFFull) MTG_DIE("k = %llu is not supported by the device stage (32-bit distances)", (unsigned long long)k);
     if (k > 65535) {
@@ -2155,29 +2195,9 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id) {
         if (E) hipLaunchKernelGGL(build_fill_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_ext_off, d_fill, d->d_recs, d->d_ext_col);
         hipLaunchKernelGGL(build_nodes_kernel, dim3(vb), dim3(256), 0, st, V, d->d_odeg, d->d_mirror, d_ext_off, d_from, d_w, d->d_recs,
                            d->d_ext_col, d->d_ext_w, d_row0, d_adj0);
-        d->w8 = k <= 255;
-        if (d->w8) {  // goal-directed lower bounds: k - 1 rounds over a 32-bit distance array, then the 8:8 format of the weight slots
-            uint32_t *d_D = nullptr;
-            uint8_t *d_lb8 = nullptr;
-            uint16_t *d_lbx = nullptr;
-            hu::device_malloc(&d_D, V * 4);
-            hu::device_malloc(&d_lb8, V);
-            hu::device_malloc(&d_lbx, V * 2);
-            hipLaunchKernelGGL(lb_init_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, d->d_mirror, V, d_D);
-            for (uint32_t r = 0; r < d->K1; r++)
-                hipLaunchKernelGGL(lb_round_kernel, dim3(vb), dim3(256), 0, st, d->d_recs, d->d_ext_col, d->d_ext_w, V, r, d->K1, d_D);
-            hipLaunchKernelGGL(lb_mirror_kernel, dim3(vb), dim3(256), 0, st, d->d_mirror, d_D, V, d_lb8);
-            hipLaunchKernelGGL(build_lbx_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d->d_ext_col, d->d_ext_w, d_lb8, d->K1, d_lbx, d->d_odeg);
-            hipLaunchKernelGGL(build_lb_kernel, dim3(vb), dim3(256), 0, st, V, d->d_recs, d_lbx);
-            hipLaunchKernelGGL(build_children_kernel<true>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipStreamSynchronize(st));
-            hu::device_free(d_D);
-            hu::device_free(d_lb8);
-            hu::device_free(d_lbx);
-        } else {
-            hipLaunchKernelGGL(build_children_kernel<false>, dim3(vb), dim3(256), 0, st, V, d->d_recs);
-        }
+        d->w8 = false;
+        if (lower_bounds && k <= 255) build_lower_bounds(d, st);  // (writes the second halves too)
+        else hipLaunchKernelGGL(build_children_kernel<false>, dim3(vb), dim3(256), 0, st, V, d->d_recs, (const uint16_t *)nullptr);
         HIP_CHECK(hipGetLastError());
     }
     dl.lap("build kernels (+ lower bounds)");

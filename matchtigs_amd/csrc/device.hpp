@@ -18,7 +18,12 @@ void device_reserve_async(uint64_t V, uint64_t E, int device_id = -1);  // helpe
 void device_arena_stats(int device_id, uint64_t out[4]);  // bytes in chunks, live bytes, peak of live bytes, chunks taken from the driver so far
 void device_set_default(int device_id);
 int device_get_default();
-Device *device_create(const HostGraph &g, uint64_t k, int device_id);
+// lower_bounds: the goal-directed lower bounds (k <= 255) are computed with the graph; without them the search explores full balls
+// (same candidate lists) until device_build_lower_bounds adds them
+Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_bounds = true);
+void device_build_lower_bounds(Device *d, void *stream);
+double device_lower_bounds_ms(const Device *d);   // GPU time (HIP events) of that precompute, 0 if the device graph has none
+bool device_has_lower_bounds(const Device *d);
 void device_free(Device *d);
 void device_set_single_use(Device *d);  // the caller searches once: the search's arrays go back before the claim replay (device.hip)
 uint64_t device_graph_bytes(const Device *d);

@@ -169,6 +169,16 @@ mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id) {
     // bounds need weights >= 1 -- the reference computes weight = len + 1 - k >= 1, bin.rs:369-376)
     return new mtg_device{device_create(g->g, k, device_id)};
 }
+mtg_device *mtg_device_create_opts(const mtg_graph *g, uint64_t k, int device_id, int flags) {
+    if (!g || !g->g.built) MTG_DIE("mtg_device_create_opts: graph is not built");
+    if (flags & ~MTG_DEVICE_NO_LOWER_BOUNDS) MTG_DIE("mtg_device_create_opts: unknown flags %d", flags);
+    return new mtg_device{device_create(g->g, k, device_id, !(flags & MTG_DEVICE_NO_LOWER_BOUNDS))};
+}
+void mtg_device_build_lower_bounds(mtg_device *d, void *stream) {
+    if (!d) MTG_DIE("mtg_device_build_lower_bounds: null device");
+    device_build_lower_bounds(d->d, stream);
+}
+double mtg_device_lower_bounds_ms(const mtg_device *d) { return d ? device_lower_bounds_ms(d->d) : 0.0; }
 void mtg_device_free(mtg_device *d) {
     if (!d) return;
     device_free(d->d);
@@ -719,8 +729,9 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
             std::vector<mtg_device *> devs((size_t)n_dev, nullptr);
             {
                 std::vector<std::thread> th;
-                for (int i = 1; i < n_dev; i++) th.emplace_back([&, i]() { devs[(size_t)i] = mtg_device_create(g, k, cfg->device_ids[i]); });
-                devs[0] = mtg_device_create(g, k, cfg->device_ids[0]);
+                // (searched once: no goal-directed lower bounds -- their precompute costs several times what it saves one search)
+                for (int i = 1; i < n_dev; i++) th.emplace_back([&, i]() { devs[(size_t)i] = mtg_device_create_opts(g, k, cfg->device_ids[i], MTG_DEVICE_NO_LOWER_BOUNDS); });
+                devs[0] = mtg_device_create_opts(g, k, cfg->device_ids[0], MTG_DEVICE_NO_LOWER_BOUNDS);
                 for (auto &t : th) t.join();
             }
             mtg_device *dev = devs[0];

@@ -166,6 +166,45 @@ def test_t1_candidate_lists(gpu, oracle, idx, plan):
         assert int((count > 0).sum()) <= searched <= S
 
 
+@pytest.mark.parametrize("plan", [0, 1, 2, 3])
+@pytest.mark.parametrize("idx", range(5))
+def test_t1_device_graph_without_lower_bounds_and_upgraded(gpu, oracle, idx, plan):
+    """mtg_device_create_opts(MTG_DEVICE_NO_LOWER_BOUNDS) -- the device graph mtg_compute_tigs_cfg builds for its one search: plain
+    weights, no pruning, full balls -- gives the oracle's candidate lists; mtg_device_build_lower_bounds then rewrites the blocks into
+    the 8:8 format (the same kernels as a build with bounds), after which the search prunes and gives the same lists again."""
+    from matchtigs_amd import api, torch_glue
+
+    name, bg = graphs()[idx]
+    o_on, off, keys, st = _oracle(oracle, bg).candidate_lists(bg.k)
+    G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)
+    dev = api.DeviceGraph(G, bg.k, lower_bounds=False)
+    dev.set_plan(plan)
+    assert not dev.prunes() and dev.lower_bounds_ms() == 0.0
+
+    def lists():
+        S = dev.classify(torch_glue.current_stream_ptr())
+        start, count, pool = torch_glue.candidates_to_numpy(torch_glue.run_sssp(dev, 0, S))
+        idx_arr = np.concatenate([np.arange(s, s + c, dtype=np.int64) for s, c in zip(start, count)]) if S else np.zeros(0, np.int64)
+        return S, count, pool[idx_arr]
+
+    S, count, got = lists()
+    assert S == len(o_on) and np.array_equal(count.astype(np.uint64), np.diff(off)) and np.array_equal(got, keys), name
+    cnt = dev.sssp_count(0, S)
+    assert (cnt["settled_nodes"], cnt["relaxed_edges"], cnt["emitted"]) == (st["settled_nodes"], st["relaxed_edges"], len(keys))
+    ms = dev.build_lower_bounds()
+    if bg.k <= 255:
+        assert ms > 0 and dev.prunes() == (plan in (0, 2, 3))
+    else:
+        assert ms == 0.0 and not dev.prunes()
+    S2, count2, got2 = lists()
+    assert S2 == S and np.array_equal(count2, count) and np.array_equal(got2, keys), name
+    if dev.prunes():  # the same units as a device graph built with its bounds
+        ref = api.DeviceGraph(G, bg.k)
+        ref.set_plan(plan)
+        ref.classify()
+        assert dev.sssp_count_visited(0, S) == ref.sssp_count_visited(0, S)
+
+
 @pytest.mark.parametrize("plan", [0, 2, 4])
 def test_t1_long_lists_from_the_enumeration_level(gpu, oracle, plan):
     """Short unitigs and many in-nodes: the enumeration level itself finishes sources with 5-8, 9-16 and more than 16 candidates
