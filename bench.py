@@ -148,6 +148,7 @@ def main():
                          "has the memory (>= 170 GB of HBM and >= 140 GB of host memory free); 0 = skip")
     ap.add_argument("--no-one-shot", dest="one_shot", action="store_false",
                     help="skip the one_shot block (the consuming one-shot call, host arrays in -> clib.rs arrays out, in a child process of its own per Euler mode)")
+    ap.add_argument("--keep-awake", action="store_true", help="measurement: a trivial kernel every 2 ms while the host walks (mtg_set_finish_tuning flag 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate --pmc pass")
@@ -178,6 +179,8 @@ def main():
     from matchtigs_amd import api, synth, torch_glue
     from matchtigs_amd import distributed as mdist
 
+    if args.keep_awake:
+        api.set_finish_tuning(keep_awake=True)
     api.set_default_device(local_rank)  # (the GPU whose memory a graph's construction reserves ahead of the call that follows)
     k = args.k
     # ---- the consuming one-shot call (clib.rs:280-291: every real call of the reference is a first call), each Euler mode in a

@@ -121,6 +121,10 @@ typedef struct {
 /* Library / device probes. */
 const char *mtg_version(void);
 int mtg_device_count(void); /* hipGetDeviceCount; 0 when no GPU (never initialises a context) */
+/* Which setting of the four out-of-tree policies (include/mtg_policy.h: heap tie-break, inclusive bound, adjacency order, union-find
+ * tie) this library was built with: bit i set = policy P(i+1) flipped. 0 for libmatchtigs.so; 15 for the libmatchtigs_flipped.so
+ * that `make flipped` builds for the parity suite. */
+unsigned mtg_policies(void);
 
 /* ---- host graph ------------------------------------------------------------------------ */
 /* Edges in id order: edge 2u = unitig u forwards, edge 2u+1 = its mirror (clib.rs:239-248).
@@ -376,7 +380,8 @@ void mtg_set_default_device(int device_id);
  * environment variable for any of it, and none changes a result). records: walk-record format of the reference-order mode, 0 = the
  * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records. flags: bit 0 = the walk
  * waits until all of its records have arrived (instead of starting on the 32-byte ones), bit 1 = never page-lock the record arena,
- * bit 2 = keep nothing of a graph on the device between calls (edges, mirror, buckets). record_delay_us: slows the arrival of the
+ * bit 2 = keep nothing of a graph on the device between calls (edges, mirror, buckets), bit 3 = a trivial kernel every 2 ms while the
+ * host walks in the reference's order (measurement: what the GPU's idle state costs the first kernels of the next step). record_delay_us: slows the arrival of the
  * records by that much per slice (tests: small graphs then take the 32-byte path for most of their steps). */
 void mtg_set_finish_tuning(int records, int flags, int64_t record_delay_us);
 /* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,

@@ -96,7 +96,8 @@ def declared_symbols() -> list[str]:
     for h in sorted(INCLUDE_DIR.glob("*.h")):
         text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
         names += re.findall(r"\b((?:mtg|matchtigs)_[a-z0-9_]+)\s*\(", text)
-    return sorted(set(names))
+    # (include/mtg_policy.h defines static inline helpers, mtg_policy_*: compiled into their users, not exported)
+    return sorted(n for n in set(names) if not n.startswith("mtg_policy_"))
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -118,18 +119,22 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+
+    lib_path = Path(os.environ["MATCHTIGS_LIBRARY"]) if os.environ.get("MATCHTIGS_LIBRARY") else LIB_PATH  # (another build of the library, e.g. `make flipped`)
+    if not lib_path.exists():
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C matchtigs_amd/csrc`. matchtigs_amd has no fallback without its HIP library."
         )
     _share_hip_runtime_with_torch()
-    L = C.CDLL(str(LIB_PATH))
+    L = C.CDLL(str(lib_path))
     vp, u32, u64, i64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_int32
     P = C.POINTER
     sig = {
         "mtg_version": (C.c_char_p, []),
         "mtg_device_count": (C.c_int, []),
+        "mtg_policies": (C.c_uint, []),
         "mtg_graph_from_edges": (vp, [u64, vp, u64, vp, vp, vp]),
         "mtg_graph_builder_new": (vp, [u64]),
         "mtg_graph_builder_merge": (None, [vp, u64, C.c_int, u64, C.c_int]),

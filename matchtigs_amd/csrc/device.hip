@@ -39,6 +39,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "../../include/mtg_policy.h"
 #include "device.hpp"
 #include "hip_util.hpp"
 #include "parallel.hpp"
@@ -251,21 +252,23 @@ __global__ __launch_bounds__(64) void active_range_kernel(const uint32_t *act_in
 // Out-edges are kept in edge-id order per node (slots are claimed in any order, then sorted by edge id), so the content is
 // independent of thread timing.
 // ------------------------------------------------------------------------------------------------
-__global__ void build_count_kernel(const uint32_t *e_from, uint64_t n_edges, uint32_t *odeg) {
+// (the count and the edge's slot at its from-node come from the same atomic: `rank` is read back, coalesced, by build_fill_kernel --
+// one random atomic per edge instead of two: 18.5 -> see DESIGN 3.1)
+__global__ void build_count_kernel(const uint32_t *e_from, uint64_t n_edges, uint32_t *odeg, uint32_t *rank) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n_edges) atomicAdd(&odeg[e_from[e]], 1u);
+    if (e < n_edges) rank[e] = atomicAdd(&odeg[e_from[e]], 1u);
 }
 __global__ void build_ext_need_kernel(const uint32_t *odeg, uint64_t n_nodes, uint32_t *ext_need) {
     const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n < n_nodes) ext_need[n] = odeg[n] > 4 ? odeg[n] : 0u;
 }
-// every edge claims a slot of its from-node and leaves its EDGE ID there (inline slot or spill position)
+// every edge leaves its EDGE ID in the slot of its from-node the counting pass gave it (inline slot or spill position)
 __global__ void build_fill_kernel(const uint32_t *e_from, uint64_t n_edges, const uint32_t *odeg, const unsigned long long *ext_off,
-                                  uint32_t *fill, NodeBlock *blocks, uint32_t *ext_col) {
+                                  const uint32_t *rank, NodeBlock *blocks, uint32_t *ext_col) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const uint32_t f = e_from[e];
-    const uint32_t slot = atomicAdd(&fill[f], 1u);
+    const uint32_t slot = rank[e];
     if (odeg[f] > 4) ext_col[ext_off[f] + slot] = (uint32_t)e;
     else blocks[f].nbr[slot] = (uint32_t)e;
 }
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(BLOCK) void sssp_kernel(SsspArgs a) {
                     const unsigned long long key = M::ld(&stage[i]);
                     const uint32_t lo_ = s.off[src], hi_ = lo_ + s.cnt[src];
                     uint32_t rank = 0;
-                    for (uint32_t j = lo_; j < hi_; j++) rank += (M::ld(&stage[j]) < key) ? 1u : 0u;
+                    for (uint32_t j = lo_; j < hi_; j++) rank += mtg_policy_pops_before(M::ld(&stage[j]), key) ? 1u : 0u;  // policy P1 (mtg_policy.h)
                     const unsigned long long dst = base + lo_ + rank;
                     if (dst < a.pool_cap) a.pool[dst] = key;
                 }
@@ -1267,8 +1270,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             if (c > 3) k3 = mem[hit_word(blk, 3)];
             bool fix = c > 4;
             if (__any(c >= 2 && c <= 4)) {  // (a longer list is sorted as a whole by the post-pass: no need to run the network for it alone)
-                auto cswap = [](unsigned long long &x, unsigned long long &y) {
-                    const unsigned long long lo = x < y ? x : y, hi = x < y ? y : x;
+                auto cswap = [](unsigned long long &x, unsigned long long &y) {  // pop order: policy P1 (mtg_policy.h)
+                    const bool xf = mtg_policy_pops_before(x, y);
+                    const unsigned long long lo = xf ? x : y, hi = xf ? y : x;
                     x = lo; y = hi;
                 };
                 cswap(k0, k1); cswap(k2, k3); cswap(k0, k2); cswap(k1, k3); cswap(k1, k2);  // (longer lists are sorted again anyway)
@@ -1435,7 +1439,8 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
             for (int j = k >> 1; j > 0; j >>= 1) {
                 const unsigned long long other = __shfl_xor(key, j);
                 const bool take_min = ((g & (uint32_t)k) == 0) == ((g & (uint32_t)j) == 0);
-                const unsigned long long lo = key < other ? key : other, hi = key < other ? other : key;
+                const bool kf = mtg_policy_pops_before(key, other);  // pop order: policy P1 (mtg_policy.h)
+                const unsigned long long lo = kf ? key : other, hi = kf ? other : key;
                 key = take_min ? lo : hi;
             }
         }
@@ -1785,7 +1790,7 @@ static void run_dense_level(Device *d, hipStream_t st, const SsspArgs &a, const 
         keys.resize(n_keys);
         if (n_keys) HIP_CHECK(hipMemcpyAsync(keys.data(), d_keys, n_keys * 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        std::sort(keys.begin(), keys.end());
+        std::sort(keys.begin(), keys.end(), [](unsigned long long x, unsigned long long y) { return mtg_policy_pops_before(x, y) != 0; });  // policy P1
         const unsigned long long start = d->h_counters[C_POOL];  // host mirror of the pool cursor (read_counters ran after the last level)
         d->h_counters[C_POOL] += n_keys;
         if (start + n_keys <= a.pool_cap && n_keys) HIP_CHECK(hipMemcpyAsync(a.pool + start, keys.data(), n_keys * 8, hipMemcpyHostToDevice, st));
@@ -1981,7 +1986,7 @@ int device_count() {
 // estimate that is too small costs a second chunk, one that is too large memory the driver has to map for nothing.
 size_t device_call_bytes_estimate(uint64_t V, uint64_t E, uint64_t k) {
     (void)k;
-    return (size_t)(V * 106 + E * 12) + (64u << 20);
+    return (size_t)(V * 106 + E * 14) + (64u << 20);
 }
 
 // Kernel code objects load lazily, at the first launch of a kernel of their translation unit (3-10 ms each on a cold process); asking
@@ -2105,7 +2110,8 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
     Device *d = new Device();
     d->dev = device_id;
     d->k = k;
-    d->K1 = (uint32_t)(k - 1);
+    if (MTG_POLICY_BOUND_EXCLUSIVE && k < 2) MTG_DIE("k must be >= 2 under the exclusive-bound policy");
+    d->K1 = (uint32_t)mtg_policy_search_bound(k);  // the largest distance a target is found at: policy P2 (mtg_policy.h)
     d->V = g.node_count();
     d->E0 = g.n_original_edges;
     hipDeviceProp_t prop;
@@ -2153,7 +2159,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
         hu::device_malloc(&d_adj0, E * 4);
     }
     hu::device_malloc(&d_w, std::max<uint64_t>(U, 1) * 2);
-    hu::device_malloc(&d_fill, std::max<uint64_t>(V, 1) * 4);
+    hu::device_malloc(&d_fill, std::max<uint64_t>(E, 1) * 4);  // rank of every edge among the out-edges of its from-node (arrival order of the counting pass)
     hu::device_malloc(&d_need, std::max<uint64_t>(V, 1) * 4);
     hu::device_malloc(&d_ext_off, std::max<uint64_t>(V, 1) * 8);
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
@@ -2169,16 +2175,15 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
     }
     if (V) hu::upload_sliced(d->d_mirror, g.mirror.data(), V * 4, st, device_id);
     HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, st));
-    HIP_CHECK(hipMemsetAsync(d_fill, 0, std::max<uint64_t>(V, 1) * 4, st));
     dl.lap("uploads + memsets");
     const unsigned eb = (unsigned)((E + 255) / 256), vb = (unsigned)((V + 255) / 256);
     uint64_t ext_total = 0;
     if (V) {
-        if (E) hipLaunchKernelGGL(build_count_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg);
+        if (E) hipLaunchKernelGGL(build_count_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_fill);
         hipLaunchKernelGGL(build_ext_need_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, V, d_need);
         HIP_CHECK(hipGetLastError());
         scan_u32(d, st, d->replay, d_need, V, d_ext_off, &d->d_counters[C_OVF_LIST]);
-        if (want_buckets) {  // row0 = exclusive scan of the out-degrees (d_fill's memory serves as the scan's block sums until build_fill_kernel runs)
+        if (want_buckets) {  // row0 = exclusive scan of the out-degrees
             uint32_t *d_bs = nullptr;
             hu::device_malloc(&d_bs, (hu::scan_blocks(V) + 2) * 4);
             hu::scan_u32<uint32_t>(st, d->d_odeg, V, d_row0, d_bs, d_row0 + V);

@@ -18,6 +18,7 @@
 
 #include "../../include/matchtigs.h"
 #include "../../include/mtg_engine.h"
+#include "../../include/mtg_policy.h"
 #include "device.hpp"
 #include "euler_lean.hpp"
 #include "host_graph.hpp"
@@ -85,10 +86,26 @@ static void log_info(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Giving a large graph back takes as long as unmapping its memory does (0.05 s for the edge arrays of the 2^27 graph, 1 s with the
+// 23 GB of walk records a reference-order finish leaves in its arena): the device copy goes at once, the host memory on a thread
+// of its own -- the caller (clib.rs:291 consumes the handle inside matchtigs_compute_tigs) has its result and does not wait for munmap.
+template <typename T>
+static void free_graph_object(T *obj, HostGraph &g) {
+    if (!obj) return;
+    if (g.edge_count() < (1u << 22)) {
+        delete obj;
+        return;
+    }
+    device_release_graph_cache(g);
+    g.arena.unpin_all();  // (what is left for the thread makes no HIP call)
+    std::thread([obj]() { delete obj; }).detach();
+}
+
 extern "C" {
 
 const char *mtg_version(void) { return "matchtigs-amd 0.1 (gfx950; reference algbio/matchtigs 2.1.9)"; }
 int mtg_device_count(void) { return device_count(); }
+unsigned mtg_policies(void) { return MTG_POLICY_MASK; }
 
 // ---- host graph ----
 mtg_graph *mtg_graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n_edges, const uint32_t *edge_from,
@@ -119,7 +136,9 @@ void mtg_graph_builder_build(mtg_graph *g, const uint64_t *unitig_weights) {
     if (!g) MTG_DIE("mtg_graph_builder_build: null graph");
     builder_build(&g->g, unitig_weights);
 }
-void mtg_graph_free(mtg_graph *g) { delete g; }
+void mtg_graph_free(mtg_graph *g) {
+    if (g) free_graph_object(g, g->g);
+}
 void mtg_graph_reset(mtg_graph *g) {
     if (!g || !g->g.built) MTG_DIE("mtg_graph_reset: graph is not built");
     g->g.reset_to_original();
@@ -917,7 +936,7 @@ size_t matchtigs_compute_tigs(MatchtigsData *data, size_t tig_algorithm, size_t 
     cfg.matcher_path = matcher_path;
     const uint64_t n = mtg_compute_tigs_clib(&data->graph, tig_algorithm, &cfg, reinterpret_cast<int64_t *>(tigs_edge_out),
                                              reinterpret_cast<uint64_t *>(tigs_insert_out), reinterpret_cast<uint64_t *>(tigs_out_limits));
-    delete data;  // Box::from_raw at clib.rs:291: the handle is consumed
+    free_graph_object(data, data->graph.g);  // Box::from_raw at clib.rs:291: the handle is consumed
     return n;
 }
 

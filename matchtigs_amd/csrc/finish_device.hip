@@ -35,6 +35,7 @@
 #include <numeric>
 #include <vector>
 
+#include "../../include/mtg_policy.h"
 #include "device.hpp"
 #include "finish_device.hpp"
 #include "hugebuf.hpp"
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(EB) void lean_build_kernel(uint64_t n_nodes, const 
         r.eid[p] = NONE;
         r.to[p] = NONE;
     }
-    for (uint32_t p = 0; p < d; p++) {  // position p = p-th NEWEST out-dart (petgraph order): buckets are ascending
-        const uint32_t e = adj[lo + d - 1 - p];
+    for (uint32_t p = 0; p < d; p++) {  // position p of the iteration order (default: the p-th NEWEST out-dart, petgraph's order): policy P3 (mtg_policy.h); buckets ascend
+        const uint32_t e = adj[lo + mtg_policy_adjacency_index(p, d)];
         const uint32_t t = mirror[from[e ^ 1]];
         if (p < 3) {
             r.eid[p] = e;
@@ -621,6 +622,30 @@ static hipStream_t finish_side_stream(int device_id) {
     return streams[device_id];
 }
 
+// Measurement aid (mtg_set_finish_tuning flag 8): while the host walks the Euler cycles in the reference's order the GPU idles for
+// seconds; with this a trivial kernel runs every 2 ms, which shows what the idle state costs the first kernels of the next step.
+__global__ void keep_awake_kernel(uint32_t *p) { if (p && threadIdx.x == 1024) *p = 0; }
+struct KeepAwake {
+    std::atomic<bool> stop{false};
+    std::thread th;
+    KeepAwake(bool on, int device_id) {
+        if (!on) return;
+        th = std::thread([this, device_id]() {
+            HIP_CHECK(hipSetDevice(device_id));
+            hipStream_t s = finish_side_stream(device_id);
+            while (!stop.load(std::memory_order_relaxed)) {
+                keep_awake_kernel<<<1, 64, 0, s>>>(nullptr);
+                (void)hipStreamSynchronize(s);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        });
+    }
+    ~KeepAwake() {
+        stop.store(true);
+        if (th.joinable()) th.join();
+    }
+};
+
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
                     const mtg_pair *d_pairs_resident, TigSink *sink) {
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
@@ -928,6 +953,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release();
     } else {
         Walks cycles;
+        KeepAwake keep_awake((finish_tuning().flags.load() & FT_KEEP_AWAKE) != 0, device_id);
         {
             Buf b_row, b_adj, b_need, b_off, b_tot, b_nodes, b_xe, b_xt;
             uint32_t *d_row = b_row.alloc<uint32_t>(st, V + 1), *d_adj = b_adj.alloc<uint32_t>(st, E);
@@ -1176,17 +1202,22 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             const uint32_t *pw = h_pw.get();
             int64_t *eo = sink->edge_out;
             uint64_t *io = sink->insert_out;
+            // (16 bytes written per 4 read, never read again here: streaming stores -- no read-for-ownership of the caller's lines)
             auto expand = [=](size_t first, const uint32_t *e, size_t n) {
                 for (size_t i = 0; i < n; i++) {
                     const uint32_t x = e[i];
+                    int64_t ev;
+                    uint64_t iv;
                     if (x < E0u) {
-                        eo[first + i] = (x & 1u) ? -(int64_t)(x >> 1) : (int64_t)(x >> 1);
-                        io[first + i] = 0;
+                        ev = (x & 1u) ? -(int64_t)(x >> 1) : (int64_t)(x >> 1);
+                        iv = 0;
                     } else {
                         const uint64_t b = (x - E0u) >> 1;
-                        eo[first + i] = 0;
-                        io[first + i] = b < n_pairs ? (pairs ? pairs[b].distance : (uint64_t)pw[b]) : k;
+                        ev = 0;
+                        iv = b < n_pairs ? (pairs ? pairs[b].distance : (uint64_t)pw[b]) : k;
                     }
+                    __builtin_nontemporal_store(ev, &eo[first + i]);
+                    __builtin_nontemporal_store(iv, &io[first + i]);
                 }
             };
             if (n_kept * 4 < (64u << 20)) {

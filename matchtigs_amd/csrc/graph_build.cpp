@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <thread>
 
+#include "../../include/mtg_policy.h"
 #include "device.hpp"
 #include "parallel.hpp"
 
@@ -32,18 +33,28 @@ void HostGraph::reserve_edges(uint64_t n) {
 // (newest first, like petgraph's per-node edge list). One pass partitions the edge ids by node range (a thread per edge range,
 // one bucket per node range), then every node range prepends its edges, edge ranges in ascending order: O(E) reads instead of
 // the O(threads x E) of letting every node-range thread scan all edges.
+// One edge joins its from-node's list; edges arrive in ascending id. Iteration order of a list = policy P3 (mtg_policy.h): newest
+// edge first (petgraph: the new edge becomes the head) or oldest first (the new edge goes to the tail: `tail_out` keeps it).
+static inline void link_one(const HostGraph &g, uint32_t e) {
+    const uint32_t f = g.e_from[e];
+    if (!MTG_POLICY_ADJACENCY_OLDEST_FIRST) {
+        g.e_next_out[e] = g.head_out[f];
+        g.head_out[f] = e;
+    } else {
+        g.e_next_out[e] = NONE;
+        if (g.head_out[f] == NONE) g.head_out[f] = e;
+        else g.e_next_out[g.tail_out[f]] = e;
+        g.tail_out[f] = e;
+    }
+    g.out_deg[f]++;
+}
 static void link_range(const HostGraph &g, uint64_t lo, uint64_t hi) {
     const uint64_t n = hi - lo, V = g.node_count();
     if (!n) return;
     unsigned T = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     if (n < (1u << 16) || V < 1024) T = 1;
     if (T == 1) {
-        for (uint64_t e = lo; e < hi; e++) {
-            const uint32_t f = g.e_from[e];
-            g.e_next_out[e] = g.head_out[f];
-            g.head_out[f] = (uint32_t)e;
-            g.out_deg[f]++;
-        }
+        for (uint64_t e = lo; e < hi; e++) link_one(g, (uint32_t)e);
         return;
     }
     unsigned shift = 0;
@@ -59,12 +70,7 @@ static void link_range(const HostGraph &g, uint64_t lo, uint64_t hi) {
     }, T);
     parallel_tasks(NB, [&](uint64_t j) {
         for (unsigned i = 0; i < T; i++)
-            for (const uint32_t e : bucket[i][j]) {
-                const uint32_t f = g.e_from[e];
-                g.e_next_out[e] = g.head_out[f];
-                g.head_out[f] = e;
-                g.out_deg[f]++;
-            }
+            for (const uint32_t e : bucket[i][j]) link_one(g, e);
     }, T);
 }
 
@@ -76,6 +82,7 @@ void HostGraph::ensure_linked() const {
     std::lock_guard<std::mutex> lock(*link_mutex);
     if (!adjacency_ready) {  // first use of the host adjacency on this graph: the per-node heads come into being now
         head_out.assign(node_count(), NONE);
+        if (MTG_POLICY_ADJACENCY_OLDEST_FIRST) tail_out.assign(node_count(), NONE);
         out_deg.assign(node_count(), 0);
         linked_edges = 0;
         __atomic_store_n(&adjacency_ready, true, __ATOMIC_RELEASE);
@@ -123,7 +130,11 @@ void HostGraph::reset_to_original() {
     // pop the linked dummy edges: the newest edge of a node unwinds the node's list down to its newest original edge
     // (exactly one edge per touched node is the head, so every node is handled by one thread)
     const uint64_t linked = std::min(linked_edges, total);
-    if (linked > keep)
+    if (MTG_POLICY_ADJACENCY_OLDEST_FIRST && linked > keep) {
+        // (the dummy edges sit at the tails of the lists under this policy: the lists are simply linked again when next needed)
+        adjacency_ready = false;
+        linked_edges = 0;
+    } else if (linked > keep)
         parallel_ranges(linked - keep, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t e = keep + lo; e < keep + hi; e++) {
                 const uint32_t f = e_from[e];
@@ -257,7 +268,8 @@ void builder_merge(HostGraph *g, uint64_t ua, bool sa, uint64_t ub, bool sb) {
         uint8_t ra = g->uf_rank[a], rb = g->uf_rank[b];
         if (ra > rb) g->uf_parent[b] = a;
         else if (rb > ra) g->uf_parent[a] = b;
-        else { g->uf_parent[a] = b; g->uf_rank[b]++; }
+        else if (mtg_policy_union_tie_first_goes_below()) { g->uf_parent[a] = b; g->uf_rank[b]++; }  // equal ranks: policy P4 (mtg_policy.h)
+        else { g->uf_parent[b] = a; g->uf_rank[a]++; }
     }
 }
 

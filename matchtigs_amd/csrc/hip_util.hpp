@@ -35,9 +35,10 @@ struct FinishTuning {
     std::atomic<int> records{0};           // walk records of the reference-order mode: 0 = the engine's choice, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte
     std::atomic<int> flags{0};             // bit 0: the walk waits for all of its records; bit 1: never page-lock the record arena;
                                            // bit 2: keep nothing of the graph on the device between calls (edges, mirror, buckets)
+                                           // bit 3: a trivial kernel every 2 ms while the host walks (measurement: what the GPU's idle state costs the next step)
     std::atomic<long> record_delay_us{0};  // tests: slows the arrival of the walk's records
 };
-enum : int { FT_NO_RECORD_OVERLAP = 1, FT_NO_PIN = 2, FT_NO_EDGE_CACHE = 4 };
+enum : int { FT_NO_RECORD_OVERLAP = 1, FT_NO_PIN = 2, FT_NO_EDGE_CACHE = 4, FT_KEEP_AWAKE = 8 };
 inline FinishTuning &finish_tuning() {
     static FinishTuning t;
     return t;

@@ -167,6 +167,7 @@ struct HostGraph {
     // finish appends its dummy edges to the edge arrays only, and a host stage that walks adjacency calls ensure_linked() first.
     mutable std::vector<uint32_t> head_out;  // [V] newest outgoing edge among the linked ones
     mutable std::vector<uint32_t> out_deg;   // [V] over the linked edges; in_deg(n) == out_deg(mirror(n)) by the mirror property
+    mutable std::vector<uint32_t> tail_out;  // [V] last edge of the list (only under the oldest-first adjacency policy, mtg_policy.h P3)
     PodVec<uint32_t> e_from, e_to;              // [E]
     mutable PodVec<uint32_t> e_next_out;        // [E]
     mutable uint64_t linked_edges = 0;

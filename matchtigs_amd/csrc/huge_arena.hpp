@@ -89,6 +89,15 @@ struct HugeArena {
             }
         return false;
     }
+    // page-locked mappings are given back to the runtime (so that release() makes no HIP call: it may run on a thread of its own)
+    void unpin_all() {
+        std::lock_guard<std::mutex> l(mu);
+        for (Slot &s : slots)
+            if (s.pinned && unpin_hook()) {
+                unpin_hook()(s.p);
+                s.pinned = false;
+            }
+    }
     void release() {
         std::lock_guard<std::mutex> l(mu);
         for (Slot &s : slots) unmap_slot(s);

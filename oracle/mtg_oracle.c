@@ -10,6 +10,7 @@
  *
  * Citations: file:line into /root/reference/.
  */
+#include "../include/mtg_policy.h"
 #include "mtg_oracle.h"
 
 #include <pthread.h>
@@ -129,8 +130,17 @@ uint32_t og_add_edge(og_graph *g, uint32_t from, uint32_t to, uint64_t weight, u
     g->from[e] = from; g->to[e] = to;
     g->weight[e] = weight; g->dummy_id[e] = dummy_id; g->handle[e] = handle;
     g->forwards[e] = forwards ? 1 : 0;
-    g->next_out[e] = g->head_out[from]; g->head_out[from] = e; /* newest first */
-    g->next_in[e] = g->head_in[to]; g->head_in[to] = e;
+    if (!MTG_POLICY_ADJACENCY_OLDEST_FIRST) { /* policy P3 (include/mtg_policy.h): newest first */
+        g->next_out[e] = g->head_out[from]; g->head_out[from] = e;
+        g->next_in[e] = g->head_in[to]; g->head_in[to] = e;
+    } else { /* the other setting: the new edge goes to the end of both lists (degrees are tiny where this build is used) */
+        g->next_out[e] = OG_NONE;
+        if (g->head_out[from] == OG_NONE) g->head_out[from] = e;
+        else { uint32_t t = g->head_out[from]; while (g->next_out[t] != OG_NONE) t = g->next_out[t]; g->next_out[t] = e; }
+        g->next_in[e] = OG_NONE;
+        if (g->head_in[to] == OG_NONE) g->head_in[to] = e;
+        else { uint32_t t = g->head_in[to]; while (g->next_in[t] != OG_NONE) t = g->next_in[t]; g->next_in[t] = e; }
+    }
     g->out_deg[from]++; g->in_deg[to]++;
     return e;
 }
@@ -142,6 +152,7 @@ og_graph *og_graph_from_arrays(uint32_t n_nodes, const uint32_t *mirror, uint32_
     for (uint32_t e = 0; e < n_edges; e++) og_add_edge(g, from[e], to[e], weight[e], 0, e / 2, e % 2 == 0);
     return g;
 }
+unsigned og_policies(void) { return MTG_POLICY_MASK; } /* which setting of the four out-of-tree policies this build follows */
 uint32_t og_node_count(const og_graph *g) { return g->n_nodes; }
 uint32_t og_edge_count(const og_graph *g) { return g->n_edges; }
 uint32_t og_mirror_node(const og_graph *g, uint32_t n) { return g->mirror[n]; }
@@ -220,7 +231,8 @@ static void uf_union(og_builder *b, uint64_t x, uint64_t y) {
     uint8_t ra = b->rank[a], rc = b->rank[c];
     if (ra > rc) b->parent[c] = a;
     else if (rc > ra) b->parent[a] = c;
-    else { b->parent[a] = c; b->rank[c]++; }
+    else if (mtg_policy_union_tie_first_goes_below()) { b->parent[a] = c; b->rank[c]++; } /* policy P4 (include/mtg_policy.h) */
+    else { b->parent[c] = a; b->rank[a]++; }
 }
 og_builder *og_builder_new(uint64_t unitig_amount) { /* clib.rs:97-102 */
     og_builder *b = xmalloc(sizeof *b);
@@ -337,7 +349,8 @@ typedef struct {
     int hashed; uint32_t *mkey; uint64_t *mval; uint32_t mcap, mn; uint32_t *mtouched;
 } dijkstra;
 
-static inline int hless(hitem a, hitem b) { return a.w < b.w || (a.w == b.w && a.n < b.n); }
+/* pop order among equal distances: policy P1 (include/mtg_policy.h) */
+static inline int hless(hitem a, hitem b) { return a.w < b.w || (a.w == b.w && (MTG_POLICY_HEAP_TIE_DESCENDING ? a.n > b.n : a.n < b.n)); }
 static void hpush(dijkstra *d, uint64_t w, uint32_t n) {
     if (d->hn == d->hcap) { d->hcap = d->hcap ? d->hcap * 2 : 64; d->heap = xrealloc(d->heap, d->hcap * sizeof(hitem)); }
     size_t i = d->hn++;
@@ -436,7 +449,7 @@ static void shortest_path_lens(const og_graph *g, dijkstra *d, uint32_t source, 
         if (st) st->iterations++;
         uint64_t actual = dget(d, it.n);
         if (actual < it.w) { if (st) st->unnecessary++; continue; }
-        if (it.w > max_weight) break;
+        if (MTG_POLICY_BOUND_EXCLUSIVE ? it.w >= max_weight : it.w > max_weight) break; /* inclusive bound: policy P2 (include/mtg_policy.h) */
         if (targets[it.n] && !(forbid_source_target && it.n == source)) {
             dv_push(distances, it.n, it.w);
             if (distances->n == target_amount) break;

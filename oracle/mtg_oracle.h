@@ -43,6 +43,7 @@ uint32_t og_add_edge(og_graph *g, uint32_t from, uint32_t to, uint64_t weight,
 /* Bulk constructor for benchmarks: original edges in id order (edge 2u forwards of unitig u, 2u+1 its mirror). */
 og_graph *og_graph_from_arrays(uint32_t n_nodes, const uint32_t *mirror, uint32_t n_edges, const uint32_t *from,
                                const uint32_t *to, const uint64_t *weight);
+unsigned og_policies(void); /* include/mtg_policy.h: bit i = policy P(i+1) flipped in this build */
 uint32_t og_node_count(const og_graph *g);
 uint32_t og_edge_count(const og_graph *g);
 uint32_t og_mirror_node(const og_graph *g, uint32_t n);

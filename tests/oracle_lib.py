@@ -42,11 +42,16 @@ class Walks(C.Structure):
 
 
 def build_oracle(force: bool = False) -> Path:
-    so = ORACLE_DIR / "libmtg_oracle.so"
-    src = ORACLE_DIR / "mtg_oracle.c"
-    hdr = ORACLE_DIR / "mtg_oracle.h"
-    if force or not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
-        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", "libmtg_oracle.so"], check=True, capture_output=True)
+    """libmtg_oracle.so -- or, when MTG_POLICY names another setting of the four out-of-tree policies (include/mtg_policy.h; the
+    flipped-policy fuzz sets 15 = all four flipped), the build of the oracle that follows it."""
+    import os
+
+    flipped = int(os.environ.get("MTG_POLICY", "0")) != 0
+    name = "libmtg_oracle_flipped.so" if flipped else "libmtg_oracle.so"
+    so = ORACLE_DIR / name
+    deps = [ORACLE_DIR / "mtg_oracle.c", ORACLE_DIR / "mtg_oracle.h", ORACLE_DIR.parent / "include" / "mtg_policy.h"]
+    if force or not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+        subprocess.run(["make", "-C", str(ORACLE_DIR), "-B", name], check=True, capture_output=True)
     return so
 
 
@@ -54,8 +59,13 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    import os
+
     so = build_oracle()
     L = C.CDLL(str(so))
+    L.og_policies.restype = C.c_uint
+    if int(L.og_policies()) != int(os.environ.get("MTG_POLICY", "0")):
+        raise RuntimeError(f"{so} follows policy mask {int(L.og_policies())}, MTG_POLICY asks for {os.environ.get('MTG_POLICY', '0')}")
     vp, u32, u64, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64
     P = C.POINTER
     sig = {

@@ -7,7 +7,15 @@ Citations: file:line into /root/reference/.  Third-party behaviour: SURVEY Appen
 from __future__ import annotations
 
 import heapq
+import os
 from dataclasses import dataclass
+
+# The four out-of-tree policies (include/mtg_policy.h: P1 heap tie-break, P2 inclusive bound, P3 adjacency order, P4 union-find tie),
+# as a bit mask like mtg_policies() / og_policies(): 0 = the behaviour SURVEY App. A describes, bit i set = P(i+1) flipped. The
+# flipped-policy fuzz runs this module, the oracle and the product under the same non-zero mask (tests/test_fuzz_small.py).
+POLICY = int(os.environ.get("MTG_POLICY", "0"))
+P_HEAP_TIE_DESCENDING, P_BOUND_EXCLUSIVE, P_ADJACENCY_OLDEST_FIRST, P_UNION_TIE_SECOND_UNDER_FIRST = (bool(POLICY & 1), bool(POLICY & 2),
+                                                                                                    bool(POLICY & 4), bool(POLICY & 8))
 
 
 @dataclass
@@ -42,8 +50,8 @@ class PyBigraph:
         self.inn[t].append(e)
         return e
 
-    def out_neighbors(self, n):
-        return reversed(self.out[n])
+    def out_neighbors(self, n):  # iteration order: policy P3
+        return iter(self.out[n]) if P_ADJACENCY_OLDEST_FIRST else reversed(self.out[n])
 
     def mirror_edge(self, e):
         d = self.edges[e]
@@ -79,9 +87,12 @@ def from_unitig_links(weights, links):
             parent[b] = a
         elif rank[b] > rank[a]:
             parent[a] = b
-        else:
+        elif not P_UNION_TIE_SECOND_UNDER_FIRST:  # equal ranks: policy P4
             parent[a] = b
             rank[b] += 1
+        else:
+            parent[b] = a
+            rank[a] += 1
 
     fi, fo, bi, bo = (lambda u: 4 * u), (lambda u: 4 * u + 2), (lambda u: 4 * u + 3), (lambda u: 4 * u + 1)
     for (ua, sa, ub, sb) in links:  # clib.rs:144-169
@@ -107,14 +118,16 @@ def from_unitig_links(weights, links):
 
 def dijkstra(g: PyBigraph, source, live, target_amount, max_weight, stats=None):
     """traitgraph-algo shortest_path_lens (App. A.1), forbid_source_target = true."""
-    heap = [(0, source)]
+    sgn = -1 if P_HEAP_TIE_DESCENDING else 1  # pop order among equal distances: policy P1
+    heap = [(0, sgn * source)]
     dist = {source: 0}
     found = []
     while heap:
         w, n = heapq.heappop(heap)
+        n *= sgn
         if dist[n] < w:
             continue
-        if w > max_weight:
+        if (w >= max_weight) if P_BOUND_EXCLUSIVE else (w > max_weight):  # policy P2
             break
         if live[n] and n != source:
             found.append((n, w))
@@ -129,7 +142,7 @@ def dijkstra(g: PyBigraph, source, live, target_amount, max_weight, stats=None):
             nw = w + ed.weight
             if nw < dist.get(ed.to, 1 << 62):
                 dist[ed.to] = nw
-                heapq.heappush(heap, (nw, ed.to))
+                heapq.heappush(heap, (nw, sgn * ed.to))
     return found
 
 

@@ -202,7 +202,9 @@ def test_t1_device_graph_without_lower_bounds_and_upgraded(gpu, oracle, idx, pla
         ref = api.DeviceGraph(G, bg.k)
         ref.set_plan(plan)
         ref.classify()
-        assert dev.sssp_count_visited(0, S) == ref.sssp_count_visited(0, S)
+        a, b = dev.sssp_count_visited(0, S), ref.sssp_count_visited(0, S)
+        for key in ("sources", "settled_nodes", "relaxed_edges", "emitted"):  # (relax_attempts of the label-correcting levels depend on thread timing)
+            assert a[key] == b[key], (name, key)
 
 
 @pytest.mark.parametrize("plan", [0, 2, 4])
