@@ -79,6 +79,8 @@ __device__ __forceinline__ bool uf_union(uint32_t *parent, uint32_t a, uint32_t 
     return false;
 }
 
+__device__ __forceinline__ bool bit_of(const uint32_t *bits, uint32_t e) { return (bits[e >> 5] >> (e & 31)) & 1u; }
+
 // ---- step 1: bucket darts by from-node ------------------------------------------------------------------------
 // (dart ids are 32-bit and may use all 32 bits: element indices are computed in 64 bits, hu::gid())
 // (the count and the dart's place in its bucket come from the same atomic: `rank` is read back, coalesced, by the fill -- one random
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(EB) void hook_kernel(uint64_t n_biedges, uint32_t *
     if (p == ~0ull) return;
     best[r] = ~0ull;
     parent2[r] = (uint32_t)(p >> 32);  // r was a root when it was proposed for, and only this thread writes it
-    selected[(uint32_t)p] = 1u;        // the passage whose out-dart this is joins its node's rotation
+    const uint32_t x = (uint32_t)p;    // the passage whose out-dart this is joins its node's rotation (one bit per dart: 23 MB at 2^27,
+    atomicOr(&selected[x >> 5], 1u << (x & 31u));  // resident in L2 for the rotation's lookups, where a word per dart was 0.75 GB to clear and to gather from)
 }
 __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
                                                    const uint32_t *selected, uint32_t *succ) {
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint
             b0 = b;
             return;
         }
-        if (!selected[b]) return;
+        if (!bit_of(selected, b)) return;
         succ[a_prev] = b;
         succ[b ^ 1] = a_prev ^ 1;
         a_prev = a;
@@ -272,7 +275,6 @@ __global__ __launch_bounds__(EB) void rotate_kernel(const uint32_t *mirror, uint
 }
 
 // ---- step 5: ranking ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bit_of(const uint32_t *bits, uint32_t e) { return (bits[e >> 5] >> (e & 31)) & 1u; }
 
 // Splitters (round 4, second form): every 64th dart id (dart ids are unrelated to the order of the trails, so these are as evenly
 // spread as a hash) and the smallest dart of every connected component ("root": the closed walk starts there, and only the trail
@@ -728,8 +730,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     uint32_t *d_pos2 = b_pos2.alloc<uint32_t>(st, d_row0 ? n_b : E);
     uint32_t *d_succ = b_succ.alloc<uint32_t>(st, E);
     uint32_t *d_comp = b_comp.alloc<uint32_t>(st, n_b);  // union-find over biedges -> labels of the trail pairs, in place
-    uint32_t *d_flag = b_flag.alloc<uint32_t>(st, E);
     const uint64_t n_words = (E + 31) / 32;
+    uint32_t *d_flag = b_flag.alloc<uint32_t>(st, n_words);  // `selected`: one bit per dart
     uint32_t *d_rbits = b_rbits.alloc<uint32_t>(st, n_words);
     unsigned long long *d_best = b_best.alloc<unsigned long long>(st, n_b);
     uint8_t *d_active = b_active.alloc<uint8_t>(st, V);
@@ -766,7 +768,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
     lap("trail labels");
     // 4. merge the trails of every connected component
-    HIP_CHECK(hipMemsetAsync(d_flag, 0, E * 4, st));  // `selected`
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, n_words * 4, st));  // `selected`
     HIP_CHECK(hipMemsetAsync(d_best, 0xFF, n_b * 8, st));
     int hook_rounds = 0;
     for (;; hook_rounds++) {  // (a round in which no binode sees two components is the last: nothing to hook, nothing to flatten)

@@ -516,16 +516,18 @@ inline TransferRing &transfer_ring(int device_id) {
 }
 // (progress, optional: called with the number of leading bytes that have reached their place, after every slice -- by one of the
 // copying threads; slices complete in order)
+// (max_threads: host threads that empty the ring -- 8 move a plain copy at PCIe speed; a `put` that writes several bytes per byte it
+// reads, like the clib.rs flattening, takes more)
 template <typename Put>
 inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st, int device_id, Put &&put,
-                                 const std::function<void(size_t)> *progress = nullptr) {
+                                 const std::function<void(size_t)> *progress = nullptr, unsigned max_threads = 8) {
     constexpr size_t SLICE = RING_SLICE;
     constexpr int NS = RING_SLOTS;
     TransferRing &r = transfer_ring(device_id);
     std::lock_guard<std::mutex> lock(r.m);
     r.ready();
     const size_t n_slices = (bytes + SLICE - 1) / SLICE;
-    const unsigned T = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned T = std::max(1u, std::min(max_threads, std::thread::hardware_concurrency()));
     std::vector<std::atomic<uint32_t>> done(n_slices);
     for (auto &x : done) x.store(0, std::memory_order_relaxed);
     std::atomic<long> recorded{-1};  // highest slice whose copy and event have been enqueued
