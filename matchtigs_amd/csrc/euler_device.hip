@@ -142,11 +142,6 @@ __global__ __launch_bounds__(EB) void succ_node_kernel(const uint32_t *mirror, u
     }
     for (uint32_t j = 0; j < dv; j++) succ[adj[lom + j] ^ 1u] = adj[lo + j];
 }
-__global__ __launch_bounds__(EB) void iota_kernel(uint32_t *a, uint64_t n) {
-    const uint64_t i = gid();
-    if (i < n) a[i] = (uint32_t)i;
-}
-
 // ---- step 3: labels of the trail pairs, over biedges ---------------------------------------------------------------
 // A biedge b has exactly two neighbours in the graph whose components are the trail pairs: succ[2b] >> 1 and succ[2b + 1] >> 1
 // (the passage e -> f and its mirror f^1 -> e^1 name the same two biedges, so the predecessors are the same two). Components of
@@ -174,12 +169,24 @@ __global__ __launch_bounds__(EB) void label_hook_kernel(const uint32_t *succ, ui
 // another thread (parent[e] = some ancestor it read earlier) could land after this thread's parent[e] = root and leave a
 // non-root behind -- harmless for a union-find that is only ever read through uf_find, wrong for an array read as labels.
 // Every slot is written by its own thread only; readers passing through see the old parent or the root, both ancestors.
-__global__ __launch_bounds__(EB) void flatten_kernel(uint32_t *parent, uint64_t n) {
+// (parent2, optional: the second union-find -- over the LABELS, i.e. the roots of this one -- starts as the identity on them; a
+// non-root is never looked up there, so only the roots are written: no pass of its own over all biedges)
+__global__ __launch_bounds__(EB) void flatten_kernel(uint32_t *parent, uint64_t n, uint32_t *parent2) {
     const uint64_t e = gid();
     if (e >= n) return;
     uint32_t cur = (uint32_t)e, next;
     while ((next = __hip_atomic_load(&parent[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != cur) cur = next;
     __hip_atomic_store(&parent[e], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (parent2 && cur == (uint32_t)e) parent2[e] = (uint32_t)e;
+}
+// the same for the second union-find after a hooking round: only the labels (comp[b] == b) are ever looked up in it, and only the
+// few that hang below another label change -- one streaming pass over comp instead of a chase and a store per biedge
+__global__ __launch_bounds__(EB) void flatten_labels_kernel(const uint32_t *comp, uint32_t *parent2, uint64_t n) {
+    const uint64_t e = gid();
+    if (e >= n || comp[e] != (uint32_t)e) return;
+    uint32_t cur = (uint32_t)e, next;
+    while ((next = __hip_atomic_load(&parent2[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != cur) cur = next;
+    if (cur != (uint32_t)e) __hip_atomic_store(&parent2[e], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // ---- step 4: spanning forest (deterministic hooking rounds) + successor rotation ------------------------------
 // Component labels and roots are biedge ids (the smallest biedge of the trail pair / of the merged component).
@@ -763,9 +770,8 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
     lap("pairing");
     label_init_kernel<<<grid_for(n_b), EB, 0, st>>>(d_succ, n_b, d_comp);
     label_hook_kernel<<<grid_for(n_b), EB, 0, st>>>(d_succ, n_b, d_comp);
-    flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b);
     uint32_t *d_parent2 = d_pos2;
-    iota_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
+    flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, n_b, d_parent2);
     lap("trail labels");
     // 4. merge the trails of every connected component
     HIP_CHECK(hipMemsetAsync(d_flag, 0, n_words * 4, st));  // `selected`
@@ -779,7 +785,7 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
         HIP_CHECK(hipStreamSynchronize(st));
         if (!h_small[4]) break;
         hook_kernel<<<grid_for(n_b), EB, 0, st>>>(n_b, d_parent2, d_best, d_flag);
-        flatten_kernel<<<grid_for(n_b), EB, 0, st>>>(d_parent2, n_b);
+        flatten_labels_kernel<<<grid_for(n_b), EB, 0, st>>>(d_comp, d_parent2, n_b);
     }
     lap("hooking rounds");
     b_best.release();
