@@ -2019,13 +2019,19 @@ void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
     {
         hu::DeviceArena &arena = hu::device_arena(dev);
         std::lock_guard<std::mutex> lock(arena.m);
-        if (arena.pending.valid()) return;  // (one at a time)
+        // (one at a time; a reservation nobody had to wait for is over by now)
+        if (arena.pending.valid() && arena.pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
         arena.pending = fut;
     }
     std::thread([dev, bytes](std::promise<void> p) {
         if (device_count() > dev && hipSetDevice(dev) == hipSuccess) {
             hu::device_arena(dev).reserve(bytes);
             (void)hu::finish_stream(dev);
+            {   // the pinned ring of the sliced transfers (4 x 16 MB of page-locked memory: 10 ms the first upload would pay)
+                hu::TransferRing &r = hu::transfer_ring(dev);
+                std::lock_guard<std::mutex> lock(r.m);
+                r.ready();
+            }
             device_warm_device_kernels();
             device_warm_finish_kernels();
             device_warm_euler_kernels();
