@@ -356,9 +356,9 @@ def main():
             torch.cuda.empty_cache()
         cold["note"] = ("first step on a fresh graph and a fresh device graph (beside the main one): its device arrays are new ranges of the "
                         "library's arena (new chunks from the driver where the arena has no room), host result arrays and the walk's arena are mapped "
-                        "for the first time. The arena is NOT released first: memory given back with hipFree is wiped by the driver at ~28 GB/s and "
-                        "allocations that arrive during the wipe wait for it (tools/alloc_probe.hip) -- a release right before the step would put "
-                        "that wait into it; the one_shot block is the consuming call in a process of its own")
+                        "for the first time. The arena is NOT released first: a release would put its frees and the fresh allocations that follow -- driver "
+                        "calls, which sporadically stall for seconds on this pool (tools/alloc_probe.hip, DESIGN 2.1) -- into the measured step; the "
+                        "one_shot block is the consuming call in a process of its own")
 
     # ---- second mode, first class: the same step with the parallel Euler decomposition on the GPU, in its own timed region.
     # It runs BEFORE the headline region: the two modes use different sets of device work arrays, and the runtime's stream-ordered
@@ -502,9 +502,8 @@ def main():
             dev = graph = bufs = None
             count_ref[0] = None
             torch.cuda.empty_cache()
-            held = api.device_memory_held(local_rank)
             api.release_device_memory(local_rank)
-            time.sleep(1.0 + held / 20e9)  # (the driver wipes what was just given back, and allocations wait for that: tools/alloc_probe.hip)
+            time.sleep(1.0)  # (let the driver settle after ~30 GB of frees: DESIGN 2.1)
             full_size = full_size_step(args, k, local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {

@@ -130,13 +130,14 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 
 // ---- device memory: one arena per device ----------------------------------------------------------------------------------
 // Every device array of the library -- device graph, search and replay work arrays, the finishing stages' arrays, the graph's kept
-// edge arrays -- is a range of a few large hipMalloc'd CHUNKS, handed out by a best-fit free list with coalescing. Why: what a
-// hipMalloc costs differs by two orders of magnitude between the boxes of one pool (0.1 ms to 30-60 ms per GB: the driver's cold
-// step of round 4 paid 0.44 s for the ~24 GB its stages allocated one after the other, most of it memory an earlier stage had just
-// given back), and a one-shot caller -- the only kind the reference has, clib.rs:291 -- pays all of it. With the arena a call's
-// stages reuse each other's memory (the device graph's blocks become the finish's dart arrays), the first chunk is sized for the
-// whole call from (V, E) and reserved by ONE hipMalloc on a helper thread while the host still builds the graph
-// (arena_reserve_async), and a caller that iterates allocates nothing after its first call.
+// edge arrays -- is a range of a few large hipMalloc'd CHUNKS, handed out by a best-fit free list with coalescing. Why: a hipMalloc
+// normally takes 0.3 ms whatever its size, but single hipMalloc / hipFree calls sporadically stall for 0.5 to 5 s on the shared hosts
+// of this pool (tools/alloc_probe.hip) -- and until round 4 a call of the path made ~200 of them, every stage taking
+// its arrays from the driver and giving them back for the next stage to ask for again (0.44 s of waits in the driver's cold step of
+// round 4), all of which a one-shot caller -- the only kind the reference has, clib.rs:291 -- pays. With the arena a call's stages
+// reuse each other's memory (the device graph's blocks become the finish's dart arrays), the first chunk is sized for the whole call
+// from (V, E) and reserved by ONE hipMalloc on a helper thread while the host still builds the graph (device_reserve_async), and a
+// caller that iterates makes no driver call at all after its first call.
 // Ordering: a range released by a hu::Buf may still be in use by work queued on the device's finish stream ("dirty"); a Buf
 // allocation takes it as it is (same stream: ordered), any other allocation synchronises that stream first. device_free() keeps
 // hipFree's meaning (the device is idle when it returns).

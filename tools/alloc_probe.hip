@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -56,6 +57,35 @@ int main(int argc, char **argv) {
             t0 = now_ms();
             CK(hipFree(p));
             std::printf("         hipFree   %8.2f ms\n", now_ms() - t0);
+        }
+    }
+    {
+        // does waiting help? free 16 GB (touched), sleep, then time allocations of 4 GB
+        std::printf("-- free 16 GB, wait, allocate 4 GB three times\n");
+        for (double wait_s : {0.0, 0.25, 1.0, 3.0}) {
+            void *big = nullptr;
+            CK(hipMalloc(&big, 16ull << 30));
+            touch_kernel<<<4096, 256>>>((uint4 *)big, (16ull << 30) / 16);
+            CK(hipDeviceSynchronize());
+            CK(hipFree(big));
+            const double t_free = now_ms();
+            if (wait_s > 0) {
+                struct timespec ts = {(time_t)wait_s, (long)((wait_s - (time_t)wait_s) * 1e9)};
+                nanosleep(&ts, nullptr);
+            }
+            double worst = 0, total = 0;
+            for (int i = 0; i < 3; i++) {
+                void *p = nullptr;
+                t0 = now_ms();
+                CK(hipMalloc(&p, 4ull << 30));
+                const double dt = now_ms() - t0;
+                worst = dt > worst ? dt : worst;
+                total += dt;
+                touch_kernel<<<4096, 256>>>((uint4 *)p, (4ull << 30) / 16);
+                CK(hipDeviceSynchronize());
+                CK(hipFree(p));
+            }
+            std::printf("  waited %.2f s: three hipMalloc(4 GB) took %.1f ms in all (worst %.1f ms); %.2f s after the free\n", wait_s, total, worst, (now_ms() - t_free) / 1e3);
         }
     }
     {

@@ -2,10 +2,10 @@
 first call): host edge arrays -> mtg_graph_from_edges -> mtg_compute_tigs_clib (= what matchtigs_compute_tigs runs once it has built
 its configuration: the whole path into clib.rs-sized output arrays) -> graph freed.
 
-Device memory: the library's arena is NOT released between the calls (--release-between does, and then waits for the driver: memory
-given back with hipFree is wiped by the driver at ~28 GB/s, and an allocation that arrives during the wipe waits for all of it --
-tools/alloc_probe.hip, profiles/r05_alloc_probe.txt -- so a release right before a call puts up to a second of the PREVIOUS
-owner's clean-up into it; a fresh hipMalloc costs 0.3 ms whatever its size, which is what a first call in a fresh process pays).
+Device memory: the library's arena is NOT released between the calls (--release-between does, for comparison: every release adds
+driver calls -- the frees, then fresh allocations -- to the next call, and single driver calls sporadically stall for 0.5-5 s on
+this pool's shared hosts: tools/alloc_probe.hip; a fresh hipMalloc normally costs 0.3 ms whatever its size, which is
+what a first call in a fresh process pays).
 
 The input arrays come from the GPU generator (a graph is generated, exported to numpy arrays, freed): the generator is NOT timed.
 `--calls 2` repeats the call on the same arrays: call 0 is the FIRST call of the process (the HIP runtime's queues, the pinned
@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--euler", choices=["host", "device"], default="device")
     ap.add_argument("--calls", type=int, default=2)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--release-between", action="store_true", help="mtg_release_device_memory before every call, then wait for the driver's wipe of the freed memory")
+    ap.add_argument("--release-between", action="store_true", help="mtg_release_device_memory (and a second of rest) before every call")
     args = ap.parse_args()
     L = _lib.load()
     k = args.k
@@ -70,9 +70,8 @@ def main():
     del g, ex
     for i in range(args.calls):
         if args.release_between:
-            held = api.device_memory_held(args.device)
             api.release_device_memory(args.device)
-            time.sleep(1.0 + held / 20e9)  # (the wipe of what was just given back: see the header)
+            time.sleep(1.0)
         r = one_call(L, arrays, k, mode)
         r.update(call=i, euler_mode=args.euler, V=int(V), E=int(E), log2_edges=args.log2_edges)
         print(json.dumps(r), flush=True)
