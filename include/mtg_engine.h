@@ -243,7 +243,8 @@ const mtg_pair *mtg_resident_pairs(const mtg_device *d, uint64_t *n_pairs_out);
 /* A host copy of them (malloc'd, free with mtg_free), in the reference's push order. */
 uint64_t mtg_download_resident_pairs(mtg_device *d, mtg_pair **pairs_out);
 /* Geometry of the claim replay's cooperative launch, for measurements and tests (0 = the engine's choice for that parameter): number
- * of index-ordered admission windows, threads per workgroup (1024 or 256), workgroups, one admitting workgroup in `role_mod`, and
+ * of index-ordered admission windows (bits 0-15; bits 16-23: the sixteenth of them from which they grow, bits 24-31: by which factor
+ * -- the engine's own choice is 36 windows, the second half twice as large), threads per workgroup (1024 or 256), workgroups, one admitting workgroup in `role_mod`, and
  * plain_barrier != 0 = every workgroup releases at the grid barrier (without the per-XCD stage that leans on gfx942 / gfx950
  * hardware). The pair list never depends on any of them. (The library reads no environment variable for this.) */
 void mtg_set_replay_tuning(mtg_device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier);

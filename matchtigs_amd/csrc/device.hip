@@ -2518,9 +2518,26 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     // index-ordered admission windows over the dense list: ~32 K listed sources each, between 4 and 48 of them (a round costs a
     // grid barrier plus one dependent-access chain, so tiny windows are latency bound; huge ones bring the waiting visits back)
     {
-        uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(48, (n_dense + (1u << 15) - 1) >> 15));
-        if (d->tune_windows) n_win = d->tune_windows;  // (tuning only: the pair list does not depend on it)
-        a.window = std::max<uint64_t>((n_dense + n_win - 1) / n_win, 256);
+        // Round 5: 36 windows instead of 48, the second half of them twice as large -- the late windows meet mostly dead candidates (their
+        // retries fall from a third of a window to nothing), so they can be larger and the rounds fewer: 50 -> 39 rounds, rounds kernel
+        // 4.41 -> 4.14 ms at 2^27, 1.58 -> 1.46 ms at 2^24 (tools/replay_window_sweep.py; fewer windows of ONE size lose more to
+        // retries than they save in rounds: 36 equal windows 4.65 ms)
+        uint64_t n_win = std::max<uint64_t>(4, std::min<uint64_t>(36, (n_dense + (1u << 15) - 1) >> 15));
+        // (tuning only -- the pair list does not depend on any of it: bits 0-15 of tune_windows = number of windows, bits 16-23 = the
+        // sixteenth of them from which they grow, bits 24-31 = by which factor)
+        uint64_t grow_16th = n_win >= 8 ? 8 : 16, grow_mul = n_win >= 8 ? 2 : 1;
+        if (d->tune_windows & 0xFFFF) { n_win = d->tune_windows & 0xFFFF; grow_16th = 16; grow_mul = 1; }
+        if (d->tune_windows >> 16) { grow_16th = (d->tune_windows >> 16) & 0xFF; grow_mul = std::max<uint64_t>(1, (d->tune_windows >> 24) & 0xFF); }
+        const uint64_t g = std::min<uint64_t>(n_win, n_win * grow_16th / 16);  // windows of the base size
+        // g windows of `window` sources, the other n_win - g of grow_mul times as many
+        a.window = std::max<uint64_t>((n_dense + g + (n_win - g) * grow_mul - 1) / std::max<uint64_t>(g + (n_win - g) * grow_mul, 1), 256);
+        a.grow_from = g;
+        a.grow_mul = grow_mul;
+        {
+            const uint64_t base_cover = g * a.window;
+            a.n_windows = n_dense <= base_cover ? (n_dense + a.window - 1) / a.window
+                                                : g + (n_dense - base_cover + a.window * grow_mul - 1) / (a.window * grow_mul);
+        }
     }
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
     // deadlock. Workgroups of 1024 when a round's tiles (a window to admit, about as many sources to check) fill the device, of 256
