@@ -2464,9 +2464,11 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     }
     // reservation tags decrease with every round of every call, so the two reservation arrays are never cleared; only when
     // the 32-bit tag space is used up (or the arrays are new)
+#if MTG_REPLAY_RECORDS
+    w.tag_base = 0;  // (the records are written whole below, reservation words included)
+#endif
     if ((uint64_t)w.tag_base + REPLAY_MAX_ROUNDS + 128 >= 0xFFFFFFF0ull) {
 #if MTG_REPLAY_RECORDS
-        HIP_CHECK(hipMemsetAsync(w.state, 0xFF, ((V + 1) / 2) * 64, st));  // (the states are written next)
 #else
         HIP_CHECK(hipMemsetAsync(w.resv[0], 0xFF, V * 8, st));
         HIP_CHECK(hipMemsetAsync(w.resv[1], 0xFF, V * 8, st));
@@ -2476,9 +2478,14 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     HIP_CHECK(hipEventRecord(d->ev_r[0], st));
     // working copy of the classification state; per-source outputs start at "nothing claimed"
     {
+#if MTG_REPLAY_RECORDS
+        const uint64_t n_quarters = ((V + 1) / 2) * 4;
+        hipLaunchKernelGGL(replay_record_init_kernel, dim3((unsigned)((n_quarters + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, w.state);
+#else
         ReplayArgs ia{};
         ia.state = w.state; ia.resv[0] = w.resv[0]; ia.resv[1] = w.resv[1];
         hipLaunchKernelGGL(replay_state_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d->d_mirror, d->d_mult, d->d_cls, V, ia);
+#endif
         HIP_CHECK(hipGetLastError());
     }
     // the sources that have candidates, in order, with the static words of their admission (Dense)
