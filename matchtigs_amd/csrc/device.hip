@@ -454,16 +454,21 @@ __global__ void build_children_kernel(uint64_t n_nodes, NodeBlock *blocks, const
             cmeta |= 16u << j;
         }
     }
-    uint32_t *out = reinterpret_cast<uint32_t *>(blocks + n);
-    if constexpr (W8) {
-        out[4] = slot[0] | (slot[1] << 16);
-        out[5] = slot[2] | (slot[3] << 16);
-    }
-    out[6] = (meta & 0xFFFFu) | (cmeta << 16);
+    // The WHOLE block is stored, the unchanged neighbour words included (four 16-byte stores per thread): a line that leaves the L2
+    // partly written is a masked write, which the ECC-protected HBM turns into a read-modify-write (round 5; the same finding as the
+    // claim replay's records, replay_kernels.inc). Readers of this node's first half see old or new words, which decode alike (above).
+    uint32_t o[16];
+    o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2]; o[3] = nb[3];
+    o[4] = W8 ? (slot[0] | (slot[1] << 16)) : w45[0];
+    o[5] = W8 ? (slot[2] | (slot[3] << 16)) : w45[1];
+    o[6] = (meta & 0xFFFFu) | (cmeta << 16);
 #pragma unroll
-    for (int i = 0; i < GSLOTS; i++) out[7 + i] = gn[i];
+    for (int i = 0; i < GSLOTS; i++) o[7 + i] = gn[i];
 #pragma unroll
-    for (int i = 0; i < GSLOTS / 2; i++) out[13 + i] = gwt[2 * i] | (gwt[2 * i + 1] << 16);
+    for (int i = 0; i < GSLOTS / 2; i++) o[13 + i] = gwt[2 * i] | (gwt[2 * i + 1] << 16);
+    uint4 *out = reinterpret_cast<uint4 *>(blocks + n);
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
 // ------------------------------------------------------------------------------------------------
