@@ -1229,7 +1229,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 download_sliced_with(d_te, n_kept * 4, st, device_id,
                                      [&expand](size_t off, const char *src, size_t n) { expand(off / 4, reinterpret_cast<const uint32_t *>(src), n / 4); },
                                      nullptr, 16);
-            download_sliced_widen(sink->limits_out, d_tl, n_tigs, st, device_id);
+            download_sliced_widen(sink->limits_out, d_tl, n_tigs, st, device_id, 16);
             sink->n_tigs = n_tigs;
             sink->n_edges = n_kept;
         } else {

@@ -565,7 +565,7 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
     download_sliced_with(d_src, bytes, st, device_id, [dst](size_t off, const char *src, size_t n) { std::memcpy((char *)dst + off, src, n); });
 }
 // n 32-bit words on the device -> n 64-bit words on the host: half the bytes over PCIe, widened by the threads that empty the ring
-inline void download_sliced_widen(uint64_t *dst, const uint32_t *d_src, size_t n, hipStream_t st, int device_id) {
+inline void download_sliced_widen(uint64_t *dst, const uint32_t *d_src, size_t n, hipStream_t st, int device_id, unsigned max_threads = 8) {
     if (n * 4 < (64u << 20)) {
         std::vector<uint32_t> tmp(n);
         if (n) HIP_CHECK(hipMemcpyAsync(tmp.data(), d_src, n * 4, hipMemcpyDeviceToHost, st));
@@ -576,8 +576,8 @@ inline void download_sliced_widen(uint64_t *dst, const uint32_t *d_src, size_t n
     download_sliced_with(d_src, n * 4, st, device_id, [dst](size_t off, const char *src, size_t bytes) {
         const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
         uint64_t *out = dst + off / 4;
-        for (size_t i = 0; i < bytes / 4; i++) out[i] = w[i];
-    });
+        for (size_t i = 0; i < bytes / 4; i++) __builtin_nontemporal_store((uint64_t)w[i], &out[i]);  // (written once, read by the caller later)
+    }, nullptr, max_threads);
 }
 
 // Pageable host memory -> device through the same pinned ring, the other way round: host threads fill slice i + 1 while slice i

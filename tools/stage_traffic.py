@@ -21,6 +21,7 @@ MARKERS = [
     ("active_range_kernel", "sssp"),
     ("sssp_enum_kernel", "sssp"),
     ("replay_state_init_kernel", "replay"),
+    ("replay_record_init_kernel", "replay"),
     ("row_degree_kernel", "insert_eulerise"),
     ("pair_degree_kernel", "insert_eulerise"),
     ("degree_rank_offset_kernel", "buckets"),   # re-labelled below: decomposition (device mode) or records (reference order)
