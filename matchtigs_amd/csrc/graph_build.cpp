@@ -3,7 +3,6 @@
 #include "host_graph.hpp"
 
 #include <chrono>
-#include <immintrin.h>
 
 #include <algorithm>
 #include <thread>
@@ -212,12 +211,12 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
             // graph.verify_edge_mirror_property(), clib.rs:252: the partner must be mirror(to) -> mirror(from)
             if (from[e + 1] != g->mirror[t] || to[e + 1] != g->mirror[f] || weight[e + 1] != weight[e])
                 MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (edge %llu)", (unsigned long long)e);
-            // (streaming stores: 1.6 GB at 2^27 that nothing reads again before the upload -- no read-for-ownership of fresh lines)
-            _mm_stream_si64(reinterpret_cast<long long *>(&g->e_from[e]), (long long)((uint64_t)f | ((uint64_t)from[e + 1] << 32)));
-            _mm_stream_si64(reinterpret_cast<long long *>(&g->e_to[e]), (long long)((uint64_t)t | ((uint64_t)to[e + 1] << 32)));
-            _mm_stream_si64(reinterpret_cast<long long *>(&g->w_biedge[u]), (long long)weight[e]);  // (edge 2u = unitig u forwards, edge 2u + 1 its mirror: host_graph.hpp)
+            // (plain stores: streaming stores into these freshly mapped arrays measured 1.5-2 x slower, 0.15-0.22 s against 0.07-0.13 s
+            // alternating on one box -- the page faults of first touch do not mix with write-combining)
+            g->e_from[e] = f; g->e_to[e] = t;
+            g->e_from[e + 1] = from[e + 1]; g->e_to[e + 1] = to[e + 1];
+            g->w_biedge[u] = weight[e];  // (edge 2u = unitig u forwards, edge 2u + 1 its mirror: host_graph.hpp)
         }
-        _mm_sfence();
     });
     lap("edge arrays");
     link_adjacency(*g, n_edges);
