@@ -204,6 +204,8 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
     g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
     g->w_biedge.resize(n_edges / 2);
     parallel_ranges(n_edges / 2, [&](uint64_t lo, uint64_t hi) {
+        // (measured and dropped: MADV_POPULATE_WRITE on the thread's parts of the three fresh arrays before it fills them -- no faster
+        // at 2^27, 20 % slower at 2^30 -- and streaming stores, see below)
         for (uint64_t u = lo; u < hi; u++) {
             const uint64_t e = 2 * u;
             const uint32_t f = from[e], t = to[e];

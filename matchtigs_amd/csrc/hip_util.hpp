@@ -193,15 +193,16 @@ struct DeviceArena {
             if ((const char *)p >= c.base && (const char *)p < c.base + c.bytes) return &c;
         return nullptr;
     }
-    // A chunk for a whole call is only taken while it is small next to the device (a quarter of its memory): the stand-ins of BASELINE
-    // configs[3] and [4] (2^30, 2^31 edges) fill most of the HBM, and a chunk sized for the call's peak would sit half empty beside the
-    // other allocators of the process. Beyond that size every array gets a chunk of its own, exactly as large as it is.
+    // A chunk for a whole call is only taken while it leaves the device mostly free (up to a third of its memory: BASELINE configs[3]
+    // at its nominal size, 2^30 edges, is 90 GB of 309): the stand-in of configs[4] (2^31 edges) fills most of the HBM, and a chunk sized
+    // for the call's peak would sit half empty beside the other allocators of the process. Beyond that size every array gets a chunk
+    // of its own, exactly as large as it is.
     size_t whole_call_limit() {
         if (!device_total) {
             size_t free_b = 0, total_b = 0;
             device_total = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b : (size_t)(64ull << 30);
         }
-        return device_total / 4;
+        return device_total / 3;
     }
     bool add_chunk(size_t bytes) {  // (under the lock)
         bytes = (bytes + BIG - 1) / BIG * BIG;
