@@ -5,6 +5,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 #include "../../include/mtg_policy.h"
@@ -229,85 +230,234 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
 }
 
 // ---------------------------------------------------------------------------------------------
-// Union-find with the representative choice of disjoint-sets 0.4.2 (Cargo.lock:412-416; SURVEY
-// App. A.4): union by rank, ties attach the first argument's root under the second's.
+// The clib.rs builder (clib.rs:94-259). matchtigs_merge_nodes is called once per link of the unitig graph -- hundreds of millions
+// of times for a human genome -- and each call is two unions in a union-find over 4 slots per unitig: two to four dependent random
+// accesses into gigabytes, ~90 ns per call when done on the spot (measured, 24 M links over 8 M unitigs). Since round 5 a call only
+// RECORDS its link (8 bytes, after the same argument checks) and matchtigs_build_graph performs the unions -- in the order of the
+// calls, so that every root is the one the reference's union-find (disjoint-sets 0.4.2: union by rank, ties by policy P4) ends
+// with -- in one loop that knows the future: the slots of the links a few iterations ahead are prefetched while the current one
+// is united, which hides most of the DRAM latency the per-call form had to wait for.
 // ---------------------------------------------------------------------------------------------
-static inline uint64_t uf_root(HostGraph *g, uint64_t x) {
-    auto &p = g->uf_parent;
-    uint64_t r = x;
-    while (p[r] != r) r = p[r];
-    while (p[x] != r) {  // full compression; does not change which element is the root
-        uint64_t nx = p[x];
-        p[x] = r;
-        x = nx;
-    }
-    return r;
-}
+constexpr uint64_t LINK_CHUNK = 1ull << 24;  // links per chunk of the record (128 MB)
 
 HostGraph *builder_new(uint64_t unitig_amount) {
+    if (unitig_amount >= (1ull << 31)) MTG_DIE("matchtigs_initialise_graph: %llu unitigs: edge ids are 32-bit", (unsigned long long)unitig_amount);
     // (a helper thread starts the HIP runtime and reserves the device memory of the call that will follow, while the caller reports
     // its links: a compacted de Bruijn graph has about 1.4 nodes per unitig)
     device_reserve_async(unitig_amount + unitig_amount / 2, 2 * unitig_amount);
     HostGraph *g = new HostGraph();
     g->has_builder = true;
     g->unitig_amount = unitig_amount;
-    g->uf_parent.resize(unitig_amount * 4);
-    for (uint64_t i = 0; i < unitig_amount * 4; i++) g->uf_parent[i] = i;
-    g->uf_rank.assign(unitig_amount * 4, 0);
     return g;
 }
 
 void builder_merge(HostGraph *g, uint64_t ua, bool sa, uint64_t ub, bool sb) {
     if (!g || !g->has_builder || g->built) MTG_DIE("matchtigs_merge_nodes: graph is not in the building state");
     if (ua >= g->unitig_amount || ub >= g->unitig_amount) MTG_DIE("matchtigs_merge_nodes: unitig id out of range");
-    // slots (clib.rs:104-122): fwd-in 4u, bwd-out 4u+1, fwd-out 4u+2, bwd-in 4u+3
-    const uint64_t out_a = sa ? ua * 4 + 2 : ua * 4 + 1;
-    const uint64_t in_b = sb ? ub * 4 : ub * 4 + 3;
-    const uint64_t mirror_in_a = sa ? ua * 4 + 3 : ua * 4;
-    const uint64_t mirror_out_b = sb ? ub * 4 + 1 : ub * 4 + 2;
-    const uint64_t pairs[2][2] = {{out_a, in_b}, {mirror_in_a, mirror_out_b}};  // clib.rs:168-169
-    for (auto &pr : pairs) {
-        uint64_t a = uf_root(g, pr[0]), b = uf_root(g, pr[1]);
-        if (a == b) continue;
-        uint8_t ra = g->uf_rank[a], rb = g->uf_rank[b];
-        if (ra > rb) g->uf_parent[b] = a;
-        else if (rb > ra) g->uf_parent[a] = b;
-        else if (mtg_policy_union_tie_first_goes_below()) { g->uf_parent[a] = b; g->uf_rank[b]++; }  // equal ranks: policy P4 (mtg_policy.h)
-        else { g->uf_parent[b] = a; g->uf_rank[a]++; }
+    if (g->link_chunks.empty() || g->link_chunks.back().size() == LINK_CHUNK) {
+        g->link_chunks.emplace_back();
+        g->link_chunks.back().reserve(LINK_CHUNK);
     }
+    // (unitig ids are below 2^31: 32 bits hold an id and its strand)
+    g->link_chunks.back().push_back(((ua << 1 | (sa ? 1u : 0u)) << 32) | (ub << 1 | (sb ? 1u : 0u)));
 }
+
+namespace {
+// Union-find with the representative choice of disjoint-sets 0.4.2 (Cargo.lock:412-416): union by rank, ties
+// by policy P4 (mtg_policy.h: the first argument's root goes below the second's). A root keeps its RANK in its own parent word
+// (top bit set + rank) instead of pointing at itself, so that a union touches one array, not two -- a rank array would cost one more
+// cache miss per union. Index = uint32_t while the 4 U slots fit below its top bit.
+template <typename Index>
+struct UnionFind {
+    static constexpr Index ROOT = (Index)1 << (sizeof(Index) * 8 - 1);
+    Index *parent;
+    inline Index root(Index x) {
+        Index r = x, p;
+        while (!((p = parent[r]) & ROOT)) r = p;
+        while (x != r) {  // full compression; does not change which element is the root
+            const Index nx = parent[x];
+            parent[x] = r;
+            x = nx;
+        }
+        return r;
+    }
+    inline void unite(Index x, Index y) {
+        const Index a = root(x), b = root(y);
+        if (a == b) return;
+        const Index ra = parent[a], rb = parent[b];  // ROOT | rank
+        // equal ranks: policy P4 decides who goes below (mtg_policy.h); written without branches -- which root is the taller one is
+        // a coin flip to the branch predictor
+        const bool a_stays = mtg_policy_union_tie_first_goes_below() ? ra > rb : ra >= rb;
+        const Index top = a_stays ? a : b, below = a_stays ? b : a;
+        parent[top] = (a_stays ? ra : rb) + (ra == rb ? 1 : 0);
+        parent[below] = top;
+    }
+};
+// slots (clib.rs:104-122): fwd-in 4u, bwd-out 4u+1, fwd-out 4u+2, bwd-in 4u+3
+struct LinkSlots { uint64_t out_a, in_b, mirror_in_a, mirror_out_b; };
+inline LinkSlots slots_of(uint64_t link) {
+    const uint64_t a = link >> 32, b = link & 0xFFFFFFFFull;
+    const uint64_t ua = a >> 1, ub = b >> 1;
+    const bool sa = a & 1u, sb = b & 1u;
+    return LinkSlots{sa ? ua * 4 + 2 : ua * 4 + 1, sb ? ub * 4 : ub * 4 + 3, sa ? ua * 4 + 3 : ua * 4, sb ? ub * 4 + 1 : ub * 4 + 2};
+}
+}  // namespace
+
+template <typename Index>
+static void build_from_links(HostGraph *g, const uint64_t *unitig_weights);
 
 void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
     if (!g || !g->has_builder || g->built) MTG_DIE("matchtigs_build_graph: graph is not in the building state");
     if (!unitig_weights) MTG_DIE("assertion failed: !unitig_weights.is_null() (clib.rs:188)");
+    if (g->unitig_amount * 4 < (1ull << 31)) build_from_links<uint32_t>(g, unitig_weights);
+    else build_from_links<uint64_t>(g, unitig_weights);
+}
+
+template <typename Index>
+static void build_from_links(HostGraph *g, const uint64_t *unitig_weights) {
     const uint64_t slots = g->unitig_amount * 4;
-    // node id = rank of the representative among the sorted distinct representatives (clib.rs:193-234):
-    // mark roots, prefix-count them.
-    std::vector<uint32_t> node_of_root(slots, 0);
-    uint64_t n_nodes = 0;
-    for (uint64_t i = 0; i < slots; i++)
-        if (g->uf_parent[i] == i) {
-            if (n_nodes >= NONE - 1) MTG_DIE("too many nodes for 32-bit ids");
-            node_of_root[i] = (uint32_t)n_nodes++;
-        }
-    g->init_nodes(n_nodes);
     const uint64_t U = g->unitig_amount, n_edges = 2 * U;
     if (n_edges >= NONE - 1) MTG_DIE("edge ids are 32-bit; too many edges");
-    for (uint64_t i = 0; i < slots; i++) (void)uf_root(g, i);  // full compression once: the parallel fill below only reads parents
+    static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mtg] build_graph: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
+    // (0) the unions, in the order of the matchtigs_merge_nodes calls (clib.rs:168-169: (out_a, in_b), then (mirror_in_a, mirror_out_b))
+    PodVec<Index> parent_v(slots);
+    Index *parent = parent_v.data();
+    constexpr Index ROOT = UnionFind<Index>::ROOT;
+    parallel_ranges(slots, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) parent[i] = ROOT;  // every slot a root of rank 0
+    });
+    {
+        UnionFind<Index> uf{parent};
+        // two requests in flight per link: its slots' own words FAR links ahead, and -- NEAR links ahead, when those have arrived --
+        // the words they point at (after compression almost every slot is a root or points at one)
+        constexpr uint64_t FAR = 32, NEAR = 16;
+        auto fetch_second = [&](uint64_t slot) {
+            const Index p = parent[slot];
+            if (!(p & ROOT)) __builtin_prefetch(&parent[p]);
+        };
+        for (size_t c = 0; c < g->link_chunks.size(); c++) {
+            const PodVec<uint64_t> &chunk = g->link_chunks[c];
+            const uint64_t n = chunk.size();
+            for (uint64_t i = 0; i < n; i++) {
+                if (i + FAR < n) {
+                    const LinkSlots f = slots_of(chunk[i + FAR]);
+                    __builtin_prefetch(&parent[f.out_a]);  // (a unitig's four slots share a cache line: two requests per link)
+                    __builtin_prefetch(&parent[f.in_b]);
+                }
+                if (i + NEAR < n) {
+                    const LinkSlots f = slots_of(chunk[i + NEAR]);
+                    fetch_second(f.out_a);
+                    fetch_second(f.in_b);
+                    fetch_second(f.mirror_in_a);
+                    fetch_second(f.mirror_out_b);
+                }
+                const LinkSlots s = slots_of(chunk[i]);
+                uf.unite((Index)s.out_a, (Index)s.in_b);
+                uf.unite((Index)s.mirror_in_a, (Index)s.mirror_out_b);
+            }
+        }
+        std::vector<PodVec<uint64_t>>().swap(g->link_chunks);
+    }
+    // (from here on a root points at itself, as the passes below expect)
+    parallel_ranges(slots, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++)
+            if (parent[i] & ROOT) parent[i] = (Index)i;
+    });
+    lap("unions");
+    // Every pass over the 4 U slots below runs on host threads (until round 5 they were sequential loops of ~30 ns per slot: 8 s for
+    // a human-sized unitig set, more than the whole computation that follows). The union-find is final here, so everything below only
+    // reads it, except the compression of pass 1.
+    // (1) full compression: every slot points at its root. A thread writes only its own slots; a chase may pass through a slot another
+    // thread has just pointed at its root -- still an ancestor --, and roots never change.
+    parallel_ranges(slots, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            Index r = (Index)i, p;
+            while ((p = __atomic_load_n(&parent[r], __ATOMIC_RELAXED)) != r) r = p;
+            __atomic_store_n(&parent[i], r, __ATOMIC_RELAXED);
+        }
+    });
+    lap("compression");
+    // (2) node id = rank of the representative among the sorted distinct representatives (clib.rs:193-234): roots counted per range,
+    // ranges prefix-summed, roots numbered
+    PodVec<uint32_t> node_of_root(slots);  // (only read at roots)
+    uint64_t n_nodes = 0;
+    {
+        constexpr unsigned MAXR = 64;
+        uint64_t range_lo[MAXR], range_cnt[MAXR];
+        std::atomic<unsigned> n_ranges{0};
+        parallel_ranges(slots, [&](uint64_t lo, uint64_t hi) {
+            uint64_t c = 0;
+            for (uint64_t i = lo; i < hi; i++) c += parent[i] == i;
+            const unsigned id = n_ranges++;
+            if (id >= MAXR) MTG_DIE("matchtigs_build_graph: too many host threads");
+            range_lo[id] = lo;
+            range_cnt[id] = c;
+        });
+        const unsigned R = n_ranges.load();
+        unsigned order[MAXR];
+        for (unsigned i = 0; i < R; i++) order[i] = i;
+        std::sort(order, order + R, [&](unsigned x, unsigned y) { return range_lo[x] < range_lo[y]; });
+        uint64_t base_of_lo[MAXR], lo_sorted[MAXR];
+        for (unsigned i = 0; i < R; i++) {
+            lo_sorted[i] = range_lo[order[i]];
+            base_of_lo[i] = n_nodes;
+            n_nodes += range_cnt[order[i]];
+        }
+        if (n_nodes >= NONE - 1) MTG_DIE("too many nodes for 32-bit ids");
+        parallel_ranges(slots, [&](uint64_t lo, uint64_t hi) {  // (the same ranges: parallel_ranges cuts [0, n) the same way for the same n)
+            unsigned k = 0;
+            while (k < R && lo_sorted[k] != lo) k++;
+            if (k == R) MTG_DIE("matchtigs_build_graph: internal error (range split changed)");
+            uint64_t next = base_of_lo[k];
+            for (uint64_t i = lo; i < hi; i++)
+                if (parent[i] == i) node_of_root[i] = (uint32_t)next++;
+        });
+    }
+    lap("node numbers");
+    g->init_nodes(n_nodes);
     g->reserve_edges(n_edges + n_edges / 2 + 1024);  // (room for the dummy edges: see graph_from_edges)
     g->e_from.resize(n_edges); g->e_to.resize(n_edges); g->e_next_out.resize(n_edges);
     g->w_biedge.resize(n_edges / 2);
     parallel_ranges(n_nodes, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; i++) g->mirror[i] = NONE;
     });
-    auto node_of = [&](uint64_t slot) { return node_of_root[g->uf_parent[slot]]; };
-    // set_mirror_nodes (clib.rs:236-237) is an assignment in unitig order: a later unitig re-pairs a node an earlier one
-    // paired differently (then verify_node_pairing fails below, as in the reference); kept sequential for that order
-    for (uint64_t u = 0; u < U; u++) {
-        const uint32_t n1 = node_of(u * 4), n2 = node_of(u * 4 + 2), mirror_n2 = node_of(u * 4 + 3), mirror_n1 = node_of(u * 4 + 1);
-        g->mirror[n1] = mirror_n1; g->mirror[mirror_n1] = n1;   // clib.rs:236
-        g->mirror[n2] = mirror_n2; g->mirror[mirror_n2] = n2;   // clib.rs:237
+    lap("arrays");
+    auto node_of = [&](uint64_t slot) { return node_of_root[parent[slot]]; };
+    // (3) set_mirror_nodes (clib.rs:236-237) is an assignment in unitig order: a later unitig re-pairs a node an earlier one paired
+    // differently (then verify_node_pairing fails below, as in the reference). For a consistent input every node only ever receives
+    // one value, and the assignments commute: they run on host threads, each one an exchange that notices a node that had ANOTHER
+    // value before -- then the pass is repeated in the reference's order, on one thread.
+    {
+        uint32_t *mir = g->mirror.data();
+        std::atomic<bool> conflict{false};
+        parallel_ranges(U, [&](uint64_t lo, uint64_t hi) {
+            bool bad = false;
+            auto put = [&](uint32_t x, uint32_t v) {
+                const uint32_t old = __atomic_exchange_n(&mir[x], v, __ATOMIC_RELAXED);
+                bad |= old != NONE && old != v;
+            };
+            for (uint64_t u = lo; u < hi; u++) {
+                const uint32_t n1 = node_of(u * 4), n2 = node_of(u * 4 + 2), mirror_n2 = node_of(u * 4 + 3), mirror_n1 = node_of(u * 4 + 1);
+                put(n1, mirror_n1); put(mirror_n1, n1);   // clib.rs:236
+                put(n2, mirror_n2); put(mirror_n2, n2);   // clib.rs:237
+            }
+            if (bad) conflict.store(true);
+        });
+        if (conflict.load())
+            for (uint64_t u = 0; u < U; u++) {
+                const uint32_t n1 = node_of(u * 4), n2 = node_of(u * 4 + 2), mirror_n2 = node_of(u * 4 + 3), mirror_n1 = node_of(u * 4 + 1);
+                mir[n1] = mirror_n1; mir[mirror_n1] = n1;
+                mir[n2] = mirror_n2; mir[mirror_n2] = n2;
+            }
     }
+    lap("mirror nodes");
     parallel_ranges(U, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t u = lo; u < hi; u++) {
             const uint64_t e = 2 * u;
@@ -316,17 +466,22 @@ void builder_build(HostGraph *g, const uint64_t *unitig_weights) {
             g->w_biedge[u] = unitig_weights[u];
         }
     });
+    lap("edges");
     link_adjacency(*g, n_edges);
     g->validate_pairing();  // clib.rs:251
+    lap("verify_node_pairing");
     // clib.rs:252 verify_edge_mirror_property: with a valid pairing the two edges of a unitig are mirrors of
     // each other by construction only if later set_mirror_nodes calls did not re-pair their endpoints.
-    for (uint64_t e = 0; e < g->edge_count(); e += 2)
-        if (g->e_from[e + 1] != g->mirror[g->e_to[e]] || g->e_to[e + 1] != g->mirror[g->e_from[e]])
-            MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (unitig %llu)", (unsigned long long)(e / 2));
+    parallel_ranges(U, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t u = lo; u < hi; u++) {
+            const uint64_t e = 2 * u;
+            if (g->e_from[e + 1] != g->mirror[g->e_to[e]] || g->e_to[e + 1] != g->mirror[g->e_from[e]])
+                MTG_DIE("assertion failed: graph.verify_edge_mirror_property() (unitig %llu)", (unsigned long long)u);
+        }
+    });
+    lap("verify_edge_mirror");
     g->n_original_edges = g->edge_count();
     g->built = true;
-    std::vector<uint64_t>().swap(g->uf_parent);
-    std::vector<uint8_t>().swap(g->uf_rank);
 }
 
 }  // namespace mtg

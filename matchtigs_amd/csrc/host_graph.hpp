@@ -158,8 +158,7 @@ struct HostGraph {
     bool has_builder = false;
     bool built = false;
     uint64_t unitig_amount = 0;
-    std::vector<uint64_t> uf_parent;
-    std::vector<uint8_t> uf_rank;
+    std::vector<PodVec<uint64_t>> link_chunks;  // the links reported so far, packed (graph_build.cpp): united by matchtigs_build_graph, in order
 
     // ---- graph ----
     PodVec<uint32_t> mirror;         // [V] (filled by host threads)

@@ -476,3 +476,34 @@ def unitig_graph_of_arrays(ua: UnitigArrays) -> UnitigGraph:
 
     return UnitigGraph(ua.k, ua.unitig_list(), [(int(a), bool(b), int(c), bool(d)) for a, b, c, d in ua.links],
                        {decode(c) for c in ua.kmers})
+
+
+def dbg_like_links(U: int, seed: int = 1) -> np.ndarray:
+    """Links [n, 4] (unitig a, strand a, unitig b, strand b) of a unitig graph with the degree structure of a compacted de Bruijn
+    graph: 1.4 node sides per unitig, every end arriving at a side linked with every end leaving it, listed unitig by unitig the way
+    BCALM2 does -- input for the clib.rs builder (clib.rs:94-259) at sizes no sequence generator reaches quickly."""
+    rng = np.random.default_rng(seed)
+    M = int(1.4 * U) & ~1  # node sides; the mirror of side x is x ^ 1
+    s = rng.integers(0, M, U)  # where the forward unitig starts
+    t = rng.integers(0, M, U)  # where it ends
+    u = np.arange(U, dtype=np.int64)
+    arr_node = np.concatenate([t, s ^ 1])  # ends arriving at a side: (u, fwd) at t, (u, bwd) at s^1
+    arr_id = np.concatenate([u << 1 | 1, u << 1])
+    lea_node = np.concatenate([s, t ^ 1])  # ends leaving a side
+    lea_id = np.concatenate([u << 1 | 1, u << 1])
+    oa = np.argsort(arr_node, kind="stable")
+    ol = np.argsort(lea_node, kind="stable")
+    arr_node, arr_id = arr_node[oa], arr_id[oa]
+    lea_node, lea_id = lea_node[ol], lea_id[ol]
+    ca = np.bincount(arr_node, minlength=M)
+    cl = np.bincount(lea_node, minlength=M)
+    start_l = np.concatenate([[0], np.cumsum(cl)[:-1]])
+    # every arrival at side x pairs with every leaving end of x
+    rep = cl[arr_node]
+    a_rep = np.repeat(arr_id, rep)
+    base = np.repeat(start_l[arr_node], rep)
+    off = np.arange(len(a_rep)) - np.repeat(np.concatenate([[0], np.cumsum(rep)[:-1]]), rep)
+    b_rep = lea_id[base + off]
+    links = np.stack([a_rep >> 1, a_rep & 1, b_rep >> 1, b_rep & 1], axis=1).astype(np.int64)
+    # BCALM2 lists links unitig by unitig: order by the first unitig
+    return np.ascontiguousarray(links[np.argsort(links[:, 0], kind="stable")])

@@ -141,6 +141,36 @@ def test_clib_builder_matches_oracle_and_pyref(seed, oracle, product_lib):
         assert n == n_o and np.array_equal(eo, eo_o) and np.array_equal(io, io_o) and np.array_equal(lo, lo_o)
 
 
+@pytest.mark.parametrize("kind", ["dbg_like", "random"])
+def test_clib_builder_on_host_threads_matches_oracle(kind, oracle, product_lib):
+    """matchtigs_build_graph at a size where every pass runs on several host threads (clib.rs:186-259): the links are recorded and
+    united at build time, with prefetching, in call order; numbering, mirror assignment and edges are parallel passes. `random` links
+    give components without any structure, union-find chains deeper than a de Bruijn graph's, and nodes that are their own mirror
+    (the mirror assignment's conflict path)."""
+    from matchtigs_amd import synth
+    U = 150_000
+    rng = np.random.default_rng(11)
+    if kind == "dbg_like":
+        links = synth.dbg_like_links(U, seed=3)
+    else:
+        n = int(0.8 * U)  # (the oracle's builder is quadratic in the size of a node: no giant component)
+        links = np.stack([rng.integers(0, U, n), rng.integers(0, 2, n), rng.integers(0, U, n), rng.integers(0, 2, n)], axis=1).astype(np.int64)
+        links[::7, 2] = links[::7, 0]       # a unitig linked with itself ...
+        links[::14, 3] = 1 - links[::14, 1]  # ... on the other strand: nodes that are their own mirror
+    weights = rng.integers(1, 50, U).astype(np.uint64)
+    og = oracle.OracleGraph.from_unitig_links_arrays(weights, links)
+    G = api.Bigraph.from_unitig_links_arrays(weights, links)
+    ex = G.export()
+    assert og.node_count == G.node_count() and og.edge_count == G.edge_count()
+    assert np.array_equal(og.mirror(), ex["mirror"])
+    oe = og.edges()
+    assert np.array_equal(np.array([e[0] for e in oe], np.uint32), ex["edge_from"])
+    assert np.array_equal(np.array([e[1] for e in oe], np.uint32), ex["edge_to"])
+    assert np.array_equal(np.array([e[2] for e in oe], np.uint64), ex["edge_weight"])
+    assert np.array_equal(np.array([e[4] for e in oe], np.uint64), ex["edge_unitig"])
+    assert np.array_equal(np.array([e[5] for e in oe], np.uint8), ex["edge_forwards"])
+
+
 def test_clib_flattening_on_host_threads_equals_oracle(oracle, product_lib):
     """clib.rs:393-407 at a size where the flattening runs on several host threads (> 2^16 walk edges): eulertigs of a real
     de Bruijn graph through matchtigs_compute_tigs, all three output arrays against the oracle's."""
