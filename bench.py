@@ -99,6 +99,26 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
     }
 
 
+def stage_minimum_models(V: int, E0: int, P: int, N: int, E: int, S: int, C: int, kept: int, tigs: int) -> dict:
+    """Bytes a stage cannot avoid whatever its pass structure: its inputs read once and its outputs written once, per unit of the
+    PROBLEM (not of the implementation: stage_models() above moves when kernels are re-cut, this does not, so `frac_of_minimum` is
+    comparable across rounds). V nodes, E0 original darts, P pairs, N Euleriser units, E darts after the finish, S sources, C
+    candidates in the lists the search emitted, kept = tig edges, tigs = tig count.
+      replay           candidates (key 8 B + source 4 B) + per source its multiplicity and mirror (8 B) -> pairs (12 B)
+      insert_eulerise  pairs (12 B) + out-degree and mirror per node (8 B) -> two darts per pair and per unit (from, to, weight: 12 B each)
+      decomposition    darts (from, to: 8 B) -> the closed walks (4 B per biedge) and their limits
+      records          darts (from, to: 8 B) -> one adjacency entry per dart (4 B) and one offset per node (4 B): what a walk needs at least
+      cut              closed walks (4 B per biedge) + the weight of every edge on them (2 B) -> tig edges (4 B) + limits (8 B per tig)"""
+    n = E // 2
+    return {
+        "replay": 12 * C + 8 * S + 12 * P,
+        "insert_eulerise": 12 * P + 8 * V + 24 * P + 24 * N,
+        "decomposition": 8 * E + 4 * n,
+        "records": 8 * E + 4 * E + 4 * V,
+        "cut": 6 * n + 4 * kept + 8 * tigs,
+    }
+
+
 def stage_traffic(args, world: int, mode: str):
     """PMC traffic per stage (profiles/stage_traffic.json, tools/stage_traffic.py over separate rocprofv3 --pmc passes of this very
     command) for this workload and Euler mode, or {}."""
@@ -462,6 +482,9 @@ def main():
                      "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, recording splitter walks, ranking, copy",
                      "records": "walk records (reference-order mode): bucket merge + lean_build + wide_build kernels (the records' download is not in it)",
                      "cut": "rotate + cut: cycle heads / rotation / rotate_cycles / cut_flags / 3 scans / cut_write (the tig download is not in it)"}
+            minimum = stage_minimum_models(n_nodes, n_edges, result_info.get("pairs", 0), result_info.get("units", 0), result_info.get("darts", 0),
+                                           result_info.get("S", 0), int(total_stats.get("emitted", 0)), result_info.get("tig_edges", 0),
+                                           result_info.get("tigs", 0))
             roofline_stages = []
             for mode_name in ("device", "host"):
                 tr = stage_traffic(args, world, mode_name)
@@ -474,7 +497,10 @@ def main():
                     entry = {"stage": st_name, "euler_mode": mode_name, "kernels": names[st_name], "bound": "hbm", "avg_launch_ms": round(ms, 4),
                              "algorithmic_bytes": int(b), "achieved": round(b / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                             "traffic": (tr.get(st_name) or {}).get("traffic_bytes")}
+                             "traffic": (tr.get(st_name) or {}).get("traffic_bytes"),
+                             # (inputs once + outputs once, independent of the pass structure: stage_minimum_models)
+                             "minimum_bytes": int(minimum[st_name]),
+                             "frac_of_minimum": round(minimum[st_name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
                     if st_name == "replay":
                         rk = [v for v in stage_ms[mode_name].get("replay_rounds_kernel", []) if v > 0]
                         entry["rounds_kernel_ms"] = round(float(np.mean(rk)), 4) if rk else None

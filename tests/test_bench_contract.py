@@ -41,6 +41,8 @@ def test_bench_json_line(product_lib):
             ("replay", "host"), ("insert_eulerise", "host"), ("records", "host"), ("cut", "host")} <= stages
     for x in d["roofline_stages"]:
         assert x["avg_launch_ms"] > 0 and x["algorithmic_bytes"] > 0 and abs(x["frac"] - x["achieved"] / 8000.0) < 1e-4
+        # the pass-independent floor (inputs once + outputs once) lies below what the implementation's passes move
+        assert 0 < x["minimum_bytes"] <= x["algorithmic_bytes"] and 0 < x["frac_of_minimum"] <= x["frac"] + 1e-6
     cs = d["cold_step_ms"]
     assert cs["device"]["step_ms"] > 0 and cs["host"]["step_ms"] > 0 and cs["device"]["device_graph_build_ms"] > 0
     assert d["full_size"] is None  # (only the headline configuration runs the nominal-size step)
