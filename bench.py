@@ -206,6 +206,7 @@ def main():
     # ---- the consuming one-shot call (clib.rs:280-291: every real call of the reference is a first call), each Euler mode in a
     # process of its own, before this process takes any device memory ----
     one_shot = run_one_shot(args) if (world == 1 and args.one_shot and args.workload == "g_csr") else None
+    clib_route = run_clib_route(args) if (world == 1 and args.one_shot and args.workload == "g_csr") else None
     # fixed total graph (strong scaling): the same unitig graph on every rank, sources block-partitioned.
     # G-csr is generated ON each rank's GPU (csrc/synth_device.hip, the twin of synth.g_csr): seconds, no numpy argsort.
     t_gen = time.perf_counter()
@@ -556,6 +557,7 @@ def main():
             "roofline": roofline,
             "roofline_stages": roofline_stages,
             "one_shot": one_shot,
+            "clib_route": clib_route,
             "cold_step_ms": cold,
             "full_size": full_size,
             # claim replay (one cooperative kernel): cost model = source visits x (32-B touch record + 8-B state and 8-B reservation
@@ -599,6 +601,33 @@ def run_one_shot(args) -> dict:
             out[mode] = {"first_call_of_the_process": {kk: lines[0][kk] for kk in keep},
                          "later_call": {kk: lines[1][kk] for kk in keep}, "total_s": lines[1]["total_s"],
                          "same_result_both_calls": lines[0]["checksum"] == lines[1]["checksum"] and lines[0]["tigs"] == lines[1]["tigs"]}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+            out[mode] = {"error": repr(e)[:300]}
+    return out
+
+
+def run_clib_route(args) -> dict:
+    """tools/clib_route_timing.py as a child process: the reference's own way in (clib.rs:94-410) -- initialise, one merge_nodes per
+    link, build_graph, compute into clib.rs-sized arrays -- on a unitig graph with a compacted de Bruijn graph's degree structure,
+    8 M unitigs unless the bench graph is smaller (the link list is made with numpy: 2^27's 65 M unitigs would take minutes)."""
+    import subprocess
+
+    unitigs = min(8_000_000, max(1 << (args.log2_edges - 1), 1024))
+    out = {"note": "mtg_graph_builder_new / _merge_links (= matchtigs_merge_nodes from one C loop) / _build + mtg_compute_tigs_clib on "
+                   "synth.dbg_like_links; the builder is host code (union-find in the order of the calls: sequential by the API's shape); "
+                   "second repetition of the process reported"}
+    for mode in ("device", "host"):
+        if mode == "host" and args.euler == "device":
+            continue
+        cmd = [sys.executable, str(ROOT / "tools" / "clib_route_timing.py"), "--unitigs", str(unitigs), "--k", str(args.k), "--reps", "2",
+               "--compute", mode]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+            if r.returncode != 0 or len(lines) < 2:
+                out[mode] = {"error": f"rc={r.returncode}: {r.stderr[-300:]}"}
+                continue
+            out[mode] = {kk: vv for kk, vv in lines[1].items() if kk not in ("rep", "euler_mode")}
         except (subprocess.TimeoutExpired, OSError, ValueError) as e:
             out[mode] = {"error": repr(e)[:300]}
     return out

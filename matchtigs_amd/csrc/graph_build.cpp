@@ -207,8 +207,15 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
     parallel_ranges(n_edges / 2, [&](uint64_t lo, uint64_t hi) {
         // (measured and dropped: MADV_POPULATE_WRITE on the thread's parts of the three fresh arrays before it fills them -- no faster
         // at 2^27, 20 % slower at 2^30 -- and streaming stores, see below)
+        constexpr uint64_t AHEAD = 24;  // biedges: the two mirror[] lookups of the check below are random reads into 4 V bytes
+        const uint32_t *mir = g->mirror.data();
         for (uint64_t u = lo; u < hi; u++) {
             const uint64_t e = 2 * u;
+            if (u + AHEAD < hi) {
+                const uint32_t pf = from[e + 2 * AHEAD], pt = to[e + 2 * AHEAD];
+                if (pf < n_nodes) __builtin_prefetch(&mir[pf]);
+                if (pt < n_nodes) __builtin_prefetch(&mir[pt]);
+            }
             const uint32_t f = from[e], t = to[e];
             if (f >= n_nodes || t >= n_nodes) MTG_DIE("edge %llu: node id out of range", (unsigned long long)e);
             // graph.verify_edge_mirror_property(), clib.rs:252: the partner must be mirror(to) -> mirror(from)
@@ -271,26 +278,39 @@ template <typename Index>
 struct UnionFind {
     static constexpr Index ROOT = (Index)1 << (sizeof(Index) * 8 - 1);
     Index *parent;
+    // Written without data-dependent branches for the chains that occur (a slot is a root, points at one, or at a slot that does):
+    // whether a slot is a root is a coin flip to the branch predictor, and a mispredicted branch costs more here than the loads,
+    // which the caller has prefetched. Full compression; does not change which element is the root.
     inline Index root(Index x) {
-        Index r = x, p;
-        while (!((p = parent[r]) & ROOT)) r = p;
-        while (x != r) {  // full compression; does not change which element is the root
-            const Index nx = parent[x];
-            parent[x] = r;
-            x = nx;
+        const Index p0 = parent[x];
+        const bool is0 = p0 & ROOT;
+        const Index r1 = is0 ? x : p0;
+        const Index p1 = parent[r1];
+        const bool is1 = p1 & ROOT;
+        Index r = is1 ? r1 : p1;
+        Index p = parent[r];
+        if (__builtin_expect(!(p & ROOT), 0)) {  // (deeper than two: rare after compression)
+            do { r = p; p = parent[r]; } while (!(p & ROOT));
+            Index y = r1;
+            while (y != r) {
+                const Index ny = parent[y];
+                parent[y] = r;
+                y = ny;
+            }
         }
+        parent[x] = is0 ? p0 : r;  // (a root keeps its own word; depth one rewrites the same value)
         return r;
     }
     inline void unite(Index x, Index y) {
         const Index a = root(x), b = root(y);
-        if (a == b) return;
         const Index ra = parent[a], rb = parent[b];  // ROOT | rank
-        // equal ranks: policy P4 decides who goes below (mtg_policy.h); written without branches -- which root is the taller one is
-        // a coin flip to the branch predictor
+        // equal ranks: policy P4 decides who goes below (mtg_policy.h). Already united (a == b): both stores rewrite the root's word.
+        const bool same = a == b;
         const bool a_stays = mtg_policy_union_tie_first_goes_below() ? ra > rb : ra >= rb;
         const Index top = a_stays ? a : b, below = a_stays ? b : a;
-        parent[top] = (a_stays ? ra : rb) + (ra == rb ? 1 : 0);
-        parent[below] = top;
+        const Index top_word = (a_stays ? ra : rb) + (ra == rb ? 1 : 0);
+        parent[top] = same ? ra : top_word;
+        parent[below] = same ? ra : top;
     }
 };
 // slots (clib.rs:104-122): fwd-in 4u, bwd-out 4u+1, fwd-out 4u+2, bwd-in 4u+3

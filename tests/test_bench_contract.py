@@ -21,7 +21,7 @@ def test_bench_json_line(product_lib):
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "device_mode", "scaling_stages_ms", "seeds",
-                "roofline_stages", "cold_step_ms", "visited_per_step", "full_size", "one_shot"):
+                "roofline_stages", "cold_step_ms", "visited_per_step", "full_size", "one_shot", "clib_route"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
@@ -52,6 +52,12 @@ def test_bench_json_line(product_lib):
         assert "error" not in os_, os_
         assert os_["total_s"] > 0 and os_["same_result_both_calls"] and os_["later_call"]["tigs"] == d["config"]["tigs"]
         assert set(os_["later_call"]["phases_s"]) >= {"device_build", "sssp", "eulerise", "euler", "cut"}
+    # the reference's own way in (initialise / merge_nodes per link / build_graph / compute): same number of tigs in both Euler modes (T3)
+    cr = d["clib_route"]
+    for mode in ("device", "host"):
+        assert "error" not in cr[mode], cr[mode]
+        assert cr[mode]["links"] > cr[mode]["unitigs"] > 0 and cr[mode]["build_graph_s"] > 0 and cr[mode]["compute_tigs_s"] > 0
+    assert cr["device"]["tigs"] == cr["host"]["tigs"] > 0 and cr["device"]["tig_edges"] == cr["host"]["tig_edges"]
     dm = d["device_mode"]
     assert dm["ms_per_step"] > 0 and dm["tigs"] == d["config"]["tigs"] and "finish" in dm["phases_ms"]   # T3 across the two modes
     assert set(d["seeds"]) == {"2", "3"} and all(v["sssp_stage_ms"] > 0 for v in d["seeds"].values())
