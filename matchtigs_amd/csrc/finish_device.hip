@@ -1220,7 +1220,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                     __builtin_nontemporal_store(iv, &io[first + i]);
                 }
             };
-            if (n_kept * 4 < (64u << 20)) {
+            if (n_kept * 4 < hu::PLAIN_COPY_LIMIT) {  // (few tigs: one copy, one thread)
                 std::vector<uint32_t> tmp(n_kept);
                 if (n_kept) HIP_CHECK(hipMemcpyAsync(tmp.data(), d_te, n_kept * 4, hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));

@@ -243,7 +243,8 @@ HostGraph *graph_from_edges(uint64_t n_nodes, const uint32_t *mirror, uint64_t n
 // RECORDS its link (8 bytes, after the same argument checks) and matchtigs_build_graph performs the unions -- in the order of the
 // calls, so that every root is the one the reference's union-find (disjoint-sets 0.4.2: union by rank, ties by policy P4) ends
 // with -- in one loop that knows the future: the slots of the links a few iterations ahead are prefetched while the current one
-// is united, which hides most of the DRAM latency the per-call form had to wait for.
+// is united, which hides part of the DRAM latency the per-call form had to wait for (137 M links over 48 M unitigs: 13 -> 6.6-8 s
+// for all calls + the build; what remains is the chain of dependent loads and stores from one union to the next).
 // ---------------------------------------------------------------------------------------------
 constexpr uint64_t LINK_CHUNK = 1ull << 24;  // links per chunk of the record (128 MB)
 
@@ -355,28 +356,18 @@ static void build_from_links(HostGraph *g, const uint64_t *unitig_weights) {
     });
     {
         UnionFind<Index> uf{parent};
-        // two requests in flight per link: its slots' own words FAR links ahead, and -- NEAR links ahead, when those have arrived --
-        // the words they point at (after compression almost every slot is a root or points at one)
-        constexpr uint64_t FAR = 32, NEAR = 16;
-        auto fetch_second = [&](uint64_t slot) {
-            const Index p = parent[slot];
-            if (!(p & ROOT)) __builtin_prefetch(&parent[p]);
-        };
+        // the slots' own words are requested AHEAD links before their union (a unitig's four slots share a cache line: two requests
+        // per link). Measured and dropped: a second stage that requests the words those point at -- its four extra loads per link cost
+        // more than the misses it hides (8 M unitigs: 1.0 s with it, 0.72 s without; 48 M: 6.2 against 5.3-6.3 s).
+        constexpr uint64_t AHEAD = 32;
         for (size_t c = 0; c < g->link_chunks.size(); c++) {
             const PodVec<uint64_t> &chunk = g->link_chunks[c];
             const uint64_t n = chunk.size();
             for (uint64_t i = 0; i < n; i++) {
-                if (i + FAR < n) {
-                    const LinkSlots f = slots_of(chunk[i + FAR]);
-                    __builtin_prefetch(&parent[f.out_a]);  // (a unitig's four slots share a cache line: two requests per link)
+                if (i + AHEAD < n) {
+                    const LinkSlots f = slots_of(chunk[i + AHEAD]);
+                    __builtin_prefetch(&parent[f.out_a]);
                     __builtin_prefetch(&parent[f.in_b]);
-                }
-                if (i + NEAR < n) {
-                    const LinkSlots f = slots_of(chunk[i + NEAR]);
-                    fetch_second(f.out_a);
-                    fetch_second(f.in_b);
-                    fetch_second(f.mirror_in_a);
-                    fetch_second(f.mirror_out_b);
                 }
                 const LinkSlots s = slots_of(chunk[i]);
                 uf.unite((Index)s.out_a, (Index)s.in_b);

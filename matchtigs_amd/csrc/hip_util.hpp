@@ -557,8 +557,11 @@ inline void download_sliced_with(const void *d_src, size_t bytes, hipStream_t st
     for (auto &x : th) x.join();
     HIP_CHECK(hipStreamSynchronize(st));
 }
+// (a plain copy into pageable memory is staged by the runtime on one thread, ~9 GB/s: worth it only where starting the ring's threads
+// costs more -- until round 5 the limit was 64 MB, 7 ms of a small graph's 40-ms call)
+constexpr size_t PLAIN_COPY_LIMIT = 4u << 20;
 inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStream_t st, int device_id) {
-    if (bytes < (64u << 20)) {
+    if (bytes < PLAIN_COPY_LIMIT) {
         if (bytes) HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         return;
@@ -567,7 +570,7 @@ inline void download_sliced(void *dst, const void *d_src, size_t bytes, hipStrea
 }
 // n 32-bit words on the device -> n 64-bit words on the host: half the bytes over PCIe, widened by the threads that empty the ring
 inline void download_sliced_widen(uint64_t *dst, const uint32_t *d_src, size_t n, hipStream_t st, int device_id, unsigned max_threads = 8) {
-    if (n * 4 < (64u << 20)) {
+    if (n * 4 < PLAIN_COPY_LIMIT) {
         std::vector<uint32_t> tmp(n);
         if (n) HIP_CHECK(hipMemcpyAsync(tmp.data(), d_src, n * 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
