@@ -309,11 +309,11 @@ def test_reference_order_walk_starts_while_its_records_arrive(gpu, oracle, log2_
 
 
 @pytest.mark.parametrize("log2_edges, algorithm, euler", [(12, 5, "host"), (12, 3, "device"), (18, 5, "host"), (18, 5, "device"), (18, 3, "host"),
-                                                         (25, 5, "device"), (25, 3, "device")])
+                                                         (22, 5, "device"), (23, 3, "device"), (25, 5, "device"), (25, 3, "device")])
 def test_compute_tigs_clib_equals_compute_plus_flatten(gpu, oracle, log2_edges, algorithm, euler):
     """mtg_compute_tigs_clib (what matchtigs_compute_tigs runs, clib.rs:280-410): with a finish on the GPU the tigs go from the
-    download ring straight into the caller's clib.rs arrays (flattened by the host threads that empty the ring; the 2^25 cases take
-    the ring, the others the plain copy). Same arrays as mtg_compute_tigs_cfg + mtg_flatten_clib (clib.rs:393-407), and -- in the
+    download ring straight into the caller's clib.rs arrays (flattened by the host threads that empty the ring; the cases from 2^22 on
+    take the ring -- 2^22 with a single partial slice --, the others the plain copy). Same arrays as mtg_compute_tigs_cfg + mtg_flatten_clib (clib.rs:393-407), and -- in the
     reference's walk order, on the sizes the oracle finishes -- as the oracle's tigs flattened by the same rule."""
     import ctypes as C
 
