@@ -2180,30 +2180,37 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
     dl.lap("allocations");
     // (through the pinned ring: host threads fill the next slice while one crosses PCIe -- the runtime stages a pageable upload on one
     // thread. from + mirror + 2 bytes per unitig: the heads are mirror(from(e ^ 1)), 6.3 B per edge + 4 B per node in all)
-    if (E) {
-        hu::upload_sliced(d_from, g.e_from.data(), E * 4, st, device_id);
-        hu::upload_sliced(d_w, wclamp.data(), U * 2, st, device_id);
-    }
-    if (V) hu::upload_sliced(d->d_mirror, g.mirror.data(), V * 4, st, device_id);
-    HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, st));
-    dl.lap("uploads + memsets");
+    // `from` first: the counting pass and the scans over its degrees (12 ms of kernels at 2^27) need nothing else and run on a stream
+    // of their own (non-blocking: `st` is the legacy default stream, which every ordinary stream waits for) while the weights and the
+    // mirror array (0.49 GB, 10 ms of PCIe) come up on `st`.
+    if (E) hu::upload_sliced(d_from, g.e_from.data(), E * 4, st, device_id);
+    dl.lap("upload of from");
     const unsigned eb = (unsigned)((E + 255) / 256), vb = (unsigned)((V + 255) / 256);
     uint64_t ext_total = 0;
+    uint32_t *d_bs = nullptr;
+    hipStream_t bs = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+    HIP_CHECK(hipMemsetAsync(d->d_odeg, 0, std::max<uint64_t>(V, 1) * 4, bs));
     if (V) {
-        if (E) hipLaunchKernelGGL(build_count_kernel, dim3(eb), dim3(256), 0, st, d_from, E, d->d_odeg, d_fill);
-        hipLaunchKernelGGL(build_ext_need_kernel, dim3(vb), dim3(256), 0, st, d->d_odeg, V, d_need);
+        if (E) hipLaunchKernelGGL(build_count_kernel, dim3(eb), dim3(256), 0, bs, d_from, E, d->d_odeg, d_fill);
+        hipLaunchKernelGGL(build_ext_need_kernel, dim3(vb), dim3(256), 0, bs, d->d_odeg, V, d_need);
         HIP_CHECK(hipGetLastError());
-        scan_u32(d, st, d->replay, d_need, V, d_ext_off, &d->d_counters[C_OVF_LIST]);
+        scan_u32(d, bs, d->replay, d_need, V, d_ext_off, &d->d_counters[C_OVF_LIST]);
         if (want_buckets) {  // row0 = exclusive scan of the out-degrees
-            uint32_t *d_bs = nullptr;
             hu::device_malloc(&d_bs, (hu::scan_blocks(V) + 2) * 4);
-            hu::scan_u32<uint32_t>(st, d->d_odeg, V, d_row0, d_bs, d_row0 + V);
-            HIP_CHECK(hipStreamSynchronize(st));
-            hu::device_free(d_bs);
+            hu::scan_u32<uint32_t>(bs, d->d_odeg, V, d_row0, d_bs, d_row0 + V);
         }
-        read_counters(d, st);
+    }
+    if (E) hu::upload_sliced(d_w, wclamp.data(), U * 2, st, device_id);
+    if (V) hu::upload_sliced(d->d_mirror, g.mirror.data(), V * 4, st, device_id);  // (both calls return when the data is there)
+    if (V) {
+        read_counters(d, bs);
+        if (d_bs) hu::device_free(d_bs);
         ext_total = d->h_counters[C_OVF_LIST];
     }
+    HIP_CHECK(hipStreamSynchronize(bs));
+    HIP_CHECK(hipStreamDestroy(bs));
+    dl.lap("count + scans beside the uploads of weights and mirror");
     d->ext_n = ext_total;
     hu::device_malloc(&d->d_ext_col, std::max<uint64_t>(ext_total, 1) * 4);
     hu::device_malloc(&d->d_ext_w, std::max<uint64_t>(ext_total, 1) * 2);
