@@ -851,6 +851,7 @@ uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_c
             if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
         }
         toucher = std::thread([=]() {
+            const double t_touch = now_s();
             parallel_ranges((n_e * 8 + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t pg = lo; pg < hi; pg++) {
                     *((volatile char *)tigs_edge_out + pg * 4096) = 0;
@@ -860,6 +861,7 @@ uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_c
             parallel_ranges((n_l * 8 + 4095) / 4096, [&](uint64_t lo, uint64_t hi) {
                 for (uint64_t pg = lo; pg < hi; pg++) *((volatile char *)tigs_out_limits + pg * 4096) = 0;
             }, 6);
+            if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] output arrays touched (%.2f GB) %.1f ms after the call began\n", (2 * n_e + n_l) * 8 / 1e9, (now_s() - t_touch) * 1e3);
         });
     }
     g_clib_sink = &sink;
