@@ -667,6 +667,45 @@ def finish_greedytigs_np(graph: Bigraph, pairs: np.ndarray, k: int, euler_mode: 
     return _take_walks_np(L, L.mtg_finish_greedytigs_cfg(graph.handle, _ptr(p) if len(p) else None, len(p), C.byref(c)))
 
 
+class Tigs:
+    """Handle of a tig set (mtg_walks). After a finish on the GPU the tigs are still in HBM: count() and total_edges() cost nothing,
+    arrays() brings them to the host -- once, through the pinned ring -- and returns (limits, edges) as views of the library's arrays
+    (valid while this object lives)."""
+
+    def __init__(self, L, wp):
+        self._L, self._wp = L, wp
+
+    def __del__(self):
+        wp, self._wp = getattr(self, "_wp", None), None
+        if wp:
+            self._L.mtg_walks_free(C.c_void_p(wp))
+
+    def count(self) -> int:
+        return int(self._L.mtg_walks_count(self._wp))
+
+    def total_edges(self) -> int:
+        return int(self._L.mtg_walks_total_edges(self._wp))
+
+    def arrays(self):
+        n, tot = self.count(), self.total_edges()
+        if not (n and tot):
+            return np.zeros(n, np.uint64), np.zeros(tot, np.uint32)
+        lp, ep = C.c_void_p(), C.c_void_p()
+        self._L.mtg_walks_data(self._wp, C.byref(lp), C.byref(ep))
+        lim = np.frombuffer((C.c_char * (n * 8)).from_address(lp.value), dtype=np.uint64)
+        ed = np.frombuffer((C.c_char * (tot * 4)).from_address(ep.value), dtype=np.uint32)
+        self._views = (lim, ed)
+        return lim, ed
+
+
+def finish_greedytigs_resident(graph: Bigraph, device: "DeviceGraph", k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
+                               device_id: int = 0, finish_stage: FinishStage = FinishStage.Auto) -> Tigs:
+    """mtg_finish_greedytigs_resident as a handle: the tigs of a finish on the GPU stay in HBM until Tigs.arrays() asks for them."""
+    L = _lib.load()
+    c = GreedytigAlgorithmConfiguration(1, k, euler_mode=euler_mode, device_ids=(device_id,), finish_stage=finish_stage).to_c()
+    return Tigs(L, L.mtg_finish_greedytigs_resident(graph.handle, device.handle, C.byref(c)))
+
+
 def finish_greedytigs_resident_np(graph: Bigraph, device: "DeviceGraph", k: int, euler_mode: EulerMode = EulerMode.HostReferenceOrder,
                                   device_id: int = 0, finish_stage: FinishStage = FinishStage.Auto):
     """mtg_finish_greedytigs_resident: the finish over the pairs the last replay_claims_resident left on the GPU."""

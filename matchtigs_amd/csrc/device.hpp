@@ -75,8 +75,22 @@ struct TigSink {
     uint64_t *limits_out = nullptr; // [>= tigs]        exclusive end of tig i (clib.rs:405-406)
     uint64_t n_tigs = 0, n_edges = 0;  // filled by the finish
 };
+// (resident_out: the tigs stay in the HBM of `device_id` -- the returned Walks is empty, *resident_out owns the cutter's output
+// arrays; whoever wants them on the host calls download(): a caller that asks for counts, flattens through a sink or spells on the GPU
+// never pays for the 0.37-GB copy into pageable memory that a step at 2^27 used to end with)
+struct ResidentTigs {
+    int device = 0;
+    uint32_t *d_edges = nullptr;   // [n_edges] edge ids of the tigs, one after the other
+    uint32_t *d_limits = nullptr;  // [n_tigs]  exclusive end of tig i
+    uint64_t n_edges = 0, n_tigs = 0;
+    ResidentTigs() = default;
+    ResidentTigs(const ResidentTigs &) = delete;
+    ResidentTigs &operator=(const ResidentTigs &) = delete;
+    ~ResidentTigs();
+    void download(Walks &w) const;  // through the pinned ring; limits widened to 64 bits on the way
+};
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
-                    const mtg_pair *d_pairs_resident = nullptr, TigSink *sink = nullptr);
+                    const mtg_pair *d_pairs_resident = nullptr, TigSink *sink = nullptr, ResidentTigs **resident_out = nullptr);
 void device_set_finish_tuning(int records, int flags, long record_delay_us);
 void device_release_memory(int device_id);
 uint64_t device_memory_held(int device_id);

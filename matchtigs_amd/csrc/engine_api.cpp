@@ -12,6 +12,8 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,7 +33,32 @@ extern char **environ;
 
 struct mtg_graph { HostGraph g; };
 struct mtg_device { Device *d; };
-struct mtg_walks { Walks w; };
+// The tigs of a finish on the GPU stay in HBM (`dev`) until somebody asks for them on the host: host() downloads them once. Counts
+// come from `dev` without a copy; a clib.rs caller's tigs never get here (TigSink).
+struct mtg_walks {
+    mutable Walks w;
+    mutable std::unique_ptr<ResidentTigs> dev;
+    mutable std::mutex m;
+    mtg_walks() = default;
+    explicit mtg_walks(Walks &&walks, ResidentTigs *resident = nullptr) : w(std::move(walks)), dev(resident) {}
+    const Walks &host() const {
+        std::lock_guard<std::mutex> lock(m);
+        if (dev) {
+            dev->download(w);
+            dev.reset();
+        }
+        return w;
+    }
+    Walks &host() { return const_cast<Walks &>(static_cast<const mtg_walks *>(this)->host()); }
+    uint64_t count() const {
+        std::lock_guard<std::mutex> lock(m);
+        return dev ? dev->n_tigs : w.limits.size();
+    }
+    uint64_t total_edges() const {
+        std::lock_guard<std::mutex> lock(m);
+        return dev ? dev->n_edges : w.edges.size();
+    }
+};
 // The clib.rs handle is the same object as the engine graph.
 struct MatchtigsData { mtg_graph graph; };
 
@@ -70,7 +97,7 @@ static Walks euler_cycles_by_mode(const HostGraph &g, const mtg_config &cfg) {
 }
 
 static size_t tig_count(const mtg_walks *tigs) {  // (a device finish with a sink delivers no walks)
-    return g_clib_sink && g_clib_sink_used ? (size_t)g_clib_sink->n_tigs : tigs->w.limits.size();
+    return g_clib_sink && g_clib_sink_used ? (size_t)g_clib_sink->n_tigs : (size_t)tigs->count();
 }
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -323,7 +350,7 @@ mtg_walks *mtg_euler_cycles_device(const mtg_graph *g, int device_id) {
 double mtg_last_euler_kernel_ms(void) { return g_last_euler_kernel_ms; }
 void mtg_set_euler_device_tuning(int splitter_bitmap) { device_euler_force_bitmap(splitter_bitmap); }
 mtg_walks *mtg_cut_cycles(const mtg_graph *g, const mtg_walks *cycles, uint64_t k) {
-    return new mtg_walks{cut_cycles(g->g, cycles->w, k)};
+    return new mtg_walks{cut_cycles(g->g, cycles->host(), k)};
 }
 
 // The device finish takes a graph that holds only its original edges and matched pairs shorter than k (what the claim loop
@@ -345,7 +372,10 @@ static mtg_walks *finish_on_device(HostGraph &g, const mtg_pair *pairs, uint64_t
     log_info("Finding Eulerian bicycle");
     double *t = g_last_finish_times;
     if (g_clib_sink) g_clib_sink_used = true;
-    mtg_walks *tigs = new mtg_walks{device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t, d_pairs_resident, g_clib_sink)};
+    ResidentTigs *resident = nullptr;
+    Walks host_walks = device_finish(g, reinterpret_cast<const Pair *>(pairs), n_pairs, cfg.k, cfg.device_ids[0], cfg.euler_mode, t, d_pairs_resident, g_clib_sink,
+                                     g_clib_sink ? nullptr : &resident);
+    mtg_walks *tigs = new mtg_walks(std::move(host_walks), resident);
     g_phase[5] = t[0] + t[1];
     g_phase[6] = t[2];
     g_phase[7] = t[3];
@@ -483,15 +513,17 @@ mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k) {
     return mtg_compute_eulertigs_cfg(g, &cfg);
 }
 
-uint64_t mtg_walks_count(const mtg_walks *w) { return w->w.limits.size(); }
-uint64_t mtg_walks_total_edges(const mtg_walks *w) { return w->w.edges.size(); }
+uint64_t mtg_walks_count(const mtg_walks *w) { return w->count(); }
+uint64_t mtg_walks_total_edges(const mtg_walks *w) { return w->total_edges(); }
 void mtg_walks_export(const mtg_walks *w, uint64_t *limits, uint32_t *edges) {
-    if (limits && !w->w.limits.empty()) std::memcpy(limits, w->w.limits.data(), w->w.limits.size() * 8);
-    if (edges && !w->w.edges.empty()) std::memcpy(edges, w->w.edges.data(), w->w.edges.size() * 4);
+    const Walks &h = w->host();
+    if (limits && !h.limits.empty()) std::memcpy(limits, h.limits.data(), h.limits.size() * 8);
+    if (edges && !h.edges.empty()) std::memcpy(edges, h.edges.data(), h.edges.size() * 4);
 }
 void mtg_walks_data(const mtg_walks *w, const uint64_t **limits, const uint32_t **edges) {
-    if (limits) *limits = w->w.limits.data();
-    if (edges) *edges = w->w.edges.data();
+    const Walks &h = w->host();
+    if (limits) *limits = h.limits.data();
+    if (edges) *edges = h.edges.data();
 }
 void mtg_walks_free(mtg_walks *w) { delete w; }
 mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const uint32_t *edges) {
@@ -509,7 +541,7 @@ mtg_walks *mtg_walks_from_arrays(uint64_t n_walks, const uint64_t *limits, const
 
 uint64_t mtg_flatten_clib(const mtg_graph *g, const mtg_walks *tigs, int64_t *tigs_edge_out, uint64_t *tigs_insert_out,
                           uint64_t *tigs_out_limits) {
-    return flatten_clib(g->g, tigs->w, tigs_edge_out, tigs_insert_out, tigs_out_limits);
+    return flatten_clib(g->g, tigs->host(), tigs_edge_out, tigs_insert_out, tigs_out_limits);
 }
 
 uint64_t mtg_write_walks_fasta(const mtg_graph *g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
@@ -548,7 +580,7 @@ uint64_t mtg_write_duplication_bitvector(const mtg_graph *g, uint64_t n_walks, c
 uint64_t mtg_write_tigs_duplication_bitvector_file(const mtg_graph *g, const mtg_walks *tigs, const char *path) {
     if (!g || !tigs || !path) MTG_DIE("mtg_write_tigs_duplication_bitvector_file: null argument");
     char *buf = nullptr;
-    const uint64_t n = write_duplication_bitvector(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), &buf);
+    const uint64_t n = write_duplication_bitvector(g->g, tigs->host().limits.size(), tigs->host().limits.data(), tigs->host().edges.data(), &buf);
     write_file(path, buf, n, 0);  // the reference writes this file uncompressed (implementation/mod.rs:665)
     std::free(buf);
     return n;
@@ -579,9 +611,9 @@ uint64_t mtg_write_tigs_text_file_device(const mtg_graph *g, const mtg_walks *ti
     if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_text_file_device: null argument");
     char *buf = nullptr;
     const uint64_t n = device_count() > device_id && device_id >= 0
-                           ? device_write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k, unitigs->s->data.data(),
+                           ? device_write_walks_text(g->g, tigs->host().limits.size(), tigs->host().limits.data(), tigs->host().edges.data(), k, unitigs->s->data.data(),
                                                      unitigs->s->off.data(), gfa != 0, gfa_header, device_id, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
-                           : write_walks_text(g->g, tigs->w.limits.size(), tigs->w.limits.data(), tigs->w.edges.data(), k,
+                           : write_walks_text(g->g, tigs->host().limits.size(), tigs->host().limits.data(), tigs->host().edges.data(), k,
                                               unitigs->s->data.data(), unitigs->s->off.data(), gfa != 0, gfa_header, &buf);
     write_file(path, buf, n, compression_level);
     std::free(buf);
@@ -687,7 +719,7 @@ mtg_walks *mtg_finish_matchtigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_
         begin = cycles.limits[c];
     }
     mtg_walks *tigs = new mtg_walks{cut_cycles(g->g, cycles, k)};
-    log_info("Found %zu matchtigs", tigs->w.limits.size());
+    log_info("Found %zu matchtigs", (size_t)tigs->count());
     return tigs;
 }
 mtg_walks *mtg_compute_matchtigs_cfg(mtg_graph *g, const mtg_config *cfg) {
@@ -869,7 +901,7 @@ uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_c
     mtg_walks *tigs = mtg_compute_tigs_cfg(g, tig_algorithm, cfg);
     g_clib_sink = nullptr;
     if (toucher.joinable()) toucher.join();
-    const uint64_t n = g_clib_sink_used ? sink.n_tigs : flatten_clib(g->g, tigs->w, tigs_edge_out, tigs_insert_out, tigs_out_limits);
+    const uint64_t n = g_clib_sink_used ? sink.n_tigs : flatten_clib(g->g, tigs->host(), tigs_edge_out, tigs_insert_out, tigs_out_limits);
     delete tigs;
     return n;
 }

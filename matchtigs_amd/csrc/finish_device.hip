@@ -646,8 +646,26 @@ struct KeepAwake {
     }
 };
 
+ResidentTigs::~ResidentTigs() {
+    hu::device_free_on(device, d_edges);
+    hu::device_free_on(device, d_limits);
+}
+void ResidentTigs::download(Walks &w) const {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t st = finish_stream(device);
+    w.edges.resize(n_edges);
+    w.limits.resize(n_tigs);
+    download_sliced(w.edges.data(), d_edges, n_edges * 4, st, device);
+    download_sliced_widen(w.limits.data(), d_limits, n_tigs, st, device);
+    (void)hipSetDevice(cur);
+}
+
 Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t k, int device_id, int euler_mode, double times_out[12],
-                    const mtg_pair *d_pairs_resident, TigSink *sink) {
+                    const mtg_pair *d_pairs_resident, TigSink *sink, ResidentTigs **resident_out) {
+    if (sink) resident_out = nullptr;
+    if (resident_out) *resident_out = nullptr;
     const uint64_t V = g.node_count(), E0 = g.n_original_edges;
     if (n_pairs && !pairs && !d_pairs_resident) MTG_DIE("device_finish: null pairs");
     if (g.edge_count() != E0) MTG_DIE("device_finish: the graph already holds dummy edges");
@@ -911,13 +929,13 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     std::thread prefault_thread;
     {
         const uint64_t bound_edges = E0 / 2 + n_pairs, bound_tigs = n_dummy / 2 + 4096;
-        if (!sink) {
+        if (!sink && !resident_out) {
             tigs.edges.resize(bound_edges);  // (PodVec: no element is written; shrunk to the real sizes after the cut)
             tigs.limits.resize(bound_tigs);
         }
         // (a sink's arrays are sized as clib.rs:332-348: 2 E0 / 2 E0 / E0 entries. Its first array is touched here, the second by the
         // same threads through the offset below; a caller that passes touched memory loses nothing)
-        if ((bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
+        if (!resident_out && (bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
             char *pe = sink ? reinterpret_cast<char *>(sink->edge_out) : reinterpret_cast<char *>(tigs.edges.data());
             char *pl = sink ? reinterpret_cast<char *>(sink->limits_out) : reinterpret_cast<char *>(tigs.limits.data());
             char *pi = sink ? reinterpret_cast<char *>(sink->insert_out) : nullptr;
@@ -1232,6 +1250,15 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
             download_sliced_widen(sink->limits_out, d_tl, n_tigs, st, device_id, 16);
             sink->n_tigs = n_tigs;
             sink->n_edges = n_kept;
+        } else if (resident_out) {
+            // the tigs stay where the cutter wrote them: the two arrays leave their Bufs and belong to the caller's object
+            HIP_CHECK(hipStreamSynchronize(st));
+            ResidentTigs *r = new ResidentTigs();
+            r->device = device_id;
+            r->d_edges = d_te; r->d_limits = d_tl;
+            r->n_edges = n_kept; r->n_tigs = n_tigs;
+            b_te.p = nullptr; b_tl.p = nullptr;
+            *resident_out = r;
         } else {
             tigs.edges.resize(n_kept);
             tigs.limits.resize(n_tigs);

@@ -230,6 +230,52 @@ def test_resident_pairs_finish_equals_finish_from_host_pairs(gpu, idx):
     assert np.array_equal(lim_a, lim_b) and np.array_equal(ed_a, ed_b), name
 
 
+@pytest.mark.parametrize("log2_edges, euler", [(14, "host"), (14, "device"), (23, "device"), (23, "host")])
+def test_tigs_stay_in_hbm_until_asked_for(gpu, log2_edges, euler):
+    """The tigs of a finish on the GPU stay in HBM: the handle answers count() / total_edges() without a copy, arrays()
+    brings them to the host once (plain copy at 2^14, through the pinned ring at 2^23), equal to what the array-returning call of the
+    same finish delivers; the handle can be dropped without ever being downloaded; flattening (clib.rs:393-407) works on either."""
+    from matchtigs_amd import api, synth, torch_glue
+
+    k = 31
+    L = gpu
+    mode = api.EulerMode.Device if euler == "device" else api.EulerMode.HostReferenceOrder
+
+    G = synth.g_csr_device(int((1 << log2_edges) / 3), seed=70 + log2_edges, k=k)
+    E0 = G.edge_count()
+    dev = api.DeviceGraph(G, k)
+    S = dev.classify()
+    bufs = torch_glue.run_sssp(dev, 0, S)
+
+    def run():
+        dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr())
+        return api.finish_greedytigs_resident(G, dev, k, mode, 0, api.FinishStage.Device)
+
+    t = run()
+    n, tot = t.count(), t.total_edges()
+    assert n > 0 and tot >= n
+    lim, ed = t.arrays()
+    assert len(lim) == n and len(ed) == tot and int(lim[-1]) == tot and np.all(np.diff(lim.astype(np.int64)) > 0)
+    lim2, ed2 = t.arrays()  # (a second request returns the same host arrays)
+    assert np.array_equal(lim, lim2) and np.array_equal(ed, ed2)
+    e1, i1, l1 = np.full(2 * E0, -7, np.int64), np.full(2 * E0, 7, np.uint64), np.full(E0, 7, np.uint64)
+    assert L.mtg_flatten_clib(G.handle, t._wp, e1.ctypes.data, i1.ctypes.data, l1.ctypes.data) == n
+    assert np.array_equal(l1[:n], lim)
+    lim, ed = lim.copy(), ed.copy()
+    del t
+    G.reset()
+    t2 = run()            # the same finish again: same tigs; flattened straight from the handle, never asked for as walks
+    assert t2.count() == n and t2.total_edges() == tot
+    e2, i2, l2 = np.full(2 * E0, -7, np.int64), np.full(2 * E0, 7, np.uint64), np.full(E0, 7, np.uint64)
+    assert L.mtg_flatten_clib(G.handle, t2._wp, e2.ctypes.data, i2.ctypes.data, l2.ctypes.data) == n
+    assert np.array_equal(e1[:tot], e2[:tot]) and np.array_equal(i1[:tot], i2[:tot]) and np.array_equal(l1[:n], l2[:n])
+    del t2
+    G.reset()
+    t3 = run()            # ... and dropped without a download
+    assert t3.count() == n
+    del t3
+
+
 def test_resident_finish_with_the_dummy_edges_downloaded_beside_the_gpu_stages(gpu):
     """A graph with more than 2^20 dummy darts: in device Euler mode the dummy edges reach the host graph on a side stream from a
     thread of their own, the tig limits travel as 32-bit words. Graph and tigs as after the finish from host pairs, twice."""
