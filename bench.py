@@ -399,8 +399,8 @@ def main():
     if args.euler == "host" and dm_steps > 0:
         dm_ms, dm_acc = timed_region(api.EulerMode.Device, 1, dm_steps)
         tig_dl: list[float] = []
-        if rank == 0:
-            step(api.EulerMode.Device, {}, tig_download_ms=tig_dl)  # one more step, untimed: what bringing its tigs to the host as walks costs
+        step(api.EulerMode.Device, {}, tig_download_ms=tig_dl)  # one more step on every rank (it gathers), untimed: what bringing its tigs to the host as walks costs
+        sync_barrier()
         device_mode = {"steps": dm_steps, "ms_per_step": round(dm_ms, 3),
                        "phases_ms": {kk: round(v / dm_steps * 1e3, 3) for kk, v in dm_acc.items()},
                        "tigs": result_info.get("tigs"),
