@@ -101,7 +101,7 @@ HostGraph *device_synth_g_csr(uint64_t n_binodes, uint64_t n_self_mirrors, uint6
 // spell_device.hip: tig spelling on the GPU (bin.rs:466-606 / 667-818), byte-identical to spell.cpp for ACGT input
 uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
                                  const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, int device_id,
-                                 char **out_buf, double *kernel_ms_out, uint64_t *bytes_out);
+                                 char **out_buf, double *kernel_ms_out, uint64_t *bytes_out, const struct ResidentTigs *resident = nullptr);
 void device_candidates_to_host(Device *d, void *stream, std::vector<uint64_t> &cand_start,
                                std::vector<uint32_t> &cand_count, std::vector<uint64_t> &pool);
 

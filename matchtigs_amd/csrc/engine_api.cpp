@@ -50,6 +50,11 @@ struct mtg_walks {
         return w;
     }
     Walks &host() { return const_cast<Walks &>(static_cast<const mtg_walks *>(this)->host()); }
+    // (the device arrays, if the tigs are still on that GPU; valid until a call brings them to the host -- one thread per handle)
+    const ResidentTigs *resident_on(int device_id) const {
+        std::lock_guard<std::mutex> lock(m);
+        return dev && dev->device == device_id ? dev.get() : nullptr;
+    }
     uint64_t count() const {
         std::lock_guard<std::mutex> lock(m);
         return dev ? dev->n_tigs : w.limits.size();
@@ -610,7 +615,11 @@ uint64_t mtg_write_tigs_text_file_device(const mtg_graph *g, const mtg_walks *ti
                                          const char *gfa_header, const char *path, int compression_level, int device_id) {
     if (!g || !tigs || !unitigs || !path) MTG_DIE("mtg_write_tigs_text_file_device: null argument");
     char *buf = nullptr;
-    const uint64_t n = device_count() > device_id && device_id >= 0
+    // (tigs a finish on the same GPU left in HBM are spelled from there: no download, no upload)
+    const ResidentTigs *res = tigs->resident_on(device_id);
+    const uint64_t n = res ? device_write_walks_text(g->g, 0, nullptr, nullptr, k, unitigs->s->data.data(), unitigs->s->off.data(), gfa != 0, gfa_header, device_id, &buf,
+                                                     &g_last_spell_kernel_ms, &g_last_spell_bytes, res)
+                       : device_count() > device_id && device_id >= 0
                            ? device_write_walks_text(g->g, tigs->host().limits.size(), tigs->host().limits.data(), tigs->host().edges.data(), k, unitigs->s->data.data(),
                                                      unitigs->s->off.data(), gfa != 0, gfa_header, device_id, &buf, &g_last_spell_kernel_ms, &g_last_spell_bytes)
                            : write_walks_text(g->g, tigs->host().limits.size(), tigs->host().limits.data(), tigs->host().edges.data(), k,

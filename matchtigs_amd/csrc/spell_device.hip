@@ -220,24 +220,40 @@ __global__ void mark_starts_kernel(const unsigned long long *limits, uint64_t n_
     walk_start[at] = (uint32_t)(i + 1);
 }
 
+// the same for tigs that are still on the device (32-bit exclusive ends, as the cutter wrote them), with the input checks of the
+// host path made here: err[0] = 1 + index of the first empty walk / of the first walk that starts with a dummy edge (atomicMin)
+__global__ void mark_starts32_kernel(const uint32_t *limits, const uint32_t *edges, uint64_t n_walks, uint64_t n_pos, uint32_t n_orig,
+                                     uint32_t *walk_start, unsigned long long *err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_walks) return;
+    const uint32_t at = i == 0 ? 0u : limits[i - 1];
+    if (i == n_walks) { walk_start[n_pos] = (uint32_t)(n_walks + 1); return; }
+    if (limits[i] <= at) { atomicMin(&err[0], (unsigned long long)i); return; }
+    if (edges[at] >= n_orig) atomicMin(&err[1], (unsigned long long)i);
+    walk_start[at] = (uint32_t)(i + 1);
+}
+
 }  // namespace
 
 // Returns the number of bytes; *out_buf is malloc'd (caller frees with mtg_free). kernel_ms_out / bytes_out: the spelling kernel's
 // HIP-event time and the HBM bytes it moves (output written once + packed bases read once + per-position metadata).
+// (resident: the tigs as a finish on the same GPU left them in HBM -- `limits` / `edges` are then not read, nothing is uploaded for them)
 uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uint64_t *limits, const uint32_t *edges, uint64_t k,
                                  const char *seqs, const uint64_t *seq_off, bool gfa, const char *gfa_header, int device_id,
-                                 char **out_buf, double *kernel_ms_out, uint64_t *bytes_out) {
+                                 char **out_buf, double *kernel_ms_out, uint64_t *bytes_out, const ResidentTigs *resident) {
+    if (resident && resident->device != device_id) resident = nullptr;
+    if (resident) n_walks = resident->n_tigs;
     if (k < 1) MTG_DIE("k must be >= 1");
     if (device_count() <= device_id) MTG_DIE("no HIP device %d for the GPU tig spelling", device_id);
     if (n_walks >= 0xFFFFFFFEull) MTG_DIE("too many walks for the device spelling");
     HIP_CHECK(hipSetDevice(device_id));
     std::string head;
     if (gfa) head = (gfa_header ? std::string(gfa_header) : "H\tKL:Z:" + std::to_string(k)) + "\n";
-    const uint64_t P = n_walks ? limits[n_walks - 1] : 0;
+    const uint64_t P = resident ? resident->n_edges : (n_walks ? limits[n_walks - 1] : 0);
     const uint64_t n_orig = g.n_original_edges, n_dummy = g.edge_count() - n_orig, U = n_orig / 2;
     const uint64_t n_bases = seq_off[U];
     uint64_t begin = 0;
-    for (uint64_t i = 0; i < n_walks; i++) {  // the same input checks as the host path
+    for (uint64_t i = 0; i < n_walks && !resident; i++) {  // the same input checks as the host path
         if (limits[i] <= begin) MTG_DIE("empty walk %llu", (unsigned long long)i);
         if (edges[begin] >= n_orig) MTG_DIE("walk %llu starts with a dummy edge (bin.rs:489)", (unsigned long long)i);
         begin = limits[i];
@@ -261,8 +277,13 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     for (uint64_t i = 0; i < n_dummy / 2; i++) h_dw[i] = (uint32_t)std::min<uint64_t>(g.w_biedge[n_orig / 2 + i], 0xFFFFFFFFull);
     hu::device_malloc(&d_dw, std::max<uint64_t>(n_dummy / 2, 1) * 4);
     hu::device_malloc(&d_seq_off, (U + 1) * 8);
-    hu::device_malloc(&d_edges, std::max<uint64_t>(P, 1) * 4);
-    hu::device_malloc(&d_limits, std::max<uint64_t>(n_walks, 1) * 8);
+    if (!resident) {
+        hu::device_malloc(&d_edges, std::max<uint64_t>(P, 1) * 4);
+        hu::device_malloc(&d_limits, std::max<uint64_t>(n_walks, 1) * 8);
+    }
+    unsigned long long *d_err = nullptr;
+    hu::device_malloc(&d_err, 16);
+    HIP_CHECK(hipMemsetAsync(d_err, 0xFF, 16, st));
     hu::device_malloc(&d_ws, (P + 1) * 4);
     hu::device_malloc(&d_lo, (P + 1) * 4);
     hu::device_malloc(&d_hi, (P + 1) * 4);
@@ -271,21 +292,30 @@ uint64_t device_write_walks_text(const HostGraph &g, uint64_t n_walks, const uin
     hu::device_malloc(&d_bsum, nb * 8);
     if (n_dummy) HIP_CHECK(hipMemcpyAsync(d_dw, h_dw.data(), n_dummy / 2 * 4, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(d_seq_off, seq_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
-    if (P) HIP_CHECK(hipMemcpyAsync(d_edges, edges, P * 4, hipMemcpyHostToDevice, st));
-    if (n_walks) HIP_CHECK(hipMemcpyAsync(d_limits, limits, n_walks * 8, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(d_ws, 0, (P + 1) * 4, st));
-    hipLaunchKernelGGL(mark_starts_kernel, dim3((unsigned)((n_walks + 1 + 255) / 256)), dim3(256), 0, st, d_limits, n_walks, P, d_ws);
+    if (resident) {
+        hipLaunchKernelGGL(mark_starts32_kernel, dim3((unsigned)((n_walks + 1 + 255) / 256)), dim3(256), 0, st, resident->d_limits, resident->d_edges, n_walks, P,
+                           (uint32_t)n_orig, d_ws, d_err);
+    } else {
+        if (P) HIP_CHECK(hipMemcpyAsync(d_edges, edges, P * 4, hipMemcpyHostToDevice, st));
+        if (n_walks) HIP_CHECK(hipMemcpyAsync(d_limits, limits, n_walks * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mark_starts_kernel, dim3((unsigned)((n_walks + 1 + 255) / 256)), dim3(256), 0, st, d_limits, n_walks, P, d_ws);
+    }
     SpellArgs a{};
-    a.edges = d_edges; a.walk_start = d_ws; a.dummy_w = d_dw; a.seq_off = d_seq_off; a.packed = d_packed;
+    a.edges = resident ? resident->d_edges : d_edges; a.walk_start = d_ws; a.dummy_w = d_dw; a.seq_off = d_seq_off; a.packed = d_packed;
     a.n_pos = P; a.n_orig = n_orig; a.k = (uint32_t)k; a.rec_prefix = gfa ? 2 : 1; a.sep = gfa ? '\t' : '\n'; a.head_bytes = head.size();
     hipLaunchKernelGGL(extent_kernel, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, a, d_lo, d_hi);
     hipLaunchKernelGGL(scan64_reduce_kernel, dim3((unsigned)nb), dim3(1024), 0, st, d_lo, d_hi, P + 1, d_bsum);
     hipLaunchKernelGGL(scan64_sums_kernel, dim3(1), dim3(1024), 0, st, d_bsum, nb, d_tot, (unsigned long long)head.size());
     hipLaunchKernelGGL(scan64_apply_kernel, dim3((unsigned)nb), dim3(1024), 0, st, d_lo, d_hi, P + 1, d_bsum, d_start);
     HIP_CHECK(hipGetLastError());
-    unsigned long long h_tot[2] = {0, 0};
+    unsigned long long h_tot[2] = {0, 0}, h_err[2] = {~0ull, ~0ull};
     HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, 16, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    hu::device_free(d_err);
+    if (h_err[0] != ~0ull && h_err[0] < h_err[1]) MTG_DIE("empty walk %llu", h_err[0]);  // (the first offending walk, as the host loop reports it)
+    if (h_err[1] != ~0ull) MTG_DIE("walk %llu starts with a dummy edge (bin.rs:489)", h_err[1]);
     if (h_tot[1] != none) MTG_DIE("unitig sequences: character at offset %llu is not in the DNA alphabet (ACGT)", h_tot[1]);
     const uint64_t total = n_walks ? h_tot[0] : head.size();
     char *out = static_cast<char *>(std::malloc(total + 1));
