@@ -397,6 +397,11 @@ void mtg_last_finish_device_stage_ms(double out[6]);
 mtg_walks *mtg_finish_greedytigs_cfg(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs, const mtg_config *cfg);
 mtg_walks *mtg_compute_eulertigs_cfg(mtg_graph *g, const mtg_config *cfg);
 
+/* A walk set. The tigs of a finish on the GPU (finish_stage auto / device) stay in that GPU's memory until a call needs them on the
+ * host: the two counts below never copy; mtg_walks_export, mtg_walks_data, mtg_flatten_clib, the duplication bit vectors and the host
+ * writers bring them over once (0.37 GB at the human-like bench size, through the pinned transfer ring) and release the device
+ * arrays; mtg_write_tigs_text_file_device spells them in place when asked for the same GPU; mtg_walks_free of an unread handle copies
+ * nothing. One thread per handle. */
 uint64_t mtg_walks_count(const mtg_walks *w);
 uint64_t mtg_walks_total_edges(const mtg_walks *w);
 /* limits[i] = exclusive end of walk i in edges[] (edge ids into the mutated graph). */
