@@ -2277,6 +2277,8 @@ uint64_t device_classify(Device *d, void *stream) {
         hu::device_malloc(&d->d_out_nodes, std::max<uint64_t>(d->V, 1) * 4);
     }
     if (d->V) {
+        static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(classify_kernel, dim3((unsigned)d->n_cls_blocks), dim3(CLS_BLOCK), 0, st, d->d_odeg, d->d_mirror, (uint32_t)d->V,
                            d->d_mult, d->d_cls, d->d_block_counts, d->d_block_counts + d->n_cls_blocks, d->d_act_blocks);
         HIP_CHECK(hipGetLastError());
@@ -2284,7 +2286,11 @@ uint64_t device_classify(Device *d, void *stream) {
                            &d->d_counters[C_OVF_LIST], d->d_block_counts + d->n_cls_blocks, &d->d_counters[C_DEMAND],
                            d->d_act_blocks, d->d_act_total);
         HIP_CHECK(hipGetLastError());
+        const auto t1 = std::chrono::steady_clock::now();
         read_counters(d, st);  // (the number of sources sizes the lists the compaction writes)
+        if (dbg) std::fprintf(stderr, "[mtg] classify: two launches issued in %.3f ms, their results back after %.3f ms more\n",
+                              std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         d->n_sources = d->h_counters[C_OVF_LIST];
         d->total_demand = d->h_counters[C_DEMAND];
         const uint64_t act_need = d->w8 ? d->n_sources : 0;  // (without the 8:8 format no source carries the flag: the lists stay empty)

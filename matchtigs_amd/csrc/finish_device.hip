@@ -1286,6 +1286,15 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         times_out[11] = (double)n_cycles;
     }
     finish_trim(device_id, E * 40 + V * 28);
+    {
+        static const bool dbg = std::getenv("MTG_DEBUG") != nullptr;
+        if (dbg) {
+            DeviceArena &a = device_arena(device_id);
+            std::lock_guard<std::mutex> lock(a.m);
+            std::fprintf(stderr, "[mtg] device_finish: arena after the call: %.2f GB in %zu chunk(s), %llu taken from the driver so far, %.2f GB live\n", a.chunk_bytes / 1e9,
+                         a.chunks.size(), (unsigned long long)a.n_chunk_allocs, a.live_bytes / 1e9);
+        }
+    }
     return tigs;
 }
 
