@@ -1010,7 +1010,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 }
                 // 256-byte records (two levels of copied adjacency: 2.6 steps per DRAM miss) while they fit comfortably, 128-byte
                 // ones (one level: 1.9 steps per miss) up to 100 GB of them, the 32-byte records themselves beyond (one miss per
-                // step, an eighth of the memory). Same walk either way; MTG_EULER_RECORDS=lean|mid|wide overrides the choice
+                // step, an eighth of the memory). Same walk either way; mtg_set_finish_tuning(records) overrides the choice
                 // (speed / memory only).
                 // The larger formats are only chosen when the host has room for them next to the walk's entry arrays (16 bytes
                 // per dart) -- free memory as the kernel and the cgroup report it.
