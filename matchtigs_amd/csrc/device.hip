@@ -2558,7 +2558,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         // sixteenth of them from which they grow, bits 24-31 = by which factor)
         uint64_t grow_16th = n_win >= 8 ? 8 : 16, grow_mul = n_win >= 8 ? 2 : 1;
         if (d->tune_windows & 0xFFFF) { n_win = d->tune_windows & 0xFFFF; grow_16th = 16; grow_mul = 1; }
-        if (d->tune_windows >> 16) { grow_16th = (d->tune_windows >> 16) & 0xFF; grow_mul = std::max<uint64_t>(1, (d->tune_windows >> 24) & 0xFF); }
+        if ((d->tune_windows >> 16) & 0xFFFF) { grow_16th = (d->tune_windows >> 16) & 0xFF; grow_mul = std::max<uint64_t>(1, (d->tune_windows >> 24) & 0xFF); }
         const uint64_t g = std::min<uint64_t>(n_win, n_win * grow_16th / 16);  // windows of the base size
         // g windows of `window` sources, the other n_win - g of grow_mul times as many
         a.window = std::max<uint64_t>((n_dense + g + (n_win - g) * grow_mul - 1) / std::max<uint64_t>(g + (n_win - g) * grow_mul, 1), 256);
@@ -2569,7 +2569,15 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
             a.n_windows = n_dense <= base_cover ? (n_dense + a.window - 1) / a.window
                                                 : g + (n_dense - base_cover + a.window * grow_mul - 1) / (a.window * grow_mul);
         }
+        // Bit 32 of the tuning word lets the windows ADAPT on top of this list (replay_kernels.inc: while a round is short and the share
+        // of checks sent on does not grow, every third round doubles the window, up to a sixth of the list). Measured, not the default:
+        // how often sources block each other is a property of the graph -- on a real compacted de Bruijn graph (100 Mbp) a fifth of
+        // the checks are retried whatever the window and eight windows beat thirty-six by 2.4 x, on the G-csr graphs retries explode
+        // with the window (8 windows at 2^24: 4.5 x the visits) and do so several rounds AFTER the doubling that caused them, so a
+        // controller that serves the first (1.68 -> 1.44 ms) costs the second (2^22: 1.08 -> 1.64 ms). tools/replay_window_sweep.py.
+        a.window_cap = (d->tune_windows >> 32) & 1u ? std::max<uint64_t>(a.window, n_dense / 6) : 0;
     }
+    const uint64_t widest = a.window_cap ? a.window_cap : a.window * a.grow_mul;
     // one cooperative launch for all rounds: the runtime refuses a grid that cannot be co-resident, so the grid barrier cannot
     // deadlock. Workgroups of 1024 when a round's tiles (a window to admit, about as many sources to check) fill the device, of 256
     // when they do not (replay_kernels.inc); as many workgroups as a round has tiles, at least 64, at most what is co-resident.
@@ -2584,11 +2592,14 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         w.grid = (unsigned)d->n_cu * (unsigned)std::min(occ, 2);
         w.grid_small = (unsigned)d->n_cu * (unsigned)std::min(occ_small, 2);
     }
-    bool small = 2 * ((a.window + REPLAY_BLOCK - 1) / REPLAY_BLOCK) < (uint64_t)d->n_cu;
+    // (by the WIDEST window since round 5: a real de Bruijn graph of 100 Mbp -- 4.6 M listed sources, windows of 86 K and 172 K -- ran
+    // its rounds kernel in 2.60 ms with workgroups of 256 and runs it in 1.68 ms with workgroups of 1024: a third as many arrivals at
+    // the grid barrier and tile counters; the G-csr graph of 2^24, windows of 19 K and 39 K, stays with 256)
+    bool small = 2 * ((widest + REPLAY_BLOCK - 1) / REPLAY_BLOCK) < (uint64_t)d->n_cu;
     if (d->tune_block) small = d->tune_block < REPLAY_BLOCK;  // (tuning only)
     const uint64_t block = small ? REPLAY_BLOCK_SMALL : REPLAY_BLOCK;
     unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)(small ? w.grid_small : w.grid), (n_dense + block - 1) / block,
-                                                                       std::max<uint64_t>(64, 2 * ((a.window + block - 1) / block))}));
+                                                                       std::max<uint64_t>(64, 2 * (((a.window_cap ? widest : a.window) + block - 1) / block))}));
     if (d->tune_grid) grid = std::max(1u, std::min(grid, (unsigned)d->tune_grid));  // (tuning only)
     // one workgroup in role_mod admits, the others check (the longer chain). Measured with the per-XCD barrier: 2^27 (the grid fills
     // the device) role_mod 2 / 4 / 6 / 8 = 6.6 / 6.7 / 7.2 / 8.2 ms; 2^24 (64 workgroups) 2.7 / 2.2 / 2.4 / 2.8 ms
@@ -2630,6 +2641,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     for (int r = 0; r < rounds && r < RC_TRACE_ROUNDS; r++) d->last_replay_visits += w.h_ctl[RC_TRACE + 2 * r];
     static const bool replay_debug = std::getenv("MTG_DEBUG") != nullptr;
     if (replay_debug) {
+        std::fprintf(stderr, "[mtg] replay: %llu listed sources, windows from %llu (cap %llu), widest admitted %llu; %llu checks sent on\n", (unsigned long long)n_dense,
+                     (unsigned long long)a.window, (unsigned long long)a.window_cap, (unsigned long long)w.h_ctl[RC_WIDEST], (unsigned long long)w.h_ctl[RC_RETRIED]);
         std::fprintf(stderr, "[mtg] replay: %d rounds, %llu left; per round (pending, us since kernel start):", rounds, (unsigned long long)w.h_ctl[RC_LEFT]);
         for (int r = 0; r < rounds && r < RC_TRACE_ROUNDS; r++)
             std::fprintf(stderr, " (%llu, %.0f)", (unsigned long long)w.h_ctl[RC_TRACE + 2 * r], (double)(w.h_ctl[RC_TRACE + 2 * r + 1] - w.h_ctl[RC_LEFT_PAR + 2]) * 0.01);
