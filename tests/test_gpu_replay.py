@@ -141,7 +141,9 @@ def test_gpu_replay_grid_barrier_forms_and_launch_geometries(oracle, product_lib
     # own choice -- dict() -- is 36 windows, the second half twice as large)
     for tuning in (dict(), dict(plain_barrier=True), dict(windows=7, role_mod=3), dict(windows=96, plain_barrier=True, role_mod=1),
                    dict(block=256, grid=100), dict(block=256, plain_barrier=True), dict(windows=48), dict(windows=20 | (4 << 16) | (5 << 24)),
-                   dict(windows=9 | (15 << 16) | (3 << 24), role_mod=2)):
+                   dict(windows=9 | (15 << 16) | (3 << 24), role_mod=2),
+                   # bit 32: the windows adapt to the measured round duration and retry rate, on top of the default list / of 24 windows
+                   dict(windows=1 << 32), dict(windows=(1 << 32) | 24, block=1024), dict(windows=(1 << 32) | 12, plain_barrier=True, block=256)):
         dev.set_replay_tuning(**tuning)
         got = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), torch_glue.current_stream_ptr())
         assert _pairs_equal(got, host_pairs), tuning
