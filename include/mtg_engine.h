@@ -165,8 +165,14 @@ mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id);
  * the search then explores full balls (identical candidate lists). mtg_compute_tigs_cfg, whose device graph is searched once (the
  * reference's calling convention, clib.rs:291), builds it this way; a caller that holds an mtg_device and iterates keeps the default,
  * or adds the bounds later with mtg_device_build_lower_bounds (which repeats the classification if there was one).
- * mtg_device_lower_bounds_ms: GPU time (HIP events) of that precompute, 0 while the device graph has none. */
-enum { MTG_DEVICE_DEFAULT = 0, MTG_DEVICE_NO_LOWER_BOUNDS = 1 };
+ * mtg_device_lower_bounds_ms: GPU time (HIP events) of that precompute, 0 while the device graph has none.
+ * MTG_DEVICE_RESERVE_WORK: for a caller that will STEP through the stages with this device graph (mtg_classify / mtg_sssp_candidates /
+ * mtg_replay_claims_* / a finish on the same GPU), once or again and again: the device memory those stages take beside the graph
+ * (about 60 bytes per node + 62 per edge at their peak) is taken from the driver now, in one piece, unless the library's arena holds it
+ * already -- the first step then makes no driver allocation (it makes five otherwise, and single driver calls sporadically stall for
+ * a second on shared hosts). Nothing is reserved if that would leave less than a sixth of the device to the process's other
+ * allocators. Never changes a result. mtg_compute_tigs_cfg does not need it: its whole call is reserved when the graph is constructed. */
+enum { MTG_DEVICE_DEFAULT = 0, MTG_DEVICE_NO_LOWER_BOUNDS = 1, MTG_DEVICE_RESERVE_WORK = 2 };
 mtg_device *mtg_device_create_opts(const mtg_graph *g, uint64_t k, int device_id, int flags);
 void mtg_device_build_lower_bounds(mtg_device *d, void *stream);
 double mtg_device_lower_bounds_ms(const mtg_device *d);
@@ -369,6 +375,9 @@ mtg_walks *mtg_finish_greedytigs_resident(mtg_graph *g, mtg_device *d, const mtg
  * Neither changes a result; the next call simply allocates / uploads again. */
 void mtg_release_device_memory(int device_id);
 uint64_t mtg_device_memory_held(int device_id);
+/* The arena of that GPU in numbers: out[0] bytes in chunks taken from the driver, [1] bytes of live arrays, [2] their peak since the last
+ * reset, [3] driver allocations made so far. reset_peak != 0: the peak restarts at what is live now (measurements: what a stage needs). */
+void mtg_device_arena_stats(int device_id, uint64_t out[4], int reset_peak);
 void mtg_graph_release_device_cache(mtg_graph *g);
 /* The GPU whose memory a graph's construction reserves ahead of the call that will follow (default 0): building a graph of more
  * than a few million edges (mtg_graph_from_edges, matchtigs_initialise_graph, mtg_synth_g_csr on its own device) starts a helper
@@ -377,6 +386,11 @@ void mtg_graph_release_device_cache(mtg_graph *g);
  * driver. A process that runs one rank per GPU names its GPU here before it builds graphs. Never changes a result; without a GPU
  * nothing happens. */
 void mtg_set_default_device(int device_id);
+/* on = 0: host-only graph constructors (mtg_graph_from_edges, matchtigs_initialise_graph) start no helper thread and reserve nothing
+ * on any GPU -- for callers that want them free of GPU side effects; the first computing call then reserves for itself. Default 1.
+ * Either way a reservation is provisional: a call that computes on other GPUs than the one it was made on gives it back when it
+ * ends, and the helper threads are joined (each new one joins those that are through, the library's teardown joins the rest). */
+void mtg_set_reserve_ahead(int on);
 /* Tuning of the finishing stages for measurements and tests (process-wide, read at the start of a call; the library reads no
  * environment variable for any of it, and none changes a result). records: walk-record format of the reference-order mode, 0 = the
  * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records. flags: bit 0 = the walk
@@ -485,7 +499,8 @@ mtg_walks *mtg_compute_tigs(mtg_graph *g, uint64_t tig_algorithm, uint64_t k, in
 void mtg_last_performance_data(mtg_dijkstra_performance_data *out);
 
 /* Phase timings (seconds) of the last mtg_compute_tigs on this thread:
- * [0] device build+upload, [1] classify, [2] sssp (all levels), [3] download, [4] replay,
+ * [0] device build+upload, [1] classify, [2] sssp (all levels; with several GPUs + the gather), [3] download of the matched pairs
+ * (0 when they stay in HBM for a finish on the same GPU), [4] claim replay,
  * [5] dummy insertion + Euleriser, [6] Euler decomposition, [7] cut. */
 void mtg_last_phase_seconds(double out[8]);
 

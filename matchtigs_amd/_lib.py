@@ -221,8 +221,10 @@ def load():
         "mtg_finish_greedytigs_resident": (vp, [vp, vp, P(MtgConfig)]),
         "mtg_release_device_memory": (None, [C.c_int]),
         "mtg_device_memory_held": (u64, [C.c_int]),
+        "mtg_device_arena_stats": (None, [C.c_int, P(u64), C.c_int]),
         "mtg_graph_release_device_cache": (None, [vp]),
         "mtg_set_default_device": (None, [C.c_int]),
+        "mtg_set_reserve_ahead": (None, [C.c_int]),
         "mtg_device_create_opts": (vp, [vp, u64, C.c_int, C.c_int]),
         "mtg_device_build_lower_bounds": (None, [vp, vp]),
         "mtg_device_lower_bounds_ms": (C.c_double, [vp]),

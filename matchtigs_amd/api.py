@@ -397,15 +397,16 @@ def _take_walks_np(L, wp):
 class DeviceGraph:
     """One GPU's resident copy of a Bigraph (mtg_device). Raises/aborts without a GPU: no CPU path."""
 
-    def __init__(self, graph: Bigraph, k: int, device_id: int = 0, lower_bounds: bool = True):
+    def __init__(self, graph: Bigraph, k: int, device_id: int = 0, lower_bounds: bool = True, reserve_work: bool = False):
         """lower_bounds=False: mtg_device_create_opts(MTG_DEVICE_NO_LOWER_BOUNDS) -- the device graph of a caller that searches once
-        (what mtg_compute_tigs_cfg builds); build_lower_bounds() adds them later."""
+        (what mtg_compute_tigs_cfg builds); build_lower_bounds() adds them later. reserve_work=True: MTG_DEVICE_RESERVE_WORK -- the
+        device memory the stages of a step take beside the graph is reserved now, in one piece (a caller that steps through the stages)."""
         self._L = _lib.load()
         if self._L.mtg_device_count() <= device_id:
             raise RuntimeError(f"no HIP device {device_id}: the matchtigs_amd device stage has no CPU fallback")
         self.graph = graph
         self.k = k
-        self._d = self._L.mtg_device_create_opts(graph.handle, k, device_id, 0 if lower_bounds else 1)
+        self._d = self._L.mtg_device_create_opts(graph.handle, k, device_id, (0 if lower_bounds else 1) | (2 if reserve_work else 0))
         self.n_sources = None
 
     def build_lower_bounds(self, stream: int = 0) -> float:
@@ -731,9 +732,21 @@ def set_default_device(device_id: int) -> None:
     _lib.load().mtg_set_default_device(device_id)
 
 
+def set_reserve_ahead(on: bool) -> None:
+    """mtg_set_reserve_ahead: False = host-only graph constructors reserve nothing on any GPU (no helper thread)."""
+    _lib.load().mtg_set_reserve_ahead(1 if on else 0)
+
+
 def release_device_memory(device_id: int = 0) -> None:
     """mtg_release_device_memory: the work arrays the finishing stages keep on that GPU between calls."""
     _lib.load().mtg_release_device_memory(device_id)
+
+
+def device_arena_stats(device_id: int = 0, reset_peak: bool = False) -> dict:
+    """mtg_device_arena_stats: bytes in chunks, bytes live, peak of live bytes since the last reset, driver allocations so far."""
+    a = (C.c_uint64 * 4)()
+    _lib.load().mtg_device_arena_stats(device_id, a, 1 if reset_peak else 0)
+    return {"chunk_bytes": int(a[0]), "live_bytes": int(a[1]), "peak_bytes": int(a[2]), "driver_allocations": int(a[3])}
 
 
 def device_memory_held(device_id: int = 0) -> int:

@@ -1529,6 +1529,7 @@ struct Device {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_r[4] = {nullptr, nullptr, nullptr, nullptr};  // claim replay: start, before / after the rounds kernel, end of the GPU work
     double last_replay_kernel_ms = 0.0, last_replay_gpu_ms = 0.0;
+    double last_wall_s[3] = {0, 0, 0};  // host wall clock of the last device_pairs[_multi]: SSSP stage (+ gather), claim replay, pair download
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
@@ -2014,6 +2015,11 @@ void device_arena_stats(int device_id, uint64_t out[4]) {
     std::lock_guard<std::mutex> lock(a.m);
     out[0] = a.chunk_bytes; out[1] = a.live_bytes; out[2] = a.peak_bytes; out[3] = a.n_chunk_allocs;
 }
+void device_arena_reset_peak(int device_id) {
+    hu::DeviceArena &a = hu::device_arena(device_id);
+    std::lock_guard<std::mutex> lock(a.m);
+    a.peak_bytes = a.live_bytes;
+}
 static std::atomic<int> g_default_device{0};
 void device_set_default(int device_id) { g_default_device.store(device_id); }
 int device_get_default() { return g_default_device.load(); }
@@ -2021,9 +2027,42 @@ int device_get_default() { return g_default_device.load(); }
 // Called when a host graph of V nodes and E edges comes into being (graph_build.cpp): on a helper thread, beside the host's own work,
 // the HIP runtime starts, the code objects load, and the arena of the default device gets its chunk for the call that will follow --
 // ONE hipMalloc, whose cost (nothing to 60 ms per GB depending on the box) no stage then waits for. Small graphs reserve nothing.
+// A host-only constructor does not know which GPU the computation will name, so what it reserves is provisional: the device is
+// remembered, and a call that computes elsewhere gives the chunk back when it ends (device_drop_foreign_reservation);
+// mtg_set_reserve_ahead(0) turns the whole thing off for callers that want a constructor without GPU side effects. The helper threads
+// are joinable: each new reservation joins the ones that are through, and the library's teardown joins the rest.
+static std::atomic<int> g_reserve_ahead{1};
+static std::atomic<int> g_reserved_device{-1};  // device of the last provisional reservation no call has confirmed yet
+void device_set_reserve_ahead(int on) { g_reserve_ahead.store(on ? 1 : 0); }
+namespace {
+struct ReserveThreads {
+    std::mutex m;
+    std::vector<std::pair<std::thread, std::shared_future<void>>> th;
+    void reap(bool all) {
+        std::vector<std::thread> done;
+        {
+            std::lock_guard<std::mutex> lock(m);
+            for (size_t i = 0; i < th.size();) {
+                if (all || th[i].second.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+                    done.push_back(std::move(th[i].first));
+                    th.erase(th.begin() + (long)i);
+                } else i++;
+            }
+        }
+        for (std::thread &t : done) if (t.joinable()) t.join();
+    }
+    ~ReserveThreads() { reap(true); }  // library teardown: no helper thread is left inside HIP when the process goes on to exit
+};
+ReserveThreads &reserve_threads() {
+    static ReserveThreads r;
+    return r;
+}
+}  // namespace
 void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
     const size_t bytes = device_call_bytes_estimate(V, E, 31);
     if (bytes < (256u << 20)) return;
+    const bool provisional = device_id < 0;
+    if (provisional && !g_reserve_ahead.load()) return;
     const int dev = device_id >= 0 ? device_id : device_get_default();
     std::promise<void> done;
     std::shared_future<void> fut = done.get_future().share();
@@ -2034,7 +2073,10 @@ void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
         if (arena.pending.valid() && arena.pending.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
         arena.pending = fut;
     }
-    std::thread([dev, bytes](std::promise<void> p) {
+    if (provisional) g_reserved_device.store(dev);
+    ReserveThreads &rt = reserve_threads();
+    rt.reap(false);
+    std::thread t([dev, bytes](std::promise<void> p) {
         if (device_count() > dev && hipSetDevice(dev) == hipSuccess) {
             hu::device_arena(dev).reserve(bytes);
             (void)hu::finish_stream(dev);
@@ -2049,7 +2091,26 @@ void device_reserve_async(uint64_t V, uint64_t E, int device_id) {
         }
         (void)hipGetLastError();
         p.set_value();
-    }, std::move(done)).detach();
+    }, std::move(done));
+    std::lock_guard<std::mutex> lock(rt.m);
+    rt.th.emplace_back(std::move(t), fut);
+}
+// A call that computed on `used` (n of them): a provisional reservation that sits on another device goes back to the driver.
+void device_drop_foreign_reservation(const int *used, int n) {
+    const int dev = g_reserved_device.exchange(-1);
+    if (dev < 0) return;
+    for (int i = 0; i < n; i++) if (used[i] == dev) return;
+    hu::DeviceArena &arena = hu::device_arena(dev);
+    {
+        std::unique_lock<std::mutex> lock(arena.m);
+        if (arena.pending.valid()) {
+            std::shared_future<void> f = arena.pending;
+            arena.pending = std::shared_future<void>();
+            lock.unlock();
+            f.wait();
+        }
+    }
+    arena.release_free_chunks(true);
 }
 
 // The goal-directed lower bounds of a device graph whose blocks hold plain weights (k <= 255): k - 1 rounds over a 32-bit distance
@@ -2243,6 +2304,23 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
     return d;
 }
 
+// What the stages of a STEP take from the arena beside a device graph that stays (classification, search lists, claim-replay records,
+// the finish's dart arrays at their peak), calibrated on G-csr 2^24 / 2^27 / 2^30 (bench.py full_size.arena: 1.77 / 13.4 / 106.5 GB):
+// 60 bytes per node + 62 per original edge, + 8 %.
+size_t device_step_work_bytes_estimate(uint64_t V, uint64_t E) { return (size_t)((V * 60 + E * 62) / 100 * 108) + (64u << 20); }
+// mtg_device_create_opts(MTG_DEVICE_RESERVE_WORK): a caller that will step through the stages with this device graph (classify /
+// search / replay / finish, again and again) takes that memory NOW, as ONE chunk, unless the arena has it free already -- the first
+// step then makes no driver call (five otherwise, each of which can stall for a second on this pool: DESIGN 2.1). Asked for
+// explicitly, so the whole-call limit of the implicit reservations does not apply; what must remain is room for the other
+// allocators of the process (a sixth of the device), else nothing is reserved and the arrays come piece by piece as before.
+void device_reserve_step_work(Device *d) {
+    HIP_CHECK(hipSetDevice(d->dev));
+    const size_t want = device_step_work_bytes_estimate(d->V, d->E0);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    hu::device_arena(d->dev).ensure_free(want, /*explicit_request=*/true, free_b > total_b / 6 ? free_b - total_b / 6 : 0);
+}
+
 void device_free(Device *d) {
     if (!d) return;
     (void)hipSetDevice(d->dev);
@@ -2433,6 +2511,8 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
     if (!d->classified || n_sources != d->n_sources) MTG_DIE("mtg_replay_claims_device: classify first; n_sources must be all sources");
     ReplayWork &w = d->replay;  // buffers are re-used across calls on this device
     const uint64_t V = d->V, S = n_sources;
+    const auto t_replay_begin = std::chrono::steady_clock::now();
+    d->last_wall_s[1] = d->last_wall_s[2] = 0;
     struct {  // MTG_DEBUG=1: host-side wall clock of the call's segments
         const bool on = std::getenv("MTG_DEBUG") != nullptr;
         std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -2691,6 +2771,9 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         d->last_replay_kernel_ms = a_ms;
         d->last_replay_gpu_ms = b_ms;
     }
+    const auto t_replay_done = std::chrono::steady_clock::now();
+    d->last_wall_s[1] = std::chrono::duration<double>(t_replay_done - t_replay_begin).count();
+    d->last_wall_s[2] = 0;
     if (!pairs_out) {  // the pairs stay in HBM for a finish on this GPU (device_resident_pairs / device_take_pairs)
         rt.lap("compact (pairs stay on the GPU)");
         return n_pairs;
@@ -2746,6 +2829,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
         }
     }
     rt.lap("compact + pair download");
+    d->last_wall_s[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_replay_done).count();
     *pairs_out = host;
     return n_pairs;
 }
@@ -2758,6 +2842,7 @@ int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }
 void device_set_replay_tuning(Device *d, uint64_t windows, int block, int grid, int role_mod, int plain_barrier) {
     d->tune_windows = windows; d->tune_block = block; d->tune_grid = grid; d->tune_role_mod = role_mod; d->tune_plain_barrier = plain_barrier != 0;
 }
+void device_last_pairs_wall_s(const Device *d, double out[3]) { for (int i = 0; i < 3; i++) out[i] = d->last_wall_s[i]; }
 void device_last_replay_ms(const Device *d, double out[2]) { out[0] = d->last_replay_kernel_ms; out[1] = d->last_replay_gpu_ms; }
 int device_id_of(const Device *d) { return d->dev; }
 // was d built from g (same node and edge counts) for bound k - 1? What the resident pairs of d may be finished on.
@@ -2812,6 +2897,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(d->dev));
     const uint64_t S = d->n_sources;
+    d->last_wall_s[0] = d->last_wall_s[1] = d->last_wall_s[2] = 0;
     if (!S) {
         if (pairs_out) *pairs_out = (mtg_pair *)std::malloc(sizeof(mtg_pair));
         d->last_n_pairs = 0;
@@ -2820,6 +2906,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
     }
     unsigned long long *d_start = nullptr, *d_pool = nullptr;
     uint32_t *d_count = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     hu::device_malloc(&d_start, S * 8);
     hu::device_malloc(&d_count, S * 4);
     uint64_t cap = std::max<uint64_t>(S * 2 + std::min<uint64_t>((S + 63) / 64, (uint64_t)d->n_cu * 8) * ENUM_POOL_CHUNK, 1024);  // keys + per-wave chunk slack
@@ -2832,6 +2919,7 @@ uint64_t device_pairs(Device *d, void *stream, mtg_pair **pairs_out, int *rounds
         cap = needed + needed / 8 + 1024;
     }
     if (d->single_use) device_drop_search_arrays(d);
+    d->last_wall_s[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     const uint64_t n = device_replay(d, stream, S, (const uint64_t *)d_start, d_count, (const uint64_t *)d_pool, pairs_out, rounds_out);
     hu::device_free(d_pool);
     hu::device_free(d_start);
@@ -2908,6 +2996,7 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
         if (rounds_out) *rounds_out = 0;
         return 0;
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     const std::vector<uint64_t> cuts = device_partition_sources(d0, nullptr, n_dev);
     struct Part { unsigned long long *start = nullptr, *pool = nullptr; uint32_t *count = nullptr; uint64_t used = 0; };
     std::vector<Part> parts((size_t)n_dev);
@@ -2968,6 +3057,7 @@ uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out
     }
     HIP_CHECK(hipSetDevice(d0->dev));
     if (d0->single_use) device_drop_search_arrays(d0);
+    d0->last_wall_s[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     const uint64_t n = device_replay(d0, nullptr, S, (const uint64_t *)g_start, g_count, (const uint64_t *)g_pool, pairs_out, rounds_out);
     hu::device_free(g_pool); hu::device_free(g_start); hu::device_free(g_count);
     return n;

@@ -1,6 +1,7 @@
 // device.hpp -- interface of the HIP device stage (device.hip) towards the C-ABI layer.
 #pragma once
 
+#include <thread>
 #include <cstdint>
 #include <vector>
 
@@ -16,7 +17,12 @@ int device_count();
 size_t device_call_bytes_estimate(uint64_t V, uint64_t E, uint64_t k);
 void device_reserve_async(uint64_t V, uint64_t E, int device_id = -1);  // helper thread: HIP runtime, code objects, one arena chunk (-1: on the default device)
 void device_arena_stats(int device_id, uint64_t out[4]);  // bytes in chunks, live bytes, peak of live bytes, chunks taken from the driver so far
+void device_arena_reset_peak(int device_id);
+void device_reserve_step_work(Device *d);  // MTG_DEVICE_RESERVE_WORK
+size_t device_step_work_bytes_estimate(uint64_t V, uint64_t E);
 void device_set_default(int device_id);
+void device_set_reserve_ahead(int on);  // 0: host-only graph constructors reserve nothing on any GPU
+void device_drop_foreign_reservation(const int *used, int n);  // a constructor's provisional chunk on a device the call did not use goes back
 int device_get_default();
 // lower_bounds: the goal-directed lower bounds (k <= 255) are computed with the graph; without them the search explores full balls
 // (same candidate lists) until device_build_lower_bounds adds them
@@ -58,6 +64,7 @@ mtg_pair *device_take_pairs(Device *d, uint64_t *n_out);
 void device_free_array(int device_id, void *p);
 uint64_t device_download_pairs(Device *d, mtg_pair **pairs_out);
 // SURVEY 8e inside the library: sources block-partitioned by work over the devices, candidate lists gathered on devs[0]
+void device_last_pairs_wall_s(const Device *d, double out[3]);  // host wall clock of the last device_pairs[_multi] on d: {SSSP stage (+ gather), claim replay, pair download}
 uint64_t device_pairs_multi(Device *const *devs, int n_dev, mtg_pair **pairs_out, int *rounds_out, double *gather_ms_out);
 std::vector<uint64_t> device_partition_sources(Device *d, void *stream, int parts);
 // euler_device.hip: Euler bicycles on the GPU (valid, but not in the reference's order)
@@ -74,6 +81,9 @@ struct TigSink {
     uint64_t *insert_out = nullptr; // [>= kept edges]  0 for an original edge, else the dummy's weight (clib.rs:399-403)
     uint64_t *limits_out = nullptr; // [>= tigs]        exclusive end of tig i (clib.rs:405-406)
     uint64_t n_tigs = 0, n_edges = 0;  // filled by the finish
+    // a caller's helper thread that touches the pages of the three arrays (it WRITES zero bytes into them): the finish joins it before
+    // its first result write, so that no helper write can land after a result (and then does not touch the arrays itself)
+    std::thread *pretoucher = nullptr;
 };
 // (resident_out: the tigs stay in the HBM of `device_id` -- the returned Walks is empty, *resident_out owns the cutter's output
 // arrays; whoever wants them on the host calls download(): a caller that asks for counts, flattens through a sink or spells on the GPU

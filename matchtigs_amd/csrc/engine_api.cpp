@@ -222,8 +222,12 @@ mtg_device *mtg_device_create(const mtg_graph *g, uint64_t k, int device_id) {
 }
 mtg_device *mtg_device_create_opts(const mtg_graph *g, uint64_t k, int device_id, int flags) {
     if (!g || !g->g.built) MTG_DIE("mtg_device_create_opts: graph is not built");
-    if (flags & ~MTG_DEVICE_NO_LOWER_BOUNDS) MTG_DIE("mtg_device_create_opts: unknown flags %d", flags);
-    return new mtg_device{device_create(g->g, k, device_id, !(flags & MTG_DEVICE_NO_LOWER_BOUNDS))};
+    if (flags & ~(MTG_DEVICE_NO_LOWER_BOUNDS | MTG_DEVICE_RESERVE_WORK)) MTG_DIE("mtg_device_create_opts: unknown flags %d", flags);
+    mtg_device *d = new mtg_device{device_create(g->g, k, device_id, !(flags & MTG_DEVICE_NO_LOWER_BOUNDS))};
+    if (flags & MTG_DEVICE_RESERVE_WORK) device_reserve_step_work(d->d);
+    const int used[1] = {device_id};
+    device_drop_foreign_reservation(used, 1);  // (a constructor's provisional chunk on another GPU goes back)
+    return d;
 }
 void mtg_device_build_lower_bounds(mtg_device *d, void *stream) {
     if (!d) MTG_DIE("mtg_device_build_lower_bounds: null device");
@@ -475,11 +479,17 @@ void mtg_set_default_device(int device_id) {
     if (device_id < 0 || device_id >= 64) MTG_DIE("mtg_set_default_device: device id %d out of range", device_id);
     device_set_default(device_id);
 }
+void mtg_set_reserve_ahead(int on) { device_set_reserve_ahead(on); }
 void mtg_set_finish_tuning(int records, int flags, int64_t record_delay_us) {
     if (records < 0 || records > 3) MTG_DIE("mtg_set_finish_tuning: unknown record format %d", records);
     device_set_finish_tuning(records, flags, (long)record_delay_us);
 }
 uint64_t mtg_device_memory_held(int device_id) { return device_memory_held(device_id); }
+void mtg_device_arena_stats(int device_id, uint64_t out[4], int reset_peak) {
+    if (device_id < 0 || device_id >= 64) MTG_DIE("mtg_device_arena_stats: device id %d out of range", device_id);
+    device_arena_stats(device_id, out);
+    if (reset_peak) device_arena_reset_peak(device_id);
+}
 void mtg_graph_release_device_cache(mtg_graph *g) {
     if (g) device_release_graph_cache(g->g);
 }
@@ -765,7 +775,14 @@ mtg_walks *mtg_compute_matchtigs_cfg(mtg_graph *g, const mtg_config *cfg) {
     return tigs;
 }
 
+static mtg_walks *compute_tigs_cfg_body(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg);
 mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg) {
+    mtg_walks *w = compute_tigs_cfg_body(g, tig_algorithm, cfg);
+    // what the graph's constructor reserved ahead on its default GPU is given back if this call ran elsewhere
+    if (tig_algorithm >= 3) device_drop_foreign_reservation(cfg->device_ids, cfg->n_devices);
+    return w;
+}
+static mtg_walks *compute_tigs_cfg_body(mtg_graph *g, uint64_t tig_algorithm, const mtg_config *cfg) {
     check_config(cfg, "mtg_compute_tigs_cfg");
     if (!g || !g->g.built) MTG_DIE("mtg_compute_tigs: graph is not built");
     for (double &p : g_phase) p = 0;
@@ -823,7 +840,13 @@ mtg_walks *mtg_compute_tigs_cfg(mtg_graph *g, uint64_t tig_algorithm, const mtg_
                 g_last_gather_ms = gather_ms;
             }
             double t3 = now_s();
-            g_phase[2] = t3 - t2;  // SSSP + gather + replay + pair download
+            {   // [2] SSSP stage (+ gather over the devices), [4] claim replay, [3] pair download (0 when the pairs stay in HBM)
+                double w[3];
+                device_last_pairs_wall_s(dev->d, w);
+                g_phase[4] = w[1];
+                g_phase[3] = w[2];
+                g_phase[2] = std::max(0.0, (t3 - t2) - w[1] - w[2]);
+            }
             for (int i = 1; i < n_dev; i++) mtg_device_free(devs[(size_t)i]);
             if (cfg->performance_data_type == MTG_PERFORMANCE_DATA_COMPLETE) {  // greedytigs/mod.rs:647-673
                 device_performance_data(dev->d, nullptr, &g_last_perf);
@@ -905,6 +928,7 @@ uint64_t mtg_compute_tigs_clib(mtg_graph *g, uint64_t tig_algorithm, const mtg_c
             if (std::getenv("MTG_DEBUG")) std::fprintf(stderr, "[mtg] output arrays touched (%.2f GB) %.1f ms after the call began\n", (2 * n_e + n_l) * 8 / 1e9, (now_s() - t_touch) * 1e3);
         });
     }
+    if (toucher.joinable()) sink.pretoucher = &toucher;  // joined by the finish before its first write into the arrays
     g_clib_sink = &sink;
     g_clib_sink_used = false;
     mtg_walks *tigs = mtg_compute_tigs_cfg(g, tig_algorithm, cfg);

@@ -935,7 +935,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         }
         // (a sink's arrays are sized as clib.rs:332-348: 2 E0 / 2 E0 / E0 entries. Its first array is touched here, the second by the
         // same threads through the offset below; a caller that passes touched memory loses nothing)
-        if (!resident_out && (bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
+        if (!resident_out && !(sink && sink->pretoucher) && (bound_edges * 4 + bound_tigs * 8) >= (64u << 20)) {
             char *pe = sink ? reinterpret_cast<char *>(sink->edge_out) : reinterpret_cast<char *>(tigs.edges.data());
             char *pl = sink ? reinterpret_cast<char *>(sink->limits_out) : reinterpret_cast<char *>(tigs.limits.data());
             char *pi = sink ? reinterpret_cast<char *>(sink->insert_out) : nullptr;
@@ -1212,6 +1212,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         HIP_CHECK(hipGetLastError());
         sev.mark(5, st);
         if (prefault_thread.joinable()) prefault_thread.join();
+        if (sink && sink->pretoucher && sink->pretoucher->joinable()) sink->pretoucher->join();  // no helper write after a result write
         if (sink) {
             // clib.rs:393-407 on the way out of the download ring: an original edge e is unitig e >> 1, forwards iff e is even
             // (host_graph.hpp); a dummy edge inside a tig is a matched pair, whose weight is its distance

@@ -144,7 +144,8 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 hipStream_t finish_stream(int device_id);
 struct DeviceArena {
     struct Chunk { char *base; size_t bytes; size_t live = 0, peak_live = 0; };
-    struct Range { size_t bytes; bool dirty; };
+    struct Range { size_t bytes; uint64_t dirty; };  // dirty: 0 = idle, else the generation in which it was released with work still queued
+    uint64_t dirty_gen = 0;
     std::mutex m;
     std::vector<Chunk> chunks;
     std::map<char *, Range> free_ranges;                  // by address (coalescing)
@@ -166,12 +167,12 @@ struct DeviceArena {
         for (auto it = r.first; it != r.second; ++it)
             if (it->second == p) { free_by_size.erase(it); return; }
     }
-    void insert_free(char *p, size_t bytes, bool dirty) {  // (under the lock) with coalescing inside the chunk
+    void insert_free(char *p, size_t bytes, uint64_t dirty) {  // (under the lock) with coalescing inside the chunk
         Chunk *c = chunk_of(p);
         auto next = free_ranges.lower_bound(p);
         if (next != free_ranges.end() && p + bytes == next->first && chunk_of(next->first) == c) {
             bytes += next->second.bytes;
-            dirty = dirty || next->second.dirty;
+            dirty = std::max(dirty, next->second.dirty);
             erase_size_entry(next->second.bytes, next->first);
             next = free_ranges.erase(next);
         }
@@ -180,7 +181,7 @@ struct DeviceArena {
             if (prev->first + prev->second.bytes == p && chunk_of(prev->first) == c) {
                 p = prev->first;
                 bytes += prev->second.bytes;
-                dirty = dirty || prev->second.dirty;
+                dirty = std::max(dirty, prev->second.dirty);
                 erase_size_entry(prev->second.bytes, prev->first);
                 free_ranges.erase(prev);
             }
@@ -198,9 +199,13 @@ struct DeviceArena {
     // for the call's peak would sit half empty beside the other allocators of the process. Beyond that size every array gets a chunk
     // of its own, exactly as large as it is.
     size_t whole_call_limit() {
-        if (!device_total) {
+        if (!device_total) {  // (of THIS arena's device, whichever is current)
             size_t free_b = 0, total_b = 0;
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (cur != device) (void)hipSetDevice(device);
             device_total = hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b ? total_b : (size_t)(64ull << 30);
+            if (cur != device) (void)hipSetDevice(cur);
         }
         return device_total / 3;
     }
@@ -217,7 +222,7 @@ struct DeviceArena {
         chunks.push_back(c);
         chunk_bytes += bytes;
         n_chunk_allocs++;
-        free_ranges[(char *)p] = Range{bytes, false};
+        free_ranges[(char *)p] = Range{bytes, 0};
         free_by_size.emplace(bytes, (char *)p);
         return true;
     }
@@ -242,13 +247,19 @@ struct DeviceArena {
             if (!all) for (Chunk &c : chunks) c.peak_live = c.live;
         }
         if (all) { std::lock_guard<std::mutex> lock(m); peak_bytes = live_bytes; }
-        if (!drop.empty()) (void)hipDeviceSynchronize();
+        if (drop.empty()) return;
+        int cur = 0;  // (the arena's device, not whichever is current: the chunks may hold ranges released with work still queued there)
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
         for (void *p : drop) (void)hipFree(p);
+        if (cur != device) (void)hipSetDevice(cur);
     }
     // `for_finish_stream`: the caller works on the device's finish stream only (hu::Buf)
     void *alloc(size_t bytes, bool for_finish_stream, size_t grow_hint = 0) {
         const size_t want = rounded(bytes);
         bool sync_finish = false;
+        uint64_t sync_mark = 0;
         void *out = nullptr;
         for (int attempt = 0; attempt < 3 && !out; attempt++) {
             {
@@ -280,7 +291,7 @@ struct DeviceArena {
                     Chunk *c = chunk_of(mine);
                     c->live += want;
                     c->peak_live = std::max(c->peak_live, c->live);
-                    if (r.dirty && !for_finish_stream) sync_finish = true;
+                    if (r.dirty && !for_finish_stream) { sync_finish = true; sync_mark = dirty_gen; }
                     out = mine;
                     break;
                 }
@@ -306,8 +317,8 @@ struct DeviceArena {
         if (!out) MTG_DIE("out of device memory: %zu bytes on device %d", want, device);
         if (sync_finish) {
             HIP_CHECK(hipStreamSynchronize(finish_stream(device)));
-            std::lock_guard<std::mutex> lock(m);  // everything released before this point is idle now
-            for (auto &kv : free_ranges) kv.second.dirty = false;
+            std::lock_guard<std::mutex> lock(m);  // what was released before the synchronisation began is idle now (later releases are not)
+            for (auto &kv : free_ranges) if (kv.second.dirty <= sync_mark) kv.second.dirty = 0;
         }
         return out;
     }
@@ -323,7 +334,7 @@ struct DeviceArena {
         live.erase(it);
         live_bytes -= bytes;
         chunk_of(p)->live -= bytes;
-        insert_free((char *)p, bytes, dirty);
+        insert_free((char *)p, bytes, dirty ? ++dirty_gen : 0);
     }
     // one chunk of `bytes` unless that much is free in one piece already
     void reserve(size_t bytes) {
@@ -334,8 +345,10 @@ struct DeviceArena {
         (void)add_chunk(bytes);  // (failure is not an error here: the allocations themselves will ask again, in smaller pieces)
     }
     // at least `bytes` free in all (not necessarily in one piece), else one more chunk for what is missing: the head of a stage that
-    // is about to take many arrays (instead of one small chunk per array)
-    void ensure_free(size_t bytes) {
+    // is about to take many arrays (instead of one small chunk per array). explicit_request: the caller asked for the memory by name
+    // (mtg_device_create_opts(MTG_DEVICE_RESERVE_WORK)) -- the whole-call limit does not apply, `budget` (bytes the driver may still
+    // be asked for) does.
+    void ensure_free(size_t bytes, bool explicit_request = false, size_t budget = ~(size_t)0) {
         std::unique_lock<std::mutex> lock(m);
         if (pending.valid()) {
             std::shared_future<void> f = pending;
@@ -346,8 +359,11 @@ struct DeviceArena {
         }
         size_t have = 0;
         for (auto &kv : free_ranges) have += kv.second.bytes;
-        if (have >= bytes || bytes > whole_call_limit()) return;
-        (void)add_chunk(bytes - have + (bytes - have) / 8);
+        if (have >= bytes) return;
+        if (!explicit_request && bytes > whole_call_limit()) return;
+        const size_t more = bytes - have + (bytes - have) / 8;
+        if (more > budget) return;
+        (void)add_chunk(more);
     }
     size_t reclaimable_bytes() {  // what release_free_chunks(true) would give back right now
         std::lock_guard<std::mutex> lock(m);

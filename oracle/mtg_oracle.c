@@ -504,19 +504,15 @@ static void pv_push(pair_vec *p, uint32_t o, uint32_t i, uint64_t d) {
     p->v[p->n].out_node = o; p->v[p->n].in_node = i; p->v[p->n].distance = d; p->n++;
 }
 
-uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sources, og_pair **pairs,
-                                og_sssp_stats *stats) {
+/* the loop itself, over a classification the caller owns (out_nodes ascending; live / mult are updated in place) */
+static uint64_t claim_loop(const og_graph *g, uint64_t k, const uint32_t *out_nodes, uint64_t limit, uint8_t *live, int64_t *mult,
+                           og_pair **pairs, og_sssp_stats *stats) {
     uint32_t nn = g->n_nodes;
-    uint32_t *out_nodes = xmalloc((size_t)nn * 4);
-    uint8_t *live = xmalloc(nn);
-    int64_t *mult = xmalloc((size_t)nn * 8);
-    uint32_t n_out = og_classify(g, out_nodes, live, mult, NULL, NULL);
     if (stats) memset(stats, 0, sizeof *stats);
     dijkstra *dj = dijkstra_new(nn);
     dist_vec distances = {0};
     pair_vec res = {0};
     if (k == 0) DIE("k must be >= 1");
-    uint64_t limit = max_sources < n_out ? max_sources : n_out;
 
     for (uint64_t i = 0; i < limit; i++) {                         /* :301 */
         uint32_t out_node = out_nodes[i];
@@ -571,9 +567,35 @@ uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sour
         }
     }
     dijkstra_free(dj);
-    free(distances.v); free(out_nodes); free(live); free(mult);
+    free(distances.v);
     *pairs = res.v;
     return res.n;
+}
+uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sources, og_pair **pairs,
+                                og_sssp_stats *stats) {
+    uint32_t nn = g->n_nodes;
+    uint32_t *out_nodes = xmalloc((size_t)nn * 4);
+    uint8_t *live = xmalloc(nn);
+    int64_t *mult = xmalloc((size_t)nn * 8);
+    uint32_t n_out = og_classify(g, out_nodes, live, mult, NULL, NULL);
+    uint64_t n = claim_loop(g, k, out_nodes, max_sources < n_out ? max_sources : n_out, live, mult, pairs, stats);
+    free(out_nodes); free(live); free(mult);
+    return n;
+}
+/* The same loop over a classification the CALLER supplies instead of og_classify's: for a graph too large for this oracle, g is the
+ * subgraph the searches of a prefix of its sources can reach (every out-edge of every node within k - 1 of one of them, nodes
+ * renumbered in order) and out_nodes / live / mult are the full graph's classification restricted to g's nodes -- computed from
+ * the full graph's degrees, which the subgraph's boundary nodes do not have. The arrays are copied. */
+uint64_t og_greedy_pairs_given(const og_graph *g, uint64_t k, const uint32_t *out_nodes, uint64_t n_out, const uint8_t *live_in,
+                               const int64_t *mult_in, og_pair **pairs, og_sssp_stats *stats) {
+    uint32_t nn = g->n_nodes;
+    uint8_t *live = xmalloc(nn ? nn : 1);
+    int64_t *mult = xmalloc(((size_t)nn + 1) * 8);
+    memcpy(live, live_in, nn);
+    memcpy(mult, mult_in, (size_t)nn * 8);
+    uint64_t n = claim_loop(g, k, out_nodes, n_out, live, mult, pairs, stats);
+    free(live); free(mult);
+    return n;
 }
 uint64_t og_greedy_pairs(const og_graph *g, uint64_t k, og_pair **pairs, og_sssp_stats *stats) {
     return og_greedy_pairs_prefix(g, k, UINT64_MAX, pairs, stats);
@@ -728,6 +750,27 @@ uint32_t og_candidate_lists_range(const og_graph *g, uint64_t k, uint32_t src_lo
     dijkstra_free(dj); free(distances.v); free(live); free(mult);
     *out_nodes_p = out_nodes; *offsets_p = offsets; *keys_p = keys ? keys : xmalloc(8);
     return n_out;
+}
+
+/* Full lists L(s) of the given sources under a live map the caller supplies (see og_greedy_pairs_given): offsets[n_sources + 1]. */
+void og_candidate_lists_given(const og_graph *g, uint64_t k, const uint32_t *sources, uint64_t n_sources, const uint8_t *live,
+                              uint64_t **offsets_p, uint64_t **keys_p, og_sssp_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    dijkstra *dj = dijkstra_new(g->n_nodes);
+    dist_vec distances = {0};
+    uint64_t *offsets = xmalloc(((size_t)n_sources + 1) * 8);
+    uint64_t *keys = NULL; uint64_t nk = 0, capk = 0;
+    for (uint64_t i = 0; i < n_sources; i++) {
+        offsets[i] = nk;
+        shortest_path_lens(g, dj, sources[i], live, UINT64_MAX, k - 1, 1, &distances, stats);
+        for (size_t c = 0; c < distances.n; c++) {
+            if (nk == capk) { capk = capk ? capk * 2 : 256; keys = xrealloc(keys, capk * 8); }
+            keys[nk++] = (distances.v[c].dist << 32) | distances.v[c].node;
+        }
+    }
+    offsets[n_sources] = nk;
+    dijkstra_free(dj); free(distances.v);
+    *offsets_p = offsets; *keys_p = keys ? keys : xmalloc(8);
 }
 
 void og_free(void *p) { free(p); }

@@ -94,6 +94,12 @@ uint64_t og_greedy_pairs(const og_graph *g, uint64_t k, og_pair **pairs, og_sssp
 uint64_t og_greedy_pairs_prefix(const og_graph *g, uint64_t k, uint64_t max_sources,
                                 og_pair **pairs, og_sssp_stats *stats);
 
+/* The same claim loop over a classification the caller supplies (copied) instead of og_classify's: g may then be the subgraph that the
+ * searches of a prefix of a LARGER graph's sources can reach, with that graph's classification restricted to g's nodes -- how the tests
+ * pin the GPU pair list's prefix at sizes the oracle cannot hold (tests/gpu_props.py). */
+uint64_t og_greedy_pairs_given(const og_graph *g, uint64_t k, const uint32_t *out_nodes, uint64_t n_out, const uint8_t *live,
+                               const int64_t *mult, og_pair **pairs, og_sssp_stats *stats);
+
 /* The same claim loop run by `threads` workers with the reference's locking scheme (greedytigs/mod.rs:528-644).
  * Thread-timing dependent like the reference with threads > 1: for the bench's multi-core timing only. */
 uint64_t og_greedy_pairs_mt(const og_graph *g, uint64_t k, uint32_t threads, og_pair **pairs, og_sssp_stats *stats);
@@ -108,6 +114,10 @@ uint32_t og_candidate_lists(const og_graph *g, uint64_t k, uint32_t **out_nodes,
 /* Same, but only sources with index in [src_lo, src_hi) are searched (the others get empty lists). */
 uint32_t og_candidate_lists_range(const og_graph *g, uint64_t k, uint32_t src_lo, uint32_t src_hi, uint32_t **out_nodes,
                                   uint64_t **offsets, uint64_t **keys, og_sssp_stats *stats);
+
+/* Full lists of the given sources under a live map the caller supplies (see og_greedy_pairs_given): offsets[n_sources + 1]. */
+void og_candidate_lists_given(const og_graph *g, uint64_t k, const uint32_t *sources, uint64_t n_sources, const uint8_t *live,
+                              uint64_t **offsets, uint64_t **keys, og_sssp_stats *stats);
 
 void og_free(void *p);
 

@@ -21,3 +21,41 @@ def test_device_arena_random_load(product_lib, tmp_path, seed):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe), str(seed), "3000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "arena_test ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_reserved_step_makes_no_driver_allocation(product_lib):
+    """mtg_device_create_opts(MTG_DEVICE_RESERVE_WORK): the stages of a step -- classification, search, claim replay with the pairs
+    resident, the finish on the GPU -- then find their arrays in the arena; the driver is not asked for memory inside the step, the
+    first time or the second (VERDICT r5 #6: a cold staged step must not pay for allocations a warm one does not make)."""
+    import torch
+
+    from matchtigs_amd import api, synth, torch_glue
+
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU")
+    k = 31
+    api.release_device_memory(0)
+    G = synth.g_csr_device(int((1 << 23) / 1.5 / 2), seed=5, k=k)
+    dev = api.DeviceGraph(G, k, 0, reserve_work=True)
+    stream = torch_glue.current_stream_ptr()
+    before = api.device_arena_stats(0, reset_peak=True)
+    counts = []
+    for _ in range(2):
+        S = dev.classify(stream)
+        bufs = torch_glue.run_sssp(dev, 0, S)  # (candidate buffers are the caller's: torch tensors, not the arena's)
+        n_pairs = dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), stream)
+        tigs = api.finish_greedytigs_resident(G, dev, k, api.EulerMode.Device, 0, api.FinishStage.Auto)
+        counts.append((S, n_pairs, tigs.count(), tigs.total_edges()))
+        del tigs, bufs
+        torch.cuda.synchronize()
+        G.reset()
+    after = api.device_arena_stats(0)
+    assert counts[0] == counts[1] and counts[0][2] > 0
+    assert after["driver_allocations"] == before["driver_allocations"], (before, after)
+    assert after["peak_bytes"] - before["live_bytes"] <= product_lib_step_estimate(G)
+
+
+def product_lib_step_estimate(G):
+    V, E = G.node_count(), G.original_edge_count()
+    return (V * 60 + E * 62) // 100 * 108 + (64 << 20)
