@@ -22,7 +22,9 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/mtg_policy.h"
 #include "euler_lean.hpp"
+#include "euler_splice_last.hpp"
 #include "host_graph.hpp"
 #include "hugebuf.hpp"
 #include "parallel.hpp"
@@ -166,6 +168,11 @@ static Walks euler_walk_records(Rec *nodes, const uint64_t V, const uint32_t *ex
                                 std::chrono::steady_clock::time_point t_begin, bool have_sub_levels, LeanNode *lean,
                                 const std::atomic<uint64_t> *arrived) {
     constexpr bool L3 = Rec::LEVELS == 3;  // records with the heads' heads
+    if (mtg_policy_euler_splice_last()) {  // policy P5, other setting (euler_splice_last.hpp): the plain walk over the records' own adjacency
+        (void)V; (void)arena_ptr; (void)t_begin; (void)have_sub_levels; (void)arrived;
+        // (records that still arrive: the 32-byte ones are complete from the start and carry the same adjacency)
+        return lean ? euler_walk_splice_last(lean, ext_eid, ext_to, e_from, e_to, E) : euler_walk_splice_last(nodes, ext_eid, ext_to, e_from, e_to, E);
+    }
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_a = std::chrono::steady_clock::now();
     constexpr unsigned BUILD_THREADS = 128;  // phases B and C are random gathers: latency bound, so more threads than cores pay

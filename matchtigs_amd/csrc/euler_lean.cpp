@@ -13,7 +13,9 @@
 #include <chrono>
 #include <cstring>
 
+#include "../../include/mtg_policy.h"
 #include "euler_lean.hpp"
+#include "euler_splice_last.hpp"
 #include "hugebuf.hpp"
 #include "parallel.hpp"
 
@@ -23,6 +25,7 @@ Walks euler_cycles_lean(LeanNode *nodes, uint64_t V, const uint32_t *ext_eid, co
                         const uint32_t *e_to, uint64_t E, HugeArena *arena) {
     if (E % 2) MTG_DIE("edge count must be even (edge / mirror pairs)");
     (void)V;
+    if (mtg_policy_euler_splice_last()) return euler_walk_splice_last(nodes, ext_eid, ext_to, e_from, e_to, E);  // policy P5, other setting
     static const bool dbg_t = std::getenv("MTG_DEBUG") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     NumaPin pin(arena ? arena->node : -1);

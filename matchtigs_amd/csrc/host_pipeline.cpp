@@ -9,6 +9,7 @@
 //
 // All citations are into /root/reference/src/. These are O(V+E) formulations that must produce the
 // same sequences as the reference's (BTreeMap / Vec::rotate_left based) code; see DESIGN.md.
+#include "../../include/mtg_policy.h"
 #include "host_graph.hpp"
 
 #include <algorithm>
@@ -275,7 +276,8 @@ uint64_t make_eulerian(HostGraph &g, uint64_t dummy_edge_id, uint64_t k) {
 //  * cycles start at the lowest unused edge id; the walk always takes the first unused out-edge in
 //    adjacency order (newest first) and can only get stuck at its start node;
 //  * the reference then scans the cycle vector from index 0 for the first edge whose from-node still
-//    has an unused out-edge, rotate_left()s the vector to that index and appends the next closed
+//    has an unused out-edge (policy P5 of mtg_policy.h; under its other setting: from the last index
+//    backwards for the last such edge), rotate_left()s the vector to that index and appends the next closed
 //    sub-walk. Here the cycle is a circular singly linked list of entries and the scan is a FIFO of
 //    not-yet-exhausted entries: "rotate to x and append W" == "insert W just before x, x is the new
 //    head"; inserting before x without a prev pointer is done by moving x's edge into a fresh entry y
@@ -348,12 +350,22 @@ Walks euler_cycles_generic(const HostGraph &g) {
                 }
                 // entry w_begin itself is now unused (its edge lives in x)
                 head = y;
-                fifo[fifo_head] = y;  // x was at the front of the FIFO; y takes its place
+                if (!mtg_policy_euler_splice_last()) fifo[fifo_head] = y;  // x was at the front of the FIFO; y takes its place
+                // (policy P5's other setting: x was popped off the stack, and y needs no entry -- it leaves the same node as x's new edge)
                 fifo.push_back(x);
                 for (size_t i = w_begin + 1; i < w_end; i++) fifo.push_back((uint32_t)i);
             }
-            // ---- find the next start edge: first entry in cycle order whose from-node has an unused out-edge ----
+            // ---- find the next start edge: policy P5 (mtg_policy.h) -- the FIRST entry in cycle order whose from-node has an unused
+            // out-edge (the candidates are a queue), or the LAST one (they are a stack) ----
             start_edge = NONE;
+            if (mtg_policy_euler_splice_last()) {
+                while (!fifo.empty()) {
+                    const uint32_t ent = fifo.back();
+                    fifo.pop_back();
+                    const uint32_t cand = next_unused(g.e_from[ent_edge[ent]]);
+                    if (cand != NONE) { start_edge = cand; splice_at = ent; break; }
+                }
+            } else
             while (fifo_head < fifo.size()) {
                 const uint32_t ent = fifo[fifo_head];
                 const uint32_t cand = next_unused(g.e_from[ent_edge[ent]]);

@@ -911,8 +911,10 @@ int og_no_consecutive_dummy_edges(const og_graph *g, uint64_t k) {
 /*  * walk: from the current node take the first unused out-edge in adjacency order         */
 /*    (newest first) until none is left (then the walk is back at its start node);          */
 /*  * then scan the cycle from index 0 for the first edge whose from-node still has an      */
-/*    unused out-edge; rotate_left the cycle to that index and continue the walk with that  */
-/*    edge (the cycle then ends at that node, so the new closed sub-walk is appended);      */
+/*    unused out-edge (policy P5 of mtg_policy.h; its other setting scans from the last     */
+/*    index backwards for the last such edge); rotate_left the cycle to that index and      */
+/*    continue the walk with that edge (the cycle then ends at that node, so the new closed */
+/*    sub-walk is appended);                                                                */
 /*  * push the finished cycle.                                                             */
 /* Literal (rescanning) form; the product uses an O(E) linked-list formulation that must    */
 /* produce the same sequences.                                                              */
@@ -976,9 +978,10 @@ og_walks *og_euler_cycles(const og_graph *g) {
                 }
                 if (!has_neighbor && current != start_node) DIE("Euler walk stuck at node %u != start %u: graph not Eulerian", current, start_node);
             }
-            /* find new start edge */
+            /* find new start edge: policy P5 (mtg_policy.h) -- the first such position of the cycle, or the last */
             start_edge = OG_NONE;
-            for (size_t ci = 0; ci < len; ci++) {
+            for (size_t step = 0; step < len; step++) {
+                size_t ci = mtg_policy_euler_splice_last() ? len - 1 - step : step;
                 uint32_t fn = g->from[cycle[ci]];
                 for (uint32_t e = g->head_out[fn]; e != OG_NONE; e = g->next_out[e])
                     if (!used[e]) { start_edge = e; break; }

@@ -42,8 +42,8 @@ class Walks(C.Structure):
 
 
 def build_oracle(force: bool = False) -> Path:
-    """libmtg_oracle.so -- or, when MTG_POLICY names another setting of the four out-of-tree policies (include/mtg_policy.h; the
-    flipped-policy fuzz sets 15 = all four flipped), the build of the oracle that follows it."""
+    """libmtg_oracle.so -- or, when MTG_POLICY names another setting of the five out-of-tree policies (include/mtg_policy.h; the
+    flipped-policy fuzz sets 31 = all five flipped), the build of the oracle that follows it."""
     import os
 
     flipped = int(os.environ.get("MTG_POLICY", "0")) != 0
@@ -96,6 +96,8 @@ def lib():
         "og_greedy_pairs_mt": (u64, [vp, u64, u32, P(P(Pair)), P(Stats)]),
         "og_greedy_pairs_mt_prefix": (u64, [vp, u64, u32, u64, P(P(Pair)), P(Stats)]),
         "og_candidate_lists_range": (u32, [vp, u64, u32, u32, P(P(u32)), P(P(u64)), P(P(u64)), P(Stats)]),
+        "og_greedy_pairs_given": (u64, [vp, u64, vp, u64, vp, vp, P(P(Pair)), P(Stats)]),
+        "og_candidate_lists_given": (None, [vp, u64, vp, u64, vp, P(P(u64)), P(P(u64)), P(Stats)]),
         "og_free": (None, [vp]),
         "og_insert_pair_edges": (u64, [vp, P(Pair), u64]),
         "og_make_eulerian_with_breaking_edges": (None, [vp, P(u64), u64]),
@@ -291,6 +293,38 @@ class OracleGraph:
         self.L.og_free(off)
         self.L.og_free(keys)
         return out_nodes, offsets, ks, st.as_dict()
+
+    def candidate_lists_given(self, k, sources, live):
+        """og_candidate_lists_given: the full lists of `sources` (node ids of this graph) under the live map `live` the caller supplies
+        (this graph may be a ball subgraph of a larger one, whose classification its own degrees cannot give). -> (offsets, keys)."""
+        src = np.ascontiguousarray(sources, np.uint32)
+        lv = np.ascontiguousarray(live, np.uint8)
+        assert len(lv) == self.node_count
+        off, keys = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        st = Stats()
+        vp = C.c_void_p
+        self.L.og_candidate_lists_given(self.h, k, src.ctypes.data_as(vp), len(src), lv.ctypes.data_as(vp), C.byref(off), C.byref(keys), C.byref(st))
+        offsets = np.ctypeslib.as_array(off, shape=(len(src) + 1,)).copy()
+        nk = int(offsets[-1])
+        ks = np.ctypeslib.as_array(keys, shape=(max(nk, 1),))[:nk].copy()
+        self.L.og_free(off)
+        self.L.og_free(keys)
+        return offsets, ks
+
+    def greedy_pairs_given(self, k, out_nodes, live, mult):
+        """og_greedy_pairs_given: the reference's claim loop over `out_nodes` (ascending) with the classification the caller supplies."""
+        on = np.ascontiguousarray(out_nodes, np.uint32)
+        lv = np.ascontiguousarray(live, np.uint8)
+        mu = np.ascontiguousarray(mult, np.int64)
+        assert len(lv) == len(mu) == self.node_count
+        pp = C.POINTER(Pair)()
+        st = Stats()
+        vp = C.c_void_p
+        n = self.L.og_greedy_pairs_given(self.h, k, on.ctypes.data_as(vp), len(on), lv.ctypes.data_as(vp), mu.ctypes.data_as(vp), C.byref(pp), C.byref(st))
+        dt = np.dtype([("out", np.uint32), ("in", np.uint32), ("dist", np.uint64)])
+        arr = np.frombuffer((C.c_char * (n * C.sizeof(Pair))).from_address(C.addressof(pp.contents)), dtype=dt).copy() if n else np.zeros(0, dtype=dt)
+        self.L.og_free(pp)
+        return arr, st.as_dict()
 
     def whole_path_timed(self, k, threads=1):
         """The reference's whole greedy path, stage by stage with wall-clock timers (bench.py cpu_baseline leg).

@@ -16,6 +16,7 @@ from dataclasses import dataclass
 POLICY = int(os.environ.get("MTG_POLICY", "0"))
 P_HEAP_TIE_DESCENDING, P_BOUND_EXCLUSIVE, P_ADJACENCY_OLDEST_FIRST, P_UNION_TIE_SECOND_UNDER_FIRST = (bool(POLICY & 1), bool(POLICY & 2),
                                                                                                     bool(POLICY & 4), bool(POLICY & 8))
+P_EULER_SPLICE_LAST = bool(POLICY & 16)
 
 
 @dataclass
@@ -328,7 +329,8 @@ def euler_cycles(g: PyBigraph):
                 used[g.mirror_edge(nxt)] = True
                 cur = g.edges[nxt].to
             start = None
-            for ci, e in enumerate(cycle):
+            for ci in (range(len(cycle) - 1, -1, -1) if P_EULER_SPLICE_LAST else range(len(cycle))):  # policy P5
+                e = cycle[ci]
                 cand = next((x for x in g.out_neighbors(g.edges[e].frm) if not used[x]), None)
                 if cand is not None:
                     start = cand

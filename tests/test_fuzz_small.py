@@ -2,6 +2,7 @@
 3 000 of them through the HIP path and the clib.rs C-ABI on the GPU (tests/fuzz_small.py says what is compared and why the work
 runs in child processes). SURVEY.md 8c(3): "differential: oracle vs an independent restatement on >= 10^4 seeded random bigraphs;
 GPU vs oracle on the same"."""
+import os
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -18,15 +19,15 @@ FLIPPED_LIB = ROOT / "matchtigs_amd" / "libmatchtigs_flipped.so"
 
 
 def _flipped_env():
-    """The other setting of the four out-of-tree policies (include/mtg_policy.h: heap tie-break, inclusive bound, adjacency order,
-    union-find tie; mask 15 = all four flipped): the product built by `make flipped`, the oracle's flipped build and the Python
+    """The other setting of the five out-of-tree policies (include/mtg_policy.h: heap tie-break, inclusive bound, adjacency order,
+    union-find tie, Hierholzer's splice rule; mask 31 = all five flipped): the product built by `make flipped`, the oracle's flipped build and the Python
     restatement under MTG_POLICY. Built here when missing (14 s)."""
     import os
 
     if not FLIPPED_LIB.exists():
         subprocess.run(["make", "-C", str(ROOT / "matchtigs_amd" / "csrc"), "ARCH=gfx950", "-j8", "flipped"], check=True, capture_output=True)
     env = dict(os.environ)
-    env["MTG_POLICY"] = "15"
+    env["MTG_POLICY"] = "31"
     env["MATCHTIGS_LIBRARY"] = str(FLIPPED_LIB)
     return env
 
@@ -89,11 +90,11 @@ def test_fuzz_300_medium_bigraphs_through_the_hip_path(oracle, product_lib):
     assert sum(tally.values()) == 300 and tally.get("ok:pairs", 0) >= 150 and tally.get("panic", 0) <= 30, tally
 
 
-# ---- the same fuzz under the OTHER setting of the four policies the reference inherits from crates outside its tree --------------
+# ---- the same fuzz under the OTHER setting of the five policies the reference inherits from crates outside its tree --------------
 # Pop order among equal distances, inclusive search bound, adjacency iteration order, union-find tie (include/mtg_policy.h) were
 # restated from recollection: parity with the real binary is unpinned exactly there. Each is one named switch shared
 # by the product's kernels and host stages, the oracle and the Python restatement; these tests hold the three parties to each other
-# with all four switches flipped, so that if one recollection proves wrong the fix is one definition -- not a hunt through kernels.
+# with all five switches flipped, so that if one recollection proves wrong the fix is one definition -- not a hunt through kernels.
 def test_flipped_policies_are_a_different_behaviour(oracle, product_lib):
     """The flipped build really behaves differently: on a graph with an equal-distance tie the two settings claim different pairs."""
     import json
@@ -116,6 +117,40 @@ def test_flipped_policies_are_a_different_behaviour(oracle, product_lib):
     assert len(both) >= 300
     assert sum(1 for a, b in both if a[0] != b[0]) >= 20, "pairs never differ between the two policy settings"
     assert sum(1 for a, b in both if a[1] != b[1]) >= 50, "tigs never differ between the two policy settings"
+
+
+def test_policy_p5_alone_changes_walk_order_but_neither_tig_count_nor_cumulative_length(oracle):
+    """P5 (Hierholzer's splice rule: resume at the FIRST or at the LAST position of the cycle with an unused out-edge) isolated in the
+    Python restatement (MTG_POLICY = 16 flips nothing else): the closed walks cover the same biedges per bicycle in another order on
+    part of the graphs, and -- SURVEY 8a's invariance note -- tig count and cumulative length never move."""
+    import json
+
+    code = (
+        "import sys, json; sys.path.insert(0, 'tests'); import helpers, fuzz_small, pyref\n"
+        "out = []\n"
+        "for seed in range(0, 300):\n"
+        "    k, mirror, unitigs = fuzz_small.tiny_bigraph(seed)\n"
+        "    arrs = helpers.unitigs_to_arrays(mirror, unitigs)\n"
+        "    if fuzz_small.reference_panics(arrs, k): out.append(None); continue\n"
+        "    g = helpers.py_graph(*arrs)\n"
+        "    tigs, _, _ = pyref.compute_greedytigs(g, k)\n"
+        "    cum = sum(sum(g.edges[e].weight for e in t) + k - 1 for t in tigs)\n"
+        "    g2 = helpers.py_graph(*arrs); pairs, _ = pyref.greedy_pairs(g2, k); did = pyref.insert_pair_edges(g2, pairs); pyref.make_eulerian(g2, did, k)\n"
+        "    cyc = pyref.euler_cycles(g2)\n"
+        "    out.append([cyc, sorted(sorted(min(e, g2.mirror_edge(e)) for e in c) for c in cyc), len(tigs), cum])\n"
+        "print(json.dumps(out))\n")
+    res = []
+    for mask in ("0", "16"):
+        env = dict(os.environ)
+        env["MTG_POLICY"] = mask
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(ROOT), timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res.append(json.loads(r.stdout.splitlines()[-1]))
+    both = [(a, b) for a, b in zip(*res) if a is not None and b is not None]
+    assert len(both) >= 200
+    assert all(a[1] == b[1] for a, b in both), "the two settings cover different biedges per bicycle"
+    assert all(a[2] == b[2] and a[3] == b[3] for a, b in both), "tig count or cumulative length depends on P5"
+    assert sum(1 for a, b in both if a[0] != b[0]) >= 10, "the walk order never differs between the two settings of P5"
 
 
 def test_fuzz_flipped_policies_2000_tiny_and_100_medium_bigraphs_cpu(oracle, product_lib):

@@ -3,9 +3,11 @@
 configs[0]  E. coli K-12 BCALM2 unitigs k=31, --greedytigs-fa-out : SURVEY 8d stand-in G-seq(L = 4.6e6, H = 4, p = 0.02, k = 31),
             end to end through the BCALM2 file route; FASTA bytes == oracle, k-mer set preserved.
 configs[3]  human whole genome k=31 : G-csr stand-in at |E| = 2^27 (the bench.py default, reference-order finish) AND at SURVEY 8d's
-            nominal 2^30, through the size-independent properties of tests/gpu_props.py + GPU/host claim-loop parity.
+            nominal 2^30, through the size-independent properties of tests/gpu_props.py + GPU/host claim-loop parity + the exact
+            sampled comparison with the CPU oracle of tests/sampled_parity.py (classification in full, candidate lists of 10^5
+            sources, pair-list prefix).
 configs[4]  661k-bacteria pangenome : G-csr stand-in at |E| = 2^31 (node ids at the u32 edge, 2.98 G darts after the finish), GPU
-            stages + device finish + properties. The 2^30 / 2^31 cases skip on a box without the HBM / host memory they need.
+            stages + device finish + properties + the same exact sampled comparison and GPU/host claim-loop parity. The 2^30 / 2^31 cases skip on a box without the HBM / host memory they need.
 configs[1] / configs[2] are covered at their sizes by test_gpu_parity.py::test_full_bench_size_properties,
 test_gpu_replay.py::test_gpu_replay_full_bench_size and test_gpu_euler.py::test_device_euler_full_bench_size."""
 import gc
@@ -90,10 +92,14 @@ def _free_memory_gb(torch):
     return free_hbm, avail
 
 
-def _stand_in(gpu, log2_edges, hbm_gb, host_gb, host_replay_check, euler_mode):
+def _stand_in(gpu, oracle, log2_edges, hbm_gb, host_gb, host_replay_check, euler_mode):
     """One G-csr stand-in through the whole HIP path: generated on the GPU, device graph, classification, SSSP, GPU claim replay,
-    finish (insertion + Euleriser + Euler bicycles + cut on the GPU), every stage checked by tests/gpu_props.py."""
+    finish (insertion + Euleriser + Euler bicycles + cut on the GPU), every stage checked by tests/gpu_props.py -- and, exactly,
+    by tests/sampled_parity.py: the classification in full, the candidate lists of 10^5 sampled sources (the first 20 000, the last
+    2 000 -- the highest node ids and block offsets of the graph -- and 80 000 drawn in between) and the pair list's prefix of the
+    first 20 000 sources against the CPU oracle's own searches and claim loop on the subgraph those sources can reach."""
     import gpu_props
+    import sampled_parity
     from matchtigs_amd import api, synth, torch_glue
 
     torch = gpu
@@ -117,7 +123,12 @@ def _stand_in(gpu, log2_edges, hbm_gb, host_gb, host_replay_check, euler_mode):
         host_pairs = G.replay_claims(on, mu, li, start, count, pool)
         assert len(gpu_pairs) == len(host_pairs) and all(np.array_equal(gpu_pairs[f], host_pairs[f]) for f in ("out", "in", "dist"))
         del host_pairs, start, count, pool
-    del bufs, on, mu, li, dev
+    del dev
+    gc.collect()
+    api.release_device_memory(0)  # (the device graph's memory goes back to the driver: the check below works with torch tensors)
+    sp = sampled_parity.check_sampled_lists_and_prefix(torch, oracle, G, bufs, on, mu, li, gpu_pairs, k)
+    assert sp["sampled"] >= min(S, 100000) and sp["prefix_pairs"] > 0
+    del bufs, on, mu, li
     gc.collect()
     torch.cuda.empty_cache()
     lim, edges = api.finish_greedytigs_np(G, gpu_pairs, k, euler_mode)
@@ -128,30 +139,30 @@ def _stand_in(gpu, log2_edges, hbm_gb, host_gb, host_replay_check, euler_mode):
     return dict(V=V, E=n_orig, tigs=len(lim), cum=cum, E_total=E_total, pairs=len(gpu_pairs))
 
 
-def test_config3_human_like_2pow27_properties(gpu):
+def test_config3_human_like_2pow27_properties(gpu, oracle):
     """configs[3] at the bench's size, finish in the reference's walk order (the default)."""
     from matchtigs_amd import api
 
-    r = _stand_in(gpu, 27, 40, 40, True, api.EulerMode.HostReferenceOrder)
+    r = _stand_in(gpu, oracle, 27, 40, 40, True, api.EulerMode.HostReferenceOrder)
     assert r["E"] == 130045206 and r["tigs"] == 23687715 and r["cum"] == 1294322592
 
 
-def test_config3_human_like_2pow30_full_size(gpu):
+def test_config3_human_like_2pow30_full_size(gpu, oracle):
     """BASELINE configs[3] (human whole genome, k = 31) at SURVEY 8d's nominal size: |V| = 716 M, |E| = 1.04 G, 270 M sources on
     ONE GPU; GPU-vs-host claim parity at that size; the finish in device Euler mode (the reference-order walk at this size takes
     150 s: tools/scale_probe.py --euler host, profiles/r03_scale_probe_2p30_exact.json -- same tig count and cumulative length)."""
     from matchtigs_amd import api
 
-    r = _stand_in(gpu, 30, 170, 140, True, api.EulerMode.Device)
+    r = _stand_in(gpu, oracle, 30, 170, 140, True, api.EulerMode.Device)
     assert r["E"] == 1040327706 and r["tigs"] == 189468154 and r["cum"] == 10353599420
 
 
-def test_config4_pangenome_like_2pow31(gpu):
+def test_config4_pangenome_like_2pow31(gpu, oracle):
     """BASELINE configs[4] (661k-bacteria pangenome, ~10^9 unitigs) as its G-csr stand-in: |V| = 1.43 G, |E| = 2.08 G, 539 M
     sources, node ids up to 1.43e9 and 2.98 G darts after the finish (beyond 2^31: the dart ids use all 32 bits) on ONE GPU."""
     from matchtigs_amd import api
 
-    r = _stand_in(gpu, 31, 262, 190, False, api.EulerMode.Device)
+    r = _stand_in(gpu, oracle, 31, 262, 190, True, api.EulerMode.Device)
     assert r["E"] == 2080660578 and r["E_total"] == 2984426052 and r["tigs"] == 378964208
 
 

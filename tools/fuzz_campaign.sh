@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-off parity campaign on the GPU box, beyond what the suite holds: tests/fuzz_small.py (oracle == product through the HIP path and
-# the clib.rs C-ABI; tests/fuzz_small.py says what is compared) over fresh seeds, under BOTH settings of the four out-of-tree policies
+# the clib.rs C-ABI; tests/fuzz_small.py says what is compared) over fresh seeds, under BOTH settings of the five out-of-tree policies
 # (include/mtg_policy.h). One child process at a time; every chunk prints its TALLY line; a mismatch names its seed and ends the run.
 #   usage: [SHIFT=0] tools/fuzz_campaign.sh OUT.txt [tiny_per_setting=10000] [medium_per_setting=600]   (SHIFT moves every seed range)
 set -e -o pipefail
@@ -16,7 +16,7 @@ run() {  # label mode first n [env...]
     echo "== $label: $mode seeds $first..$((first + n - 1))" | tee -a "$OUT"
     env "$@" python tests/fuzz_small.py "$mode" "$first" "$n" 2>&1 | grep -E "^(TALLY|EVENTS|MISMATCH)" | tee -a "$OUT"
 }
-FL="MTG_POLICY=15 MATCHTIGS_LIBRARY=$PWD/matchtigs_amd/libmatchtigs_flipped.so"
+FL="MTG_POLICY=31 MATCHTIGS_LIBRARY=$PWD/matchtigs_amd/libmatchtigs_flipped.so"
 for c in $(seq 0 $((TINY / 2500 - 1))); do
     run "default policies" gpu $((100000 + SHIFT + c * 2500)) 2500 MTG_NOP=1
     run "flipped policies" gpu $((200000 + SHIFT + c * 2500)) 2500 $FL
