@@ -418,8 +418,8 @@ def main():
     # what delivering the step's tigs to the host as walks costs on top (the reference's compute_tigs always ends with them in host
     # memory; rounds 1-4 ended every timed step with that copy): the same arrays in either Euler mode, so the device-mode measurement
     # is reused when there is one, else one more untimed step measures it
-    if device_mode is not None and device_mode.get("tig_download_ms") is not None:
-        tig_download_ms = device_mode["tig_download_ms"]
+    if device_mode is not None:  # (the same branch on every rank: the extra step below gathers and ends in a barrier)
+        tig_download_ms = device_mode["tig_download_ms"]  # (measured on rank 0, which finishes; None elsewhere)
     elif not args.host_replay and not args.host_finish:
         tig_dl2: list[float] = []
         step(euler_mode, {}, tig_download_ms=tig_dl2)

@@ -396,7 +396,10 @@ void mtg_set_reserve_ahead(int on);
  * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records. flags: bit 0 = the walk
  * waits until all of its records have arrived (instead of starting on the 32-byte ones), bit 1 = never page-lock the record arena,
  * bit 2 = keep nothing of a graph on the device between calls (edges, mirror, buckets), bit 3 = a trivial kernel every 2 ms while the
- * host walks in the reference's order (measurement: what the GPU's idle state costs the first kernels of the next step). record_delay_us: slows the arrival of the
+ * host walks in the reference's order (measurement: what the GPU's idle state costs the first kernels of the next step), bit 4 = the device
+ * Euler mode builds the closed walks of every component even where the tigs can be cut straight from the pairing (cut_first_device.hip; tests and
+ * A/B measurements -- the tigs of that mode then come in another order, which the mode leaves unspecified, with the same count and cumulative
+ * length). record_delay_us: slows the arrival of the
  * records by that much per slice (tests: small graphs then take the 32-byte path for most of their steps). */
 void mtg_set_finish_tuning(int records, int flags, int64_t record_delay_us);
 /* Seconds of the last mtg_finish_device on this thread: [0] upload + insertion + Euleriser, [1] dummy edges into the host graph,

@@ -719,11 +719,11 @@ RECORD_FORMATS = {None: 0, "auto": 0, "lean": 1, "mid": 2, "wide": 3}
 
 
 def set_finish_tuning(records=None, wait_for_records: bool = False, no_pin: bool = False, no_edge_cache: bool = False,
-                      record_delay_us: int = 0, keep_awake: bool = False) -> None:
+                      record_delay_us: int = 0, keep_awake: bool = False, no_cut_first: bool = False) -> None:
     """mtg_set_finish_tuning: walk-record format of the reference-order mode ("lean" 32-byte / "mid" 128-byte / "wide" 256-byte
     records, None = the engine's choice), whether the walk waits for all of its records, page-locking, the graph's device cache, and
     a delay per arriving slice of records (tests). Process-wide; never changes a result."""
-    flags = (1 if wait_for_records else 0) | (2 if no_pin else 0) | (4 if no_edge_cache else 0) | (8 if keep_awake else 0)
+    flags = (1 if wait_for_records else 0) | (2 if no_pin else 0) | (4 if no_edge_cache else 0) | (8 if keep_awake else 0) | (16 if no_cut_first else 0)
     _lib.load().mtg_set_finish_tuning(RECORD_FORMATS[records], flags, int(record_delay_us))
 
 

@@ -703,6 +703,11 @@ void device_build_buckets_merged(hipStream_t st, const uint32_t *d_from, const u
     HIP_CHECK(hipGetLastError());
 }
 
+void device_pairing(hipStream_t st, const uint32_t *d_mirror, uint64_t V, const uint32_t *d_row, const uint32_t *d_adj, uint32_t *d_succ, uint32_t *d_error) {
+    succ_node_kernel<<<grid_for(V), EB, 0, st>>>(d_mirror, V, d_row, d_adj, d_succ, d_error);
+    HIP_CHECK(hipGetLastError());
+}
+
 // (d_scratch: E words of scratch, or null)
 void device_build_buckets(hipStream_t st, const uint32_t *d_from, uint64_t E, uint64_t V, uint32_t *d_row, uint32_t *d_adj, uint32_t *d_pos,
                           uint32_t *d_scratch) {

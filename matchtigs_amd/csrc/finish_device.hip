@@ -966,8 +966,18 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     Buf b_cyc, b_clen, b_cbase;
     uint32_t n_cycles = 0;
     double kernel_ms = 0, acc2 = 0;
+    // (device order: the tigs straight from the pairing when the graph allows it -- cut_first_device.hip; the closed walks otherwise)
+    Buf b_te, b_tl;
+    uint64_t n_kept = 0, n_tigs = 0;
+    bool have_tigs = false;
+    CutFirstStats cf_stats;
     if (euler_mode == MTG_EULER_DEVICE) {
-        device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms, d_row0, d_adj0, E0, &zip);
+        if (!(finish_tuning().flags.load() & FT_NO_CUT_FIRST)) {
+            sev.mark(2, st);
+            have_tigs = device_cut_first(st, d_from, d_mirror, E, V, E0, first_brk, d_pw, d_row0, d_adj0, &zip, b_te, b_tl, &n_kept, &n_tigs, &cf_stats);
+            sev.mark(3, st);
+        }
+        if (!have_tigs) device_euler_decompose(st, d_from, d_mirror, E, V, b_cyc, b_clen, b_cbase, &n_cycles, &kernel_ms, d_row0, d_adj0, E0, &zip);
         b_cin.release(); b_cout.release(); b_pin.release(); b_pout.release();
     } else {
         Walks cycles;
@@ -1192,11 +1202,12 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     {
         const uint64_t n = E / 2;
         const uint32_t *d_cyc = b_cyc.as<uint32_t>(), *d_clen = b_clen.as<uint32_t>(), *d_cbase = b_cbase.as<uint32_t>();
-        Buf b_rotkey, b_ck, b_ce, b_te, b_tl;
+        Buf b_rotkey, b_ck, b_ce;
+        sev.mark(4, st);
+        if (!have_tigs) {
         const uint64_t n_chunks = (n + CUT_CHUNK - 1) / CUT_CHUNK;
         unsigned long long *d_rotkey = b_rotkey.alloc<unsigned long long>(st, n_cycles);
         uint32_t *d_ck = b_ck.alloc<uint32_t>(st, n_chunks), *d_ce = b_ce.alloc<uint32_t>(st, n_chunks);
-        sev.mark(4, st);
         HIP_CHECK(hipMemsetAsync(d_rotkey, 0, (uint64_t)std::max<uint32_t>(n_cycles, 1) * 8, st));
         CutIds ids{(uint32_t)E0, (uint32_t)first_brk};
         rotation_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, n_cycles, ids, (uint32_t)k, d_pw, d_rotkey);
@@ -1205,11 +1216,13 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
         scan_u32<uint32_t>(st, d_ce, n_chunks, d_ce, d_bsum, d_small + 8);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        const uint64_t n_kept = h_small[7], n_tigs = h_small[8];
-        uint32_t *d_te = b_te.alloc<uint32_t>(st, n_kept);
-        uint32_t *d_tl = b_tl.alloc<uint32_t>(st, n_tigs);
-        cut_emit_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, d_clen, n_cycles, d_rotkey, ids, d_ck, d_ce, d_te, d_tl);
+        n_kept = h_small[7]; n_tigs = h_small[8];
+        uint32_t *d_te0 = b_te.alloc<uint32_t>(st, n_kept);
+        uint32_t *d_tl0 = b_tl.alloc<uint32_t>(st, n_tigs);
+        cut_emit_kernel<<<(unsigned)n_chunks, EB, 0, st>>>(d_cyc, n, d_cbase, d_clen, n_cycles, d_rotkey, ids, d_ck, d_ce, d_te0, d_tl0);
         HIP_CHECK(hipGetLastError());
+        }
+        uint32_t *d_te = b_te.as<uint32_t>(), *d_tl = b_tl.as<uint32_t>();
         sev.mark(5, st);
         if (prefault_thread.joinable()) prefault_thread.join();
         if (sink && sink->pretoucher && sink->pretoucher->joinable()) sink->pretoucher->join();  // no helper write after a result write
@@ -1290,6 +1303,7 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
     if (times_out) {  // [6] insertion + Euleriser, [7] buckets + walk records, [8] rotate + cut: GPU ms; [9] darts, [10] units, [11] closed walks
         times_out[6] = sev.ms(0, 1);
         times_out[7] = sev.ms(2, 3);
+        if (euler_mode == MTG_EULER_DEVICE) { times_out[4] += times_out[7]; times_out[7] = 0; }  // (cut first: the stretch passes take the decomposition's place; an attempt that fell back to the closed walks is booked with them)
         times_out[8] = sev.ms(4, 5);
         times_out[9] = (double)E;
         times_out[10] = (double)N;

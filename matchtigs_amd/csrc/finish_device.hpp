@@ -37,4 +37,17 @@ void device_euler_decompose(hipStream_t st, const uint32_t *d_from, const uint32
 void device_build_buckets_merged(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E0, uint64_t E, uint64_t V,
                                  const uint32_t *d_row0, const uint32_t *d_adj0, uint32_t *d_row, uint32_t *d_adj, const ZipBuckets *zip = nullptr);
 
+// the pairing of step 2 alone (succ[E]; *d_error bit 0 = a node is not balanced)
+void device_pairing(hipStream_t st, const uint32_t *d_mirror, uint64_t V, const uint32_t *d_row, const uint32_t *d_adj, uint32_t *d_succ, uint32_t *d_error);
+
+// cut_first_device.hip: the tigs straight from the pairing (no closed walks). false = not applicable, the caller decomposes instead.
+struct CutFirstStats {
+    uint64_t stretches = 0;            // breaking darts = walkers
+    uint64_t breaking_free_darts = 0;  // darts on trails without a breaking dart (spliced in, or the reason for a `false`)
+    uint64_t spliced_trails = 0, cyclic_tigs = 0;
+};
+bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_mirror, uint64_t E, uint64_t V, uint64_t E0, uint64_t first_brk,
+                      const uint32_t *d_pw, const uint32_t *d_row0, const uint32_t *d_adj0, const ZipBuckets *zip, hu::Buf &b_te, hu::Buf &b_tl,
+                      uint64_t *n_kept_out, uint64_t *n_tigs_out, CutFirstStats *stats);
+
 }  // namespace mtg

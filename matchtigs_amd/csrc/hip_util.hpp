@@ -38,7 +38,7 @@ struct FinishTuning {
                                            // bit 3: a trivial kernel every 2 ms while the host walks (measurement: what the GPU's idle state costs the next step)
     std::atomic<long> record_delay_us{0};  // tests: slows the arrival of the walk's records
 };
-enum : int { FT_NO_RECORD_OVERLAP = 1, FT_NO_PIN = 2, FT_NO_EDGE_CACHE = 4, FT_KEEP_AWAKE = 8 };
+enum : int { FT_NO_RECORD_OVERLAP = 1, FT_NO_PIN = 2, FT_NO_EDGE_CACHE = 4, FT_KEEP_AWAKE = 8, FT_NO_CUT_FIRST = 16 };
 inline FinishTuning &finish_tuning() {
     static FinishTuning t;
     return t;

@@ -116,6 +116,26 @@ def run_cpu(seed: int) -> str:
     return "ok:" + ("pairs" if pairs_o else "nopairs")
 
 
+def device_order_checks(ex, tigs, k, ref_tigs, mirror, what):
+    """A tig set in the device's own order: every unitig exactly once in one orientation, consecutive edges adjacent, tigs start and end
+    with original edges, no two dummies in a row, no breaking edge inside (greedytigs/mod.rs:794-798, implementation/mod.rs:319-390);
+    tig count and cumulative length equal the reference-order result's when the graph has no self-mirror node."""
+    dummy = ex["edge_dummy_id"] != 0
+    n_orig = int((~dummy).sum()) // 2
+    seen = np.zeros(n_orig, np.int64)
+    for t in tigs:
+        a = np.asarray(t, dtype=np.int64)
+        assert len(a) and not dummy[a[0]] and not dummy[a[-1]], what
+        assert np.array_equal(ex["edge_to"][a[:-1]], ex["edge_from"][a[1:]]), what
+        assert not (dummy[a[:-1]] & dummy[a[1:]]).any(), what
+        assert (ex["edge_weight"][a[dummy[a]]] < k).all(), what
+        np.add.at(seen, a[~dummy[a]] >> 1, 1)
+    assert (seen == 1).all(), what
+    if not any(int(mirror[v]) == v for v in range(len(mirror))):
+        cum = lambda ts: sum(int(ex["edge_weight"][np.asarray(t, dtype=np.int64)].sum()) + k - 1 for t in ts)
+        assert len(tigs) == len(ref_tigs) and cum(tigs) == cum(ref_tigs), what
+
+
 def run_gpu(seed: int) -> str:
     import helpers
     from matchtigs_amd import api, torch_glue
@@ -151,6 +171,20 @@ def run_gpu(seed: int) -> str:
     assert api.GreedytigAlgorithm.compute_tigs(G2, api.GreedytigAlgorithmConfiguration.new(1, k)) == tigs_o, "operator"
     et_o = helpers.oracle_graph(*arrs).compute_eulertigs(k)
     assert api.EulertigAlgorithm.compute_tigs(helpers.product_graph(*arrs), api.EulertigAlgorithmConfiguration(k)) == et_o, "eulertigs"
+    # device Euler mode (the tigs cut straight from the pairing, cut_first_device.hip; tiny graphs are full of trails without a
+    # breaking dart -- self-loops, two-cycles, balanced components -- so this is where the splicing of those is exercised), and the
+    # same mode through the closed walks: valid tig sets, and the reference's tig count and cumulative length where the order
+    # cannot matter (no self-mirror node: SURVEY 8a invariance note)
+    for no_cut_first in (False, True):
+        api.set_finish_tuning(no_cut_first=no_cut_first)
+        for algo in ("greedy", "euler"):
+            G3 = helpers.product_graph(*arrs)
+            if algo == "greedy":
+                dt = api.GreedytigAlgorithm.compute_tigs(G3, api.GreedytigAlgorithmConfiguration(1, k, euler_mode=api.EulerMode.Device))
+            else:
+                dt = api.EulertigAlgorithm.compute_tigs(G3, api.EulertigAlgorithmConfiguration(k, euler_mode=api.EulerMode.Device))
+            device_order_checks(G3.export(), dt, k, tigs_o if algo == "greedy" else et_o, mirror, f"device order, {algo}, no_cut_first={no_cut_first}")
+    api.set_finish_tuning()
     # the clib.rs C-ABI on the same graph given as unitig links (its own node numbering: union-find over the unitig ends)
     links = helpers.links_of_bigraph(mirror, unitigs)
     weights = [w for (_, _, w) in unitigs]
@@ -228,9 +262,13 @@ def run_gpu_medium(seed: int) -> str:
     # device Euler mode: same number of tigs and cumulative length when no self-mirror node can put two breaking edges next to each other
     G.reset()
     lim_d, ed_d = api.finish_greedytigs_resident_np(G, dev, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
-    w = G.export()["edge_weight"].astype(np.int64)
-    if not (bg.mirror == np.arange(bg.n_nodes)).any():
-        assert len(lim_d) == len(tigs_o) and int(w[ed_d].sum()) == sum(int(w[np.asarray(t)].sum()) for t in tigs_o), "device Euler mode T3"
+    device_order_checks(G.export(), [ed_d[(lim_d[i - 1] if i else 0):lim_d[i]].tolist() for i in range(len(lim_d))], k, tigs_o, bg.mirror, "device Euler mode")
+    api.set_finish_tuning(no_cut_first=True)  # ... and through the closed walks (the form before cut_first_device.hip)
+    G.reset()
+    n = dev.replay_claims_resident(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr())
+    lim_w, ed_w = api.finish_greedytigs_resident_np(G, dev, k, euler_mode=api.EulerMode.Device, finish_stage=api.FinishStage.Device)
+    api.set_finish_tuning()
+    device_order_checks(G.export(), [ed_w[(lim_w[i - 1] if i else 0):lim_w[i]].tolist() for i in range(len(lim_w))], k, tigs_o, bg.mirror, "device Euler mode, closed walks")
     et_o = helpers.oracle_graph(*arrs).compute_eulertigs(k)
     assert api.EulertigAlgorithm.compute_tigs(helpers.product_graph(*arrs), api.EulertigAlgorithmConfiguration(k)) == et_o, "eulertigs"
     return "ok:" + ("pairs" if n else "nopairs")

@@ -4,7 +4,7 @@ tests/test_gpu_configs.py and tools/scale_probe.py. torch is the calculator here
 
 Candidate lists (greedytigs/mod.rs:324-335 + App. A.1): keys strictly ascending per source, every node an initial in-node,
 distance in [1, k-1], the source itself excluded.  Tigs (greedytigs/mod.rs:726-801): every unitig exactly once in one
-orientation, tigs start and end with original edges, only matched dummies (weight in [1, k-1]) inside tigs, the graph Eulerian
+orientation, consecutive edges of a tig adjacent, tigs start and end with original edges, only matched dummies (weight in [1, k-1]) inside tigs, the graph Eulerian
 after Eulerisation (:708-716), cumulative-length identity."""
 import numpy as np
 
@@ -60,6 +60,8 @@ def check_tigs(torch, G, lim, edges, k, device="cuda"):
     outd = torch.zeros(V, dtype=torch.int32, device=device)
     ind = torch.zeros(V, dtype=torch.int32, device=device)
     weight = torch.empty(E, dtype=torch.int16 if k < 32768 else torch.int32, device=device)
+    e_from = torch.empty(E, dtype=torch.int32, device=device)  # (bit patterns of the u32 node ids)
+    e_to = torch.empty(E, dtype=torch.int32, device=device)
     unitig_kmers = 0
     for lo in range(0, E, CHUNK):
         n = min(CHUNK, E - lo)
@@ -67,6 +69,8 @@ def check_tigs(torch, G, lim, edges, k, device="cuda"):
         one = torch.ones(n, dtype=torch.int32, device=device)
         outd.index_add_(0, torch.from_numpy(ex["edge_from"].astype(np.int64)).to(device), one)
         ind.index_add_(0, torch.from_numpy(ex["edge_to"].astype(np.int64)).to(device), one)
+        e_from[lo:lo + n] = torch.from_numpy(ex["edge_from"].view(np.int32)).to(device)
+        e_to[lo:lo + n] = torch.from_numpy(ex["edge_to"].view(np.int32)).to(device)
         w = torch.from_numpy(ex["edge_weight"].astype(np.int64)).to(device)
         if lo < n_orig:
             m = min(n, n_orig - lo)
@@ -78,6 +82,14 @@ def check_tigs(torch, G, lim, edges, k, device="cuda"):
     assert bool((outd[~sm] == ind[~sm]).all()) and bool((outd[sm] % 2 == 0).all()), "not Eulerian after Eulerisation"
     assert bool((outd == ind[mirror]).all())
     del outd, ind, mirror, sm
+    # consecutive edges of a tig are adjacent: the head of one is the tail of the next (a tig is a walk)
+    inner = torch.ones(t_edges.numel(), dtype=torch.bool, device=device)
+    inner[t_lim - 1] = False  # positions whose successor belongs to the next tig
+    pos = torch.nonzero(inner).flatten()
+    for lo in range(0, pos.numel(), CHUNK):
+        p = pos[lo:lo + CHUNK]
+        assert bool((e_to[t_edges[p]] == e_from[t_edges[p + 1]]).all()), "consecutive edges of a tig are not adjacent"
+    del e_from, e_to, inner, pos
     w_tig = weight[t_edges].to(torch.int64)
     w_dummy = w_tig[~is_orig]
     if w_dummy.numel():

@@ -14,6 +14,8 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--stages", default="device,host")
 ap.add_argument("--eulers", default="device,exact")
+ap.add_argument("--gseq", type=int, default=0, help="a compacted de Bruijn graph of a random genome of this length (G-seq, 4 haplotypes) instead of G-csr")
+ap.add_argument("--no-cut-first", action="store_true", help="device Euler mode through the closed walks (A/B of cut_first_device.hip)")
 args = ap.parse_args()
 if args.lib:
     from matchtigs_amd import _lib
@@ -22,7 +24,14 @@ from matchtigs_amd import api, synth
 k = args.k
 nb = int(round((1 << args.log2_edges) / 3.0))
 t0 = time.perf_counter()
-G = synth.g_csr_device(nb, seed=args.seed, k=k)
+if args.gseq:
+    ua = synth.g_seq_arrays(args.gseq, seed=args.seed, k=k)
+    G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
+    del ua
+else:
+    G = synth.g_csr_device(nb, seed=args.seed, k=k)
+if args.no_cut_first:
+    api.set_finish_tuning(no_cut_first=True)
 t1 = time.perf_counter()
 out = {"log2_edges": args.log2_edges, "V": G.node_count(), "E": G.edge_count(), "generate_s": round(t1 - t0, 3)}
 dev = api.DeviceGraph(G, k)
