@@ -43,20 +43,27 @@ namespace {
 constexpr uint32_t MARK = 0x80000000u;  // bit 31 of a successor word: the first pass has walked this dart (dart ids stay below 2^31 here)
 
 // ---- pass 1: one walker per breaking dart -- length of the stretch behind it, the breaking dart that ends it, marks ------------
-// (a walker reads succ[b] of consecutive b coalesced; every further step is a dependent random gather. The mark is a plain store of
-// the word just read with bit 31 set: every dart is walked by exactly one walker, the line is in the cache from the read, and
-// nobody waits for the store.)
+// (a walker reads succ[b] of consecutive b coalesced; every further step is a dependent random gather.)
+// Marks: what has to be found afterwards are the closed trails NO walker passes. Marking every walked dart costs a store per step
+// (measured: 9.4 ms for the pass at 2^27 against 3-4 without). It is enough that every such trail PAIR keeps one dart that would
+// have been marked had a walker passed: the smallest dart m of a trail pair is even (m odd would have m ^ 1 = m - 1 in the mirror
+// trail) and not larger than its predecessor or its successor on its trail -- so only EVEN darts that are LOCAL MINIMA of the walk
+// (x <= previous dart, x <= next dart; a breaking dart counts as larger than anything) get the mark, a sixth of the darts, and the
+// search for unwalked trails looks at exactly the darts with that property (unwalked_rep_kernel). The mark is a plain store of the word
+// just read with bit 31 set: every dart is walked by one walker only, and nobody waits for the store.
+__device__ __forceinline__ bool is_rep_candidate(uint32_t x, uint32_t prev, uint32_t next) { return !(x & 1u) && x <= prev && x <= next; }
 __global__ __launch_bounds__(EB) void stretch_measure_kernel(uint32_t *succ, uint64_t first_brk, uint64_t n_brk, uint32_t *len_out, uint32_t *end_out,
-                                                            unsigned long long *walked_total, uint32_t *error) {
+                                                            unsigned long long *walked_blocks, uint32_t *error) {
     const uint64_t i = gid();
     uint32_t len = 0;
     if (i < n_brk) {
         const uint32_t b = (uint32_t)(first_brk + i);
-        uint32_t x = succ[b] & ~MARK;
+        uint32_t prev = b, x = succ[b] & ~MARK;
         while (x < first_brk) {
             const uint32_t s = succ[x];
             if (s & MARK) { atomicOr(error, 2u); break; }  // walked twice: succ is not a permutation
-            succ[x] = s | MARK;
+            if (is_rep_candidate(x, prev, s)) succ[x] = s | MARK;
+            prev = x;
             x = s;
             if (++len == 0xFFFFFFFFu) { atomicOr(error, 4u); break; }
         }
@@ -64,9 +71,30 @@ __global__ __launch_bounds__(EB) void stretch_measure_kernel(uint32_t *succ, uin
         end_out[i] = x;
         if (x == (b ^ 1u)) atomicOr(error, 8u);  // a stretch that is its own mirror image: the pairing's trails would not be disjoint from their mirrors
     }
+    // darts walked, per block (summed by sum_blocks_kernel: 740 K waves adding to one word cost more than the walk itself)
+    __shared__ unsigned long long wave_sum[EB / 64];
     unsigned long long t = len;
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    if ((threadIdx.x & 63) == 0 && t) atomicAdd(walked_total, t);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < EB / 64; w++) b += wave_sum[w];
+        walked_blocks[blockIdx.x] = b;
+    }
+}
+__global__ __launch_bounds__(1024) void sum_blocks_kernel(const unsigned long long *v, uint64_t n, unsigned long long *out) {
+    __shared__ unsigned long long part[1024 / 64];
+    unsigned long long t = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += 1024) t += v[i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < 1024 / 64; w++) b += part[w];
+        *out = b;
+    }
 }
 // the stretch behind breaking dart b = first_brk + i is emitted iff it is not empty and b < (its end ^ 1)
 __global__ __launch_bounds__(EB) void stretch_select_kernel(uint64_t first_brk, uint64_t n_brk, const uint32_t *len, const uint32_t *end, uint32_t *keep_len,
@@ -93,18 +121,38 @@ __global__ __launch_bounds__(EB) void stretch_write_kernel(const uint32_t *succ,
     }
     tig_limits[tig_idx[i]] = o + n;
 }
-// ---- the darts no walker has passed: non-breaking, unmarked = the trails without a breaking dart -----------------------------------
-__global__ __launch_bounds__(EB) void unwalked_count_kernel(const uint32_t *succ, uint64_t first_brk, uint32_t *count) {
-    const uint64_t e = gid();
-    const bool hit = e < first_brk && !(succ[e] & MARK);
-    const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
-}
-__global__ __launch_bounds__(EB) void unwalked_list_kernel(const uint32_t *succ, uint64_t first_brk, uint32_t *cursor, uint32_t cap, uint32_t *list) {
-    const uint64_t e = gid();
-    if (e < first_brk && !(succ[e] & MARK)) {
-        const uint32_t at = atomicAdd(cursor, 1u);
-        if (at < cap) list[at] = (uint32_t)e;
+// ---- the trails no walker has passed ------------------------------------------------------------------------------------------------
+// A streaming pass over the even non-breaking darts: x with the mark property (see stretch_measure_kernel; pred(x) = succ[x ^ 1] ^ 1 is
+// the neighbouring word) but without a mark lies on a trail without a breaking dart. Its thread walks that trail once: the trail
+// pair's representative is the smallest even dart of the trail and its mirror, min over the trail's darts y of (y & ~1); the thread
+// that IS the representative reports the pair -- count only (list == null), or every dart of both trails. A trail longer than
+// `max_len` raises bit 32 of *error: such a graph goes through the closed walks instead.
+__global__ __launch_bounds__(EB) void unwalked_rep_kernel(const uint32_t *succ, uint64_t first_brk, uint32_t max_len, uint32_t *cursor, uint32_t cap, uint32_t *list,
+                                                         uint32_t *error) {
+    const uint64_t x64 = gid() * 2;
+    if (x64 >= first_brk) return;
+    const uint32_t x = (uint32_t)x64;
+    const uint2 w = reinterpret_cast<const uint2 *>(succ)[x >> 1];  // succ[x], succ[x ^ 1]
+    if (w.x & MARK) return;
+    const uint32_t next = w.x, prev = (w.y & ~MARK) ^ 1u;
+    if (!(x <= prev && x <= next)) return;
+    // (an unmarked candidate: on an unwalked trail -- a walked one would have been marked)
+    uint32_t len = 0, lo = x;
+    for (uint32_t y = x;;) {
+        lo = min(lo, y & ~1u);
+        len++;
+        y = succ[y] & ~MARK;
+        if (y == x) break;
+        if (y >= first_brk || len > max_len) { atomicOr(error, y >= first_brk ? 64u : 32u); return; }
+    }
+    if (lo != x) return;
+    const uint32_t at = atomicAdd(cursor, 2u * len);
+    if (!list) return;
+    uint32_t o = at;
+    for (uint32_t y = x, j = 0; j < len; j++) {
+        if (o + 1 < cap) { list[o] = y; list[o + 1] = y ^ 1u; }
+        o += 2;
+        y = succ[y] & ~MARK;
     }
 }
 
@@ -318,7 +366,12 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
     lap("pairing");
     Buf b_len, b_end, b_keep, b_flag;
     uint32_t *d_len = b_len.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1)), *d_end = b_end.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1));
-    if (n_brk) stretch_measure_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_len, d_end, d_small, d_error);
+    Buf b_wsum;
+    unsigned long long *d_wsum = b_wsum.alloc<unsigned long long>(st, std::max<uint64_t>(grid_for(n_brk), 1));
+    if (n_brk) {
+        stretch_measure_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_len, d_end, d_wsum, d_error);
+        sum_blocks_kernel<<<1, 1024, 0, st>>>(d_wsum, grid_for(n_brk), d_small);
+    }
     unsigned long long h_small[8];
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -335,11 +388,16 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
         const uint32_t nf = (uint32_t)unwalked;
         Buf b_list, b_hs, b_hv, b_hd;
         uint32_t *d_list = b_list.alloc<uint32_t>(st, nf), *d_hs = b_hs.alloc<uint32_t>(st, nf), *d_hv = b_hv.alloc<uint32_t>(st, nf), *d_hd = b_hd.alloc<uint32_t>(st, nf);
-        unwalked_list_kernel<<<grid_for(first_brk), EB, 0, st>>>(d_succ, first_brk, d_unwalked, nf, d_list);
+        unwalked_rep_kernel<<<grid_for((first_brk + 1) / 2), EB, 0, st>>>(d_succ, first_brk, 1u << 16, d_unwalked, nf, d_list, d_error);
         std::vector<uint32_t> fd(nf), fs(nf), fv(nf), ro(nf + 1);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if ((uint32_t)h_small[2] != nf) MTG_DIE("device_cut_first: internal error (%u unmarked darts listed, %u counted)", (uint32_t)h_small[2], nf);
+        if ((uint32_t)h_small[1] & 32u) {  // a trail without a breaking dart longer than one thread should walk
+            if (dbg) std::fprintf(stderr, "[mtg] cut first: a trail without a breaking dart has more than 65536 darts\n");
+            return false;
+        }
+        if ((uint32_t)h_small[1]) MTG_DIE("device_cut_first: internal error %u while listing the unwalked trails", (uint32_t)h_small[1]);
+        if ((uint32_t)h_small[2] != nf) MTG_DIE("device_cut_first: internal error (%u darts on the unwalked trails found, %u counted)", (uint32_t)h_small[2], nf);
         // (the list comes in atomic order: sorted, so that everything that follows is a function of the graph alone)
         HIP_CHECK(hipMemcpyAsync(fd.data(), d_list, (uint64_t)nf * 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
