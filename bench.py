@@ -96,6 +96,11 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
         "decomposition": buckets + 48 * V + int(88.2 * E) + (100 + 16 * wy) * M,
         "records": buckets + 732 * V + 12 * E,
         "cut": 12 * n + 4 * P + 4 * kept + 4 * tigs,                 # three passes over the closed walks (rotation, count, emit) + the tigs
+        # device order since round 6 (cut_first_device.hip): the tigs straight from the pairing, no closed walks. Bd = breaking darts =
+        # walkers. Buckets as above; pairing reads row, mirror, adj and writes succ (12 V + 8 E); pass 1 reads every successor word once
+        # (4 E: the breaking darts' coalesced, the others gathered), marks a sixth of them, writes length + end per walker (8 Bd); selection
+        # + two scans 40 Bd; pass 2 reads (length, offset, tig index) per walker and gathers the kept darts again, writes tigs and ends
+        "tigs_from_pairing": buckets + 12 * V + 8 * E + 4 * E + 4 * E // 6 + 8 * (D - 2 * P) + 40 * (D - 2 * P) + 12 * (D - 2 * P) + 8 * kept + 4 * tigs,
     }
 
 
@@ -108,7 +113,8 @@ def stage_minimum_models(V: int, E0: int, P: int, N: int, E: int, S: int, C: int
       insert_eulerise  pairs (12 B) + out-degree and mirror per node (8 B) -> two darts per pair and per unit (from, to, weight: 12 B each)
       decomposition    darts (from, to: 8 B) -> the closed walks (4 B per biedge) and their limits
       records          darts (from, to: 8 B) -> one adjacency entry per dart (4 B) and one offset per node (4 B): what a walk needs at least
-      cut              closed walks (4 B per biedge) + the weight of every edge on them (2 B) -> tig edges (4 B) + limits (8 B per tig)"""
+      cut              closed walks (4 B per biedge) + the weight of every edge on them (2 B) -> tig edges (4 B) + limits (8 B per tig)
+      tigs_from_pairing  (device order, round 6: decomposition and cut as one stage) darts (from, to: 8 B) -> tig edges (4 B) + limits (8 B per tig)"""
     n = E // 2
     return {
         "replay": 12 * C + 8 * S + 12 * P,
@@ -116,6 +122,7 @@ def stage_minimum_models(V: int, E0: int, P: int, N: int, E: int, S: int, C: int
         "decomposition": 8 * E + 4 * n,
         "records": 8 * E + 4 * E + 4 * V,
         "cut": 6 * n + 4 * kept + 8 * tigs,
+        "tigs_from_pairing": 8 * E + 4 * kept + 8 * tigs,   # darts (from, to) -> tig edges + their ends: decomposition and cut in one
     }
 
 
@@ -512,18 +519,27 @@ def main():
                      "insert_eulerise": "matched-pair darts + Euleriser: degree / need / 3 scans / expand / zip_check / zip_emit / head kernels",
                      "decomposition": "Euler decomposition (device mode): bucket merge, pairing, union-find over biedges, hooking, recording splitter walks, ranking, copy",
                      "records": "walk records (reference-order mode): bucket merge + lean_build + wide_build kernels (the records' download is not in it)",
-                     "cut": "rotate + cut: cycle heads / rotation / rotate_cycles / cut_flags / 3 scans / cut_write (the tig download is not in it)"}
+                     "cut": "rotate + cut: cycle heads / rotation / rotate_cycles / cut_flags / 3 scans / cut_write (the tig download is not in it)",
+                     "tigs_from_pairing": "tigs straight from the pairing (device order, cut_first_device.hip; takes the place of decomposition + cut): bucket merge, "
+                                          "pairing, stretch_measure (one walker per breaking dart), selection + 2 scans, stretch_write; trails without a breaking "
+                                          "dart spliced in on the host"}
             minimum = stage_minimum_models(n_nodes, n_edges, result_info.get("pairs", 0), result_info.get("units", 0), result_info.get("darts", 0),
                                            result_info.get("S", 0), int(total_stats.get("emitted", 0)), result_info.get("tig_edges", 0),
                                            result_info.get("tigs", 0))
             roofline_stages = []
             for mode_name in ("device", "host"):
                 tr = stage_traffic(args, world, mode_name)
+                # (device order: when the cutter had nothing to do -- no closed walks were built, cut_first_device.hip made the tigs
+                # -- decomposition + cut are ONE stage with a byte model of its own)
+                cut_vals = [v for v in stage_ms[mode_name].get("cut", []) if v > 0]
+                cut_first = mode_name == "device" and bool(stage_ms[mode_name].get("decomposition")) and (not cut_vals or float(np.mean(cut_vals)) < 0.05)
                 for st_name in ("replay", "insert_eulerise", "decomposition", "records", "cut"):
                     vals = [v for v in stage_ms[mode_name].get(st_name, []) if v > 0]
-                    if not vals:
+                    if not vals or (cut_first and st_name == "cut"):
                         continue
                     ms = float(np.mean(vals))
+                    if cut_first and st_name == "decomposition":
+                        st_name = "tigs_from_pairing"
                     b = models[st_name]
                     entry = {"stage": st_name, "euler_mode": mode_name, "kernels": names[st_name], "bound": "hbm", "avg_launch_ms": round(ms, 4),
                              "algorithmic_bytes": int(b), "achieved": round(b / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -565,6 +565,13 @@ class GreedytigAlgorithm(TigAlgorithm):
         c = configuration.to_c()
         return _take_walks(L, L.mtg_compute_tigs_cfg(graph.handle, 5, C.byref(c)))
 
+    @classmethod
+    def compute_tigs_np(cls, graph: Bigraph, configuration: GreedytigAlgorithmConfiguration):
+        """The same as flat numpy arrays (exclusive tig ends, edge ids): large graphs."""
+        L = _lib.load()
+        c = configuration.to_c()
+        return _take_walks_np(L, L.mtg_compute_tigs_cfg(graph.handle, 5, C.byref(c)))
+
 
 class EulertigAlgorithm(TigAlgorithm):
     """eulertigs/mod.rs:18-39."""

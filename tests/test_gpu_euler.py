@@ -150,6 +150,48 @@ def test_device_euler_full_bench_size(gpu):
         assert len(orig) == n_orig // 2 and len(np.unique(orig >> 1)) == n_orig // 2   # every unitig exactly once
 
 
+@pytest.mark.parametrize("algorithm", ["greedy", "euler"])
+def test_device_order_with_self_mirror_nodes_at_bench_size(gpu, algorithm):
+    """Device order at |E| = 2^24 on a graph WITH self-mirror nodes (1 % of the binodes), the tigs cut straight from the pairing
+    (cut_first_device.hip) and through the closed walks: valid tig sets (tests/gpu_props.py: every unitig once, consecutive edges
+    adjacent, ends original, no breaking edge inside, Eulerian graph) whose cumulative length minus (k - 1) per tig -- the unitigs'
+    k-mers plus the matched dummies kept -- equals the reference-order result's exactly. The tig COUNT may differ where two breaking
+    edges meet at a self-mirror node (the empty stretch between them is no tig: greedytigs/mod.rs:772-774, SURVEY 8a's exception),
+    by at most one per self-mirror node; without such nodes it is equal (test_device_euler_full_bench_size)."""
+    import gpu_props
+    from matchtigs_amd import api, synth
+
+    torch = gpu
+    k = 31
+    G = synth.g_csr_device(5_592_405, seed=3, k=k, self_mirror_frac=0.01)
+    mirror = G.export_mirror()
+    n_sm = int((mirror == np.arange(len(mirror), dtype=mirror.dtype)).sum())
+    assert n_sm > 50000
+
+    def run(mode, no_cut_first=False):
+        api.set_finish_tuning(no_cut_first=no_cut_first)
+        try:
+            if algorithm == "greedy":
+                lim, ed = api.GreedytigAlgorithm.compute_tigs_np(G, api.GreedytigAlgorithmConfiguration(1, k, euler_mode=mode))
+            else:
+                lim, ed = api.EulertigAlgorithm.compute_tigs_np(G, api.EulertigAlgorithmConfiguration(k, euler_mode=mode))
+        finally:
+            api.set_finish_tuning()
+        cum, dummy_kmers = gpu_props.check_tigs(torch, G, lim, ed, k)
+        G.reset()
+        return len(lim), cum - (k - 1) * len(lim), dummy_kmers, ed
+
+    ref = run(api.EulerMode.HostReferenceOrder)
+    cut = run(api.EulerMode.Device)
+    walks = run(api.EulerMode.Device, no_cut_first=True)
+    again = run(api.EulerMode.Device)
+    assert np.array_equal(cut[3], again[3])  # reproducible
+    for got in (cut, walks):
+        assert got[1] == ref[1] and got[2] == ref[2]
+        assert abs(got[0] - ref[0]) <= n_sm
+    print(f"{algorithm}: tigs reference order {ref[0]}, cut first {cut[0]}, closed walks {walks[0]}; {n_sm} self-mirror nodes")
+
+
 def test_device_euler_is_reproducible(gpu):
     """No step of the device decomposition depends on thread timing: two runs give identical walks."""
     from matchtigs_amd import api, synth

@@ -33,10 +33,12 @@ ONE_OFF = ("degree_rank_kernel", "fill_kernel")
 # coalesced 4-byte words, where gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
 GATHER = ("sssp_enum_kernel", "sssp_kernel", "replay_rounds_kernel", "walk_measure_kernel", "walk_write_kernel", "label_hook_kernel",
           "propose_kernel", "flatten_kernel", "rotate_kernel", "wyllie_kernel", "wide_build_kernel", "mid_build_slice_kernel", "lean_build_kernel",
-          "zip_check_kernel", "sort_lists_kernel", "replay_compact_kernel", "replay_dense_fill_kernel", "root_len_kernel", "succ_node_kernel")
+          "zip_check_kernel", "sort_lists_kernel", "replay_compact_kernel", "replay_dense_fill_kernel", "root_len_kernel", "succ_node_kernel",
+          "stretch_measure_kernel", "stretch_write_kernel")
 ORDER = ["classify", "sssp", "replay", "insert_eulerise", "buckets", "cut"]
 # kernels that only occur in one kind of step tell which stage the buckets belong to
 DEVICE_ONLY = ("succ_node_kernel", "label_hook_kernel", "walk_measure_kernel")
+CUT_FIRST_ONLY = ("stretch_measure_kernel",)  # device order without closed walks (cut_first_device.hip): decomposition + cut in one stage
 HOST_ONLY = ("lean_ext_kernel", "lean_build_kernel", "wide_build_kernel", "mid_build_slice_kernel")
 
 
@@ -99,7 +101,7 @@ def main():
                 j = i
                 while j < len(order) and stage_of[order[j]] == "buckets":
                     j += 1
-                label = "decomposition" if any(any(k in names[x] for k in DEVICE_ONLY) for x in order[i:j]) else (
+                label = "tigs_from_pairing" if any(any(k in names[x] for k in CUT_FIRST_ONLY) for x in order[i:j]) else "decomposition" if any(any(k in names[x] for k in DEVICE_ONLY) for x in order[i:j]) else (
                     "records" if any(any(k in names[x] for k in HOST_ONLY) for x in order[i:j]) else "buckets")
                 for x in order[i:j]:
                     stage_of[x] = label
