@@ -218,7 +218,10 @@ def main():
     # G-csr is generated ON each rank's GPU (csrc/synth_device.hip, the twin of synth.g_csr): seconds, no numpy argsort.
     t_gen = time.perf_counter()
     if args.workload == "g_seq":
-        ua = synth.g_seq_arrays(args.genome_length, seed=args.seed, k=k, haplotypes=4, sub_rate=0.02)
+        # (the torch form of the generator, on this rank's GPU: the same graph as synth.g_seq_arrays -- tests hold them equal -- in
+        # seconds instead of minutes at 10^8)
+        ua = synth.g_seq_arrays_torch(args.genome_length, seed=args.seed, k=k, haplotypes=4, sub_rate=0.02, device=f"cuda:{local_rank}")
+        torch.cuda.empty_cache()
         graph = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
         workload = (f"G-seq REAL compacted de Bruijn graph: random genome L={args.genome_length}, 4 haplotypes, 2% substitutions, "
                     f"k={k}, {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers (clib.rs graph construction), seed={args.seed}")

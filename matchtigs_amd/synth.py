@@ -467,6 +467,191 @@ def g_seq_arrays(length: int, seed: int = 1, k: int = 31, haplotypes: int = 4, s
     return UnitigArrays(k, ascii_seq, off.astype(np.uint64), links, K)
 
 
+def kmer_codes_of_sequences_torch(seq: np.ndarray, off: np.ndarray, k: int, device: str = "cuda"):
+    """``kmer_codes_of_sequences`` with torch as the calculator: (sorted distinct canonical k-mer codes as a uint64 numpy array, number
+    of k-mer occurrences they were found in) -- the second number equals the first array's length iff no k-mer is spelled twice."""
+    import torch
+
+    dev = torch.device(device)
+    lut = np.full(256, 255, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    b = torch.from_numpy(lut[seq]).to(dev)
+    if bool((b == 255).any()):
+        raise ValueError("non-ACGT character")
+    b = b.to(torch.int64)
+    n = b.numel() - k + 1
+    fwd = torch.zeros(n, dtype=torch.int64, device=dev)
+    rc = torch.zeros(n, dtype=torch.int64, device=dev)
+    for j in range(k):
+        x = b[j:j + n]
+        fwd |= x << (2 * (k - 1 - j))
+        rc |= (3 - x) << (2 * j)
+    o = torch.from_numpy(off.astype(np.int64)).to(dev)
+    lens = o[1:] - o[:-1]
+    # k-mers that start inside [o_i, o_i+1 - k] of a sequence with at least k characters
+    start_of = torch.repeat_interleave(torch.arange(lens.numel(), device=dev), lens)[:n]
+    ok = (torch.arange(n, device=dev) + k) <= o[1:][start_of]
+    canon = torch.minimum(fwd, rc)[ok]
+    return torch.unique(canon).cpu().numpy().view(np.uint64), int(canon.numel())
+
+
+def g_seq_arrays_torch(length: int, seed: int = 1, k: int = 31, haplotypes: int = 4, sub_rate: float = 0.02, device: str = "cuda") -> UnitigArrays:
+    """``g_seq_arrays`` with torch as the calculator (on the GPU: seconds instead of minutes at the C. elegans-like 10^8 and the chr1-like
+    2.5 * 10^8 of SURVEY 8d): the same k-mer set, unitigs, unitig order, orientations and link order -- held equal to ``g_seq_arrays``
+    in the tests. Test / bench infrastructure (a workload generator), not part of the path. 64-bit codes live in int64 tensors: k-mer
+    codes have at most 62 bits, so their order is the unsigned one; the generator's unsigned arithmetic (splitmix64, the
+    reverse-complement bit tricks) is spelled with wrapping int64 operations and logical shifts."""
+    import torch
+
+    if k > 31 or k % 2 == 0:
+        raise ValueError("k must be odd and <= 31")
+    dev = torch.device(device)
+    i64 = torch.int64
+
+    def s64(c: int) -> int:  # a 64-bit pattern as the signed value torch holds
+        c &= 0xFFFFFFFFFFFFFFFF
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def lsr(x, sh: int):  # logical shift right of the 64-bit pattern
+        return (x >> sh) & ((1 << (64 - sh)) - 1) if sh else x
+
+    def splitmix(n: int, stream: int):
+        z = torch.arange(1, n + 1, dtype=i64, device=dev) * s64(0x9E3779B97F4A7C15) + s64(seed + (stream << 40))
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        return z ^ lsr(z, 31)
+
+    def kmer_codes(b):  # b: int64 bases 0..3
+        n = b.numel() - k + 1
+        fwd = torch.zeros(n, dtype=i64, device=dev)
+        rc = torch.zeros(n, dtype=i64, device=dev)
+        for j in range(k):
+            x = b[j:j + n]
+            fwd |= x << (2 * (k - 1 - j))
+            rc |= (3 - x) << (2 * j)
+        return fwd, rc
+
+    g = splitmix(length, 10) & 3
+    canon_all = []
+    for h in range(haplotypes):
+        if h == 0:
+            gh = g
+        else:
+            u01 = (lsr(splitmix(length, 20 + h), 11).to(torch.float64) + 1.0) * (1.0 / 9007199254740992.0)
+            z = splitmix(length, 40 + h)
+            shift = torch.remainder(torch.remainder(z, 3) + (z < 0).to(i64), 3) + 1  # the unsigned value mod 3 (2^64 = 1 mod 3)
+            gh = torch.where(u01 < sub_rate, torch.remainder(g + shift, 4), g)
+            del u01, z, shift
+        fwd, rc = kmer_codes(gh)
+        canon_all.append(torch.minimum(fwd, rc))
+        del fwd, rc
+    K = torch.unique(torch.cat(canon_all))
+    del canon_all
+    N = K.numel()
+
+    def revcomp_code(c):
+        x = ~c
+        for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+            x = (lsr(x, sh) & m) | ((x & m) << sh)
+        x = lsr(x, 32) | (x << 32)
+        return lsr(x, 64 - 2 * k)
+
+    code = torch.empty(2 * N, dtype=i64, device=dev)
+    code[0::2] = K
+    code[1::2] = revcomp_code(K)
+    ar2n = torch.arange(2 * N, device=dev)
+    s_order = torch.argsort(code)
+    S = code[s_order]
+    pref = S >> 2
+    first = torch.ones(2 * N, dtype=torch.bool, device=dev)
+    first[1:] = pref[1:] != pref[:-1]
+    g_start = torch.nonzero(first).flatten()
+    g_pref = pref[g_start]
+    g_end = torch.cat([g_start[1:], torch.tensor([2 * N], device=dev)])
+    suf = code & ((1 << (2 * (k - 1))) - 1)
+    pos_c = torch.clamp(torch.searchsorted(g_pref, suf), max=g_pref.numel() - 1)
+    hit = g_pref[pos_c] == suf
+    succ = torch.full((2 * N, 4), -1, dtype=i64, device=dev)
+    xs = ar2n[hit]
+    gs = pos_c[hit]
+    for t in range(4):
+        idx = g_start[gs] + t
+        ok = idx < g_end[gs]
+        ii = idx[ok]
+        succ[xs[ok], S[ii] & 3] = s_order[ii]
+    del S, pref, first, suf, pos_c, hit, xs, gs
+    out_deg = (succ >= 0).sum(dim=1)
+    in_deg = out_deg.reshape(N, 2).flip(1).reshape(2 * N)
+    only = torch.where(out_deg == 1, succ.max(dim=1).values, torch.full_like(out_deg, -1))
+    internal = (only >= 0) & (in_deg[torch.clamp(only, min=0)] == 1)
+    nxt = torch.where(internal, only, torch.full_like(only, -1))
+    prv = torch.full((2 * N,), -1, dtype=i64, device=dev)
+    prv[nxt[internal]] = ar2n[internal]
+    if bool((nxt == (ar2n ^ 1)).any()):
+        raise NotImplementedError("a unitig runs into its own reverse complement")
+    jump = prv.clone()
+    rank = (prv >= 0).to(i64)
+    mn = ar2n.clone()
+    for _ in range(64):
+        live = torch.nonzero(jump >= 0).flatten()
+        j = jump[live]
+        jj = jump[j]
+        upd = jj >= 0
+        if not bool(upd.any()):
+            break
+        idx = live[upd]
+        rank[idx] += rank[j[upd]]
+        mn[idx] = torch.minimum(mn[idx], mn[j[upd]])
+        jump[idx] = jj[upd]
+    else:
+        raise NotImplementedError("a unitig is a cycle")
+    head = torch.where(jump >= 0, jump, ar2n)
+    is_tail = nxt < 0
+    minx = torch.full((2 * N,), 2 * N, dtype=i64, device=dev)
+    minx[head[is_tail]] = torch.minimum(mn[is_tail], head[is_tail])
+    is_head = head == ar2n
+    sel_heads = torch.nonzero(is_head & (minx % 2 == 0) & (minx < 2 * N)).flatten()
+    sel_heads = sel_heads[torch.argsort(minx[sel_heads])]  # (the keys are distinct)
+    U = sel_heads.numel()
+    uid_of_head = torch.full((2 * N,), -1, dtype=i64, device=dev)
+    uid_of_head[sel_heads] = torch.arange(U, device=dev)
+    uid = uid_of_head[head]
+    members = torch.nonzero(uid >= 0).flatten()
+    if members.numel() != N:
+        raise NotImplementedError("a unitig runs into its own reverse complement")
+    m = torch.bincount(uid[members], minlength=U)
+    off = torch.zeros(U + 1, dtype=i64, device=dev)
+    off[1:] = torch.cumsum(m + k - 1, 0)
+    seq = torch.zeros(int(off[-1]), dtype=torch.uint8, device=dev)
+    seq[off[uid[members]] + k - 1 + rank[members]] = (code[members] & 3).to(torch.uint8)
+    hc = code[sel_heads]
+    for t in range(k - 1):
+        seq[off[:-1] + t] = ((hc >> (2 * (k - 1 - t))) & 3).to(torch.uint8)
+    ascii_seq = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[seq.to(i64)]
+    tails = torch.empty(U, dtype=i64, device=dev)
+    last = rank[members] == m[uid[members]] - 1
+    tails[uid[members[last]]] = members[last]
+    start_of = torch.full((2 * N,), -1, dtype=i64, device=dev)
+    start_of[sel_heads] = 2 * torch.arange(U, device=dev)
+    start_of[tails ^ 1] = 2 * torch.arange(U, device=dev) + 1
+    ends = torch.empty(2 * U, dtype=i64, device=dev)
+    ends[0::2] = tails
+    ends[1::2] = sel_heads ^ 1
+    sy = succ[ends]
+    so = torch.where(sy >= 0, start_of[torch.clamp(sy, min=0)], torch.full_like(sy, -1))
+    if bool(((sy >= 0) & (so < 0)).any()):
+        raise NotImplementedError("a unitig end is followed by the inside of a unitig (cycle / hairpin shapes)")
+    big = (1 << 63) - 1
+    so_sorted = torch.sort(torch.where(so >= 0, so, torch.full_like(so, big)), dim=1).values
+    valid = so_sorted != big
+    e_idx = torch.arange(2 * U, device=dev).repeat_interleave(4).reshape(2 * U, 4)[valid]
+    tgt = so_sorted[valid]
+    links = torch.stack([e_idx >> 1, ((e_idx & 1) == 0).to(i64), tgt >> 1, ((tgt & 1) == 0).to(i64)], dim=1)
+    return UnitigArrays(k, ascii_seq.cpu().numpy(), off.cpu().numpy().astype(np.uint64), links.cpu().numpy().astype(np.int64),
+                        K.cpu().numpy().view(np.uint64))
+
+
 def unitig_graph_of_arrays(ua: UnitigArrays) -> UnitigGraph:
     """The same graph in g_seq's object form (small sizes: builds Python strings and a set)."""
     bases = "ACGT"

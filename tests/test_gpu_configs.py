@@ -8,8 +8,11 @@ configs[3]  human whole genome k=31 : G-csr stand-in at |E| = 2^27 (the bench.py
             sources, pair-list prefix).
 configs[4]  661k-bacteria pangenome : G-csr stand-in at |E| = 2^31 (node ids at the u32 edge, 2.98 G darts after the finish), GPU
             stages + device finish + properties + the same exact sampled comparison and GPU/host claim-loop parity. The 2^30 / 2^31 cases skip on a box without the HBM / host memory they need.
-configs[1] / configs[2] are covered at their sizes by test_gpu_parity.py::test_full_bench_size_properties,
-test_gpu_replay.py::test_gpu_replay_full_bench_size and test_gpu_euler.py::test_device_euler_full_bench_size."""
+configs[1]  C. elegans k=31 greedy matchtigs : REAL de Bruijn topology at SURVEY 8d's size, G-seq(L = 10^8) generated on the GPU: pairs equal
+            the oracle's exactly, tig properties, exact k-mer set.
+configs[2]  human chr1 k=31 Eulertigs : G-seq(L = 2.5 * 10^8), device order: tig properties, exact k-mer set, no repeated k-mer.
+(configs[1] / configs[2] on the G-csr stand-in at 2^24: test_gpu_parity.py::test_full_bench_size_properties,
+test_gpu_replay.py::test_gpu_replay_full_bench_size and test_gpu_euler.py::test_device_euler_full_bench_size.)"""
 import gc
 import subprocess
 import sys
@@ -49,6 +52,10 @@ def test_config0_ecoli_like_bcalm2_to_greedytigs_fasta(gpu, oracle, tmp_path):
     k = 31
     ua = synth.g_seq_arrays(4_600_000, seed=1, k=k, haplotypes=4, sub_rate=0.02)
     assert ua.n_unitigs > 400_000
+    # the generator of the larger real-topology cases below (torch on the GPU) builds the same graph
+    ut = synth.g_seq_arrays_torch(4_600_000, seed=1, k=k, haplotypes=4, sub_rate=0.02)
+    assert np.array_equal(ua.seq, ut.seq) and np.array_equal(ua.off, ut.off) and np.array_equal(ua.links, ut.links) and np.array_equal(ua.kmers, ut.kmers)
+    del ut
     inp, out = tmp_path / "unitigs.fa", tmp_path / "greedy.fa"
     inp.write_bytes(ua.bcalm2_text())
     r = subprocess.run([sys.executable, "-m", "matchtigs_amd", "--bcalm-in", str(inp), "-k", str(k), "--greedytigs-fa-out", str(out)],
@@ -67,6 +74,98 @@ def test_config0_ecoli_like_bcalm2_to_greedytigs_fasta(gpu, oracle, tmp_path):
     assert int(off[-1]) < int(ua.off[-1])
     print(f"config0: {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers -> {len(tigs)} greedy matchtigs, "
           f"{int(ua.off[-1])} -> {int(off[-1])} characters; oracle queries {st['queries']}")
+
+
+def _fasta_sequences(fa: bytes):
+    """(sequence bytes as uint8, offsets) of a FASTA of `>header` + one sequence line per record, at sizes where a Python list of
+    records is too slow: line ends by numpy."""
+    a = np.frombuffer(fa, np.uint8)
+    nl = np.nonzero(a == 10)[0]
+    assert len(nl) % 2 == 0 and a[0] == ord(">")
+    starts = nl[0::2] + 1  # a sequence line begins after its header's line end
+    ends = nl[1::2]
+    assert (a[np.r_[0, ends[:-1] + 1]] == ord(">")).all()
+    lens = ends - starts
+    off = np.zeros(len(lens) + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    keep = np.ones(len(a), bool)
+    keep[nl] = False
+    hdr_len = nl[0::2] - np.r_[0, ends[:-1] + 1]
+    # drop the header characters: mark them through a difference array
+    d = np.zeros(len(a) + 1, np.int64)
+    np.add.at(d, np.r_[0, ends[:-1] + 1], 1)
+    np.add.at(d, nl[0::2], -1)
+    keep &= np.cumsum(d[:-1]) == 0
+    del hdr_len
+    return a[keep], off
+
+
+def test_config1_celegans_like_real_dbg_greedy(gpu, oracle):
+    """BASELINE configs[1] (C. elegans k = 31 greedy matchtigs, one GPU) on REAL de Bruijn topology at SURVEY 8d's size: G-seq(L = 10^8,
+    H = 4, p = 0.02), 9.6 M unitigs, generated with torch on the GPU (held equal to the numpy generator at 4.6 Mbp above). T1 / T2 exact:
+    the GPU's pair list equals the CPU oracle's sequential claim loop with its own truncated Dijkstras; the finish in the reference's
+    order passes the tig properties; the spelled tigs hold exactly the input k-mer set, in fewer characters than the unitigs."""
+    import gpu_props
+    from matchtigs_amd import api, synth, torch_glue
+
+    torch = gpu
+    free_hbm, free_host = _free_memory_gb(torch)
+    if free_hbm < 60 or free_host < 60:
+        pytest.skip(f"needs 60 GB of HBM and of host memory; this box has {free_hbm:.0f} / {free_host:.0f}")
+    k = 31
+    ua = synth.g_seq_arrays_torch(100_000_000, seed=1, k=k)
+    torch.cuda.empty_cache()
+    assert ua.n_unitigs > 9_000_000
+    G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
+    dev = api.DeviceGraph(G, k)
+    stream = torch_glue.current_stream_ptr()
+    S = dev.classify(stream)
+    bufs = torch_glue.run_sssp(dev, 0, S)
+    pairs = dev.replay_claims_device(bufs.start.data_ptr(), bufs.count.data_ptr(), bufs.pool.data_ptr(), stream)
+    on, mu, li = dev.classify_download()
+    n_cand = gpu_props.check_candidates(torch, bufs, on, li, k)
+    del bufs, dev
+    og = oracle.OracleGraph.from_unitig_links_arrays(ua.weights, ua.links)
+    want, st = og.greedy_pairs_np(k)
+    del og
+    assert len(pairs) == len(want) and all(np.array_equal(pairs[f], want[f]) for f in ("out", "in", "dist"))
+    lim, edges = api.finish_greedytigs_np(G, pairs, k, api.EulerMode.HostReferenceOrder)
+    cum, dummy_kmers = gpu_props.check_tigs(torch, G, lim, edges, k)
+    fa = api.write_walks_text_device(G, (lim, edges), (ua.seq, ua.off), k)
+    seq, off = _fasta_sequences(fa)
+    del fa
+    codes, n_occ = synth.kmer_codes_of_sequences_torch(seq, off, k)
+    assert np.array_equal(codes, ua.kmers)
+    assert len(off) - 1 == len(lim) < ua.n_unitigs and int(off[-1]) < int(ua.off[-1])
+    print(f"config1 (real dBG, 10^8 bp): {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers, S={S}, candidates={n_cand}, pairs={len(pairs)} "
+          f"(oracle queries {st['queries']}), tigs={len(lim)}, {int(ua.off[-1])} -> {int(off[-1])} characters, k-mer occurrences {n_occ}")
+
+
+def test_config2_chr1_like_real_dbg_eulertigs(gpu):
+    """BASELINE configs[2] (human chr1 k = 31 Eulertigs: the Euler-walk kernels only, no SSSP / matching) on REAL de Bruijn topology at
+    SURVEY 8d's size: G-seq(L = 2.5 * 10^8), device order (the tigs cut straight from the pairing). Tig properties, the exact input
+    k-mer set, and no k-mer spelled twice (an Euler tiling repeats nothing)."""
+    import gpu_props
+    from matchtigs_amd import api, synth
+
+    torch = gpu
+    free_hbm, free_host = _free_memory_gb(torch)
+    if free_hbm < 120 or free_host < 100:
+        pytest.skip(f"needs 120 GB of HBM and 100 GB of host memory; this box has {free_hbm:.0f} / {free_host:.0f}")
+    k = 31
+    ua = synth.g_seq_arrays_torch(250_000_000, seed=1, k=k)
+    torch.cuda.empty_cache()
+    G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
+    lim, edges = api.EulertigAlgorithm.compute_tigs_np(G, api.EulertigAlgorithmConfiguration(k, euler_mode=api.EulerMode.Device))
+    cum, dummy_kmers = gpu_props.check_tigs(torch, G, lim, edges, k)
+    assert dummy_kmers == 0
+    fa = api.write_walks_text_device(G, (lim, edges), (ua.seq, ua.off), k)
+    seq, off = _fasta_sequences(fa)
+    del fa
+    codes, n_occ = synth.kmer_codes_of_sequences_torch(seq, off, k)
+    assert np.array_equal(codes, ua.kmers) and n_occ == len(ua.kmers)
+    assert len(off) - 1 == len(lim) < ua.n_unitigs
+    print(f"config2 (real dBG, 2.5 * 10^8 bp): {ua.n_unitigs} unitigs, {len(ua.kmers)} k-mers -> {len(lim)} eulertigs, {int(ua.off[-1])} -> {int(off[-1])} characters")
 
 
 def _free_memory_gb(torch):

@@ -44,6 +44,20 @@ def test_g_seq_arrays_equals_g_seq():
         assert (b.weights == a.weights).all()
 
 
+def test_g_seq_arrays_torch_equals_g_seq_arrays():
+    """The torch form of the generator (on a GPU: the C. elegans-like and chr1-like sizes of SURVEY 8d in seconds) builds exactly what
+    the numpy form builds -- here with torch on the CPU; tests/test_gpu_configs.py holds the two equal at 4.6 Mbp on the GPU."""
+    import numpy as np
+    from matchtigs_amd import synth
+
+    for (L, seed, k, H, p) in [(30000, 1, 31, 4, 0.02), (120000, 5, 21, 3, 0.05), (5000, 2, 15, 2, 0.1), (60000, 9, 31, 1, 0.0)]:
+        a = synth.g_seq_arrays(L, seed=seed, k=k, haplotypes=H, sub_rate=p)
+        b = synth.g_seq_arrays_torch(L, seed=seed, k=k, haplotypes=H, sub_rate=p, device="cpu")
+        assert np.array_equal(a.seq, b.seq) and np.array_equal(a.off, b.off) and np.array_equal(a.links, b.links) and np.array_equal(a.kmers, b.kmers)
+        codes, n = synth.kmer_codes_of_sequences_torch(a.seq, a.off, k, "cpu")
+        assert np.array_equal(codes, a.kmers) and n == len(a.kmers)  # (unitigs repeat no k-mer)
+
+
 def test_real_dbg_eulertigs_at_scale_cpu(tmp_path, oracle, product_lib):
     """BCALM2 file route + eulertigs (host-only path) on a 10^5-bp genome: FASTA bytes equal the oracle's, k-mer set preserved."""
     import numpy as np

@@ -21,7 +21,7 @@ mode = api.EulerMode.Device if args.euler == "device" else api.EulerMode.HostRef
 L = _lib.load()
 out = {"k": k, "euler_mode": args.euler}
 if args.g_seq:
-    ua = synth.g_seq_arrays(args.g_seq, seed=1, k=k)
+    ua = synth.g_seq_arrays_torch(args.g_seq, seed=1, k=k)
     d = tempfile.mkdtemp()
     inp, fa = os.path.join(d, "unitigs.fa"), os.path.join(d, "tigs.fa")
     open(inp, "wb").write(ua.bcalm2_text())

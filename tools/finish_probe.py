@@ -25,7 +25,7 @@ k = args.k
 nb = int(round((1 << args.log2_edges) / 3.0))
 t0 = time.perf_counter()
 if args.gseq:
-    ua = synth.g_seq_arrays(args.gseq, seed=args.seed, k=k)
+    ua = synth.g_seq_arrays_torch(args.gseq, seed=args.seed, k=k)
     G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
     del ua
 else:

@@ -2,7 +2,7 @@ import sys
 sys.path.insert(0,'.')
 from matchtigs_amd import api, synth, torch_glue
 k=31
-ua = synth.g_seq_arrays(100000000, seed=1, k=k)
+ua = synth.g_seq_arrays_torch(100000000, seed=1, k=k)
 G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links); del ua
 dev = api.DeviceGraph(G, k); st = torch_glue.current_stream_ptr(); S = dev.classify(st); bufs = torch_glue.run_sssp(dev, 0, S)
 for _ in range(2):

@@ -10,7 +10,7 @@ from matchtigs_amd import api, synth, torch_glue
 arg = sys.argv[1] if len(sys.argv) > 1 else "27"
 k = 31
 if arg.startswith("gseq:"):
-    ua = synth.g_seq_arrays(int(arg[5:]), seed=1, k=k)
+    ua = synth.g_seq_arrays_torch(int(arg[5:]), seed=1, k=k)
     G = api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links)
     del ua
 else:

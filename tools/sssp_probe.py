@@ -66,5 +66,5 @@ def probe(tag, G):
 for lg in a.log2_edges:
     probe(f"g_csr 2^{lg}", synth.g_csr_device(int((1 << lg) / 1.5 / 2), seed=1, k=a.k))
 if a.gseq:
-    ua = synth.g_seq_arrays(a.gseq, seed=1, k=a.k, haplotypes=4, sub_rate=0.02)
+    ua = synth.g_seq_arrays_torch(a.gseq, seed=1, k=a.k, haplotypes=4, sub_rate=0.02)
     probe(f"g_seq L={a.gseq}", api.Bigraph.from_unitig_links_arrays(ua.weights, ua.links))
