@@ -1,4 +1,4 @@
-// device.hpp -- interface of the HIP device stage (device.hip) towards the C-ABI layer.
+// device.hpp -- interface of the HIP device stage (device_build.hip, device_classify.hip, device_sssp.hip, device_replay.hip, device_pairs.hip) towards the C-ABI layer.
 #pragma once
 
 #include <thread>
@@ -13,7 +13,7 @@ namespace mtg {
 struct Device;
 
 int device_count();
-// device memory of a call, reserved ahead of it (device.hip)
+// device memory of a call, reserved ahead of it (device_build.hip)
 size_t device_call_bytes_estimate(uint64_t V, uint64_t E, uint64_t k);
 void device_reserve_async(uint64_t V, uint64_t E, int device_id = -1);  // helper thread: HIP runtime, code objects, one arena chunk (-1: on the default device)
 void device_arena_stats(int device_id, uint64_t out[4]);  // bytes in chunks, live bytes, peak of live bytes, chunks taken from the driver so far
@@ -31,7 +31,7 @@ void device_build_lower_bounds(Device *d, void *stream);
 double device_lower_bounds_ms(const Device *d);   // GPU time (HIP events) of that precompute, 0 if the device graph has none
 bool device_has_lower_bounds(const Device *d);
 void device_free(Device *d);
-void device_set_single_use(Device *d);  // the caller searches once: the search's arrays go back before the claim replay (device.hip)
+void device_set_single_use(Device *d);  // the caller searches once: the search's arrays go back before the claim replay (device_pairs.hip)
 uint64_t device_graph_bytes(const Device *d);
 uint64_t device_classify(Device *d, void *stream);
 void device_classify_download(Device *d, void *stream, uint32_t *out_nodes, int32_t *mult, uint8_t *live);
