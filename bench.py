@@ -73,7 +73,7 @@ def size_label(log2_edges: int) -> str:
 
 def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, visits: int, kept: int, tigs: int, A: int = 0) -> dict:
     """Algorithmic bytes per stage of ONE step = the sum over the stage's kernels of the arrays each must read and write once
-    (a gathered array counts once per gathering pass; DESIGN.md 3.9 derives every term). V nodes, E0 original darts, P matched
+    (a gathered array counts once per gathering pass; DESIGN.md 3 derives every term). V nodes, E0 original darts, P matched
     pairs, N Euleriser units, E darts after the finish, D = E - E0 dummy darts, n = E / 2 biedges, M = E / 64 splitters."""
     D, n = E - E0, E // 2
     M = E // 64 + 1
@@ -88,7 +88,7 @@ def stage_models(V: int, E0: int, P: int, N: int, E: int, S: int, n_dense: int, 
         # classify (odeg, mirror, reach -> mult, cls) + compaction (cls, reach -> out_nodes and the A sources the SSSP stage searches)
         "classify": 19 * V + 4 * S + 8 * A,
         # state copy 17 V; dense list + claims words + pair-count scan 48 S; admission 187 B per listed source; 67.2 B per check
-        # visit (DESIGN 3.5); compaction 32 B per pair
+        # visit (DESIGN 4.4); compaction 32 B per pair
         "replay": 17 * V + 48 * S + 187 * n_dense + int(67.2 * visits) + 32 * P,
         "insert_eulerise": 48 * V + 8 * E0 + 68 * P + 38 * N + 12 * D,
         # (since the arithmetic splitters and the recorded sequence: root pass 4 E + bitmap E / 8, measuring walk 4 E gathered + 4 E
@@ -398,7 +398,7 @@ def main():
         cold["note"] = ("first step on a fresh graph and a fresh device graph (beside the main one): its device arrays are new ranges of the "
                         "library's arena (new chunks from the driver where the arena has no room), host result arrays and the walk's arena are mapped "
                         "for the first time. The arena is NOT released first: a release would put its frees and the fresh allocations that follow -- driver "
-                        "calls, which sporadically stall for seconds on this pool (tools/alloc_probe.hip, DESIGN 2.1) -- into the measured step; the "
+                        "calls, which sporadically stall for seconds on this pool (tools/alloc_probe.hip, DESIGN 9) -- into the measured step; the "
                         "one_shot block is the consuming call in a process of its own")
 
     # ---- second mode, first class: the same step with the parallel Euler decomposition on the GPU, in its own timed region.
@@ -416,7 +416,7 @@ def main():
                        "tigs": result_info.get("tigs"),
                        "tig_download_ms": round(tig_dl[0], 3) if tig_dl else None,
                        "ms_per_step_with_tigs_on_host": round(dm_ms + tig_dl[0], 3) if tig_dl else None,
-                       "note": "every stage of the step on the GPU; tig order differs from the reference's, tig count and cumulative length are equal (DESIGN 3.6). "
+                       "note": "every stage of the step on the GPU; tig order differs from the reference's, tig count and cumulative length are equal (DESIGN 4.7 / docs/history). "
                                "The step ends with the tigs in HBM (edge ids + exclusive ends, as the cutter wrote them): a caller takes counts, flattens "
                                "into clib.rs arrays (one_shot), spells on the GPU, or asks for the walks on the host -- tig_download_ms, outside the step "
                                "since round 5 (rounds 1-4 ended every step with that copy into pageable memory: +8 ms at 2^27)"}
@@ -579,7 +579,7 @@ def main():
             count_ref[0] = None
             torch.cuda.empty_cache()
             api.release_device_memory(local_rank)
-            time.sleep(1.0)  # (let the driver settle after ~30 GB of frees: DESIGN 2.1)
+            time.sleep(1.0)  # (let the driver settle after ~30 GB of frees: DESIGN 9)
             full_size = full_size_step(args, k, local_rank)
         value = total_stats["relaxed_edges"] / (ms_per_step * 1e-3)
         out = {

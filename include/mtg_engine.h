@@ -211,7 +211,7 @@ int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_
 const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */
 void mtg_sssp_count(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end, mtg_sssp_stats *stats);
-/* Goal-directed pruning (k <= 255; DESIGN.md 3.3): with the device graph the engine computes lb(v) = distance from v to the nearest
+/* Goal-directed pruning (k <= 255; DESIGN.md 4.3): with the device graph the engine computes lb(v) = distance from v to the nearest
  * initial in-node and lb+(v) = distance to the nearest one BEYOND v, and keeps weight + lb+(head) beside every edge weight and the
  * in-node flags of a node's children and grandchildren in its block. A search records an in-node it reaches at distance d <= k-1
  * from the block of its parent, and expands a node v -- reads its block, relaxes its out-edges -- only when d + lb+(v) <= k-1:
@@ -230,7 +230,7 @@ uint64_t mtg_last_sssp_searched_sources(const mtg_device *d);
  * blocks exceed 3 GB), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the counting kernels
  * use), 2 / 3 = plan 0 with the four-lanes-per-block / per-lane form of the gathers regardless of the graph's size (same
  * results; lets small graphs exercise both forms); 4 / 6 / 7 = plans 0 / 2 / 3 WITHOUT the goal-directed pruning (full balls, every
- * source searched; same results: A/B runs and tests). Returns the plan in force (DESIGN.md 3.3). */
+ * source searched; same results: A/B runs and tests). Returns the plan in force (DESIGN.md 4.3). */
 int mtg_set_sssp_plan(mtg_device *d, int plan);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified
@@ -259,7 +259,7 @@ void mtg_set_replay_tuning(mtg_device *d, uint64_t windows, int block, int grid,
 void mtg_last_replay_ms(const mtg_device *d, double out[2]);
 /* Reservation rounds the last mtg_replay_claims_device needed. */
 int mtg_last_replay_rounds(const mtg_device *d);
-/* Source visits of those rounds (sum of the pending-list lengths): the unit of the replay's cost model (DESIGN.md 3.5). */
+/* Source visits of those rounds (sum of the pending-list lengths): the unit of the replay's cost model (DESIGN.md 4.4). */
 uint64_t mtg_last_replay_visits(const mtg_device *d);
 
 /* ---- multi-GPU ------------------------------------------------------------- */
@@ -338,7 +338,7 @@ mtg_walks *mtg_compute_eulertigs(mtg_graph *g, uint64_t k);
 uint64_t mtg_insert_pair_edges(mtg_graph *g, const mtg_pair *pairs, uint64_t n_pairs); /* returns last dummy id */
 uint64_t mtg_make_eulerian(mtg_graph *g, uint64_t dummy_edge_id, uint64_t k);          /* returns last dummy id */
 mtg_walks *mtg_euler_cycles(const mtg_graph *g);
-/* The same walk over the record formats the device finish feeds it (DESIGN.md 4.3), with the records built on the host from the
+/* The same walk over the record formats the device finish feeds it (DESIGN.md 5), with the records built on the host from the
  * graph's adjacency lists: 1 = 32-byte records (euler_lean.cpp), 2 = 256-byte records seeded from 32-byte ones. Same sequences as
  * mtg_euler_cycles (format 0); exported for the CPU test suite and the sanitizer builds. */
 mtg_walks *mtg_euler_cycles_records(const mtg_graph *g, int record_format);
@@ -393,7 +393,7 @@ void mtg_set_default_device(int device_id);
 void mtg_set_reserve_ahead(int on);
 /* Tuning of the finishing stages for measurements and tests (process-wide, read at the start of a call; the library reads no
  * environment variable for any of it, and none changes a result). records: walk-record format of the reference-order mode, 0 = the
- * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records (DESIGN.md 4.3). flags: bit 0 = the walk
+ * engine's choice by size and host memory, 1 = 32-byte, 2 = 128-byte, 3 = 256-byte records (DESIGN.md 5). flags: bit 0 = the walk
  * waits until all of its records have arrived (instead of starting on the 32-byte ones), bit 1 = never page-lock the record arena,
  * bit 2 = keep nothing of a graph on the device between calls (edges, mirror, buckets), bit 3 = a trivial kernel every 2 ms while the
  * host walks in the reference's order (measurement: what the GPU's idle state costs the first kernels of the next step), bit 4 = the device

@@ -5,7 +5,7 @@
  * not under /root/reference (traitgraph-algo 8.1.2, bigraph 5.0.1, traitgraph 8.1.2 over petgraph 0.7.1, disjoint-sets 0.4.2:
  * Cargo.lock:1260, :104, :1248 / :842, :412). Five of their choices decide BYTES of the result -- which pair is claimed, which walk
  * order comes out, which node gets which number -- and were restated from the crates' published behaviour, not
- * read from source: parity with the real binary is unpinned exactly there (DESIGN.md 5). Each of them is therefore ONE named
+ * read from source: parity with the real binary is unpinned exactly there (DESIGN.md 6). Each of them is therefore ONE named
  * switch, consulted by every party through the functions below -- the product's kernels and host stages (matchtigs_amd/csrc), the C
  * oracle (oracle/mtg_oracle.c) and the Python restatement (tests/pyref.py reads the same switches through mtg_policies()) -- so
  * that, should a recollection prove wrong, one definition changes; and so that the parity suite can run under the OTHER setting of

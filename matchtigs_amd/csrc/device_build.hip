@@ -11,7 +11,7 @@ namespace mtg {
 // independent of thread timing.
 // ------------------------------------------------------------------------------------------------
 // (the count and the edge's slot at its from-node come from the same atomic: `rank` is read back, coalesced, by build_fill_kernel --
-// one random atomic per edge instead of two: 18.5 -> see DESIGN 3.1)
+// one random atomic per edge instead of two: 18.5 -> see DESIGN 4.1)
 __global__ void build_count_kernel(const uint32_t *e_from, uint64_t n_edges, uint32_t *odeg, uint32_t *rank) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n_edges) rank[e] = atomicAdd(&odeg[e_from[e]], 1u);
@@ -564,7 +564,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
 size_t device_step_work_bytes_estimate(uint64_t V, uint64_t E) { return (size_t)((V * 60 + E * 62) / 100 * 108) + (64u << 20); }
 // mtg_device_create_opts(MTG_DEVICE_RESERVE_WORK): a caller that will step through the stages with this device graph (classify /
 // search / replay / finish, again and again) takes that memory NOW, as ONE chunk, unless the arena has it free already -- the first
-// step then makes no driver call (five otherwise, each of which can stall for a second on this pool: DESIGN 2.1). Asked for
+// step then makes no driver call (five otherwise, each of which can stall for a second on this pool: DESIGN 9). Asked for
 // explicitly, so the whole-call limit of the implicit reservations does not apply; what must remain is room for the other
 // allocators of the process (a sixth of the device), else nothing is reserved and the arrays come piece by piece as before.
 void device_reserve_step_work(Device *d) {

@@ -1,6 +1,6 @@
 // device_classify.hip -- node classification on the GPU (greedytigs/mod.rs:222-255): out-degree and mirror -> multiplicity, class byte, the
 // ascending out-node list and -- in the same compaction pass -- the list of sources that can reach an in-node at all (the only ones the
-// search visits). Part of the device stage (DESIGN.md 3.2); shared types: device_internal.hpp.
+// search visits). Part of the device stage (DESIGN.md 4.2); shared types: device_internal.hpp.
 #include "device_internal.hpp"
 
 namespace mtg {

@@ -1,5 +1,5 @@
 // device_replay.hip -- the claim loop of greedytigs/mod.rs:301-523 on the GPU: kernels in replay_kernels.inc (one cooperative launch,
-// deterministic reservations), host driver, pair compaction and download (DESIGN.md 3.5). Part of the device stage; shared types:
+// deterministic reservations), host driver, pair compaction and download (DESIGN.md 4.4). Part of the device stage; shared types:
 // device_internal.hpp.
 #include "device_internal.hpp"
 

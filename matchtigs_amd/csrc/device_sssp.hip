@@ -15,7 +15,7 @@
 //   out_nodes[S] ascending source list (u32), mult[V] (i32) from classification.
 //   pool[]       candidate keys (distance << 32 | node), per source contiguous and ascending.
 //
-// SSSP stage (integer, gather/latency bound, no MFMA) = a cascade of levels (DESIGN.md 3.2); a source a
+// SSSP stage (integer, gather/latency bound, no MFMA) = a cascade of levels (DESIGN.md 4.2); a source a
 // level cannot finish is appended to a device list by that kernel and re-run from scratch by the next:
 //   level 0   sssp_enum_kernel: one LANE per source enumerates the bounded paths depth-first with a private LDS stack (a
 //             (k-1)-ball of a unitig graph is almost a tree, so no visited table is needed); one 64-byte block gather per step,
@@ -451,7 +451,7 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 // makes the output identical to the Dijkstra order. A source whose enumeration exceeds the step budget or its LDS space is handed
 // to the cooperative cascade, which is exact for any ball.
 //
-// What bounds it (DESIGN.md 3.4): the version at the end of round 2's first session was bound by instruction issue (460 VALU +
+// What bounds it (DESIGN.md 4.3): the version at the end of round 2's first session was bound by instruction issue (460 VALU +
 // 366 SALU per wave step, 188 VGPRs, 8 waves per CU). Written branch-free -- every potential push / hit is an UNCONDITIONAL LDS store to the
 // lane's next free slot (a store that does not count leaves the counter where it was), the next node always comes off the stack,
 // sources are handed out by two cross-lane permutes from chunks held in registers -- a step is half the instructions and the
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 // hit per path). Keep the smallest distance per node and order by (distance, node) -- what Dijkstra's pop order gives
 // (SURVEY App. A.1). The level itself puts lists of up to four keys in order; what it leaves here are the longer lists (5.8 % of
 // the bench graph's sources have 5-8 candidates, 2.8 % 9-16, 0.4 % more: together 58 % of all keys) and the rare short list with a
-// repeated node. What was measured on the way (2^27 bench graph; DESIGN.md 3.4): one thread per list with an insertion sort in LDS
+// repeated node. What was measured on the way (2^27 bench graph; DESIGN.md 4.3): one thread per list with an insertion sort in LDS
 // (round 2) 0.61 ms -- dependent LDS round trips and divergent loop control; one thread per list with the keys in registers and a
 // sorting network 0.15 + 0.23 ms for the lists of <= 8 / <= 16 keys, bound by the number of memory requests (every lane reads and
 // writes its own list), and a 32-slot network is 40 KB of straight-line code whose first pass runs at the latency of

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(EB) void sort_buckets_kernel(uint64_t n_nodes, cons
 // (for a self-mirror node: the neighbouring slot), which makes the successor function commute with mirroring.
 // Evaluated from the nodes' side: the j-th in-dart of v is the mirror of the j-th out-dart of mirror(v) (both buckets in
 // ascending dart id), so a node reads its own bucket and its mirror's and writes the successors -- no slot array, no per-dart
-// lookups of from / mirror / row (buckets + pairing: 32 -> see DESIGN 3.6).
+// lookups of from / mirror / row (buckets + pairing: 32 -> see DESIGN 4.7 / docs/history).
 __global__ __launch_bounds__(EB) void succ_node_kernel(const uint32_t *mirror, uint64_t n_nodes, const uint32_t *row, const uint32_t *adj,
                                                       uint32_t *succ, uint32_t *error) {
     const uint64_t i = gid();
@@ -355,7 +355,7 @@ struct SplitIndex {  // dart -> index of the splitter it is
 };
 // While dart ids leave bit 31 free (fewer than 2^31 darts) the walks do not look the splitter bitmap up at every step: the
 // PREDECESSOR of every splitter carries the mark in bit 31 of its successor word -- pred(x) = succ[x ^ 1] ^ 1, by the mirror symmetry
-// of the pairing -- set by one thread per splitter. One random load per step instead of two (walk_measure 6.8 -> see DESIGN 3.6).
+// of the pairing -- set by one thread per splitter. One random load per step instead of two (walk_measure 6.8 -> see DESIGN 4.7 / docs/history).
 constexpr uint32_t SUCC_MARK = 0x80000000u;
 __global__ __launch_bounds__(EB) void mark_pred_kernel(uint32_t *succ, const uint32_t *splitters, uint32_t n_split) {
     const uint64_t i = gid();

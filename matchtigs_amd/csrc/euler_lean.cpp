@@ -38,7 +38,7 @@ Walks euler_cycles_lean(LeanNode *nodes, uint64_t V, const uint32_t *ext_eid, co
     // MTG_WALK_SIM=1 (with MTG_DEBUG=1): how many record reads the walk of euler_fast.cpp would make on THIS walk with records of other
     // shapes -- shape (a0, a1, ...) = own positions that carry copies, positions copied per head, per head's head, ...; a hinted step
     // succeeds when the position the walk takes lies among the copied ones. Reproduces the measured counts of the shipped shapes
-    // exactly ((3,3,2): 35 961 336 at 2^27, (3,3): 49 247 138) and is how (2,2,2,2) and (3,3,3) were ruled out (DESIGN.md 4.3).
+    // exactly ((3,3,2): 35 961 336 at 2^27, (3,3): 49 247 138) and is how (2,2,2,2) and (3,3,3) were ruled out (DESIGN.md 5).
     static const bool sim_on = std::getenv("MTG_WALK_SIM") != nullptr;
     constexpr int N_SIM = 8;
     static const int SIM[N_SIM][5] = {{3, 3, 2, 0, 0}, {3, 3, 0, 0, 0}, {3, 2, 2, 2, 0}, {2, 2, 2, 2, 0}, {3, 3, 2, 2, 0}, {2, 2, 2, 2, 2}, {3, 3, 3, 0, 0}, {3, 2, 2, 0, 0}};

@@ -70,7 +70,7 @@ struct alignas(128) EulerNode2 {
 static_assert(sizeof(EulerNode2) == 128, "EulerNode2 must be 128 bytes");
 
 // The latency-optimised walk of euler_fast.cpp (256-byte records with two levels of copied adjacency) seeded from the same
-// GPU-built records: faster than euler_cycles_lean while 256 bytes per node fit the host (DESIGN.md 4.3).
+// GPU-built records: faster than euler_cycles_lean while 256 bytes per node fit the host (DESIGN.md 5).
 // (nodes[V]: the caller's buffer for the 256-byte records, filled here by host threads)
 Walks euler_cycles_from_lean(const LeanNode *lean, EulerNode3 *nodes, uint64_t V, const uint32_t *ext_eid, const uint32_t *ext_to,
                              const uint32_t *e_from, const uint32_t *e_to, uint64_t E, HugeArena *arena);

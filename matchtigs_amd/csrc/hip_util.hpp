@@ -132,7 +132,7 @@ static void scan_u32(hipStream_t st, const uint32_t *in, uint64_t n, T *out, T *
 // Every device array of the library -- device graph, search and replay work arrays, the finishing stages' arrays, the graph's kept
 // edge arrays -- is a range of a few large hipMalloc'd CHUNKS, handed out by a best-fit free list with coalescing. Why: a hipMalloc
 // normally takes 0.3 ms whatever its size, but single hipMalloc / hipFree calls sporadically stall for 0.5 to 5 s on the shared hosts
-// of this pool (tools/alloc_probe.hip, DESIGN.md 2.1) -- and until round 4 a call of the path made ~200 of them, every stage taking
+// of this pool (tools/alloc_probe.hip, DESIGN.md 9) -- and until round 4 a call of the path made ~200 of them, every stage taking
 // its arrays from the driver and giving them back for the next stage to ask for again (0.44 s of waits in the driver's cold step of
 // round 4), all of which a one-shot caller -- the only kind the reference has, clib.rs:291 -- pays. With the arena a call's stages
 // reuse each other's memory (the device graph's blocks become the finish's dart arrays), the first chunk is sized for the whole call

@@ -1,4 +1,4 @@
-"""The library's device arena (csrc/hip_util.hpp: DeviceArena; DESIGN.md 2.1) under a random allocation / free load, compiled from
+"""The library's device arena (csrc/hip_util.hpp: DeviceArena; DESIGN.md 9) under a random allocation / free load, compiled from
 tests/tools/arena_test.hip with hipcc on the GPU box: ranges never overlap, keep their content, coalesce back into whole chunks."""
 import shutil
 import subprocess

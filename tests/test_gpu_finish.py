@@ -232,7 +232,7 @@ def test_resident_pairs_finish_equals_finish_from_host_pairs(gpu, idx):
 
 @pytest.mark.parametrize("log2_edges, euler", [(14, "host"), (14, "device"), (23, "device"), (23, "host")])
 def test_tigs_stay_in_hbm_until_asked_for(gpu, log2_edges, euler):
-    """The tigs of a finish on the GPU stay in HBM (DESIGN 3.8): the handle answers count() / total_edges() without a copy, arrays()
+    """The tigs of a finish on the GPU stay in HBM (DESIGN 4.5-4.8): the handle answers count() / total_edges() without a copy, arrays()
     brings them to the host once (plain copy at 2^14, through the pinned ring at 2^23), equal to what the array-returning call of the
     same finish delivers; the handle can be dropped without ever being downloaded; flattening (clib.rs:393-407) works on either."""
     from matchtigs_amd import api, synth, torch_glue

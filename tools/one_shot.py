@@ -4,7 +4,7 @@ its configuration: the whole path into clib.rs-sized output arrays) -> graph fre
 
 Device memory: the library's arena is NOT released between the calls (--release-between does, for comparison: every release adds
 driver calls -- the frees, then fresh allocations -- to the next call, and single driver calls sporadically stall for 0.5-5 s on
-this pool's shared hosts: tools/alloc_probe.hip, DESIGN.md 2.1; a fresh hipMalloc normally costs 0.3 ms whatever its size, which is
+this pool's shared hosts: tools/alloc_probe.hip, DESIGN.md 9; a fresh hipMalloc normally costs 0.3 ms whatever its size, which is
 what a first call in a fresh process pays).
 
 The input arrays come from the GPU generator (a graph is generated, exported to numpy arrays, freed): the generator is NOT timed.
