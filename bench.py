@@ -279,12 +279,7 @@ def main():
         ph["sssp"] = t2 - t1
         if kernel_ms is not None:
             kernel_ms.append(dev.last_sssp_kernel_ms())
-            lv_ = dev.last_sssp_levels()
-            pp_ = dev.last_sssp_post_pass()
-            if pp_["ms"] > 0:  # (listed after the search levels: it runs beside them, on a stream of its own)
-                lv_.append({"level": len(lv_), "ms": pp_["ms"], "sources": pp_["lists"],
-                            "kernel": "fix_compact_kernel + sort_lists_kernel (post-pass of the enumeration level: side stream, beside the cooperative levels)"})
-            level_ms.append(lv_)
+            level_ms.append(dev.last_sssp_levels())
         if world > 1:
             start_all, count_all, pool_all = mdist.allgather_candidates(bufs.start, bufs.count, bufs.pool, bufs.used, ranges)
             torch.cuda.synchronize()
@@ -482,9 +477,7 @@ def main():
                                 "sources": int(vals[0]["sources"])})
         traffic, traffic_note = traffic_bytes(args, world, [kk["kernel"] for kk in kernels])
         roofline = {
-            "bound": "hbm", "kernel": "SSSP stage = its level kernels (see 'kernels'); avg_launch_ms = the span from the stage's first kernel to its last (HIP events on "
-                                      "the launch stream): the enumeration level's post-pass runs on a side stream beside the cooperative cascade, so the parts add up to more",
-            "kernels": kernels,
+            "bound": "hbm", "kernel": "SSSP stage = sum of its level kernels (see 'kernels')", "kernels": kernels,
             "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": traffic, "traffic_note": traffic_note,
@@ -611,8 +604,7 @@ def main():
             "euler_device_ms_per_step": None if device_mode is None else device_mode["ms_per_step"],
             # the stages that shard over ranks, max over ranks (the whole-step curve is flat by design: rank 0 finishes alone)
             "scaling_stages_ms": {"sssp_kernels": round(kmax[0], 4), "sssp_stage": round(kmax[1], 4), "allgather": round(kmax[2], 4)},
-            # (share of the sources the enumeration level finishes itself: the rest is what the first cooperative level is handed)
-            "level0_finish_rate": (round(1.0 - next((kk["sources"] for kk in kernels[1:] if kk["kernel"].startswith("sssp_kernel<")), 0) / max(kernels[0]["sources"], 1), 6)) if kernels else None,
+            "level0_finish_rate": (round(1.0 - kernels[1]["sources"] / max(kernels[0]["sources"], 1), 6) if len(kernels) > 1 else 1.0) if kernels else None,
             "setup_s": round(t_gen, 2), "setup_graph_s": round(t_graph, 2),
             "device_graph_bytes": device_graph_bytes,
             "roofline": roofline,

@@ -201,18 +201,12 @@ const uint32_t *mtg_classify_d_out_nodes(const mtg_device *d);
 int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_t src_end,
                         uint64_t *d_pool, uint64_t pool_capacity, uint64_t *d_cand_start,
                         uint32_t *d_cand_count, uint64_t *pool_needed);
-/* GPU time (ms, HIP events on `stream`) of the SSSP stage of the last mtg_sssp_candidates call: the span from its first kernel to its last when the
- * enumeration level ran (its post-pass overlaps the cooperative levels: mtg_last_sssp_post_pass), else the sum of the level kernels' durations. */
+/* Sum of the HIP-event durations (ms) of the SSSP level kernels of the last mtg_sssp_candidates call. */
 double mtg_last_sssp_kernel_ms(const mtg_device *d);
 /* Per level of that call: kernel duration (ms) and number of sources handed to the level. Level 0 is the
  * lane-per-source kernel (or the first cooperative level with preset 4); later levels re-run overflowed sources.
  * Returns the number of levels written (<= capacity). */
 int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity);
-/* The post-pass of the enumeration level in the last search (fix_compact_kernel + sort_lists_kernel: the candidate lists of more than four keys
- * put into Dijkstra order): it runs on a stream of its own, behind the enumeration kernel and BESIDE the cooperative levels (which work on the
- * sources the level could not finish), and the caller's stream is joined when the search ends. *ms_out: its GPU time (0 if none ran);
- * *lists_out: lists it handled. mtg_last_sssp_kernel_ms is the span of the whole stage, so overlapped kernels are not counted twice. */
-void mtg_last_sssp_post_pass(const mtg_device *d, double *ms_out, uint64_t *lists_out);
 /* Kernel instantiation that ran as level `level` of the last call ("" beyond the last level); valid until the next call. */
 const char *mtg_last_sssp_level_name(const mtg_device *d, int level);
 /* Runs the counting variant of the kernel (untimed instrumentation) over the same sources. */

@@ -156,7 +156,6 @@ def load():
         "mtg_sssp_candidates": (C.c_int, [vp, vp, u64, u64, vp, u64, vp, vp, P(u64)]),
         "mtg_last_sssp_kernel_ms": (C.c_double, [vp]),
         "mtg_last_sssp_levels": (C.c_int, [vp, P(C.c_double), P(u64), C.c_int]),
-        "mtg_last_sssp_post_pass": (None, [vp, P(C.c_double), P(u64)]),
         "mtg_last_sssp_level_name": (C.c_char_p, [vp, C.c_int]),
         "mtg_sssp_count": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),
         "mtg_sssp_count_visited": (None, [vp, vp, u64, u64, P(MtgSsspStats)]),

@@ -490,12 +490,6 @@ class DeviceGraph:
         return [{"level": i, "ms": float(ms[i]), "sources": int(src[i]),
                  "kernel": self._L.mtg_last_sssp_level_name(self._d, i).decode()} for i in range(n)]
 
-    def last_sssp_post_pass(self) -> dict:
-        """mtg_last_sssp_post_pass: GPU ms of the enumeration level's post-pass (side stream, beside the cooperative levels) and its lists."""
-        ms, n = C.c_double(), C.c_uint64()
-        self._L.mtg_last_sssp_post_pass(self._d, C.byref(ms), C.byref(n))
-        return {"ms": float(ms.value), "lists": int(n.value)}
-
     def sssp_count(self, src_begin: int, src_end: int, stream: int = 0) -> dict:
         st = _lib.MtgSsspStats()
         self._L.mtg_sssp_count(self._d, stream, src_begin, src_end, C.byref(st))

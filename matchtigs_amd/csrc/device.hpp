@@ -45,7 +45,6 @@ bool device_prunes(const Device *d);
 uint64_t device_last_active_sources(const Device *d);
 double device_last_kernel_ms(const Device *d);
 const char *device_last_level_name(const Device *d, int level);
-void device_last_post_pass(const Device *d, double *ms, uint64_t *lists);  // the enumeration level's post-pass (side stream, beside the cascade)
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap);
 int device_set_plan(Device *d, int plan);
 int device_last_replay_rounds(const Device *d);

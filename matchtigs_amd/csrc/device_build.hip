@@ -497,8 +497,6 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
     HIP_CHECK(hipHostMalloc(&d->h_counters, C_COUNT * sizeof(unsigned long long)));
     HIP_CHECK(hipEventCreate(&d->ev0));
     HIP_CHECK(hipEventCreate(&d->ev1));
-    for (auto &e : d->ev_s) HIP_CHECK(hipEventCreate(&e));
-    HIP_CHECK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (non-blocking: a caller may work on the legacy default stream)
     for (auto &e : d->ev_r) HIP_CHECK(hipEventCreate(&e));
     dl.lap("allocations");
     // (through the pinned ring: host threads fill the next slice while one crosses PCIe -- the runtime stages a pageable upload on one
@@ -595,8 +593,6 @@ void device_free(Device *d) {
     (void)hipHostFree(d->h_counters);
     (void)hipEventDestroy(d->ev0);
     (void)hipEventDestroy(d->ev1);
-    for (auto e : d->ev_s) (void)hipEventDestroy(e);
-    if (d->side) (void)hipStreamDestroy(d->side);
     for (auto e : d->ev_r) (void)hipEventDestroy(e);
     delete d;
 }

@@ -171,14 +171,6 @@ struct Device {
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;  // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // SSSP stage with the enumeration level: its post-pass (fix_compact + sort_lists) runs on a stream of its own, beside the cooperative
-    // cascade (different sources: they share nothing but the pool cursor's neighbourhood). ev_s[0] stage begin, [1] enumeration kernel done,
-    // [2] / [3] post-pass begin / end (on `side`), [4] stage end (after the join)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double last_post_ms = 0.0;  // the post-pass of the last search (0: none ran) and the lists it put in order
-    uint64_t last_post_lists = 0, last_fix_lists = 0;
-    bool post_pending = false;  // a post-pass is running on `side`: the caller's stream has to wait for ev_s[3]
     hipEvent_t ev_r[4] = {nullptr, nullptr, nullptr, nullptr};  // claim replay: start, before / after the rounds kernel, end of the GPU work
     double last_replay_kernel_ms = 0.0, last_replay_gpu_ms = 0.0;
     double last_wall_s[3] = {0, 0, 0};  // host wall clock of the last device_pairs[_multi]: SSSP stage (+ gather), claim replay, pair download

@@ -1035,7 +1035,7 @@ constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_N
 constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
 static std::string enum_level_name(bool quad, bool prune) {
     char b[160];
-    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s>", prune ? "active_range_kernel + " : "",
+    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
                   ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
     return b;
 }
@@ -1108,22 +1108,13 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(d->ev1, st));
-    HIP_CHECK(hipEventRecord(d->ev_s[1], st));
-    // The post-pass puts the longer lists of FINISHED sources in order, in place; the cooperative cascade that follows on `st` works on
-    // the sources the level could NOT finish (its keys go to fresh pool space behind the cursor): disjoint data, so the two run side
-    // by side -- the post-pass on the device's side stream behind the enumeration kernel, the caller's stream joined at the end of
-    // the stage (run_levels). 0.33 ms of post-pass beside 0.31 ms of cascade at 2^27 instead of one after the other.
     const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
     static_assert(ENUM_MAX_HITS <= 32, "the post-pass sorts up to 32 keys");
-    HIP_CHECK(hipStreamWaitEvent(d->side, d->ev_s[1], 0));
-    HIP_CHECK(hipEventRecord(d->ev_s[2], d->side));
-    hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, d->side, args.fix_list, args.counters, d->d_fix_dense);
-    hipLaunchKernelGGL((sort_lists_kernel<256>), dim3(3 * post_grid), dim3(256), 0, d->side, args.pool, args.pool_cap, args.cand_start,
+    hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.counters, d->d_fix_dense);
+    hipLaunchKernelGGL((sort_lists_kernel<256>), dim3(3 * post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
                        args.cand_count, d->d_fix_dense, args.counters);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(d->ev_s[3], d->side));
-    d->post_pending = true;
+    HIP_CHECK(hipEventRecord(d->ev1, st));
 }
 
 static void launch_level(Device *d, hipStream_t st, const LevelCfg &cfg, bool count, SsspArgs args) {
@@ -1328,9 +1319,6 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
         return small ? 1 : 0;
     }
     uint64_t n_first = n;  // sources the first level really launches over
-    d->post_pending = false;
-    d->last_post_ms = 0.0; d->last_post_lists = 0;
-    HIP_CHECK(hipEventRecord(d->ev_s[0], st));
     if (use_enum) launch_enum(d, st, a);
     else if (prune_count) {
         if (n) {
@@ -1345,7 +1333,6 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
     } else launch_level(d, st, coop_level(first_coop, false), count, a);
     read_counters(d, st);
     if (use_enum && enum_prunes(d)) d->last_active_sources = d->h_counters[C_ACTIVE];
-    if (use_enum) d->last_fix_lists = d->h_counters[C_FIX_CLASS0] + d->h_counters[C_FIX_CLASS0 + 1] + d->h_counters[C_FIX_CLASS0 + 2];
     d->last_n_levels = 0;
     if (n && n_first) {
         total_ms += elapsed_ms(d);
@@ -1419,22 +1406,6 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
         }
         if (debug) std::fprintf(stderr, "[mtg] dense level: %llu sources, %.3f ms\n", (unsigned long long)n_ovf, ms);
         d->h_counters[C_OVERFLOW] = 0;
-    }
-    // the stage ends when both streams are through: the caller's stream waits for the post-pass, and the stage's time is the span from
-    // its first kernel to that point (HIP events on the caller's stream) -- overlapped kernels are not counted twice, host gaps
-    // between levels (the counters' round trips) are inside it
-    if (d->post_pending) {
-        HIP_CHECK(hipStreamWaitEvent(st, d->ev_s[3], 0));
-        HIP_CHECK(hipEventRecord(d->ev_s[4], st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        float span = 0.f, post = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&span, d->ev_s[0], d->ev_s[4]));
-        HIP_CHECK(hipEventElapsedTime(&post, d->ev_s[2], d->ev_s[3]));
-        d->last_post_ms = post;
-        d->last_post_lists = d->last_fix_lists;
-        if (debug) std::fprintf(stderr, "[mtg] post-pass %.3f ms on the side stream; stage span %.3f ms (sum of its parts %.3f)\n", post, span, total_ms + post);
-        total_ms = span;
-        d->post_pending = false;
     }
     if (!count) d->last_kernel_ms = total_ms;
     if (stats) {
@@ -1517,10 +1488,6 @@ void device_performance_data(Device *d, void *stream, mtg_dijkstra_performance_d
 double device_last_kernel_ms(const Device *d) { return d->last_kernel_ms; }
 const char *device_last_level_name(const Device *d, int level) {
     return level >= 0 && level < d->last_n_levels ? d->last_level_name[level].c_str() : "";
-}
-void device_last_post_pass(const Device *d, double *ms, uint64_t *lists) {
-    if (ms) *ms = d->last_post_ms;
-    if (lists) *lists = d->last_post_lists;
 }
 int device_last_levels(const Device *d, double *ms, uint64_t *sources, int cap) {
     const int n = d->last_n_levels < cap ? d->last_n_levels : cap;

@@ -249,7 +249,6 @@ int mtg_sssp_candidates(mtg_device *d, void *stream, uint64_t src_begin, uint64_
                         uint64_t pool_capacity, uint64_t *d_cand_start, uint32_t *d_cand_count, uint64_t *pool_needed) {
     return device_sssp(d->d, stream, src_begin, src_end, d_pool, pool_capacity, d_cand_start, d_cand_count, pool_needed);
 }
-void mtg_last_sssp_post_pass(const mtg_device *d, double *ms, uint64_t *lists) { device_last_post_pass(d->d, ms, lists); }
 double mtg_last_sssp_kernel_ms(const mtg_device *d) { return device_last_kernel_ms(d->d); }
 int mtg_last_sssp_levels(const mtg_device *d, double *ms_out, uint64_t *sources_out, int capacity) {
     return device_last_levels(d->d, ms_out, sources_out, capacity);

@@ -909,9 +909,13 @@ Walks device_finish(HostGraph &g, const Pair *pairs, uint64_t n_pairs, uint64_t 
                 HIP_CHECK(hipStreamWaitEvent(side, ev_heads, 0));
                 if (!pairs && n_pairs) download_sliced(h_pw_p, d_pw, n_pairs * 4, side, device_id);
                 pw_ready.store(true, std::memory_order_release);
+                // (the weights and dummy ids need nothing but the pair weights: written beside the two downloads, which wait for PCIe --
+                // since the tigs come straight from the pairing the GPU stages are through in 14 ms at 2^27, and downloads followed by
+                // the fill took longer than that)
+                std::thread filler(fill);
                 download_sliced(h_from, d_from + E0, n_dummy * 4, side, device_id);
                 download_sliced(h_to, d_to, n_dummy * 4, side, device_id);
-                fill();
+                filler.join();
             });
         } else {
             download(st);
