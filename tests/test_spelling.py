@@ -105,6 +105,26 @@ def test_duplication_bitvector(product_lib):
     assert [len(l) for l in got.splitlines()] == [len(s) - k + 1 for s in _fasta_seqs(fa)]
 
 
+def test_duplication_bitvector_of_greedy_tigs_against_the_oracle(oracle, product_lib):
+    """The '0' branch by bytes, against data the product did not make: greedy matchtigs keep matched dummy edges, whose k-mers are
+    duplicates. Expected text = implementation/mod.rs:668-702 evaluated over the ORACLE's graph (its edge weights and dummy ids after its
+    own insertion + Eulerisation) and the oracle's tigs; the product writes the same bytes from its own graph and tigs."""
+    import helpers
+
+    k = 15
+    ug = synth.g_seq(4000, seed=3, k=k, haplotypes=4, sub_rate=0.03)
+    og = oracle.OracleGraph.from_unitig_links(ug.weights, ug.links)
+    G = api.Bigraph.from_unitig_links(ug.weights, ug.links)
+    pr = helpers.product_pairs_from_oracle_lists(G, oracle.OracleGraph.from_unitig_links(ug.weights, ug.links), k)
+    tigs = G.finish_greedytigs(pr, k)
+    otigs, _ = og.compute_greedytigs(k)
+    oe = og.edges()  # (from, to, weight, dummy id, handle, forwards) of the oracle's graph after its own finish
+    want = "".join("".join(("1" if oe[e][3] == 0 else "0") * int(oe[e][2]) for e in t) + "\n" for t in otigs)
+    got = api.write_duplication_bitvector(G, tigs).decode()
+    assert got == want
+    assert got.count("0") > 0 and got.count("1") == len(ug.kmers)
+
+
 @pytest.mark.gpu
 def test_device_spelling_is_byte_identical(oracle, product_lib):
     """SURVEY f-1 on the device (spell_device.hip): FASTA and GFA bytes equal the host speller's and the oracle's, for greedy
