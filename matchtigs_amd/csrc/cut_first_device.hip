@@ -52,7 +52,9 @@ constexpr uint32_t MARK = 0x80000000u;  // bit 31 of a successor word: the first
 // search for unwalked trails looks at exactly the darts with that property (unwalked_rep_kernel). The mark is a plain store of the word
 // just read with bit 31 set: every dart is walked by one walker only, and nobody waits for the store.
 __device__ __forceinline__ bool is_rep_candidate(uint32_t x, uint32_t prev, uint32_t next) { return !(x & 1u) && x <= prev && x <= next; }
-__global__ __launch_bounds__(EB) void stretch_measure_kernel(uint32_t *succ, uint64_t first_brk, uint64_t n_brk, uint32_t *len_out, uint32_t *end_out,
+// Output per walker: the length of its stretch if the stretch is emitted, else 0, and the emit flag. The stretch behind breaking dart b that
+// ends before breaking dart e is emitted iff it is not empty and b < (e ^ 1) (its mirror image lies behind e ^ 1 and ends before b ^ 1).
+__global__ __launch_bounds__(EB) void stretch_measure_kernel(uint32_t *succ, uint64_t first_brk, uint64_t n_brk, uint32_t *keep_len, uint32_t *is_tig,
                                                             unsigned long long *walked_blocks, uint32_t *error) {
     const uint64_t i = gid();
     uint32_t len = 0;
@@ -67,8 +69,9 @@ __global__ __launch_bounds__(EB) void stretch_measure_kernel(uint32_t *succ, uin
             x = s;
             if (++len == 0xFFFFFFFFu) { atomicOr(error, 4u); break; }
         }
-        len_out[i] = len;
-        end_out[i] = x;
+        const bool emit = len != 0 && b < (x ^ 1u);
+        keep_len[i] = emit ? len : 0u;
+        is_tig[i] = emit ? 1u : 0u;
         if (x == (b ^ 1u)) atomicOr(error, 8u);  // a stretch that is its own mirror image: the pairing's trails would not be disjoint from their mirrors
     }
     // darts walked, per block (summed by sum_blocks_kernel: 740 K waves adding to one word cost more than the walk itself)
@@ -96,16 +99,6 @@ __global__ __launch_bounds__(1024) void sum_blocks_kernel(const unsigned long lo
         *out = b;
     }
 }
-// the stretch behind breaking dart b = first_brk + i is emitted iff it is not empty and b < (its end ^ 1)
-__global__ __launch_bounds__(EB) void stretch_select_kernel(uint64_t first_brk, uint64_t n_brk, const uint32_t *len, const uint32_t *end, uint32_t *keep_len,
-                                                           uint32_t *is_tig) {
-    const uint64_t i = gid();
-    if (i >= n_brk) return;
-    const uint32_t b = (uint32_t)(first_brk + i);
-    const bool emit = len[i] != 0 && b < (end[i] ^ 1u);
-    keep_len[i] = emit ? len[i] : 0u;
-    is_tig[i] = emit ? 1u : 0u;
-}
 // ---- pass 2: the emitted stretches are walked once more and written to their places ------------------------------------------------
 __global__ __launch_bounds__(EB) void stretch_write_kernel(const uint32_t *succ, uint64_t first_brk, uint64_t n_brk, const uint32_t *keep_len,
                                                           const uint32_t *edge_off, const uint32_t *tig_idx, uint32_t *tig_edges, uint32_t *tig_limits) {
@@ -129,30 +122,42 @@ __global__ __launch_bounds__(EB) void stretch_write_kernel(const uint32_t *succ,
 // `max_len` raises bit 32 of *error: such a graph goes through the closed walks instead.
 __global__ __launch_bounds__(EB) void unwalked_rep_kernel(const uint32_t *succ, uint64_t first_brk, uint32_t max_len, uint32_t *cursor, uint32_t cap, uint32_t *list,
                                                          uint32_t *error) {
-    const uint64_t x64 = gid() * 2;
-    if (x64 >= first_brk) return;
-    const uint32_t x = (uint32_t)x64;
-    const uint2 w = reinterpret_cast<const uint2 *>(succ)[x >> 1];  // succ[x], succ[x ^ 1]
-    if (w.x & MARK) return;
-    const uint32_t next = w.x, prev = (w.y & ~MARK) ^ 1u;
-    if (!(x <= prev && x <= next)) return;
-    // (an unmarked candidate: on an unwalked trail -- a walked one would have been marked)
-    uint32_t len = 0, lo = x;
-    for (uint32_t y = x;;) {
-        lo = min(lo, y & ~1u);
-        len++;
-        y = succ[y] & ~MARK;
-        if (y == x) break;
-        if (y >= first_brk || len > max_len) { atomicOr(error, y >= first_brk ? 64u : 32u); return; }
+    // (eight successor words = four even darts with their mirrors per thread: a streaming pass at a few bytes per thread runs at a
+    // quarter of the bandwidth)
+    const uint64_t x0 = gid() * 8;
+    if (x0 >= first_brk) return;
+    uint32_t w[8];
+    if (x0 + 8 <= first_brk) {
+        const uint4 a = reinterpret_cast<const uint4 *>(succ)[x0 / 4], b = reinterpret_cast<const uint4 *>(succ)[x0 / 4 + 1];
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+        for (int t = 0; t < 8; t++) w[t] = x0 + t < first_brk ? succ[x0 + t] : MARK;
     }
-    if (lo != x) return;
-    const uint32_t at = atomicAdd(cursor, 2u * len);
-    if (!list) return;
-    uint32_t o = at;
-    for (uint32_t y = x, j = 0; j < len; j++) {
-        if (o + 1 < cap) { list[o] = y; list[o + 1] = y ^ 1u; }
-        o += 2;
-        y = succ[y] & ~MARK;
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+        const uint32_t x = (uint32_t)x0 + t;
+        if ((w[t] & MARK) || x0 + t >= first_brk) continue;
+        const uint32_t next = w[t], prev = (w[t + 1] & ~MARK) ^ 1u;
+        if (!(x <= prev && x <= next)) continue;
+        // (an unmarked candidate: on an unwalked trail -- a walked one would have been marked)
+        uint32_t len = 0, lo = x;
+        bool bad = false;
+        for (uint32_t y = x;;) {
+            lo = min(lo, y & ~1u);
+            len++;
+            y = succ[y] & ~MARK;
+            if (y == x) break;
+            if (y >= first_brk || len > max_len) { atomicOr(error, y >= first_brk ? 64u : 32u); bad = true; break; }
+        }
+        if (bad || lo != x) continue;
+        const uint32_t at = atomicAdd(cursor, 2u * len);
+        if (!list) continue;
+        uint32_t o = at;
+        for (uint32_t y = x, j = 0; j < len; j++) {
+            if (o + 1 < cap) { list[o] = y; list[o + 1] = y ^ 1u; }
+            o += 2;
+            y = succ[y] & ~MARK;
+        }
     }
 }
 
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(EB) void succ_patch_kernel(uint32_t *succ, const ui
 }
 // a stretch that took a spliced trail in: from any dart on it back to its walker (pred(x) = succ[x ^ 1] ^ 1), then measured again.
 // Several darts of one stretch arrive at the same walker and write the same values.
-__global__ __launch_bounds__(EB) void stretch_fix_kernel(uint32_t *succ, const uint32_t *darts, uint32_t n, uint64_t first_brk, uint32_t *len_out, uint32_t *end_out,
+__global__ __launch_bounds__(EB) void stretch_fix_kernel(uint32_t *succ, const uint32_t *darts, uint32_t n, uint64_t first_brk, uint32_t *keep_len, uint32_t *is_tig,
                                                         uint32_t *error) {
     const uint64_t i = gid();
     if (i >= n) return;
@@ -200,8 +205,9 @@ __global__ __launch_bounds__(EB) void stretch_fix_kernel(uint32_t *succ, const u
         x = s & ~MARK;
         if (++len == 0xFFFFFFFFu) { atomicOr(error, 4u); return; }
     }
-    len_out[y - first_brk] = len;
-    end_out[y - first_brk] = x;
+    const bool emit = len != 0 && y < (x ^ 1u);
+    keep_len[y - first_brk] = emit ? len : 0u;
+    is_tig[y - first_brk] = emit ? 1u : 0u;
     if (x == (y ^ 1u)) atomicOr(error, 8u);
 }
 
@@ -364,12 +370,12 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
     lap("buckets");
     device_pairing(st, d_mirror, V, d_row, d_adj, d_succ, d_error);
     lap("pairing");
-    Buf b_len, b_end, b_keep, b_flag;
-    uint32_t *d_len = b_len.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1)), *d_end = b_end.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1));
+    Buf b_keep, b_flag, b_off;
+    uint32_t *d_keep = b_keep.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1)), *d_flag = b_flag.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1));
     Buf b_wsum;
     unsigned long long *d_wsum = b_wsum.alloc<unsigned long long>(st, std::max<uint64_t>(grid_for(n_brk), 1));
     if (n_brk) {
-        stretch_measure_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_len, d_end, d_wsum, d_error);
+        stretch_measure_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_keep, d_flag, d_wsum, d_error);
         sum_blocks_kernel<<<1, 1024, 0, st>>>(d_wsum, grid_for(n_brk), d_small);
     }
     unsigned long long h_small[8];
@@ -388,7 +394,7 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
         const uint32_t nf = (uint32_t)unwalked;
         Buf b_list, b_hs, b_hv, b_hd;
         uint32_t *d_list = b_list.alloc<uint32_t>(st, nf), *d_hs = b_hs.alloc<uint32_t>(st, nf), *d_hv = b_hv.alloc<uint32_t>(st, nf), *d_hd = b_hd.alloc<uint32_t>(st, nf);
-        unwalked_rep_kernel<<<grid_for((first_brk + 1) / 2), EB, 0, st>>>(d_succ, first_brk, 1u << 16, d_unwalked, nf, d_list, d_error);
+        unwalked_rep_kernel<<<grid_for((first_brk + 7) / 8), EB, 0, st>>>(d_succ, first_brk, 1u << 16, d_unwalked, nf, d_list, d_error);
         std::vector<uint32_t> fd(nf), fs(nf), fv(nf), ro(nf + 1);
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -436,7 +442,7 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
             HIP_CHECK(hipMemcpyAsync(d_pv, sp.patch_value.data(), (uint64_t)np * 4, hipMemcpyHostToDevice, st));
             if (nt) HIP_CHECK(hipMemcpyAsync(d_td, sp.touched.data(), (uint64_t)nt * 4, hipMemcpyHostToDevice, st));
             succ_patch_kernel<<<grid_for(np), EB, 0, st>>>(d_succ, d_pd, d_pv, np);
-            if (nt) stretch_fix_kernel<<<grid_for(nt), EB, 0, st>>>(d_succ, d_td, nt, first_brk, d_len, d_end, d_error);
+            if (nt) stretch_fix_kernel<<<grid_for(nt), EB, 0, st>>>(d_succ, d_td, nt, first_brk, d_keep, d_flag, d_error);
             HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             if ((uint32_t)h_small[1]) MTG_DIE("device_cut_first: internal error %u after the splices", (uint32_t)h_small[1]);
@@ -446,12 +452,10 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
     }
     b_row.release();
     b_adj.release();
-    uint32_t *d_keep = b_keep.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1)), *d_flag = b_flag.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1));
+    uint32_t *d_off = b_off.alloc<uint32_t>(st, std::max<uint64_t>(n_brk, 1));
     uint32_t *d_tot = reinterpret_cast<uint32_t *>(d_small + 3);
-    if (n_brk) stretch_select_kernel<<<grid_for(n_brk), EB, 0, st>>>(first_brk, n_brk, d_len, d_end, d_keep, d_flag);
-    b_end.release();
-    // (exclusive scans, in place over the flags / into the length array that pass 1 no longer needs)
-    scan_u32<uint32_t>(st, d_keep, n_brk, d_len, d_bsum, d_tot);
+    // (exclusive scans: the emitted lengths -> edge offsets; the flags, in place -> tig indices)
+    scan_u32<uint32_t>(st, d_keep, n_brk, d_off, d_bsum, d_tot);
     scan_u32<uint32_t>(st, d_flag, n_brk, d_flag, d_bsum, d_tot + 2);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, 64, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -461,7 +465,7 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
         MTG_DIE("device_cut_first: internal error (the tigs hold %llu of %llu biedges)", (unsigned long long)(n_kept + sp.cyc_dropped), (unsigned long long)(first_brk / 2));
     lap("selection + scans");
     uint32_t *d_te = b_te.alloc<uint32_t>(st, std::max<uint64_t>(n_kept, 1)), *d_tl = b_tl.alloc<uint32_t>(st, std::max<uint64_t>(n_tigs, 1));
-    if (n_brk) stretch_write_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_keep, d_len, d_flag, d_te, d_tl);
+    if (n_brk) stretch_write_kernel<<<grid_for(n_brk), EB, 0, st>>>(d_succ, first_brk, n_brk, d_keep, d_off, d_flag, d_te, d_tl);
     HIP_CHECK(hipGetLastError());
     if (!sp.cyc_limits.empty()) {
         for (uint32_t &l : sp.cyc_limits) l += (uint32_t)n_kept_s;
