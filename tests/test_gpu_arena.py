@@ -59,3 +59,34 @@ def test_reserved_step_makes_no_driver_allocation(product_lib):
 def product_lib_step_estimate(G):
     V, E = G.node_count(), G.original_edge_count()
     return (V * 60 + E * 62) // 100 * 108 + (64 << 20)
+
+
+@pytest.mark.gpu
+def test_reserve_ahead_can_be_turned_off(product_lib):
+    """mtg_set_reserve_ahead(0): a host-only graph constructor starts no helper thread and takes no GPU memory (round-5 advice: a pure host
+    API must not have GPU side effects its caller did not opt into); with the default, the constructor's helper thread reserves the
+    call's chunk. A process of its own: the arena starts empty."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "from matchtigs_amd import api, synth\n"
+        "bg = synth.g_csr(2_000_000, seed=3, k=31)\n"
+        "api.set_reserve_ahead(False)\n"
+        "G = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)\n"
+        "time.sleep(1.0)\n"
+        "off = api.device_arena_stats(0)\n"
+        "api.set_reserve_ahead(True)\n"
+        "G2 = api.Bigraph.from_edges(bg.mirror, bg.edge_from, bg.edge_to, bg.edge_weight)\n"
+        "for _ in range(100):\n"
+        "    on = api.device_arena_stats(0)\n"
+        "    if on['chunk_bytes']: break\n"
+        "    time.sleep(0.1)\n"
+        "tigs = api.GreedytigAlgorithm.compute_tigs_np(G2, api.GreedytigAlgorithmConfiguration.new(1, 31))\n"
+        "print('RESULT', off['chunk_bytes'], off['driver_allocations'], on['chunk_bytes'], len(tigs[0]))\n") % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    off_bytes, off_allocs, on_bytes, n_tigs = (int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:])
+    assert off_bytes == 0 and off_allocs == 0
+    assert on_bytes >= (256 << 20) and n_tigs > 0
