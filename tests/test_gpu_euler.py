@@ -192,6 +192,46 @@ def test_device_order_with_self_mirror_nodes_at_bench_size(gpu, algorithm):
     print(f"{algorithm}: tigs reference order {ref[0]}, cut first {cut[0]}, closed walks {walks[0]}; {n_sm} self-mirror nodes")
 
 
+@pytest.mark.parametrize("ring", [30_000, 70_000])
+def test_device_order_with_a_large_balanced_component(gpu, ring):
+    """Trails WITHOUT a breaking dart at size (cut_first_device.hip): a G-csr graph plus a separate ring of `ring` unitigs -- a balanced
+    component: no breaking edge, two mirror trails of `ring` darts that no walker passes. 30 000: found through their unmarked local
+    minima, listed, and turned into one cyclic tig by the host's splicing step; 70 000: longer than one thread walks (65 536), so the
+    step goes through the closed walks of euler_device.hip instead. Either way: valid tigs, the reference-order tig count, every unitig
+    once; the ring is one tig of `ring` edges."""
+    import gpu_props
+    from matchtigs_amd import api, synth
+
+    torch = gpu
+    k = 31
+    bg = synth.g_csr(2_400_000, seed=8, k=k, self_mirror_frac=0.0)   # ~7.2 M original darts: a 64th of the darts is above 65 536
+    V0 = bg.n_nodes
+    a = V0 + 2 * np.arange(ring, dtype=np.uint32)            # ring node i and its mirror a + 1
+    mirror = np.concatenate([bg.mirror, np.stack([a + 1, a], axis=1).reshape(-1)]).astype(np.uint32)
+    nxt = np.roll(a, -1)
+    e_from = np.concatenate([bg.edge_from, np.stack([a, nxt + 1], axis=1).reshape(-1)]).astype(np.uint32)   # a_i -> a_{i+1}; mirror(a_{i+1}) -> mirror(a_i)
+    e_to = np.concatenate([bg.edge_to, np.stack([nxt, a + 1], axis=1).reshape(-1)]).astype(np.uint32)
+    e_w = np.concatenate([bg.edge_weight, np.full(2 * ring, 5, bg.edge_weight.dtype)])
+    G = api.Bigraph.from_edges(mirror, e_from, e_to, e_w)
+    n_orig = G.original_edge_count()
+
+    def run(mode):
+        lim, ed = api.GreedytigAlgorithm.compute_tigs_np(G, api.GreedytigAlgorithmConfiguration(1, k, euler_mode=mode))
+        cum, _ = gpu_props.check_tigs(torch, G, lim, ed, k)
+        G.reset()
+        starts = np.concatenate([[0], lim[:-1]]).astype(np.int64)
+        lens = lim.astype(np.int64) - starts
+        in_ring = ed.astype(np.int64) >= n_orig - 2 * ring
+        in_ring &= ed.astype(np.int64) < n_orig
+        ring_tigs = np.unique(np.searchsorted(lim.astype(np.int64), np.nonzero(in_ring)[0], side="right"))
+        return len(lim), cum, [int(lens[t]) for t in ring_tigs]
+
+    ref = run(api.EulerMode.HostReferenceOrder)
+    dev = run(api.EulerMode.Device)
+    assert ref[2] == [ring] and dev[2] == [ring]          # the ring: one tig holding each of its unitigs once, in either order
+    assert dev[0] == ref[0] and dev[1] == ref[1]          # (no self-mirror node: tig count and cumulative length are invariant)
+
+
 def test_device_euler_is_reproducible(gpu):
     """No step of the device decomposition depends on thread timing: two runs give identical walks."""
     from matchtigs_amd import api, synth
