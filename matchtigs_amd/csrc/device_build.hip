@@ -584,8 +584,6 @@ void device_free(Device *d) {
     for (int i = 0; i < 2; i++) hu::device_free(d->d_ovf[i]);
     hu::device_free(d->d_fix);
     hu::device_free(d->d_fix_dense);
-    hu::device_free(d->d_act_res_start);
-    hu::device_free(d->d_act_res_count);
     ReplayWork &w = d->replay;
     void *rb[] = {w.state, w.resv[0], w.resv[1], w.touch, w.src_mirror, w.dense, w.claims, w.pending[0], w.pending[1], w.spill,
                   w.final_off, w.block_sums, w.ctl, w.out};

@@ -122,8 +122,6 @@ struct SsspArgs {
     uint32_t wmask;              // inline weight slots: 0xFF in the 8:8 format (k <= 255: weight | weight + lower bound << 8), else 0xFFFF
     uint32_t prune;              // cooperative levels: 1 = skip a successor whose lower bound puts every in-node behind it beyond the bound
     const uint32_t *act_index;   // enumeration level with pruning: the classification's list of sources that can reach an in-node (absolute
-    unsigned long long *act_start;  // enumeration level with pruning: the results of the launch's searched sources, DENSE over the launch's part of
-    uint32_t *act_count;            // that list (entry = position in it): see sssp_enum_kernel's result stores and expand_active_kernel
     const uint32_t *act_node;    // indices, ascending) and their nodes; the launch's part of it is counters[C_ACT_BEGIN] .. + counters[C_ACTIVE]
                                  // (neither number travels to the host before the launch)
 };
@@ -179,8 +177,6 @@ struct Device {
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
-    unsigned long long *d_act_res_start = nullptr;  // [ovf_cap] dense (start, count) of the searched sources of a launch (pruned enumeration level)
-    uint32_t *d_act_res_count = nullptr;
     uint32_t *d_fix = nullptr, *d_fix_dense = nullptr;  // enumeration level: work list of its post-pass (chunked, as written / dense, by length class)
     uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
     prefetch_chunk();
     bool exhausted = cur_len == 0;
-    auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src, uint32_t &new_slot) -> bool {
+    auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src) -> bool {
         if (exhausted) return false;
         const unsigned long long need = __ballot(want);
         const uint32_t idx = cur_pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -566,10 +566,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         if constexpr (PRUNE) {
             const uint32_t item_cur = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ids_item), item_nxt = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)ahead_item);
             new_item = second ? item_nxt : item_cur;
-            new_slot = second ? nxt_base + idx - 64u : cur_base + idx;  // position in the launch's part of the searched-source list
         } else {
             new_item = second ? nxt_base + idx - 64u : cur_base + idx;
-            new_slot = new_item;
         }
         cur_pos += (uint32_t)__popcll(need);
         if (cur_pos >= 64u) {
@@ -583,7 +581,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 
     // ---- per-lane search state ----
     bool active = false;
-    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, item = 0, aslot = 0;
+    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, item = 0;
     uint32_t blk = SCRATCH;                       // word index of the lane's extension block
     uint32_t cur_node = 0, cur_dist = IDLE_DIST;  // the node whose block is in b0..b3
     bool cur_chk = false;                         // its own in-node flag was already evaluated from its parent's block
@@ -653,9 +651,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         return row < (uint32_t)H1 ? (uint32_t)(S1 * 64) + row * 64u + (uint32_t)lane : base + (uint32_t)(BE - 1 + H1) - row;
     };
     {
-        uint32_t ni = 0, ns = 0, nsl = 0;
-        if (take_source(true, ni, ns, nsl)) {
-            item = ni; aslot = nsl; src_node = ns; cur_node = ns; cur_dist = 0;
+        uint32_t ni = 0, ns = 0;
+        if (take_source(true, ni, ns)) {
+            item = ni; src_node = ns; cur_node = ns; cur_dist = 0;
             active = true;
         }
         load_block(active, cur_node);
@@ -789,8 +787,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const bool fin = active && !ovf && !go_on;  // the source is finished
 
         // ---- lanes without a next node take a new source; every lane's next gather leaves now ----
-        uint32_t new_item = 0, new_src = 0, new_slot = 0;
-        const bool got_new = take_source(!go_on, new_item, new_src, new_slot);
+        uint32_t new_item = 0, new_src = 0;
+        const bool got_new = take_source(!go_on, new_item, new_src);
         const uint32_t nx_node = go_on ? (uint32_t)top : new_src;
         load_block(go_on || got_new, nx_node);
         if constexpr (QUAD) __builtin_amdgcn_s_setprio(0);
@@ -836,29 +834,18 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             if (c > 3 && room) a.pool[pos + 3] = k3;
             for (uint32_t r = 4; __any(r < c); r++)
                 if (r < c && room) a.pool[pos + r] = mem[hit_word(blk, r)];
-            // (start, count): rounds 3-5 stored them only for the sources that have candidates (7 of 10 have none; their counts were zeroed
-            // before the launch) -- fewer stores, but every one of them a partial line. Round 6 stores them for EVERY finished source, into
-            // places that are consecutive per chunk, so that whole lines leave the cache:
-#ifndef MTG_EXP_NO_START_COUNT  // (development builds: what the two scattered stores per finished source cost -- tools/sssp_probe.py --lib)
-            if constexpr (PRUNE) {
-                // Round 6: with pruning the searched sources are 29 % of all, so `item` strides through cand_start / cand_count and every
-                // finished source left two partial-line stores behind -- measured (the build above, stores removed): 0.45 of the kernel's
-                // 1.4 ms. The results go to arrays that are DENSE over the searched sources instead (entry = position in the launch's part
-                // of the list: the 64 sources of a chunk fill the same four + eight lines while the chunk is in flight, every entry is
-                // written exactly once, empty lists included), and expand_active_kernel moves them to their sources' places in one
-                // streaming pass behind the kernel.
-                if (fin || ovf) {
-                    a.act_count[aslot] = ovf ? CAND_OVERFLOW : c;
-                    a.act_start[aslot] = pos;
-                }
-            } else {
-                // (every source of the launch is searched and its places are consecutive: every entry is written exactly once, empty lists
-                // included, so the 64 sources of a chunk fill whole lines and nothing has to be zeroed before the launch)
-                if (fin || ovf) {
-                    a.cand_count[item] = ovf ? CAND_OVERFLOW : c;
-                    a.cand_start[item] = pos;
-                }
-            }
+            // (7 of 10 sources have no candidate: their counts are zeroed by one streaming pass before the launch, their starts are
+            // never read -- two scattered partial-line stores less per such source: 1.85 -> 1.40 -> ... GB written per launch at 2^27)
+            // Round 6, measured on one box (tools/sssp_probe.py --lib, 2^27): without these two stores (-DMTG_EXP_NO_START_COUNT: wrong
+            // results, timing only) the kernel runs 1.00 instead of 1.26 ms -- but placing them densely (arrays over the searched sources
+            // only, every entry written once, whole lines per chunk) and moving them to the sources' places by a wave-cooperative streaming
+            // pass afterwards (0.125 ms) left the kernel at 1.25 ms: what they cost is issue slots in a loop that is bound by
+            // instruction issue, not memory traffic. Stage 1.82 -> 1.93 ms: dropped (docs/history has the kernel).
+#ifndef MTG_EXP_NO_START_COUNT
+            if (fin && c) {
+                a.cand_start[item] = pos;
+                a.cand_count[item] = c;
+            } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
 #endif
             // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
             // similar length with a network of that size)
@@ -906,7 +893,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             blk = SCRATCH;
             cur_chk = false;
             active = got_new;
-            item = new_item; aslot = new_slot; src_node = new_src; cur_node = new_src;
+            item = new_item; src_node = new_src; cur_node = new_src;
             cur_dist = got_new ? 0u : IDLE_DIST;
         }
     }
@@ -940,47 +927,6 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 // The level's work list is chunked (slot 0 of a chunk names its length class, unused slots hold FIX_NONE); this pass makes it dense:
 // class 0 first, then class 1, then class 2 (the level counted the entries per class), so that the sorting kernels below run over
 // plain ranges.
-// The pruned enumeration level's results, from the arrays that are dense over the searched sources to the sources' own places: entry a of
-// the launch's part of the list belongs to source act_index[first + a]. One WAVE per 64 consecutive entries: their sources lie in an
-// index range of a few hundred places (three of ten sources are searched), which the wave assembles in LDS -- zeros, then every lane's
-// (count, start) at its source's offset -- and writes out as one contiguous run: full lines, coalesced, zeros for the sources in between
-// (their counts are zero anyway: memset before the launch). A range beyond the LDS window (a long stretch of unsearched sources) is
-// written entry by entry instead. (First form, one thread per entry with a short zero loop behind it: 0.23 ms at 2^27, every store
-// instruction touching every fourth place; this form: see DESIGN.md 4.3.)
-constexpr uint32_t EXPAND_WINDOW = 1024;
-__global__ __launch_bounds__(64) void expand_active_kernel(const uint32_t *act_index, const unsigned long long *counters, uint64_t src_begin, uint64_t n_items,
-                                                          const unsigned long long *act_start, const uint32_t *act_count, unsigned long long *cand_start,
-                                                          uint32_t *cand_count) {
-    __shared__ uint32_t s_cnt[EXPAND_WINDOW];
-    __shared__ unsigned long long s_st[EXPAND_WINDOW];
-    const uint64_t n_act = counters[C_ACTIVE], first = counters[C_ACT_BEGIN];
-    const int lane = threadIdx.x;
-    for (uint64_t a0 = (uint64_t)blockIdx.x * 64; a0 < n_act; a0 += (uint64_t)gridDim.x * 64) {  // (block-uniform: the number of entries stays on the GPU)
-        const uint64_t a = a0 + lane;
-        const bool valid = a < n_act;
-        const uint64_t idx = valid ? (uint64_t)act_index[first + a] - src_begin : 0;
-        const uint32_t c = valid ? act_count[a] : 0u;
-        const unsigned long long st = valid ? act_start[a] : 0ull;
-        // the range this wave owns: from its first source to the next wave's first source (the last wave: only its own sources)
-        const uint64_t i_lo = __shfl(idx, 0, 64);
-        uint64_t i_hi;
-        if (a0 + 64 < n_act) i_hi = (uint64_t)act_index[first + a0 + 64] - src_begin;  // (uniform load)
-        else i_hi = __shfl(idx, (int)(n_act - a0 - 1), 64) + 1;
-        const uint64_t len = i_hi - i_lo;
-        if (len <= EXPAND_WINDOW) {  // (block-uniform)
-            for (uint32_t j = lane; j < len; j += 64) { s_cnt[j] = 0; s_st[j] = 0; }
-            __syncthreads();
-            if (valid) { s_cnt[idx - i_lo] = c; s_st[idx - i_lo] = st; }
-            __syncthreads();
-            for (uint32_t j = lane; j < len; j += 64) { cand_count[i_lo + j] = s_cnt[j]; cand_start[i_lo + j] = s_st[j]; }
-            __syncthreads();  // (the window is reused by the next round)
-        } else if (valid) {
-            cand_count[idx] = c;
-            cand_start[idx] = st;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_list, unsigned long long *counters, uint32_t *dense) {
     __shared__ uint32_t s_cnt[3], s_off[3];
     __shared__ unsigned long long s_base[3];
@@ -1100,8 +1046,8 @@ constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_N
 constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
 static std::string enum_level_name(bool quad, bool prune) {
     char b[160];
-    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s>%s + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
-                  ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "", prune ? " + expand_active_kernel" : "");
+    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
+                  ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
     return b;
 }
 
@@ -1168,14 +1114,11 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
         launch_active_list(d, st, args, args.n_items);
         args.act_index = d->d_act_index;
         args.act_node = d->d_act_node;
-        args.act_start = d->d_act_res_start;
-        args.act_count = d->d_act_res_count;
-    }  // (without pruning every source of the range is searched and stores its own count, zero included: nothing to clear)
+    } else {
+        HIP_CHECK(hipMemsetAsync(args.cand_count, 0, args.n_items * sizeof(uint32_t), st));  // (part of the level: see the kernel's result stores)
+    }
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(ENUM_WPB * 64), 0, st, args);
     HIP_CHECK(hipGetLastError());
-    if (prune)  // the results of the searched sources: from the dense arrays to the sources' places (the number of them stays on the GPU)
-        hipLaunchKernelGGL(expand_active_kernel, dim3((unsigned)std::min<uint64_t>((args.n_items + 63) / 64, (uint64_t)d->n_cu * 64)), dim3(64), 0, st, d->d_act_index, args.counters, args.src_begin,
-                           args.n_items, args.act_start, args.act_count, args.cand_start, args.cand_count);
     const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
     static_assert(ENUM_MAX_HITS <= 32, "the post-pass sorts up to 32 keys");
     hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.counters, d->d_fix_dense);
@@ -1359,9 +1302,6 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
         hu::device_malloc(&d->d_fix, fix_slots * sizeof(uint32_t));
         if (d->d_fix_dense) hu::device_free(d->d_fix_dense);
         hu::device_malloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
-        if (d->d_act_res_start) { hu::device_free(d->d_act_res_start); hu::device_free(d->d_act_res_count); }
-        hu::device_malloc(&d->d_act_res_start, std::max<uint64_t>(n, 1) * 8);
-        hu::device_malloc(&d->d_act_res_count, std::max<uint64_t>(n, 1) * 4);
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];

@@ -13,7 +13,7 @@ fetch = write = 0.0
 kernels = []
 for row in csv.DictReader(open(pmc)):
     k = row["kernel"]
-    if not k.startswith(("sssp_enum_kernel", "sort_lists_kernel", "fix_compact_kernel", "sssp_kernel", "active_range_kernel", "expand_active_kernel")):
+    if not k.startswith(("sssp_enum_kernel", "sort_lists_kernel", "fix_compact_kernel", "sssp_kernel", "active_range_kernel")):
         continue
     if row["counter"] == "FETCH_SIZE":
         fetch += float(row["mean_per_launch"]) * 1024
