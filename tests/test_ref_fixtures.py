@@ -83,3 +83,31 @@ def test_hip_path_reproduces_the_reference(product_lib):
     for rec in read_outputs():
         c = cases[rec["case"]]
         _compare(api.clib_compute_tigs(np.asarray(c["weights"], np.uint64), c["links"], rec["algorithm"], 1, c["k"]), rec)
+
+
+@pytest.mark.gpu
+def test_c_dumper_against_this_library_equals_the_oracle(product_lib, oracle, tmp_path):
+    """tools/ref_fixtures/dump_fixtures.c -- the C twin of the Rust dumper, the same program over the same five functions -- built against
+    THIS repository's libmatchtigs.so: a plain C caller drives the drop-in boundary over every case of ref_inputs.txt and algorithms 1, 3
+    and 5, and the JSON lines it prints (the format ref_outputs.jsonl will have) must be what the CPU oracle computes. Exercises the input
+    file, the output format and the consumer of the reference-side fixtures end to end; pins nothing (both sides are this repository's)."""
+    import subprocess
+
+    from matchtigs_amd import _lib
+
+    if product_lib.mtg_device_count() < 1:
+        pytest.fail("needs a GPU: the matchtigs_amd hot path has no CPU fallback")
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "dump_fixtures"
+    libdir = _lib.LIB_PATH.parent
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", str(root / "include"), str(root / "tools" / "ref_fixtures" / "dump_fixtures.c"),
+                    "-o", str(exe), "-L", str(libdir), "-lmatchtigs", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(INPUTS)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    cases = read_inputs()
+    assert len(recs) == 3 * len(cases) and [x["case"] for x in recs[0::3]] == list(cases)
+    for rec in recs:
+        c = cases[rec["case"]]
+        assert rec["k"] == c["k"]
+        _compare(oracle.OracleGraph.from_unitig_links(c["weights"], c["links"]).clib_compute_tigs(rec["algorithm"], c["k"]), rec)
