@@ -183,6 +183,10 @@ __global__ __launch_bounds__(EB) void unwalked_adj_kernel(const uint32_t *node, 
         out_pred[o0 + j] = (succ[o ^ 1u] & ~MARK) ^ 1u;
     }
 }
+__global__ __launch_bounds__(EB) void dummy_weight_kernel(const uint32_t *darts, uint32_t n, uint32_t E0, const uint32_t *pair_w, uint32_t *out) {
+    const uint64_t i = gid();
+    if (i < n) out[i] = pair_w[(darts[i] - E0) >> 1];
+}
 __global__ __launch_bounds__(EB) void succ_patch_kernel(uint32_t *succ, const uint32_t *dart, const uint32_t *value, uint32_t n) {
     const uint64_t i = gid();
     if (i < n) succ[dart[i]] = (succ[dart[i]] & MARK) | value[i];
@@ -219,10 +223,10 @@ struct SpliceResult {
     uint64_t spliced = 0, cyc_dropped = 0;
 };
 // fd: the darts on trails without a breaking dart; fs[i] = succ[fd[i]]; (ro[i], ro[i + 1]) = range of the out-darts od[] of from[fd[i]]
-// with their predecessors op[]. dummy_weight(dart) = weight of a matched dummy dart.
+// with their predecessors op[]. dummy_weights(darts) = the weights of those matched dummy darts.
 template <typename W>
 SpliceResult splice_breaking_free(const std::vector<uint32_t> &fd, const std::vector<uint32_t> &fs, const std::vector<uint32_t> &ro, const std::vector<uint32_t> &od,
-                                  const std::vector<uint32_t> &op, uint64_t E0, uint64_t first_brk, W &&dummy_weight) {
+                                  const std::vector<uint32_t> &op, uint64_t E0, uint64_t first_brk, W &&dummy_weights) {
     SpliceResult r;
     const uint32_t n = (uint32_t)fd.size();
     std::unordered_map<uint32_t, uint32_t> idx;  // dart -> position in fd
@@ -306,6 +310,14 @@ SpliceResult splice_breaking_free(const std::vector<uint32_t> &fd, const std::ve
         if (c) by_class.emplace_back(c, fd[i]);
     }
     std::sort(by_class.begin(), by_class.end());
+    // (the weights of their matched dummies, fetched in one go: a graph may have many small components that the matching balanced completely)
+    std::unordered_map<uint32_t, uint32_t> w_of;
+    {
+        std::vector<uint32_t> dd;
+        for (auto &cd : by_class) if (cd.second >= E0) dd.push_back(cd.second);
+        const std::vector<uint32_t> ww = dummy_weights(dd);
+        for (size_t q = 0; q < dd.size(); q++) w_of.emplace(dd[q], ww[q]);
+    }
     for (size_t g0 = 0; g0 < by_class.size();) {
         size_t g1 = g0;
         while (g1 < by_class.size() && by_class[g1].first == by_class[g0].first) g1++;
@@ -322,7 +334,7 @@ SpliceResult splice_breaking_free(const std::vector<uint32_t> &fd, const std::ve
         size_t rot = 0;
         for (size_t q = 0; q < cyc.size(); q++)
             if (cyc[q] >= E0) {
-                const uint64_t w = dummy_weight(cyc[q]);
+                const uint64_t w = w_of.at(cyc[q]);
                 if (w > best_w) { best_w = w; rot = q; }
             }
         std::rotate(cyc.begin(), cyc.begin() + (long)rot, cyc.end());
@@ -427,13 +439,18 @@ bool device_cut_first(hipStream_t st, const uint32_t *d_from, const uint32_t *d_
             HIP_CHECK(hipMemcpyAsync(op.data(), d_op, tot * 4, hipMemcpyDeviceToHost, st));
         }
         HIP_CHECK(hipStreamSynchronize(st));
-        auto dummy_weight = [&](uint32_t dart) -> uint64_t {  // (only asked for the matched dummies of a component without any breaking dart)
-            uint32_t w = 0;
-            HIP_CHECK(hipMemcpyAsync(&w, d_pw + ((dart - E0) >> 1), 4, hipMemcpyDeviceToHost, st));
+        auto dummy_weights = [&](const std::vector<uint32_t> &darts) -> std::vector<uint32_t> {  // (the matched dummies of components without any breaking dart)
+            std::vector<uint32_t> w(darts.size());
+            if (darts.empty()) return w;
+            Buf b_d, b_w;
+            uint32_t *d_d = b_d.alloc<uint32_t>(st, darts.size()), *d_w = b_w.alloc<uint32_t>(st, darts.size());
+            HIP_CHECK(hipMemcpyAsync(d_d, darts.data(), darts.size() * 4, hipMemcpyHostToDevice, st));
+            dummy_weight_kernel<<<grid_for(darts.size()), EB, 0, st>>>(d_d, (uint32_t)darts.size(), (uint32_t)E0, d_pw, d_w);
+            HIP_CHECK(hipMemcpyAsync(w.data(), d_w, darts.size() * 4, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             return w;
         };
-        sp = splice_breaking_free(fd, fs, ro, od, op, E0, first_brk, dummy_weight);
+        sp = splice_breaking_free(fd, fs, ro, od, op, E0, first_brk, dummy_weights);
         if (!sp.patch_dart.empty()) {
             const uint32_t np = (uint32_t)sp.patch_dart.size(), nt = (uint32_t)sp.touched.size();
             Buf b_pd, b_pv, b_td;
