@@ -586,17 +586,32 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     uint32_t cur_node = 0, cur_dist = IDLE_DIST;  // the node whose block is in b0..b3
     bool cur_chk = false;                         // its own in-node flag was already evaluated from its parent's block
     // The gather. QUAD = false: every lane loads the four quarters of its own block (four requests per lane to the same line).
-    // QUAD = true: the four lanes of a quad load one block together -- in load l lane q fetches quarter q of the block of quad
-    // lane l -- and transpose the quad's 4 x 4 quarters in registers (DPP) when the data is needed. An instruction then touches
+    // QUAD = true: four lanes load one block together -- in load l member q of a group fetches quarter q of the block of the group's
+    // member l -- and transpose the group's 4 x 4 quarters in registers when the data is needed. An instruction then touches
     // 16 lines instead of 64. Measured (tools/gather_bench_tlb.hip): with a 5.7-GB table (the 2^27 graph) dependent random
     // 64-byte gathers run at 18.8 G/s with four requests per lane and at 44 G/s either way of making it one request per lane
     // and line -- beyond ~4 GB every lane-request pays an address translation; below 3 GB both forms reach 51-55 G/s.
     uint4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0}, g3 = {0, 0, 0, 0};  // as loaded
     uint4 b0 = g0, b1 = g0, b2 = g0, b3 = g0;                                          // block of cur_node
     constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
-    auto quad_bcast = [](uint32_t v, auto sel) -> uint32_t {  // value of lane `sel` of the quad
-        constexpr int L = decltype(sel)::value;
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, L * 0x55, 0xF, 0xF, false);
+    // The four lanes of a gather group are the lanes of one COLUMN of the wave seen as 4 rows of 16 (lane, lane ^ 16, lane ^ 32,
+    // lane ^ 48), not four neighbours: gfx950 exchanges the odd rows of one register with the even rows of another
+    // (v_permlane16_swap) and the upper half of one with the lower half of another (v_permlane32_swap) in ONE instruction, so the
+    // 4 x 4 transposition of the group's quarters is 16 instructions where the neighbour form needed 128 (two stages of DPP
+    // quad_perm moves + selects per word: a fifth of the level's instructions, in a loop bound by instruction issue). The memory
+    // system does not care which four lanes share a line (tools/gather_bench_rows.hip: 48 G gathers/s either way at 5.7 GB).
+    auto swap_halves = [](uint32_t &x, uint32_t &y) {  // x[lanes 32..63] <-> y[lanes 0..31]
+        const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+        x = r[0]; y = r[1];
+    };
+    auto swap_rows = [](uint32_t &x, uint32_t &y) {  // x[rows 1, 3] <-> y[rows 0, 2]
+        const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+        x = r[0]; y = r[1];
+    };
+    // (row r of the wave, register j) <- (row j, register r), within every column
+    auto transpose_rows = [&](uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3) {
+        swap_halves(x0, x2); swap_halves(x1, x3);
+        swap_rows(x0, x1); swap_rows(x2, x3);
     };
     auto load_block = [&](bool need, uint32_t node) {
         if constexpr (!QUAD) {
@@ -606,39 +621,22 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             }
         } else {
             const uint32_t want = need ? node : NO_NODE;
-            const uint32_t q = (uint32_t)lane & 3u;
-            const uint32_t n0 = quad_bcast(want, std::integral_constant<int, 0>{}), n1 = quad_bcast(want, std::integral_constant<int, 1>{});
-            const uint32_t n2 = quad_bcast(want, std::integral_constant<int, 2>{}), n3 = quad_bcast(want, std::integral_constant<int, 3>{});
+            const uint32_t q = (uint32_t)lane >> 4;
+            uint32_t n0 = want, n1 = want, n2 = want, n3 = want;  // n_j <- what row j of this column wants
+            transpose_rows(n0, n1, n2, n3);
             if (n0 != NO_NODE) g0 = reinterpret_cast<const uint4 *>(a.recs + n0)[q];
             if (n1 != NO_NODE) g1 = reinterpret_cast<const uint4 *>(a.recs + n1)[q];
             if (n2 != NO_NODE) g2 = reinterpret_cast<const uint4 *>(a.recs + n2)[q];
             if (n3 != NO_NODE) g3 = reinterpret_cast<const uint4 *>(a.recs + n3)[q];
         }
     };
-    auto arrive_block = [&]() {  // g -> b (QUAD: transpose of the quad's quarters, two exchange stages)
-        if constexpr (!QUAD) {
-            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
-        } else {
-            // two exchange stages (lane ^ 1, lane ^ 2); in a stage even lanes take hi <- partner's lo, odd lanes lo <- partner's hi.
-            // (v_cndmask_b32_dpp would do select and exchange in one instruction, but the compiler emits mov_dpp + cndmask for the
-            // builtin, and two inline-asm forms -- one block per word pair, one per stage and register quadruple, the latter with the
-            // block ADDRESS handed round the quad instead of the node id -- measured 3 % slower: fewer instructions, more stalls.)
-            b0 = g0; b1 = g1; b2 = g2; b3 = g3;
-            const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
-            auto xchg = [](uint32_t &lo, uint32_t &hi, bool odd, auto ctrl) {
-                constexpr int C = decltype(ctrl)::value;
-                const uint32_t from_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, C, 0xF, 0xF, false);
-                const uint32_t from_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, C, 0xF, 0xF, false);
-                lo = odd ? from_hi : lo;
-                hi = odd ? hi : from_lo;
-            };
-            auto xchg4 = [&](uint4 &lo, uint4 &hi, bool odd, auto ctrl) {
-                xchg(lo.x, hi.x, odd, ctrl); xchg(lo.y, hi.y, odd, ctrl); xchg(lo.z, hi.z, odd, ctrl); xchg(lo.w, hi.w, odd, ctrl);
-            };
-            xchg4(b0, b1, odd1, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
-            xchg4(b2, b3, odd1, std::integral_constant<int, 0xB1>{});
-            xchg4(b0, b2, odd2, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
-            xchg4(b1, b3, odd2, std::integral_constant<int, 0x4E>{});
+    auto arrive_block = [&]() {  // g -> b (QUAD: g_j of row r is quarter r of the block of row j; b_q of row r is quarter q of its own)
+        b0 = g0; b1 = g1; b2 = g2; b3 = g3;
+        if constexpr (QUAD) {
+            transpose_rows(b0.x, b1.x, b2.x, b3.x);
+            transpose_rows(b0.y, b1.y, b2.y, b3.y);
+            transpose_rows(b0.z, b1.z, b2.z, b3.z);
+            transpose_rows(b0.w, b1.w, b2.w, b3.w);
         }
     };
     // LDS word of stack / hit row `row` of this lane: first tier (slot-major / lane-minor: conflict free), then the extension block
