@@ -468,21 +468,17 @@ constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr uint32_t ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
 constexpr uint32_t FIX_CLASS_TAG = 0xFFFFFF00u;  // slot 0 of a work-list chunk: FIX_CLASS_TAG | class (0: <= 8 keys, 1: <= 16, 2: <= 32)
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
-#ifndef MTG_ENUM_S1
-#define MTG_ENUM_S1 4
-#define MTG_ENUM_H1 4
-#define MTG_ENUM_NB 40
+#ifndef MTG_ENUM_HOME
+#define MTG_ENUM_HOME 8
+#define MTG_ENUM_NB 41
 #define MTG_ENUM_BE 16
 #endif
 constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
-// LDS words between the starts of two extension blocks: one more than a block holds. With a stride of 16 eight-byte entries
-// (128 bytes = all 32 banks once) the same row of every block falls on the same bank pair, and lanes that work in different
-// blocks -- the common case -- collide on every access (3.6 conflict cycles per LDS instruction in the round-2 PMC pass); an odd
-// stride walks the rows of consecutive blocks through the banks.
-#ifndef MTG_ENUM_BS
-#define MTG_ENUM_BS (MTG_ENUM_BE + 1)
-#endif
-constexpr int ENUM_BS = MTG_ENUM_BS;
+// LDS words between the starts of two extension blocks: one more than a block holds. With a stride of
+// 16 eight-byte entries (128 bytes = all 32 banks once) the same row of every block falls on the same bank pair, and lanes that work
+// in different blocks -- the common case -- collide on every access (3.6 conflict cycles per LDS instruction in the round-2 PMC
+// pass); an odd stride walks the rows of consecutive blocks through the banks.
+constexpr int ENUM_BS = MTG_ENUM_BE + 1;
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {  // value of the first lane, known uniform to the compiler
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -497,23 +493,43 @@ __device__ unsigned long long g_enum_prof[16384][3];  // development build: per 
 #endif
 // W8: the blocks are in the 8:8 format (k <= 255). PRUNE (needs W8): successors are tested against distance + weight + lower bound,
 // and the sources come from the launch's list of sources that can reach an in-node at all (act_index / act_node, counters[C_ACTIVE]).
-template <int WPB, int S1, int H1, int NB, bool QUAD, bool W8, bool PRUNE>
+//
+// Where a lane's entries live (round 6; before: S1 stack rows and H1 hit rows per lane in a slot-major first tier, the rest in an
+// extension block, every one of a step's 21 potential stores unconditional -- to the next free slot, counted or not -- and computing
+// its word from its row: tier test, two address forms, a select, the byte offset: 8 vector instructions per store in a loop whose
+// time is its vector instructions). Now every lane has a HOME BLOCK of HOME entries (stack rows from its bottom, hits from its top,
+// like an extension block) and at most one extension block; a step's stores all go to ONE of them -- the home block while the step's
+// entries fit it, the extension block from the step on that outgrows it -- so that a store is `under the lanes' condition: write at
+// the pointer, move the pointer by one word': one vector instruction beside the write. The stack is then split at row s0 (rows below
+// it in the home block, rows from it in the extension block; a step that starts below s0 lowers it: the rows above are dead), the
+// hits at row h0 (fixed when the extension block arrives); only the pop and the reads of a finished list select between the two.
+template <int WPB, int HOME, int NB, bool QUAD, bool W8, bool PRUNE>
 __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_kernel(SsspArgs a) {
     static_assert(W8 || !PRUNE, "the lower bounds live in the 8:8 format");
-    static_assert(NB >= 1 && NB <= 64 && H1 >= 2, "pool free mask is one 64-bit word; lists of two are sorted from the first tier");
+    static_assert(NB >= 1 && NB <= 64 && HOME >= 4, "pool free mask is one 64-bit word; lists of up to four are read from fixed rows");
     constexpr int BE = ENUM_BE, BS = ENUM_BS;
-    static_assert(BS >= BE, "block stride below the block size");
-    constexpr uint32_t T1 = (uint32_t)(S1 + H1) * 64u;     // words of the per-lane tiers
-    constexpr uint32_t SCRATCH = T1 + (uint32_t)NB * BS;   // block that absorbs the stores of lanes without a block of their own
-    constexpr uint32_t IDLE_DIST = 0xFFFF0000u;            // distance of a lane without a source: nothing is within the bound from there
-    // stack entry: node | (distance | own-flag-done << 16) << 32; hit entry = candidate key: node | distance << 32
-    __shared__ unsigned long long s_mem[WPB][T1 + (NB + 1) * BS];
+    static_assert(BS % 2 == 1, "odd block stride");
+    constexpr uint32_t T1 = 64u * HOME;                         // words of the home blocks
+    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS;     // + pool
+    constexpr uint32_t IDLE_DIST = 0xFFFF0000u;                 // distance of a lane without a source: nothing is within the bound from there
+    // stack entry: node | (distance | own-flag-still-open << 16) << 32; hit entry = candidate key: node | distance << 32
+    __shared__ unsigned long long s_mem[WPB][WAVE_WORDS];
     __shared__ uint32_t s_cnt[WPB];
     __shared__ WaveOvfBuf s_ovf[WPB];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t K1 = a.K1;
-    unsigned long long *const mem = s_mem[wv];
+    // every LDS position below is a BYTE offset into s_mem (the array's own address is the instruction's immediate offset)
+    auto lds = [&](uint32_t off) -> unsigned long long & {
+        return *reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(&s_mem[0][0]) + off);
+    };
+    const uint32_t wave_off = (uint32_t)__builtin_amdgcn_readfirstlane(wv) * WAVE_WORDS * 8u;  // (known uniform to the compiler: the pool's free mask stays scalar)
+    // home blocks: row-major over the wave (word r of lane l at r * 64 + l: whatever rows the lanes work in, they never share a bank --
+    // lane-major blocks measured the loss: random rows, three or four lanes per bank pair); extension blocks: BS consecutive words
+    constexpr uint32_t HOME_SHIFT = 9, EXT_SHIFT = 3;          // log2 of the bytes from one word of a block to the next
+    constexpr uint32_t HOME_STEP = 1u << HOME_SHIFT, EXT_STEP = 1u << EXT_SHIFT;
+    const uint32_t home_b = wave_off + (uint32_t)lane * 8u, home_t = home_b + (HOME - 1) * HOME_STEP;  // first stack word / first hit word
+    const uint32_t pool_off = wave_off + T1 * 8u;
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
     unsigned long long pool_base = 0;                                                // wave-uniform
@@ -581,8 +597,12 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 
     // ---- per-lane search state ----
     bool active = false;
-    uint32_t sp = 0, nhit = 0, pops = 0, src_node = 0, item = 0;
-    uint32_t blk = SCRATCH;                       // word index of the lane's extension block
+    uint32_t sp = 0, nhit = 0;        // stack entries / hits of the lane's source
+    uint32_t s0 = 0, h0 = 0;          // first stack row / first hit of the lane's store block (0 while that is its home block)
+    uint32_t cb = home_b, ct = home_t;  // the lane's store block: its first stack word and its first hit word (LDS byte offsets) ...
+    uint32_t step = HOME_STEP, shift = HOME_SHIFT;  // ... and the bytes between two of its words
+    uint32_t pops = 0, src_node = 0, item = 0;
+    bool src_tgt = false;             // the source is an in-node itself: its own hits are taken out when it finishes (see hv[0])
     uint32_t cur_node = 0, cur_dist = IDLE_DIST;  // the node whose block is in b0..b3
     bool cur_chk = false;                         // its own in-node flag was already evaluated from its parent's block
     // The gather. QUAD = false: every lane loads the four quarters of its own block (four requests per lane to the same line).
@@ -591,9 +611,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     // 16 lines instead of 64. Measured (tools/gather_bench_tlb.hip): with a 5.7-GB table (the 2^27 graph) dependent random
     // 64-byte gathers run at 18.8 G/s with four requests per lane and at 44 G/s either way of making it one request per lane
     // and line -- beyond ~4 GB every lane-request pays an address translation; below 3 GB both forms reach 51-55 G/s.
-    uint4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0}, g3 = {0, 0, 0, 0};  // as loaded
-    uint4 b0 = g0, b1 = g0, b2 = g0, b3 = g0;                                          // block of cur_node
-    constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+    uint4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;  // as loaded; after arrive_block(): the block of cur_node
     // The four lanes of a gather group are the lanes of one COLUMN of the wave seen as 4 rows of 16 (lane, lane ^ 16, lane ^ 32,
     // lane ^ 48), not four neighbours: gfx950 exchanges the odd rows of one register with the even rows of another
     // (v_permlane16_swap) and the upper half of one with the lower half of another (v_permlane32_swap) in ONE instruction, so the
@@ -617,21 +635,22 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         if constexpr (!QUAD) {
             if (need) {
                 const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + node);
-                g0 = rp[0]; g1 = rp[1]; g2 = rp[2]; g3 = rp[3];
+                b0 = rp[0]; b1 = rp[1]; b2 = rp[2]; b3 = rp[3];
             }
         } else {
-            const uint32_t want = need ? node : NO_NODE;
+            // (a lane without a next node asks for block 0: its group's loads are unconditional, what arrives is never looked at --
+            // the distance of an idle lane puts everything beyond the bound)
+            const uint32_t want = need ? node : 0u;
             const uint32_t q = (uint32_t)lane >> 4;
             uint32_t n0 = want, n1 = want, n2 = want, n3 = want;  // n_j <- what row j of this column wants
             transpose_rows(n0, n1, n2, n3);
-            if (n0 != NO_NODE) g0 = reinterpret_cast<const uint4 *>(a.recs + n0)[q];
-            if (n1 != NO_NODE) g1 = reinterpret_cast<const uint4 *>(a.recs + n1)[q];
-            if (n2 != NO_NODE) g2 = reinterpret_cast<const uint4 *>(a.recs + n2)[q];
-            if (n3 != NO_NODE) g3 = reinterpret_cast<const uint4 *>(a.recs + n3)[q];
+            b0 = reinterpret_cast<const uint4 *>(a.recs + n0)[q];
+            b1 = reinterpret_cast<const uint4 *>(a.recs + n1)[q];
+            b2 = reinterpret_cast<const uint4 *>(a.recs + n2)[q];
+            b3 = reinterpret_cast<const uint4 *>(a.recs + n3)[q];
         }
     };
-    auto arrive_block = [&]() {  // g -> b (QUAD: g_j of row r is quarter r of the block of row j; b_q of row r is quarter q of its own)
-        b0 = g0; b1 = g1; b2 = g2; b3 = g3;
+    auto arrive_block = [&]() {  // QUAD: b_j of row r is quarter r of the block of row j; afterwards b_q of row r is quarter q of its own
         if constexpr (QUAD) {
             transpose_rows(b0.x, b1.x, b2.x, b3.x);
             transpose_rows(b0.y, b1.y, b2.y, b3.y);
@@ -639,15 +658,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             transpose_rows(b0.w, b1.w, b2.w, b3.w);
         }
     };
-    // LDS word of stack / hit row `row` of this lane: first tier (slot-major / lane-minor: conflict free), then the extension block
-    // at `base` (stack from its bottom, hits from its top). Rows are in range by construction: a lane whose step would not fit
-    // is redirected to the scratch block BEFORE it stores anything.
-    auto stack_word = [&](uint32_t base, uint32_t row) -> uint32_t {
-        return row < (uint32_t)S1 ? row * 64u + (uint32_t)lane : base - (uint32_t)S1 + row;
-    };
-    auto hit_word = [&](uint32_t base, uint32_t row) -> uint32_t {
-        return row < (uint32_t)H1 ? (uint32_t)(S1 * 64) + row * 64u + (uint32_t)lane : base + (uint32_t)(BE - 1 + H1) - row;
-    };
+    // hit r of the lane's source: in the home block below h0, in the store block from there
+    auto hit_at = [&](uint32_t r) -> uint32_t { return r >= h0 ? ct - ((r - h0) << shift) : home_t - (r << HOME_SHIFT); };
     {
         uint32_t ni = 0, ns = 0;
         if (take_source(true, ni, ns)) {
@@ -666,41 +678,49 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const uint32_t meta = b1.z;
         const uint32_t nb[4] = {b0.x, b0.y, b0.z, b0.w};
         const uint32_t gn[GSLOTS] = {b1.w, b2.x, b2.y, b2.z, b2.w, b3.x};
-        // distance of a child / grandchild, and (PRUNE) the smallest distance of any in-node through it
-        uint32_t dc[4], dg[GSLOTS], lc[4], lg[GSLOTS];
+        // weight of the edge to a child / of the path to a grandchild, and (PRUNE) that weight + the lower bound of what lies beyond it
+        uint32_t wc[4], wg[GSLOTS], lc[4], lg[GSLOTS];
         {
             const uint32_t cs[4] = {b1.x & 0xFFFFu, b1.x >> 16, b1.y & 0xFFFFu, b1.y >> 16};
             const uint32_t gs[GSLOTS] = {b3.y & 0xFFFFu, b3.y >> 16, b3.z & 0xFFFFu, b3.z >> 16, b3.w & 0xFFFFu, b3.w >> 16};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                dc[j] = d + (W8 ? (cs[j] & 0xFFu) : cs[j]);
-                lc[j] = PRUNE ? d + (cs[j] >> 8) : dc[j];
+                wc[j] = W8 ? (cs[j] & 0xFFu) : cs[j];
+                lc[j] = PRUNE ? (cs[j] >> 8) : wc[j];
             }
 #pragma unroll
             for (int t = 0; t < GSLOTS; t++) {
-                dg[t] = d + (W8 ? (gs[t] & 0xFFu) : gs[t]);
-                lg[t] = PRUNE ? d + (gs[t] >> 8) : dg[t];
+                wg[t] = W8 ? (gs[t] & 0xFFu) : gs[t];
+                lg[t] = PRUNE ? (gs[t] >> 8) : wg[t];
             }
         }
+        // what is left of the bound at this node (an idle lane: nothing; an unused slot holds 0xFFFF or 0xFF: beyond any bound)
+        const int32_t left = active ? (int32_t)(K1 - d) : -1;
         const bool is_ext = active && (meta & ((uint32_t)F_EXT << 8));
         // PRUNE: a grandchild that is an in-node (cmeta bit 8 + t) is recorded from THIS block, like the children, and pushed -- with its
         // own flag done -- only if something lies beyond it (the high bytes carry weight + lb+): a quarter of the node visits of the
         // bench graph are in-nodes with nothing behind them within the bound, and their blocks are never gathered.
+        // forbid_source_target (greedytigs/mod.rs:329) is NOT tested here: a hit names the source itself only if the source is an
+        // in-node (then hv[0] is true at its root, distance 0), and such a source strikes its own node from its list when it finishes.
+        // What a step costs is its VECTOR instructions (round 6, counters: 4 waves per SIMD keep its vector pipe busy all the time; the
+        // kernel's time followed their number, not the scalar instructions'): a condition is one compare of a byte against `left' and a
+        // bit test, a store happens under the lanes' condition (write, move the pointer: scalar mask handling + one vector instruction).
         bool hv[5], hg[GSLOTS], pv[4 + GSLOTS];
-        hv[0] = active && !cur_chk && (meta & ((uint32_t)F_TARGET << 8)) && u != src_node;  // forbid_source_target, greedytigs/mod.rs:329
+        hv[0] = active & !cur_chk & ((meta & ((uint32_t)F_TARGET << 8)) != 0u);
+        src_tgt |= hv[0] & (d == 0u);
         uint32_t nh_f = nhit + (hv[0] ? 1u : 0u), sp_f = sp;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            hv[1 + j] = dc[j] <= K1 && (meta & (0x10000u << j)) && nb[j] != src_node;
-            pv[j] = lc[j] <= K1 && (meta & (0x100000u << j));
+            hv[1 + j] = ((int32_t)wc[j] <= left) & ((meta & (0x10000u << j)) != 0u);
+            pv[j] = ((int32_t)lc[j] <= left) & ((meta & (0x100000u << j)) != 0u);
             nh_f += hv[1 + j] ? 1u : 0u;
             sp_f += pv[j] ? 1u : 0u;
         }
 #pragma unroll
         for (int t = 0; t < GSLOTS; t++) {
-            pv[4 + t] = lg[t] <= K1;
+            pv[4 + t] = (int32_t)lg[t] <= left;
             sp_f += pv[4 + t] ? 1u : 0u;
-            hg[t] = PRUNE && dg[t] <= K1 && (meta & (0x1000000u << t)) && gn[t] != src_node;
+            hg[t] = PRUNE & ((int32_t)wg[t] <= left) & ((meta & (0x1000000u << t)) != 0u);
             nh_f += hg[t] ? 1u : 0u;
         }
         if (__any(is_ext)) {  // spilled adjacency (more than 4 out-edges; never in a de Bruijn graph): count first
@@ -709,79 +729,74 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 for (uint32_t j = 0; j < b0.z; j++) sp_f += d + a.ext_w[ext_begin + j] <= K1 ? 1u : 0u;
             }
         }
-        // ---- extension blocks for the lanes that outgrow their first tier in this step ----
-        const bool need_blk = blk == SCRATCH && (sp_f > (uint32_t)S1 || nh_f > (uint32_t)H1);
+        // ---- an extension block for the lanes whose entries outgrow their home block in this step ----
+        const bool need_blk = cb == home_b && sp_f + nh_f > (uint32_t)HOME;
         unsigned long long nm = __ballot(need_blk);
+        uint32_t blk_new = 0;
         while (nm && free_mask) {
             const int l = __builtin_ctzll(nm);
             const int bi = __builtin_ctzll(free_mask);
             nm &= nm - 1;
             free_mask &= free_mask - 1;
-            blk = lane == l ? T1 + (uint32_t)bi * BS : blk;
+            blk_new = lane == l ? pool_off + (uint32_t)bi * (BS * 8u) : blk_new;
         }
-        const uint32_t es = sp_f > (uint32_t)S1 ? sp_f - (uint32_t)S1 : 0u, eh = nh_f > (uint32_t)H1 ? nh_f - (uint32_t)H1 : 0u;
+        const bool got_blk = need_blk && blk_new != 0u;  // (pool_off > 0: the home blocks come first)
+        cb = got_blk ? blk_new : cb;
+        ct = got_blk ? blk_new + (BE - 1) * EXT_STEP : ct;
+        step = got_blk ? EXT_STEP : step;
+        shift = got_blk ? EXT_SHIFT : shift;
+        s0 = got_blk ? sp : (s0 < sp ? s0 : sp);  // (a step that starts below the split lowers it: the rows above are dead)
+        h0 = got_blk ? nhit : h0;
         pops += active ? 1u : 0u;
         // (a lane the pool had no block for, or whose block is full, hands its source to the cascade)
-        // (one word stays free: the store after the last one that counts must not land on the other side's newest entry)
-        const bool ovf = active && ((need_blk && blk == SCRATCH) || es + eh >= (uint32_t)BE || pops > ENUM_POP_BUDGET);
+        const bool starved = need_blk && !got_blk;
+        const bool ovf = active && (starved || (sp_f - s0) + (nh_f - h0) > (uint32_t)BE || pops > ENUM_POP_BUDGET);
 #ifdef MTG_ENUM_STATS  // development build: why sources leave this level, how many steps run, how full the lanes are
-        st_starved += (uint32_t)__popcll(__ballot(active && need_blk && blk == SCRATCH));
-        st_full += (uint32_t)__popcll(__ballot(active && !(need_blk && blk == SCRATCH) && es + eh >= (uint32_t)BE));
+        st_starved += (uint32_t)__popcll(__ballot(active && starved));
+        st_full += (uint32_t)__popcll(__ballot(active && !starved && (sp_f - s0) + (nh_f - h0) > (uint32_t)BE));
         st_budget += (uint32_t)__popcll(__ballot(active && pops > ENUM_POP_BUDGET));
         st_steps += 1;
         st_lanes += (uint32_t)__popcll(__ballot(active));
 #endif
 
-        // ---- hits and successors, straight into LDS (an overflowing lane scribbles into the scratch block instead) ----
-        const uint32_t base = ovf ? SCRATCH : blk;
-        uint32_t wsp = ovf ? 0u : sp, wnh = ovf ? 0u : nhit;
-        if (!PRUNE || __any(hv[0])) {  // (PRUNE: only the successors of a spilled adjacency arrive with their own flag still open)
-            mem[hit_word(base, wnh)] = ((unsigned long long)d << 32) | u;
-            wnh += hv[0] ? 1u : 0u;
-        }
+        // ---- hits and successors into LDS (a lane that leaves the level stores nothing) ----
+        uint32_t spt = cb + ((sp - s0) << shift);    // the next free stack word ...
+        uint32_t hpt = ct - ((nhit - h0) << shift);  // ... and the next free hit word of the store block
+        auto put = [&](uint32_t at, uint32_t node, uint32_t hi) {  // (two 32-bit halves from wherever they are: no register pairing)
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + at) = node;
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + at + 4u) = hi;
+        };
+        if (!ovf) {
+            if (hv[0]) { put(hpt, u, d); hpt -= step; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < 2 || __any(hv[1 + j])) {
-                mem[hit_word(base, wnh)] = ((unsigned long long)dc[j] << 32) | nb[j];
-                wnh += hv[1 + j] ? 1u : 0u;
+            for (int j = 0; j < 4; j++)
+                if (hv[1 + j]) { put(hpt, nb[j], d + wc[j]); hpt -= step; }
+            if constexpr (PRUNE) {
+#pragma unroll
+                for (int t = 0; t < GSLOTS; t++)
+                    if (hg[t]) { put(hpt, gn[t], d + wg[t]); hpt -= step; }
             }
-        }
-        if constexpr (PRUNE) {
-#pragma unroll
-            for (int t = 0; t < GSLOTS; t++) {
-                if (__any(hg[t])) {
-                    mem[hit_word(base, wnh)] = ((unsigned long long)dg[t] << 32) | gn[t];
-                    wnh += hg[t] ? 1u : 0u;
+            if (__any(is_ext)) {
+                if (is_ext) {
+                    const uint64_t ext_begin = ((uint64_t)b0.y << 32) | b0.x;
+                    for (uint32_t j = 0; j < b0.z; j++) {
+                        const uint32_t nd = d + a.ext_w[ext_begin + j];
+                        if (nd <= K1) { put(spt, a.ext_col[ext_begin + j], nd | 0x10000u); spt += step; }  // (its own flag is still open)
+                    }
                 }
             }
-        }
-        if (__any(is_ext)) {
-            if (is_ext && !ovf) {
-                const uint64_t ext_begin = ((uint64_t)b0.y << 32) | b0.x;
-                for (uint32_t j = 0; j < b0.z; j++) {
-                    const uint32_t nd = d + a.ext_w[ext_begin + j];
-                    if (nd <= K1) { mem[stack_word(base, wsp)] = ((unsigned long long)nd << 32) | a.ext_col[ext_begin + j]; wsp++; }
-                }
-            }
-        }
 #pragma unroll
-        for (int t = GSLOTS - 1; t >= 0; t--) {
-            if (t < 4 || __any(pv[4 + t])) {
-                mem[stack_word(base, wsp)] = ((unsigned long long)(dg[t] | (PRUNE ? 0x10000u : 0u)) << 32) | gn[t];  // (PRUNE: flag done above)
-                wsp += pv[4 + t] ? 1u : 0u;
-            }
-        }
+            for (int t = GSLOTS - 1; t >= 0; t--)
+                if (pv[4 + t]) { put(spt, gn[t], (d + wg[t]) | (PRUNE ? 0u : 0x10000u)); spt += step; }  // (PRUNE: its flag was evaluated above)
 #pragma unroll
-        for (int j = 3; j >= 0; j--) {  // (children come off the stack before grandchildren: nearer nodes first)
-            if (j < 2 || __any(pv[j])) {
-                mem[stack_word(base, wsp)] = ((unsigned long long)(dc[j] | 0x10000u) << 32) | nb[j];  // its in-node flag is done
-                wsp += pv[j] ? 1u : 0u;
-            }
+            for (int j = 3; j >= 0; j--)  // (children come off the stack before grandchildren: nearer nodes first)
+                if (pv[j]) { put(spt, nb[j], d + wc[j]); spt += step; }
         }
-        sp = wsp; nhit = wnh;
-        const bool go_on = active && !ovf && sp > 0;  // the next node comes off the stack
-        const unsigned long long top = mem[stack_word(base, sp > 0 ? sp - 1u : 0u)];
-        sp -= go_on ? 1u : 0u;
+        const bool go_on = active && !ovf && sp_f > 0;  // the next node comes off the stack
+        // (the newest row is in the store block if that holds any row at all, else it is the home block's last one)
+        const unsigned long long top = lds(sp_f > s0 ? cb + ((sp_f - s0 - 1u) << shift) : home_b + (((sp_f > 1u ? sp_f : 1u) - 1u) << HOME_SHIFT));
+        sp = sp_f - (go_on ? 1u : 0u);
+        nhit = nh_f;
         const bool fin = active && !ovf && !go_on;  // the source is finished
 
         // ---- lanes without a next node take a new source; every lane's next gather leaves now ----
@@ -795,12 +810,22 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const unsigned long long donemask = __ballot(fin || ovf);
         if (donemask) {
             uint32_t c = fin ? nhit : 0u;
+            if (__any(fin && src_tgt)) {  // a source that is an in-node strikes itself from its list (forbid_source_target)
+                if (fin && src_tgt) {
+                    uint32_t w = 0;
+                    for (uint32_t r = 0; r < c; r++) {
+                        const unsigned long long key = lds(hit_at(r));
+                        if ((uint32_t)key != src_node) { lds(hit_at(w)) = key; w++; }
+                    }
+                    c = w;
+                }
+            }
             // lists of up to four keys are put in Dijkstra order in registers; longer ones (and repeated nodes) go to the post-pass
             unsigned long long k0 = ~0ull, k1 = ~0ull, k2 = ~0ull, k3 = ~0ull;
-            if (c > 0) k0 = mem[hit_word(blk, 0)];
-            if (c > 1) k1 = mem[hit_word(blk, 1)];
-            if (c > 2) k2 = mem[hit_word(blk, 2)];
-            if (c > 3) k3 = mem[hit_word(blk, 3)];
+            if (c > 0) k0 = lds(hit_at(0u));
+            if (c > 1) k1 = lds(hit_at(1u));
+            if (c > 2) k2 = lds(hit_at(2u));
+            if (c > 3) k3 = lds(hit_at(3u));
             bool fix = c > 4;
             if (__any(c >= 2 && c <= 4)) {  // (a longer list is sorted as a whole by the post-pass: no need to run the network for it alone)
                 auto cswap = [](unsigned long long &x, unsigned long long &y) {  // pop order: policy P1 (mtg_policy.h)
@@ -831,7 +856,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             if (c > 2 && room) a.pool[pos + 2] = k2;
             if (c > 3 && room) a.pool[pos + 3] = k3;
             for (uint32_t r = 4; __any(r < c); r++)
-                if (r < c && room) a.pool[pos + r] = mem[hit_word(blk, r)];
+                if (r < c && room) a.pool[pos + r] = lds(hit_at(r));
             // (7 of 10 sources have no candidate: their counts are zeroed by one streaming pass before the launch, their starts are
             // never read -- two scattered partial-line stores less per such source: 1.85 -> 1.40 -> ... GB written per launch at 2^27)
             // Round 6, measured on one box (tools/sssp_probe.py --lib, 2^27): without these two stores (-DMTG_EXP_NO_START_COUNT: wrong
@@ -872,11 +897,11 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 #else
             (void)append_fix;
 #endif
-            unsigned long long rel = __ballot((fin || ovf) && blk != SCRATCH);  // extension blocks go back to the pool
+            unsigned long long rel = __ballot((fin || ovf) && cb != home_b);  // extension blocks go back to the pool
             while (rel) {
                 const int l = __builtin_ctzll(rel);
                 rel &= rel - 1;
-                free_mask |= 1ull << ((((uint32_t)__builtin_amdgcn_readlane((int)blk, l) - T1) / (uint32_t)BS) & 63u);
+                free_mask |= 1ull << ((((uint32_t)__builtin_amdgcn_readlane((int)cb, l) - pool_off) / (uint32_t)(BS * 8)) & 63u);
             }
             wave_ovf_push(s_ovf[wv], n_overflow, ovf, (uint32_t)(a.src_begin + item), a, lane);
         }
@@ -885,11 +910,12 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         if (go_on) {
             cur_node = nx_node;
             cur_dist = (uint32_t)(top >> 32) & 0xFFFFu;
-            cur_chk = ((uint32_t)(top >> 32) & 0x10000u) != 0u;
+            cur_chk = ((uint32_t)(top >> 32) & 0x10000u) == 0u;
         } else {
-            sp = 0; nhit = 0; pops = 0;
-            blk = SCRATCH;
+            sp = 0; nhit = 0; pops = 0; s0 = 0; h0 = 0;
+            cb = home_b; ct = home_t; step = HOME_STEP; shift = HOME_SHIFT;
             cur_chk = false;
+            src_tgt = false;
             active = got_new;
             item = new_item; src_node = new_src; cur_node = new_src;
             cur_dist = got_new ? 0u : IDLE_DIST;
@@ -1040,12 +1066,12 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-constexpr int ENUM_WPB = 4, ENUM_S1 = MTG_ENUM_S1, ENUM_H1 = MTG_ENUM_H1, ENUM_NB = MTG_ENUM_NB;  // 40 KB of LDS per workgroup: 4 workgroups = 16 waves per CU
-constexpr int ENUM_MAX_HITS = ENUM_H1 + ENUM_BE - 1;  // longest list the level can emit
+constexpr int ENUM_WPB = 4, ENUM_HOME = MTG_ENUM_HOME, ENUM_NB = MTG_ENUM_NB;  // 40 KB of LDS per workgroup: 4 workgroups = 16 waves per CU
+constexpr int ENUM_MAX_HITS = ENUM_HOME + ENUM_BE;  // longest list the level can emit
 static std::string enum_level_name(bool quad, bool prune) {
     char b[160];
-    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
-                  ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
+    std::snprintf(b, sizeof b, "%ssssp_enum_kernel<%d,%d,%d,%s%s> + fix_compact_kernel + sort_lists_kernel", prune ? "active_range_kernel + " : "",
+                  ENUM_WPB, ENUM_HOME, ENUM_NB, quad ? "quad" : "lane", prune ? ",pruned" : "");
     return b;
 }
 
@@ -1094,9 +1120,9 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     if (args.n_items == 0) return;
     const bool quad = enum_uses_quad_gathers(d), prune = enum_prunes(d);
     sssp_fn fn;
-    if (prune) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, true, true> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, true, true>;
-    else if (d->w8) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, true, false> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, true, false>;
-    else fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, true, false, false> : sssp_enum_kernel<ENUM_WPB, ENUM_S1, ENUM_H1, ENUM_NB, false, false, false>;
+    if (prune) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, true, true, true> : sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, false, true, true>;
+    else if (d->w8) fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, true, true, false> : sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, false, true, false>;
+    else fn = quad ? sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, true, false, false> : sssp_enum_kernel<ENUM_WPB, ENUM_HOME, ENUM_NB, false, false, false>;
     int occ = 1;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, ENUM_WPB * 64, 0));
     if (occ < 1) occ = 1;
