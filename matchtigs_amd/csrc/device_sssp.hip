@@ -470,8 +470,11 @@ constexpr uint32_t FIX_CLASS_TAG = 0xFFFFFF00u;  // slot 0 of a work-list chunk:
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #ifndef MTG_ENUM_HOME
 #define MTG_ENUM_HOME 8
-#define MTG_ENUM_NB 41
+#define MTG_ENUM_NB 25
 #define MTG_ENUM_BE 16
+#endif
+#ifndef MTG_ENUM_KRING
+#define MTG_ENUM_KRING 256  // keys of the wave's output ring (a power of two)
 #endif
 constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
 // LDS words between the starts of two extension blocks: one more than a block holds. With a stride of
@@ -510,7 +513,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     constexpr int BE = ENUM_BE, BS = ENUM_BS;
     static_assert(BS % 2 == 1, "odd block stride");
     constexpr uint32_t T1 = 64u * HOME;                         // words of the home blocks
-    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS;     // + pool
+    constexpr uint32_t KRING = MTG_ENUM_KRING;                  // keys on their way to the pool
+    static_assert((KRING & (KRING - 1)) == 0 && KRING >= 64 && KRING <= ENUM_POOL_CHUNK, "the ring is indexed by the chunk offset modulo its size");
+    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING;  // + pool + output ring
     constexpr uint32_t IDLE_DIST = 0xFFFF0000u;                 // distance of a lane without a source: nothing is within the bound from there
     // stack entry: node | (distance | own-flag-still-open << 16) << 32; hit entry = candidate key: node | distance << 32
     __shared__ unsigned long long s_mem[WPB][WAVE_WORDS];
@@ -530,9 +535,14 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     constexpr uint32_t HOME_STEP = 1u << HOME_SHIFT, EXT_STEP = 1u << EXT_SHIFT;
     const uint32_t home_b = wave_off + (uint32_t)lane * 8u, home_t = home_b + (HOME - 1) * HOME_STEP;  // first stack word / first hit word
     const uint32_t pool_off = wave_off + T1 * 8u;
+    const uint32_t ring_off = pool_off + (uint32_t)NB * (BS * 8u);
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
     unsigned long long pool_base = 0;                                                // wave-uniform
+    // Keys leave through a ring in LDS: a finished list is copied to the ring at its offset in the wave's pool chunk, and the wave writes
+    // the ring to the pool in whole rows of 64 keys (512 bytes, one instruction, every line written once and in full) -- before, every
+    // finished lane stored its own keys (4 + the longest list's length store instructions per step, each a few partial lines).
+    uint32_t staged = ENUM_POOL_CHUNK, flushed = ENUM_POOL_CHUNK;  // (no chunk yet) wave-uniform chunk offsets: keys below `staged' are in the ring or the pool, below `flushed' in the pool
     unsigned long long fix_next[3] = {0, 0, 0}, fix_end[3] = {0, 0, 0};             // wave-uniform: the wave's open work-list chunk per length class
     uint32_t fix_total[3] = {0, 0, 0};                                              // wave-uniform: entries appended per class
     uint32_t n_overflow = 0;                                                         // wave-uniform
@@ -656,6 +666,15 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             transpose_rows(b0.y, b1.y, b2.y, b3.y);
             transpose_rows(b0.z, b1.z, b2.z, b3.z);
             transpose_rows(b0.w, b1.w, b2.w, b3.w);
+        }
+    };
+    auto ring = [&](uint32_t chunk_offset) -> unsigned long long & { return lds(ring_off + ((chunk_offset & (KRING - 1u)) << 3)); };
+    auto flush_keys = [&](uint32_t lo, uint32_t hi) {  // chunk offsets [lo, hi) from the ring to the pool
+        for (uint32_t j = lo + (uint32_t)lane; j < hi; j += 64u) {
+            const unsigned long long pos = pool_base + j;
+#ifndef MTG_EXP_NO_POOL_STORES  // (timing experiments only)
+            if (pos < a.pool_cap) a.pool[pos] = ring(j);  // (pool too small: the host retries with a larger one)
+#endif
         }
     };
     // hit r of the lane's source: in the home block below h0, in the store block from there
@@ -840,7 +859,11 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 else fix |= dup;
             }
             uint32_t off = c ? atomicAdd(&s_cnt[wv], c) : 0u;  // any order: (start, count) index the content
-            if (__builtin_amdgcn_readfirstlane(s_cnt[wv]) > ENUM_POOL_CHUNK) {  // chunk used up: this step's lists go to a new one
+            // (read as it is in LDS now: lane 0's own view of the counter is its reset below, not the other lanes' additions)
+            auto chunk_fill = [&]() -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile uint32_t *>(&s_cnt[wv])); };
+            uint32_t total = chunk_fill();
+            if (total > ENUM_POOL_CHUNK) {  // chunk used up: this step's lists go to a new one (what the old one still has in the ring leaves now)
+                flush_keys(flushed, staged);
                 unsigned long long p0 = 0;
                 if (lane == 0) {
                     p0 = atomicAdd(&a.counters[C_POOL], (unsigned long long)ENUM_POOL_CHUNK);
@@ -848,15 +871,42 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 }
                 pool_base = uniform_u64(p0);
                 off = c ? atomicAdd(&s_cnt[wv], c) : 0u;
+                total = chunk_fill();
+                staged = 0; flushed = 0;
             }
+            // this step's keys are the chunk offsets [staged, total)
+            if (total - flushed > KRING) { flush_keys(flushed, staged); flushed = staged; }  // (room for them: the ring's partial row leaves early)
             const unsigned long long pos = pool_base + off;
-            const bool room = pos + c <= a.pool_cap;  // (pool too small: the host retries with a larger one)
-            if (c > 0 && room) a.pool[pos] = k0;
-            if (c > 1 && room) a.pool[pos + 1] = k1;
-            if (c > 2 && room) a.pool[pos + 2] = k2;
-            if (c > 3 && room) a.pool[pos + 3] = k3;
-            for (uint32_t r = 4; __any(r < c); r++)
-                if (r < c && room) a.pool[pos + r] = lds(hit_at(r));
+#ifdef MTG_DBG_RING_OFF
+            if (false) {
+#else
+            if (total - flushed <= KRING) {
+#endif
+                if (c > 0) ring(off) = k0;
+                if (c > 1) ring(off + 1u) = k1;
+                if (c > 2) ring(off + 2u) = k2;
+                if (c > 3) ring(off + 3u) = k3;
+                for (uint32_t r = 4; __any(r < c); r++)
+                    if (r < c) ring(off + r) = lds(hit_at(r));
+                staged = total;
+#ifdef MTG_DBG_RING_ALL
+                const uint32_t rows = staged;
+#else
+                const uint32_t rows = staged & ~63u;
+#endif
+                if (rows > flushed) { flush_keys(flushed, rows); flushed = rows; }
+            } else {  // more keys in one step than the ring holds (at most 64 lists of HOME + BE keys): straight to the pool
+                const bool room = pos + c <= a.pool_cap;
+#ifndef MTG_EXP_NO_POOL_STORES
+                if (c > 0 && room) a.pool[pos] = k0;
+                if (c > 1 && room) a.pool[pos + 1] = k1;
+                if (c > 2 && room) a.pool[pos + 2] = k2;
+                if (c > 3 && room) a.pool[pos + 3] = k3;
+                for (uint32_t r = 4; __any(r < c); r++)
+                    if (r < c && room) a.pool[pos + r] = lds(hit_at(r));
+#endif
+                staged = total; flushed = total;
+            }
             // (7 of 10 sources have no candidate: their counts are zeroed by one streaming pass before the launch, their starts are
             // never read -- two scattered partial-line stores less per such source: 1.85 -> 1.40 -> ... GB written per launch at 2^27)
             // Round 6, measured on one box (tools/sssp_probe.py --lib, 2^27): without these two stores (-DMTG_EXP_NO_START_COUNT: wrong
@@ -890,7 +940,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 fix_next[cls] += nf;
                 fix_total[cls] += nf;
             };
-#ifndef MTG_EXP_NO_START_COUNT  // (without the lists' places the post-pass must get no work)
+#if !defined(MTG_EXP_NO_START_COUNT) && !defined(MTG_EXP_NO_FIX)  // (without the lists' places the post-pass must get no work)
             append_fix(fix && c <= 8, 0);
             append_fix(fix && c > 8 && c <= 16, 1);
             append_fix(fix && c > 16, 2);
@@ -921,6 +971,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             cur_dist = got_new ? 0u : IDLE_DIST;
         }
     }
+    flush_keys(flushed, staged);
     for (int cls = 0; cls < 3; cls++) {
         for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
         if (lane == 0 && fix_total[cls]) atomicAdd(&a.counters[C_FIX_CLASS0 + cls], (unsigned long long)fix_total[cls]);
