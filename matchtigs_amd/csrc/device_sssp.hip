@@ -474,7 +474,8 @@ constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #define MTG_ENUM_BE 16
 #endif
 #ifndef MTG_ENUM_KRING
-#define MTG_ENUM_KRING 256  // keys of the wave's output ring (a power of two)
+#define MTG_ENUM_KRING 128  // keys of the wave's output ring (a power of two)
+#define MTG_ENUM_RCAP 96    // finished sources whose (start, count) wait in LDS for the wave's next burst of stores
 #endif
 constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
 // LDS words between the starts of two extension blocks: one more than a block holds. With a stride of
@@ -515,7 +516,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     constexpr uint32_t T1 = 64u * HOME;                         // words of the home blocks
     constexpr uint32_t KRING = MTG_ENUM_KRING;                  // keys on their way to the pool
     static_assert((KRING & (KRING - 1)) == 0 && KRING >= 64 && KRING <= ENUM_POOL_CHUNK, "the ring is indexed by the chunk offset modulo its size");
-    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING;  // + pool + output ring
+    constexpr uint32_t RCAP = MTG_ENUM_RCAP;                    // records on their way to cand_start / cand_count / the post-pass work list
+    static_assert(RCAP >= 64 && RCAP % 2 == 0, "a step adds up to 64 records");
+    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING + RCAP + RCAP / 2;  // + pool + output ring + records (8 + 4 bytes each)
     constexpr uint32_t IDLE_DIST = 0xFFFF0000u;                 // distance of a lane without a source: nothing is within the bound from there
     // stack entry: node | (distance | own-flag-still-open << 16) << 32; hit entry = candidate key: node | distance << 32
     __shared__ unsigned long long s_mem[WPB][WAVE_WORDS];
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     const uint32_t home_b = wave_off + (uint32_t)lane * 8u, home_t = home_b + (HOME - 1) * HOME_STEP;  // first stack word / first hit word
     const uint32_t pool_off = wave_off + T1 * 8u;
     const uint32_t ring_off = pool_off + (uint32_t)NB * (BS * 8u);
+    const uint32_t recv_off = ring_off + KRING * 8u, reci_off = recv_off + RCAP * 8u;  // record values (8 bytes), record sources (4 bytes)
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
     unsigned long long pool_base = 0;                                                // wave-uniform
@@ -676,6 +680,61 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             if (pos < a.pool_cap) a.pool[pos] = ring(j);  // (pool too small: the host retries with a larger one)
 #endif
         }
+    };
+    // A finished source's (start, count) -- and its entry in the post-pass work list -- wait in LDS as a record: source | value =
+    // start << 9 | needs-the-post-pass << 8 | count (0xFF: handed to the cascade); the wave stores them in bursts of up to RCAP.
+    // What the result stores cost the level (round 6, G-csr 2^27, under the profiler): 0.55 of 1.30 ms -- the search alone runs in
+    // 0.75 ms; keys 0.18, (start, count) 0.25-0.31, work list 0.06-0.10. What did NOT change that: issuing the stores after the next
+    // step's wait instead of behind the gather; dense arrays over the searched sources (round 6's first experiment); bursts in the
+    // sources' order (a 64-lane sorting network); runs of consecutive chunks per wave (the lines of a run then meet in L2). What did:
+    // fewer store instructions (this ring and the keys' ring: 0.08 ms together) and, with made-up addresses, fewer distinct LINES per
+    // instruction (36 lines per 64 records: -0.12 ms, 12 lines: -0.21 ms). A record's two stores touch two lines of their own
+    // whatever the order -- one source in 3.5 is searched, one in 3.5 of those has a list, a line holds 8 starts or 16 counts -- so
+    // what is left of this cost is the price of (start, count) arrays indexed by the source: tools/kstats_multi.sh, -DMTG_EXP_*.
+    uint32_t n_rec = 0;  // wave-uniform
+    auto flush_records = [&]() {
+        for (uint32_t i = (uint32_t)lane; __any(i < n_rec); i += 64u) {
+            const bool have = i < n_rec;
+            const unsigned long long v = have ? lds(recv_off + (i << 3)) : 0ull;
+            const uint32_t r_item = have ? *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + reci_off + (i << 2)) : 0u;
+            const uint32_t r_c = (uint32_t)v & 0xFFu;
+            const bool r_fix = ((uint32_t)v & 0x100u) != 0u;
+#ifndef MTG_EXP_NO_START_COUNT
+            if (have && r_c != 0xFFu) {
+                a.cand_start[r_item] = v >> 9;
+                a.cand_count[r_item] = r_c;
+            } else if (have) a.cand_count[r_item] = CAND_OVERFLOW;
+#endif
+            // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
+            // similar length with a network of that size)
+            auto append_fix = [&](bool f, int cls) {
+                const unsigned long long fm = __ballot(f);
+                if (!fm) return;
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                if (fix_next[cls] + nf > fix_end[cls]) {  // the rest of the old chunk is marked unused
+                    for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
+                    unsigned long long f0 = 0;
+                    if (lane == 0) {
+                        f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
+                        a.fix_list[f0] = FIX_CLASS_TAG | (uint32_t)cls;
+                    }
+                    fix_next[cls] = uniform_u64(f0) + 1;
+                    fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
+                }
+                if (f) a.fix_list[fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = r_item;
+                fix_next[cls] += nf;
+                fix_total[cls] += nf;
+            };
+#if !defined(MTG_EXP_NO_START_COUNT) && !defined(MTG_EXP_NO_FIX)  // (without the lists' places the post-pass must get no work)
+            const bool f = have && r_fix && r_c != 0xFFu;
+            append_fix(f && r_c <= 8, 0);
+            append_fix(f && r_c > 8 && r_c <= 16, 1);
+            append_fix(f && r_c > 16, 2);
+#else
+            (void)append_fix; (void)r_fix;
+#endif
+        }
+        n_rec = 0;
     };
     // hit r of the lane's source: in the home block below h0, in the store block from there
     auto hit_at = [&](uint32_t r) -> uint32_t { return r >= h0 ? ct - ((r - h0) << shift) : home_t - (r << HOME_SHIFT); };
@@ -908,45 +967,19 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 staged = total; flushed = total;
             }
             // (7 of 10 sources have no candidate: their counts are zeroed by one streaming pass before the launch, their starts are
-            // never read -- two scattered partial-line stores less per such source: 1.85 -> 1.40 -> ... GB written per launch at 2^27)
-            // Round 6, measured on one box (tools/sssp_probe.py --lib, 2^27): without these two stores (-DMTG_EXP_NO_START_COUNT: wrong
-            // results, timing only) the kernel runs 1.00 instead of 1.26 ms -- but placing them densely (arrays over the searched sources
-            // only, every entry written once, whole lines per chunk) and moving them to the sources' places by a wave-cooperative streaming
-            // pass afterwards (0.125 ms) left the kernel at 1.25 ms: what they cost is issue slots in a loop that is bound by
-            // instruction issue, not memory traffic. Stage 1.82 -> 1.93 ms: dropped (docs/history has the kernel).
-#ifndef MTG_EXP_NO_START_COUNT
-            if (fin && c) {
-                a.cand_start[item] = pos;
-                a.cand_count[item] = c;
-            } else if (ovf) a.cand_count[item] = CAND_OVERFLOW;
-#endif
-            // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
-            // similar length with a network of that size)
-            auto append_fix = [&](bool f, int cls) {
-                const unsigned long long fm = __ballot(f);
-                if (!fm) return;
-                const uint32_t nf = (uint32_t)__popcll(fm);
-                if (fix_next[cls] + nf > fix_end[cls]) {  // the rest of the old chunk is marked unused
-                    for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
-                    unsigned long long f0 = 0;
-                    if (lane == 0) {
-                        f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
-                        a.fix_list[f0] = FIX_CLASS_TAG | (uint32_t)cls;
-                    }
-                    fix_next[cls] = uniform_u64(f0) + 1;
-                    fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
+            // never read: no record for them)
+            {  // the lists' places (and the sources handed to the cascade) as records; the wave stores them in bursts
+                const bool rec = (fin && c) || ovf;
+                const unsigned long long rm = __ballot(rec);
+                const uint32_t n_new = (uint32_t)__popcll(rm);
+                if (n_rec + n_new > RCAP) flush_records();
+                if (rec) {
+                    const uint32_t slot = n_rec + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                    lds(recv_off + (slot << 3)) = ovf ? 0xFFull : ((pos << 9) | (fix ? 0x100ull : 0ull) | c);
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + reci_off + (slot << 2)) = item;
                 }
-                if (f) a.fix_list[fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = item;
-                fix_next[cls] += nf;
-                fix_total[cls] += nf;
-            };
-#if !defined(MTG_EXP_NO_START_COUNT) && !defined(MTG_EXP_NO_FIX)  // (without the lists' places the post-pass must get no work)
-            append_fix(fix && c <= 8, 0);
-            append_fix(fix && c > 8 && c <= 16, 1);
-            append_fix(fix && c > 16, 2);
-#else
-            (void)append_fix;
-#endif
+                n_rec += n_new;
+            }
             unsigned long long rel = __ballot((fin || ovf) && cb != home_b);  // extension blocks go back to the pool
             while (rel) {
                 const int l = __builtin_ctzll(rel);
@@ -972,6 +1005,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         }
     }
     flush_keys(flushed, staged);
+    flush_records();
     for (int cls = 0; cls < 3; cls++) {
         for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
         if (lane == 0 && fix_total[cls]) atomicAdd(&a.counters[C_FIX_CLASS0 + cls], (unsigned long long)fix_total[cls]);
