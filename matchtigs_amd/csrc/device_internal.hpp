@@ -117,6 +117,8 @@ struct SsspArgs {
     unsigned long long *ws;      // global workspace (GLOBAL_WS levels)
     uint64_t ws_stride;          // 64-bit words per block
     uint32_t *ovf_list;          // out: absolute indices of the sources this launch could not finish (cursor: C_OVERFLOW)
+    unsigned long long *fix_val; // out (enumeration level): beside every work-list entry its list's place, start << 8 | count -- the post-pass
+                                 // reads its lists' places in the order of its work list, not from cand_start / cand_count at the sources' indices
     uint32_t *fix_list;          // out (enumeration level): post-pass work list in chunks of ENUM_FIX_CHUNK slots (cursor: C_FIX): slot 0 = the
                                  // chunk's length class, then indices (relative to src_begin) of lists of that class, FIX_NONE = unused
     uint32_t wmask;              // inline weight slots: 0xFF in the 8:8 format (k <= 255: weight | weight + lower bound << 8), else 0xFFFF
@@ -177,6 +179,7 @@ struct Device {
     double last_kernel_ms = 0.0;  // sum of the SSSP level kernels' HIP-event durations of the last call
     uint32_t *d_mirror = nullptr;             // [V] mirror node (claim replay)
     uint32_t *d_ovf[2] = {nullptr, nullptr};  // ping-pong overflow source lists
+    unsigned long long *d_fix_val = nullptr, *d_fix_dense_val = nullptr;  // ... and the lists' places beside the entries
     uint32_t *d_fix = nullptr, *d_fix_dense = nullptr;  // enumeration level: work list of its post-pass (chunked, as written / dense, by length class)
     uint64_t ovf_cap = 0;
     int last_n_levels = 0;           // per-level record of the last call: kernel ms and sources handed to the level

@@ -10,7 +10,7 @@ void device_set_single_use(Device *d) { d->single_use = true; }
 void device_drop_search_arrays(Device *d) {
     HIP_CHECK(hipDeviceSynchronize());
     for (void **p : {(void **)&d->d_recs, (void **)&d->d_ext_col, (void **)&d->d_ext_w, (void **)&d->d_act_index, (void **)&d->d_act_node,
-                     (void **)&d->d_ovf[0], (void **)&d->d_ovf[1], (void **)&d->d_fix, (void **)&d->d_fix_dense}) {
+                     (void **)&d->d_ovf[0], (void **)&d->d_ovf[1], (void **)&d->d_fix, (void **)&d->d_fix_dense, (void **)&d->d_fix_val, (void **)&d->d_fix_dense_val}) {
         if (*p) hu::device_arena(d->dev).free(*p, false);
         *p = nullptr;
     }

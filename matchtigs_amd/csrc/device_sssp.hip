@@ -721,7 +721,11 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                     fix_next[cls] = uniform_u64(f0) + 1;
                     fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
                 }
-                if (f) a.fix_list[fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = r_item;
+                if (f) {
+                    const unsigned long long slot = fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                    a.fix_list[slot] = r_item;
+                    a.fix_val[slot] = ((v >> 9) << 8) | r_c;
+                }
                 fix_next[cls] += nf;
                 fix_total[cls] += nf;
             };
@@ -1036,7 +1040,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 // The level's work list is chunked (slot 0 of a chunk names its length class, unused slots hold FIX_NONE); this pass makes it dense:
 // class 0 first, then class 1, then class 2 (the level counted the entries per class), so that the sorting kernels below run over
 // plain ranges.
-__global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_list, unsigned long long *counters, uint32_t *dense) {
+__global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_list, const unsigned long long *fix_val, unsigned long long *counters,
+                                                          uint32_t *dense, unsigned long long *dense_val) {
     __shared__ uint32_t s_cnt[3], s_off[3];
     __shared__ unsigned long long s_base[3];
     const unsigned long long n_slots = counters[C_FIX];
@@ -1066,15 +1071,19 @@ __global__ __launch_bounds__(256) void fix_compact_kernel(const uint32_t *fix_li
         uint32_t base = 0;
         if ((threadIdx.x & 63) == 0) base = atomicAdd(&s_off[cls], (uint32_t)__popcll(m));
         base = __shfl(base, 0);
-        if (e != FIX_NONE) dense[s_base[cls] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e;
+        if (e != FIX_NONE) {  // (the list's place, start << 8 | count, travels with its entry)
+            const unsigned long long to = s_base[cls] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            dense[to] = e;
+            dense_val[to] = fix_val[sl];
+        }
     }
 }
 
 // Lane-parallel form: G lanes per list, one key per lane -- coalesced reads and writes (a list is one or two memory requests instead
 // of one per key or key pair), bitonic sort across the lanes, then each key looks at the keys before it for its node.
 template <int G, int CLS, int BLOCK>
-__device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
-                                                 uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters, uint32_t block,
+__device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint64_t pool_cap, uint32_t *cand_count, const uint32_t *dense,
+                                                 const unsigned long long *dense_val, const unsigned long long *counters, uint32_t block,
                                                  uint32_t n_blocks) {
     constexpr uint32_t LPB = BLOCK / G;  // lists per workgroup pass
     unsigned long long begin = 0;
@@ -1083,9 +1092,12 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
     const uint32_t g = threadIdx.x % G;
     for (unsigned long long l0 = (unsigned long long)block * LPB; l0 < n; l0 += (unsigned long long)n_blocks * LPB) {
         const unsigned long long l = l0 + threadIdx.x / G;
-        const uint32_t i = l < n ? dense[begin + l] : FIX_NONE;
-        uint32_t c = i != FIX_NONE ? cand_count[i] : 0u;
-        const unsigned long long st = i != FIX_NONE ? cand_start[i] : 0ull;
+        // (the list's place comes with its entry: no look-up at the source's index -- those were two of the pass's three scattered reads
+        // per list: 0.30 -> 0.23 ms at 2^27, the compaction 0.045 -> 0.065 ms. Measured and dropped: no compaction at all, a workgroup
+        // per work-list chunk -- most chunks are the half-filled last ones of their wave and class: 0.42 ms)
+        const unsigned long long place = l < n ? dense_val[begin + l] : 0ull;
+        uint32_t c = (uint32_t)place & 0xFFu;
+        const unsigned long long st = place >> 8;
         if (c < 2 || c > (uint32_t)G || st + c > pool_cap) c = 0;  // (pool too small: the host retries with a larger one)
         unsigned long long key = g < c ? pool[st + g] : ~0ull;
 #pragma unroll
@@ -1112,19 +1124,19 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
             const unsigned long long group = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (lane - g);
             const uint32_t before = (uint32_t)__popcll(dm & group & ((1ull << lane) - 1ull));
             if (g < c && !dup) pool[st + g - before] = key;
-            if (g == 0 && (dm & group)) cand_count[i] = c - (uint32_t)__popcll(dm & group);
+            if (g == 0 && (dm & group)) cand_count[dense[begin + l]] = c - (uint32_t)__popcll(dm & group);
         } else if (g < c) pool[st + g] = key;
     }
 }
 // the three length classes in ONE launch (a third of the grid each: their lists are disjoint, and three launches in a row spent more
 // on their gaps and tails than on sorting)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, const unsigned long long *cand_start,
-                                                           uint32_t *cand_count, const uint32_t *dense, const unsigned long long *counters) {
+__global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, uint32_t *cand_count, const uint32_t *dense,
+                                                           const unsigned long long *dense_val, const unsigned long long *counters) {
     const uint32_t per = gridDim.x / 3u, cls = blockIdx.x / per, block = blockIdx.x % per;
-    if (cls == 0) sort_lists_class<8, 0, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
-    else if (cls == 1) sort_lists_class<16, 1, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
-    else if (cls == 2) sort_lists_class<32, 2, BLOCK>(pool, pool_cap, cand_start, cand_count, dense, counters, block, per);
+    if (cls == 0) sort_lists_class<8, 0, BLOCK>(pool, pool_cap, cand_count, dense, dense_val, counters, block, per);
+    else if (cls == 1) sort_lists_class<16, 1, BLOCK>(pool, pool_cap, cand_count, dense, dense_val, counters, block, per);
+    else if (cls == 2) sort_lists_class<32, 2, BLOCK>(pool, pool_cap, cand_count, dense, dense_val, counters, block, per);
 }
 
 
@@ -1230,9 +1242,9 @@ static void launch_enum(Device *d, hipStream_t st, SsspArgs args) {
     HIP_CHECK(hipGetLastError());
     const unsigned post_grid = (unsigned)std::min<uint64_t>((args.n_items + 255) / 256 + 1, (uint64_t)d->n_cu * 8);
     static_assert(ENUM_MAX_HITS <= 32, "the post-pass sorts up to 32 keys");
-    hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.counters, d->d_fix_dense);
-    hipLaunchKernelGGL((sort_lists_kernel<256>), dim3(3 * post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_start,
-                       args.cand_count, d->d_fix_dense, args.counters);
+    hipLaunchKernelGGL(fix_compact_kernel, dim3(d->n_cu * 4), dim3(256), 0, st, args.fix_list, args.fix_val, args.counters, d->d_fix_dense, d->d_fix_dense_val);
+    hipLaunchKernelGGL((sort_lists_kernel<256>), dim3(3 * post_grid), dim3(256), 0, st, args.pool, args.pool_cap, args.cand_count, d->d_fix_dense,
+                       d->d_fix_dense_val, args.counters);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(d->ev1, st));
 }
@@ -1411,10 +1423,15 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
         hu::device_malloc(&d->d_fix, fix_slots * sizeof(uint32_t));
         if (d->d_fix_dense) hu::device_free(d->d_fix_dense);
         hu::device_malloc(&d->d_fix_dense, std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+        if (d->d_fix_val) hu::device_free(d->d_fix_val);
+        hu::device_malloc(&d->d_fix_val, fix_slots * sizeof(unsigned long long));
+        if (d->d_fix_dense_val) hu::device_free(d->d_fix_dense_val);
+        hu::device_malloc(&d->d_fix_dense_val, std::max<uint64_t>(n, 1) * sizeof(unsigned long long));
         d->ovf_cap = n;
     }
     a.ovf_list = d->d_ovf[0];
     a.fix_list = d->d_fix;
+    a.fix_val = d->d_fix_val;
     double total_ms = 0.0;
     // the counting instantiations (untimed instrumentation) exist for the cooperative kernel only: it counts DISTINCT
     // settled nodes, an enumeration counts path steps
