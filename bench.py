@@ -290,6 +290,7 @@ def main():
         if rank == 0:
             if args.host_replay:
                 cs, cc, po = mdist.to_numpy_u(start_all, count_all, pool_all)
+                count_ref[0] = count_all
                 on, mu, li = dev.classify_download(stream)
                 t4 = time.perf_counter()
                 ph["download"] = t4 - t3
@@ -342,7 +343,7 @@ def main():
                     stages.setdefault(kk, []).append(v)
                 result_info.update(darts=fs["darts"], units=fs["units"])
             result_info.update(S=int(S), pairs=int(n_pairs), tigs=int(n_tigs), tig_edges=int(n_tig_edges),
-                               candidates=int(len(po)), graph_edges_after=int(graph.edge_count()))
+                               pool_words=int(len(po)), graph_edges_after=int(graph.edge_count()))
             graph.reset()
             ph["reset"] = time.perf_counter() - t6
         for kk, v in ph.items():
@@ -511,6 +512,10 @@ def main():
             roofline["pruned_search_pays_off_after_steps"] = (int(np.ceil(pre_ms / gain)) if gain > 0 and pre_ms > 0 else None)
         # ---- the other GPU stages of the step, each against the HBM roofline: GPU time from HIP events inside the engine (on the
         # stream the kernels run on), algorithmic bytes from stage_models(), counter traffic from profiles/stage_traffic.json ----
+        # (the number of candidates = the sum of the lists' lengths; the pool holds them in per-wave chunks with unused tails, whose
+        # number depends on how the sources are split over ranks)
+        if count_ref[0] is not None:
+            result_info["candidates"] = int(count_ref[0].to(torch.int64).sum().item())
         roofline_stages = None
         if world == 1 and (stage_ms["host"] or stage_ms["device"]):
             count_last = count_ref[0]

@@ -470,8 +470,8 @@ constexpr uint32_t FIX_CLASS_TAG = 0xFFFFFF00u;  // slot 0 of a work-list chunk:
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #ifndef MTG_ENUM_HOME
 #define MTG_ENUM_HOME 8
-#define MTG_ENUM_NB 25
-#define MTG_ENUM_BE 16
+#define MTG_ENUM_NB 17  // (25 blocks of 16 entries: 62 187 sources of the 2^27 bench graph outgrow the level, every one of them because its block is
+#define MTG_ENUM_BE 24  //  full -- 17 blocks of 24 entries in the same LDS: 19 388, the cascade behind 0.20 -> 0.08 ms, the level + 0.04 ms)
 #endif
 #ifndef MTG_ENUM_KRING
 #define MTG_ENUM_KRING 128  // keys of the wave's output ring (a power of two)

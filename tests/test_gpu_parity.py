@@ -219,13 +219,11 @@ def test_t1_long_lists_from_the_enumeration_level(gpu, oracle, plan):
     handed_on = levels[1]["sources"] if len(levels) > 1 else 0
     o_on, off, keys, _ = _oracle(oracle, bg).candidate_lists(bg.k)
     lens = np.diff(off).astype(np.int64)
-    # (a source with more than 24 candidates -- a full home block and a full extension block -- cannot finish in the level; of the
-    # others the cascade took over fewer than there are lists in every class, so the level finished lists of every class)
-    others_handed_on = handed_on - int((lens > 24).sum())
-    # (without the pruning the balls are searched in full and more sources run out of steps or space: there the argument only holds
-    # for the three classes together)
-    for lo_, hi_ in ((5, 8), (9, 16), (17, 24)) if plan != 4 else ((5, 24),):
-        assert int(((lens >= lo_) & (lens <= hi_)).sum()) > others_handed_on >= 0, (lo_, hi_, handed_on, np.bincount(lens)[:26])
+    # (a source with more than 32 candidates -- a full home block and a full extension block -- cannot finish in the level; the cascade
+    # took over fewer of the others than there are lists of 5 to 32 candidates, so the level itself finished lists that long: its
+    # post-pass -- the work list, its compaction by length class, the lane-parallel sorts -- ran on them)
+    others_handed_on = handed_on - int((lens > 32).sum())
+    assert int(((lens >= 5) & (lens <= 32)).sum()) > others_handed_on >= 0, (handed_on, np.bincount(lens)[:34])
     assert np.array_equal(count.astype(np.int64), lens)
     idx_arr = np.concatenate([np.arange(s, s + c, dtype=np.int64) for s, c in zip(start, count)])
     assert np.array_equal(pool[idx_arr], keys)
