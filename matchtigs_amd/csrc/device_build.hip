@@ -561,7 +561,7 @@ Device *device_create(const HostGraph &g, uint64_t k, int device_id, bool lower_
 // What the stages of a STEP take from the arena beside a device graph that stays (classification, search lists, claim-replay records,
 // the finish's dart arrays at their peak), calibrated on G-csr 2^24 / 2^27 / 2^30 (bench.py full_size.arena: 1.77 / 13.4 / 106.5 GB):
 // 60 bytes per node + 62 per original edge, + 8 %.
-size_t device_step_work_bytes_estimate(uint64_t V, uint64_t E) { return (size_t)((V * 68 + E * 62) / 100 * 108) + (64u << 20); }
+size_t device_step_work_bytes_estimate(uint64_t V, uint64_t E) { return (size_t)((V * 64 + E * 62) / 100 * 108) + (64u << 20); }
 // mtg_device_create_opts(MTG_DEVICE_RESERVE_WORK): a caller that will step through the stages with this device graph (classify /
 // search / replay / finish, again and again) takes that memory NOW, as ONE chunk, unless the arena has it free already -- the first
 // step then makes no driver call (five otherwise, each of which can stall for a second on this pool: DESIGN 9). Asked for

@@ -58,7 +58,7 @@ def test_reserved_step_makes_no_driver_allocation(product_lib):
 
 def product_lib_step_estimate(G):
     V, E = G.node_count(), G.original_edge_count()
-    return (V * 60 + E * 62) // 100 * 108 + (64 << 20)
+    return (V * 64 + E * 62) // 100 * 108 + (64 << 20)
 
 
 @pytest.mark.gpu
