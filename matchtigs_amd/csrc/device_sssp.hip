@@ -475,7 +475,6 @@ constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #endif
 #ifndef MTG_ENUM_KRING
 #define MTG_ENUM_KRING 128  // keys of the wave's output ring (a power of two)
-#define MTG_ENUM_RCAP 96    // finished sources whose (start, count) wait in LDS for the wave's next burst of stores
 #endif
 constexpr int ENUM_BE = MTG_ENUM_BE;        // entries per extension block
 // LDS words between the starts of two extension blocks: one more than a block holds. With a stride of
@@ -516,9 +515,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     constexpr uint32_t T1 = 64u * HOME;                         // words of the home blocks
     constexpr uint32_t KRING = MTG_ENUM_KRING;                  // keys on their way to the pool
     static_assert((KRING & (KRING - 1)) == 0 && KRING >= 64 && KRING <= ENUM_POOL_CHUNK, "the ring is indexed by the chunk offset modulo its size");
-    constexpr uint32_t RCAP = MTG_ENUM_RCAP;                    // records on their way to cand_start / cand_count / the post-pass work list
-    static_assert(RCAP >= 64 && RCAP % 2 == 0, "a step adds up to 64 records");
-    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING + RCAP + RCAP / 2;  // + pool + output ring + records (8 + 4 bytes each)
+    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING + 128u;  // + pool + output ring + the records of two chunks of sources
     constexpr uint32_t IDLE_DIST = 0xFFFF0000u;                 // distance of a lane without a source: nothing is within the bound from there
     // stack entry: node | (distance | own-flag-still-open << 16) << 32; hit entry = candidate key: node | distance << 32
     __shared__ unsigned long long s_mem[WPB][WAVE_WORDS];
@@ -539,7 +536,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     const uint32_t home_b = wave_off + (uint32_t)lane * 8u, home_t = home_b + (HOME - 1) * HOME_STEP;  // first stack word / first hit word
     const uint32_t pool_off = wave_off + T1 * 8u;
     const uint32_t ring_off = pool_off + (uint32_t)NB * (BS * 8u);
-    const uint32_t recv_off = ring_off + KRING * 8u, reci_off = recv_off + RCAP * 8u;  // record values (8 bytes), record sources (4 bytes)
+    const uint32_t tab_off = ring_off + KRING * 8u;  // records: [chunk parity][position in the chunk]
 
     unsigned long long free_mask = NB == 64 ? ~0ull : ((1ull << (NB & 63)) - 1ull);  // wave-uniform: free extension blocks
     unsigned long long pool_base = 0;                                                // wave-uniform
@@ -584,7 +581,13 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
     prefetch_chunk();
     bool exhausted = cur_len == 0;
-    auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src) -> bool {
+    // (the chunk in `ids' is number cur_seq of the wave; a lane remembers its source's chunk and position there, `tag' = chunk << 6 |
+    // position: where its record waits, see below. When `ids' moves on, the records of the chunk before the one that leaves `ids' are
+    // due: `evict_*' says so to the end of the step)
+    uint32_t cur_seq = 0;                                // wave-uniform
+    uint32_t prev_items = 0, evict_items = 0;            // per lane = per position: the sources (indices relative to src_begin) of chunk cur_seq - 1 / of the chunk that is due
+    bool evict_pending = false;                          // wave-uniform
+    auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src, uint32_t &new_tag) -> bool {
         if (exhausted) return false;
         const unsigned long long need = __ballot(want);
         const uint32_t idx = cur_pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -599,9 +602,13 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         } else {
             new_item = second ? nxt_base + idx - 64u : cur_base + idx;
         }
+        new_tag = ((cur_seq + (second ? 1u : 0u)) << 6) | (idx & 63u);
         cur_pos += (uint32_t)__popcll(need);
         if (cur_pos >= 64u) {
             cur_pos -= 64u;
+            evict_items = prev_items; evict_pending = true;  // (chunk cur_seq - 1: its place in the table goes to chunk cur_seq + 1)
+            prev_items = PRUNE ? ids_item : cur_base + (uint32_t)lane;
+            cur_seq++;
             ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
             prefetch_chunk();  // in flight while the chunk that just became current is handed out
         }
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     uint32_t s0 = 0, h0 = 0;          // first stack row / first hit of the lane's store block (0 while that is its home block)
     uint32_t cb = home_b, ct = home_t;  // the lane's store block: its first stack word and its first hit word (LDS byte offsets) ...
     uint32_t step = HOME_STEP, shift = HOME_SHIFT;  // ... and the bytes between two of its words
-    uint32_t pops = 0, src_node = 0, item = 0;
+    uint32_t pops = 0, src_node = 0, item = 0, tag = 0;
     bool src_tgt = false;             // the source is an in-node itself: its own hits are taken out when it finishes (see hv[0])
     uint32_t cur_node = 0, cur_dist = IDLE_DIST;  // the node whose block is in b0..b3
     bool cur_chk = false;                         // its own in-node flag was already evaluated from its parent's block
@@ -681,71 +688,78 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 #endif
         }
     };
-    // A finished source's (start, count) -- and its entry in the post-pass work list -- wait in LDS as a record: source | value =
-    // start << 9 | needs-the-post-pass << 8 | count (0xFF: handed to the cascade); the wave stores them in bursts of up to RCAP.
+    // A finished source's (start, count) -- and its entry in the post-pass work list -- wait in LDS as a record: start << 9 |
+    // needs-the-post-pass << 8 | count (0xFF: handed to the cascade), in a table [chunk parity][position in the chunk] that holds the
+    // wave's current chunk of sources and the one before. When the wave moves on to its next chunk, the records of the older of the two
+    // leave TOGETHER, lane = position = the sources' order: 64 consecutive searched sources span ~220 source indices, i.e. ~14 lines of
+    // cand_count and ~28 of cand_start -- where every record stored on its own touches two lines of its own. A source that outlives
+    // two chunks (one in seven) stores its record itself.
     // What the result stores cost the level (round 6, G-csr 2^27, under the profiler): 0.55 of 1.30 ms -- the search alone runs in
     // 0.75 ms; keys 0.18, (start, count) 0.25-0.31, work list 0.06-0.10. What did NOT change that: issuing the stores after the next
-    // step's wait instead of behind the gather; dense arrays over the searched sources (round 6's first experiment); bursts in the
-    // sources' order (a 64-lane sorting network); runs of consecutive chunks per wave (the lines of a run then meet in L2). What did:
-    // fewer store instructions (this ring and the keys' ring: 0.08 ms together) and, with made-up addresses, fewer distinct LINES per
-    // instruction (36 lines per 64 records: -0.12 ms, 12 lines: -0.21 ms). A record's two stores touch two lines of their own
-    // whatever the order -- one source in 3.5 is searched, one in 3.5 of those has a list, a line holds 8 starts or 16 counts -- so
-    // what is left of this cost is the price of (start, count) arrays indexed by the source: tools/kstats_multi.sh, -DMTG_EXP_*.
-    uint32_t n_rec = 0;  // wave-uniform
-    auto flush_records = [&]() {
-        for (uint32_t i = (uint32_t)lane; __any(i < n_rec); i += 64u) {
-            const bool have = i < n_rec;
-            const unsigned long long v = have ? lds(recv_off + (i << 3)) : 0ull;
-            const uint32_t r_item = have ? *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + reci_off + (i << 2)) : 0u;
-            const uint32_t r_c = (uint32_t)v & 0xFFu;
-            const bool r_fix = ((uint32_t)v & 0x100u) != 0u;
+    // step's wait instead of behind the gather; dense arrays over the searched sources plus an expansion pass; bursts of 96 records
+    // in finishing order or sorted by source (a 64-lane network); runs of consecutive chunks per wave (the lines of a run then meet
+    // in L2). What did: fewer store instructions (the keys' ring) and fewer distinct LINES per store instruction (made-up addresses,
+    // 36 lines per 64 records: -0.12 ms, 12 lines: -0.21 ms) -- which is what the table is for. tools/kstats_multi.sh, -DMTG_EXP_*.
+    auto table = [&](uint32_t t) -> unsigned long long & { return lds(tab_off + ((t & 127u) << 3)); };  // (t = tag: chunk << 6 | position)
+    table((uint32_t)lane) = 0ull;
+    table(64u + (uint32_t)lane) = 0ull;
+    auto emit_records = [&](unsigned long long v, uint32_t r_item) {  // v != 0: this lane has a record, of source r_item
+        const bool have = v != 0ull;
+        const uint32_t r_c = (uint32_t)v & 0xFFu;
+        const bool r_fix = ((uint32_t)v & 0x100u) != 0u;
 #ifndef MTG_EXP_NO_START_COUNT
-            if (have && r_c != 0xFFu) {
-                a.cand_start[r_item] = v >> 9;
-                a.cand_count[r_item] = r_c;
-            } else if (have) a.cand_count[r_item] = CAND_OVERFLOW;
+        if (have && r_c != 0xFFu) {
+            a.cand_start[r_item] = v >> 9;
+            a.cand_count[r_item] = r_c;
+        } else if (have) a.cand_count[r_item] = CAND_OVERFLOW;
 #endif
-            // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
-            // similar length with a network of that size)
-            auto append_fix = [&](bool f, int cls) {
-                const unsigned long long fm = __ballot(f);
-                if (!fm) return;
-                const uint32_t nf = (uint32_t)__popcll(fm);
-                if (fix_next[cls] + nf > fix_end[cls]) {  // the rest of the old chunk is marked unused
-                    for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
-                    unsigned long long f0 = 0;
-                    if (lane == 0) {
-                        f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
-                        a.fix_list[f0] = FIX_CLASS_TAG | (uint32_t)cls;
-                    }
-                    fix_next[cls] = uniform_u64(f0) + 1;
-                    fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
+        // post-pass work list: a wave fills one chunk per length class at a time (a wave of the post-pass then sorts lists of
+        // similar length with a network of that size)
+        auto append_fix = [&](bool f, int cls) {
+            const unsigned long long fm = __ballot(f);
+            if (!fm) return;
+            const uint32_t nf = (uint32_t)__popcll(fm);
+            if (fix_next[cls] + nf > fix_end[cls]) {  // the rest of the old chunk is marked unused
+                for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
+                unsigned long long f0 = 0;
+                if (lane == 0) {
+                    f0 = atomicAdd(&a.counters[C_FIX], (unsigned long long)ENUM_FIX_CHUNK);
+                    a.fix_list[f0] = FIX_CLASS_TAG | (uint32_t)cls;
                 }
-                if (f) {
-                    const unsigned long long slot = fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                    a.fix_list[slot] = r_item;
-                    a.fix_val[slot] = ((v >> 9) << 8) | r_c;
-                }
-                fix_next[cls] += nf;
-                fix_total[cls] += nf;
-            };
+                fix_next[cls] = uniform_u64(f0) + 1;
+                fix_end[cls] = fix_next[cls] - 1 + ENUM_FIX_CHUNK;
+            }
+            if (f) {
+                const unsigned long long slot = fix_next[cls] + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                a.fix_list[slot] = r_item;
+                a.fix_val[slot] = ((v >> 9) << 8) | r_c;
+            }
+            fix_next[cls] += nf;
+            fix_total[cls] += nf;
+        };
 #if !defined(MTG_EXP_NO_START_COUNT) && !defined(MTG_EXP_NO_FIX)  // (without the lists' places the post-pass must get no work)
-            const bool f = have && r_fix && r_c != 0xFFu;
-            append_fix(f && r_c <= 8, 0);
-            append_fix(f && r_c > 8 && r_c <= 16, 1);
-            append_fix(f && r_c > 16, 2);
+        const bool f = have && r_fix && r_c != 0xFFu;
+        append_fix(f && r_c <= 8, 0);
+        append_fix(f && r_c > 8 && r_c <= 16, 1);
+        append_fix(f && r_c > 16, 2);
 #else
-            (void)append_fix; (void)r_fix;
+        (void)append_fix; (void)r_fix;
 #endif
-        }
-        n_rec = 0;
+    };
+    auto flush_chunk_records = [&](uint32_t parity, uint32_t items) {  // the records of one chunk: lane = position
+        const uint32_t t = (parity << 6) | (uint32_t)lane;
+        const unsigned long long v = table(t);
+        if (!__any(v != 0ull)) return;
+        table(t) = 0ull;
+        emit_records(v, items);
     };
     // hit r of the lane's source: in the home block below h0, in the store block from there
     auto hit_at = [&](uint32_t r) -> uint32_t { return r >= h0 ? ct - ((r - h0) << shift) : home_t - (r << HOME_SHIFT); };
     {
         uint32_t ni = 0, ns = 0;
-        if (take_source(true, ni, ns)) {
-            item = ni; src_node = ns; cur_node = ns; cur_dist = 0;
+        uint32_t nt = 0;
+        if (take_source(true, ni, ns, nt)) {
+            item = ni; src_node = ns; cur_node = ns; cur_dist = 0; tag = nt;
             active = true;
         }
         load_block(active, cur_node);
@@ -882,13 +896,17 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         const bool fin = active && !ovf && !go_on;  // the source is finished
 
         // ---- lanes without a next node take a new source; every lane's next gather leaves now ----
-        uint32_t new_item = 0, new_src = 0;
-        const bool got_new = take_source(!go_on, new_item, new_src);
+        uint32_t new_item = 0, new_src = 0, new_tag = 0;
+        const bool got_new = take_source(!go_on, new_item, new_src, new_tag);
         const uint32_t nx_node = go_on ? (uint32_t)top : new_src;
         load_block(go_on || got_new, nx_node);
         if constexpr (QUAD) __builtin_amdgcn_s_setprio(0);
 
         // ---- finished / overflowed sources write their result ----
+        if (evict_pending) {  // the wave has moved on to chunk cur_seq: the records of chunk cur_seq - 2 leave, its part of the table is the new chunk's
+            flush_chunk_records(cur_seq & 1u, evict_items);
+            evict_pending = false;
+        }
         const unsigned long long donemask = __ballot(fin || ovf);
         if (donemask) {
             uint32_t c = fin ? nhit : 0u;
@@ -972,17 +990,12 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             }
             // (7 of 10 sources have no candidate: their counts are zeroed by one streaming pass before the launch, their starts are
             // never read: no record for them)
-            {  // the lists' places (and the sources handed to the cascade) as records; the wave stores them in bursts
+            {  // the list's place (or: handed to the cascade) as a record in its chunk's part of the table; a straggler stores it now
                 const bool rec = (fin && c) || ovf;
-                const unsigned long long rm = __ballot(rec);
-                const uint32_t n_new = (uint32_t)__popcll(rm);
-                if (n_rec + n_new > RCAP) flush_records();
-                if (rec) {
-                    const uint32_t slot = n_rec + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
-                    lds(recv_off + (slot << 3)) = ovf ? 0xFFull : ((pos << 9) | (fix ? 0x100ull : 0ull) | c);
-                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_mem[0][0]) + reci_off + (slot << 2)) = item;
-                }
-                n_rec += n_new;
+                const unsigned long long v = rec ? (ovf ? 0xFFull : ((pos << 9) | (fix ? 0x100ull : 0ull) | c)) : 0ull;
+                const bool resident = (tag >> 6) + 1u >= cur_seq;  // (chunk cur_seq or cur_seq - 1)
+                if (rec && resident) table(tag) = v;
+                if (__any(rec && !resident)) emit_records(resident ? 0ull : v, item);
             }
             unsigned long long rel = __ballot((fin || ovf) && cb != home_b);  // extension blocks go back to the pool
             while (rel) {
@@ -1004,12 +1017,14 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             cur_chk = false;
             src_tgt = false;
             active = got_new;
-            item = new_item; src_node = new_src; cur_node = new_src;
+            item = new_item; src_node = new_src; cur_node = new_src; tag = new_tag;
             cur_dist = got_new ? 0u : IDLE_DIST;
         }
     }
     flush_keys(flushed, staged);
-    flush_records();
+    if (evict_pending) flush_chunk_records(cur_seq & 1u, evict_items);
+    flush_chunk_records((cur_seq + 1u) & 1u, prev_items);  // (chunk cur_seq - 1)
+    flush_chunk_records(cur_seq & 1u, PRUNE ? ids_item : cur_base + (uint32_t)lane);
     for (int cls = 0; cls < 3; cls++) {
         for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
         if (lane == 0 && fix_total[cls]) atomicAdd(&a.counters[C_FIX_CLASS0 + cls], (unsigned long long)fix_total[cls]);
