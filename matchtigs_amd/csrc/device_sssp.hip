@@ -473,6 +473,9 @@ constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #define MTG_ENUM_NB 17  // (25 blocks of 16 entries: 62 187 sources of the 2^27 bench graph outgrow the level, every one of them because its block is
 #define MTG_ENUM_BE 24  //  full -- 17 blocks of 24 entries in the same LDS: 19 388, the cascade behind 0.20 -> 0.08 ms, the level + 0.04 ms)
 #endif
+#ifndef MTG_ENUM_TSLOTS
+#define MTG_ENUM_TSLOTS 2  // chunks of sources whose records wait in the wave's table (a power of two)
+#endif
 #ifndef MTG_ENUM_KRING
 #define MTG_ENUM_KRING 128  // keys of the wave's output ring (a power of two)
 #endif
@@ -515,7 +518,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     constexpr uint32_t T1 = 64u * HOME;                         // words of the home blocks
     constexpr uint32_t KRING = MTG_ENUM_KRING;                  // keys on their way to the pool
     static_assert((KRING & (KRING - 1)) == 0 && KRING >= 64 && KRING <= ENUM_POOL_CHUNK, "the ring is indexed by the chunk offset modulo its size");
-    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING + 128u;  // + pool + output ring + the records of two chunks of sources
+    constexpr uint32_t TSLOTS = MTG_ENUM_TSLOTS;
+    static_assert(TSLOTS >= 2 && (TSLOTS & (TSLOTS - 1)) == 0, "the table is indexed by the chunk number modulo its size");
+    constexpr uint32_t WAVE_WORDS = T1 + (uint32_t)NB * BS + KRING + TSLOTS * 64u;  // + pool + output ring + the records of TSLOTS chunks of sources
     constexpr uint32_t IDLE_DIST = 0xFFFF0000u;                 // distance of a lane without a source: nothing is within the bound from there
     // stack entry: node | (distance | own-flag-still-open << 16) << 32; hit entry = candidate key: node | distance << 32
     __shared__ unsigned long long s_mem[WPB][WAVE_WORDS];
@@ -585,7 +590,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     // position: where its record waits, see below. When `ids' moves on, the records of the chunk before the one that leaves `ids' are
     // due: `evict_*' says so to the end of the step)
     uint32_t cur_seq = 0;                                // wave-uniform
-    uint32_t prev_items = 0, evict_items = 0;            // per lane = per position: the sources (indices relative to src_begin) of chunk cur_seq - 1 / of the chunk that is due
+    uint32_t hist_items[TSLOTS - 1], evict_items = 0;    // per lane = per position: the sources (indices relative to src_begin) of chunks cur_seq - 1, - 2, ... / of the chunk that is due
+#pragma unroll
+    for (uint32_t q = 0; q + 1 < TSLOTS; q++) hist_items[q] = 0;
     bool evict_pending = false;                          // wave-uniform
     auto take_source = [&](bool want, uint32_t &new_item, uint32_t &new_src, uint32_t &new_tag) -> bool {
         if (exhausted) return false;
@@ -606,8 +613,10 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         cur_pos += (uint32_t)__popcll(need);
         if (cur_pos >= 64u) {
             cur_pos -= 64u;
-            evict_items = prev_items; evict_pending = true;  // (chunk cur_seq - 1: its place in the table goes to chunk cur_seq + 1)
-            prev_items = PRUNE ? ids_item : cur_base + (uint32_t)lane;
+            evict_items = hist_items[TSLOTS - 2]; evict_pending = true;  // (the oldest chunk of the table: its place goes to chunk cur_seq + 1)
+#pragma unroll
+            for (uint32_t q = TSLOTS - 2; q > 0; q--) hist_items[q] = hist_items[q - 1];
+            hist_items[0] = PRUNE ? ids_item : cur_base + (uint32_t)lane;
             cur_seq++;
             ids = ahead; ids_item = ahead_item; cur_base = nxt_base; cur_len = nxt_len;
             prefetch_chunk();  // in flight while the chunk that just became current is handed out
@@ -690,19 +699,19 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     };
     // A finished source's (start, count) -- and its entry in the post-pass work list -- wait in LDS as a record: start << 9 |
     // needs-the-post-pass << 8 | count (0xFF: handed to the cascade), in a table [chunk parity][position in the chunk] that holds the
-    // wave's current chunk of sources and the one before. When the wave moves on to its next chunk, the records of the older of the two
+    // wave's current chunk of sources and the TSLOTS - 1 before. When the wave moves on to its next chunk, the records of the oldest of them
     // leave TOGETHER, lane = position = the sources' order: 64 consecutive searched sources span ~220 source indices, i.e. ~14 lines of
     // cand_count and ~28 of cand_start -- where every record stored on its own touches two lines of its own. A source that outlives
-    // two chunks (one in seven) stores its record itself.
+    // TSLOTS chunks stores its record itself.
     // What the result stores cost the level (round 6, G-csr 2^27, under the profiler): 0.55 of 1.30 ms -- the search alone runs in
     // 0.75 ms; keys 0.18, (start, count) 0.25-0.31, work list 0.06-0.10. What did NOT change that: issuing the stores after the next
     // step's wait instead of behind the gather; dense arrays over the searched sources plus an expansion pass; bursts of 96 records
     // in finishing order or sorted by source (a 64-lane network); runs of consecutive chunks per wave (the lines of a run then meet
     // in L2). What did: fewer store instructions (the keys' ring) and fewer distinct LINES per store instruction (made-up addresses,
     // 36 lines per 64 records: -0.12 ms, 12 lines: -0.21 ms) -- which is what the table is for. tools/kstats_multi.sh, -DMTG_EXP_*.
-    auto table = [&](uint32_t t) -> unsigned long long & { return lds(tab_off + ((t & 127u) << 3)); };  // (t = tag: chunk << 6 | position)
-    table((uint32_t)lane) = 0ull;
-    table(64u + (uint32_t)lane) = 0ull;
+    auto table = [&](uint32_t t) -> unsigned long long & { return lds(tab_off + ((t & (TSLOTS * 64u - 1u)) << 3)); };  // (t = tag: chunk << 6 | position)
+#pragma unroll
+    for (uint32_t q = 0; q < TSLOTS; q++) table(q * 64u + (uint32_t)lane) = 0ull;
     auto emit_records = [&](unsigned long long v, uint32_t r_item) {  // v != 0: this lane has a record, of source r_item
         const bool have = v != 0ull;
         const uint32_t r_c = (uint32_t)v & 0xFFu;
@@ -746,8 +755,8 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         (void)append_fix; (void)r_fix;
 #endif
     };
-    auto flush_chunk_records = [&](uint32_t parity, uint32_t items) {  // the records of one chunk: lane = position
-        const uint32_t t = (parity << 6) | (uint32_t)lane;
+    auto flush_chunk_records = [&](uint32_t chunk, uint32_t items) {  // the records of one chunk: lane = position
+        const uint32_t t = (chunk << 6) | (uint32_t)lane;
         const unsigned long long v = table(t);
         if (!__any(v != 0ull)) return;
         table(t) = 0ull;
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
 
         // ---- finished / overflowed sources write their result ----
         if (evict_pending) {  // the wave has moved on to chunk cur_seq: the records of chunk cur_seq - 2 leave, its part of the table is the new chunk's
-            flush_chunk_records(cur_seq & 1u, evict_items);
+            flush_chunk_records(cur_seq, evict_items);  // (chunk cur_seq - TSLOTS: the same part of the table)
             evict_pending = false;
         }
         const unsigned long long donemask = __ballot(fin || ovf);
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
             {  // the list's place (or: handed to the cascade) as a record in its chunk's part of the table; a straggler stores it now
                 const bool rec = (fin && c) || ovf;
                 const unsigned long long v = rec ? (ovf ? 0xFFull : ((pos << 9) | (fix ? 0x100ull : 0ull) | c)) : 0ull;
-                const bool resident = (tag >> 6) + 1u >= cur_seq;  // (chunk cur_seq or cur_seq - 1)
+                const bool resident = (tag >> 6) + TSLOTS > cur_seq;  // (one of the chunks cur_seq - TSLOTS + 1 .. cur_seq)
                 if (rec && resident) table(tag) = v;
                 if (__any(rec && !resident)) emit_records(resident ? 0ull : v, item);
             }
@@ -1022,9 +1031,10 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
         }
     }
     flush_keys(flushed, staged);
-    if (evict_pending) flush_chunk_records(cur_seq & 1u, evict_items);
-    flush_chunk_records((cur_seq + 1u) & 1u, prev_items);  // (chunk cur_seq - 1)
-    flush_chunk_records(cur_seq & 1u, PRUNE ? ids_item : cur_base + (uint32_t)lane);
+    if (evict_pending) flush_chunk_records(cur_seq, evict_items);
+#pragma unroll
+    for (uint32_t q = 0; q + 1 < TSLOTS; q++) flush_chunk_records(cur_seq - 1u - q, hist_items[q]);  // (chunk numbers modulo TSLOTS: before the first chunks these parts are empty)
+    flush_chunk_records(cur_seq, PRUNE ? ids_item : cur_base + (uint32_t)lane);
     for (int cls = 0; cls < 3; cls++) {
         for (unsigned long long t = fix_next[cls] + lane; t < fix_end[cls]; t += 64) a.fix_list[t] = FIX_NONE;
         if (lane == 0 && fix_total[cls]) atomicAdd(&a.counters[C_FIX_CLASS0 + cls], (unsigned long long)fix_total[cls]);
