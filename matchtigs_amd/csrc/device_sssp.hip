@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
                 const bool rec = (fin && c) || ovf;
                 const unsigned long long v = rec ? (ovf ? 0xFFull : ((pos << 9) | (fix ? 0x100ull : 0ull) | c)) : 0ull;
                 const bool resident = (tag >> 6) + TSLOTS > cur_seq;  // (one of the chunks cur_seq - TSLOTS + 1 .. cur_seq)
+#ifdef MTG_ENUM_STATS
+                st_budget += (uint32_t)__popcll(__ballot(rec && !resident));  // (development build: counted with the step budget's)
+#endif
                 if (rec && resident) table(tag) = v;
                 if (__any(rec && !resident)) emit_records(resident ? 0ull : v, item);
             }
@@ -1506,7 +1509,7 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
                                  (unsigned long long)n, (unsigned long long)(use_enum && enum_prunes(d) ? d->h_counters[C_ACTIVE] : n_first), elapsed_ms(d),
                                  (unsigned long long)d->h_counters[C_OVERFLOW], (unsigned long long)d->h_counters[C_SETTLED]);
 #ifdef MTG_ENUM_STATS
-    if (use_enum && n) std::fprintf(stderr, "[mtg] enum stats: wave steps %llu, lane steps %llu (%.1f of 64), starved %llu, block full %llu, step budget %llu, fix cursor %llu, pool cursor %llu\n",
+    if (use_enum && n) std::fprintf(stderr, "[mtg] enum stats: wave steps %llu, lane steps %llu (%.1f of 64), starved %llu, block full %llu, step budget + records stored by stragglers %llu, fix cursor %llu, pool cursor %llu\n",
                                     d->h_counters[C_SETTLED], d->h_counters[C_RELAXED], (double)d->h_counters[C_RELAXED] / (double)std::max<unsigned long long>(d->h_counters[C_SETTLED], 1),
                                     d->h_counters[C_EMITTED], d->h_counters[C_ATTEMPTS], d->h_counters[C_PUSHES], d->h_counters[C_FIX], d->h_counters[C_POOL]);
     if (use_enum && n) {  // when the waves end, and how many steps they ran
