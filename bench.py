@@ -408,12 +408,16 @@ def main():
     device_mode = None
     dm_steps = args.steps if args.device_mode_steps is None else args.device_mode_steps
     if args.euler == "host" and dm_steps > 0:
-        dm_ms, dm_acc = timed_region(api.EulerMode.Device, 1, dm_steps)
+        dm_kernel_ms: list[float] = []
+        dm_ms, dm_acc = timed_region(api.EulerMode.Device, 1, dm_steps, dm_kernel_ms, [])
         tig_dl: list[float] = []
         step(api.EulerMode.Device, {}, tig_download_ms=tig_dl)  # one more step on every rank (it gathers), untimed: what bringing its tigs to the host as walks costs
         sync_barrier()
         device_mode = {"steps": dm_steps, "ms_per_step": round(dm_ms, 3),
                        "phases_ms": {kk: round(v / dm_steps * 1e3, 3) for kk, v in dm_acc.items()},
+                       # (the SSSP stage by the same HIP events as `roofline', inside THESE steps: they follow one another on the GPU, where a
+                       # headline step in the reference's order starts after seconds of host walk with an idle GPU)
+                       "sssp_stage_ms": round(float(np.mean(dm_kernel_ms)), 4) if dm_kernel_ms else None,
                        "tigs": result_info.get("tigs"),
                        "tig_download_ms": round(tig_dl[0], 3) if tig_dl else None,
                        "ms_per_step_with_tigs_on_host": round(dm_ms + tig_dl[0], 3) if tig_dl else None,
