@@ -230,7 +230,8 @@ uint64_t mtg_last_sssp_searched_sources(const mtg_device *d);
  * blocks exceed 3 GB), 1 = cooperative cascade only (exact for any ball; the fallback plan and the one the counting kernels
  * use), 2 / 3 = plan 0 with the four-lanes-per-block / per-lane form of the gathers regardless of the graph's size (same
  * results; lets small graphs exercise both forms); 4 / 6 / 7 = plans 0 / 2 / 3 WITHOUT the goal-directed pruning (full balls, every
- * source searched; same results: A/B runs and tests). Returns the plan in force. */
+ * source searched; same results: A/B runs and tests); + 8 = the enumeration level on one workgroup (same results, slow: lets a test graph
+ * of a few thousand sources take a wave through many chunks of sources). Returns the plan in force. */
 int mtg_set_sssp_plan(mtg_device *d, int plan);
 
 /* The claim loop (greedytigs/mod.rs:301-523, 1-thread order) on the GPU, over the candidate lists of ALL classified

@@ -509,7 +509,8 @@ class DeviceGraph:
 
     def set_plan(self, plan: int) -> int:
         """0 = default (path enumeration level + cooperative cascade), 1 = cooperative cascade only, 2 / 3 = plan 0 with
-        quad-cooperative / per-lane block gathers regardless of the graph size, + 4 = without the goal-directed pruning (mtg_engine.h)."""
+        quad-cooperative / per-lane block gathers regardless of the graph size, + 4 = without the goal-directed pruning, + 8 = the
+        enumeration level on one workgroup (tests) (mtg_engine.h)."""
         return int(self._L.mtg_set_sssp_plan(self._d, plan))
 
 

@@ -362,7 +362,7 @@ uint64_t device_replay(Device *d, void *stream, uint64_t n_sources, const uint64
 }
 
 int device_set_plan(Device *d, int plan) {
-    if (plan >= 0 && plan <= 7) d->plan = (plan & 3) == 1 ? 1 : plan;
+    if (plan >= 0 && plan <= 15) d->plan = (plan & 3) == 1 ? 1 : plan;  // (+ 8: the enumeration level on ONE workgroup -- tests)
     return d->plan;
 }
 int device_last_replay_rounds(const Device *d) { return d->last_replay_rounds; }

@@ -229,6 +229,32 @@ def test_t1_long_lists_from_the_enumeration_level(gpu, oracle, plan):
     assert np.array_equal(pool[idx_arr], keys)
 
 
+@pytest.mark.parametrize("plan", [8, 10, 12])  # plans 0 / 2 / 4 with the enumeration level on ONE workgroup (mtg_set_sssp_plan + 8)
+@pytest.mark.parametrize("which", ["long lists", "unitig-like"])
+def test_t1_one_workgroup_takes_chunk_after_chunk(gpu, oracle, plan, which):
+    """What a wave of the enumeration level does BETWEEN its chunks of 64 sources only happens when it takes several of them -- with the
+    full grid that needs hundreds of thousands of sources. On one workgroup (four waves) a graph of some ten thousand sources takes every
+    wave through dozens of chunks: the record table turns over (the records of a chunk leave together, in the sources' order, two
+    chunks later; a source that outlives them stores its own), the key ring wraps and crosses pool chunks (rows of 64 keys, the partial
+    row of a chunk that ends, lists longer than the ring), extension blocks go back and forth. Lists compared with the oracle's in full."""
+    from matchtigs_amd import synth
+
+    if which == "long lists":
+        bg = synth.g_csr(40000, seed=11, k=31, mean_out_degree=1.25, mean_weight=3.0)
+    else:
+        bg = synth.g_csr(120000, seed=12, k=31)
+    G, dev, S, start, count, pool = _gpu_candidates(bg, plan)
+    assert dev.set_plan(plan) == plan
+    levels = dev.last_sssp_levels()
+    assert "sssp_enum_kernel" in levels[0]["kernel"]
+    searched = dev.last_searched_sources() if plan != 12 else S
+    assert searched > 4 * 64 * 8, searched  # (every wave of the one workgroup took more than eight chunks)
+    o_on, off, keys, _ = _oracle(oracle, bg).candidate_lists(bg.k)
+    assert np.array_equal(count.astype(np.uint64), np.diff(off))
+    idx_arr = np.concatenate([np.arange(s, s + c, dtype=np.int64) for s, c in zip(start, count)])
+    assert np.array_equal(pool[idx_arr], keys)
+
+
 def test_t1_source_subrange(gpu, oracle):
     name, bg = graphs()[2]
     o_on, off, keys, _ = _oracle(oracle, bg).candidate_lists(bg.k)
