@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
     }
 }
 // the three length classes in ONE launch (a third of the grid each: their lists are disjoint, and three launches in a row spent more
-// on their gaps and tails than on sorting)
+// on their gaps and tails than on sorting; the grid split in proportion to the classes' workgroup passes instead: 0.246 -> 0.259 ms)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void sort_lists_kernel(unsigned long long *pool, uint64_t pool_cap, uint32_t *cand_count, const uint32_t *dense,
                                                            const unsigned long long *dense_val, const unsigned long long *counters) {
