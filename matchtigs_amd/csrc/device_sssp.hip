@@ -568,8 +568,11 @@ __global__ __launch_bounds__(WPB * 64, MTG_ENUM_WAVES_PER_SIMD) void sssp_enum_k
     uint32_t cur_base = 0, cur_len = 0, cur_pos = 0, nxt_base = 0, nxt_len = 0;  // wave-uniform
     uint32_t ids = 0, ahead = 0;
     uint32_t ids_item = 0, ahead_item = 0;  // PRUNE: the sources' indices relative to src_begin (without a list they are cur_base + position)
-    // (measured and dropped: the last quarter of the chunks handed out by a global counter, requested two chunks ahead so that the
-    // atomic is never waited for -- 7 % slower at 2^27 and no better lane utilisation at 2^24)
+    // (measured and dropped, twice: the last quarter of the chunks handed out by a global counter, requested two chunks ahead so that the
+    // atomic is never waited for -- round 3: 7 % slower at 2^27 and no better lane utilisation at 2^24. Round 6, because the waves of the
+    // static deal end 15 % apart (2^27: the first after 994 us, the median after 1166, the last after 1340): the last quarter / eighth /
+    // sixteenth of the chunks in PAIRS from one cursor -- a same-address atomic is served every ~7 ns, one per chunk would be 126 M/s --,
+    // the first pair asked for one chunk before a wave's last own one: + 0.10 / + 0.07 / + 0.06 ms on the stage)
     auto prefetch_chunk = [&]() {
         const unsigned long long lo = next_chunk * 64;
         nxt_base = (uint32_t)lo;
