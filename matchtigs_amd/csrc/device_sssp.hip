@@ -451,18 +451,15 @@ __device__ __forceinline__ void wave_ovf_flush(WaveOvfBuf &w, uint32_t nbuf, con
 // makes the output identical to the Dijkstra order. A source whose enumeration exceeds the step budget or its LDS space is handed
 // to the cooperative cascade, which is exact for any ball.
 //
-// What bounds it: the version at the end of round 2's first session was bound by instruction issue (460 VALU +
-// 366 SALU per wave step, 188 VGPRs, 8 waves per CU). Written branch-free -- every potential push / hit is an UNCONDITIONAL LDS store to the
-// lane's next free slot (a store that does not count leaves the counter where it was), the next node always comes off the stack,
-// sources are handed out by two cross-lane permutes from chunks held in registers -- a step is half the instructions and the
-// kernel becomes bound by the latency of the gathers, i.e. by the number of waves per CU, i.e. by LDS. Hence:
-//  * per lane only S1 stack and H1 hit slots; whatever a search needs beyond them lives in an EXTENSION BLOCK of 16 entries
-//    (stack from the bottom, hits from the top) taken from a per-wave pool. The pool's free mask is one wave-uniform 64-bit
-//    value: allocation and release are a few scalar instructions, no atomics;
-//  * nothing is staged: a finished source takes its pool space with one LDS atomic and writes its keys, (start, count) and, if
-//    needed, its post-pass work-list entry straight to memory.
-// 10 KB of LDS per wave -> 16 waves per CU, where the SIMDs are busy again (4 waves x 27 % active each): the level now sits between
-// instruction issue and its gather ceiling (78 % of it at 2^27).
+// What bounds it, as it stands at the end of round 6: the search itself runs at the ceiling of dependent gathers on the
+// table (2^27: 0.75 ms alone = 45 G gathers/s of 44-48); the rest of the kernel's time is the results' way out (keys, the lists'
+// places, the post-pass work list), whose cost follows the number of distinct lines its store instructions touch. The vector pipes
+// are a third busy; 2, 3 or 4 workgroups of four waves per CU measured 1.82 / 1.70 / 1.72 ms for the stage: three it is -- by the
+// kernel's 133 registers and by its LDS (12 KB per wave: home blocks 4 KB, 25 extension blocks of 24 entries 5 KB, the keys' ring 1 KB,
+// the record table of four chunks of sources 2 KB), which three workgroups per CU let it have.
+// History: round 2 wrote the step branch-free (every potential push / hit an UNCONDITIONAL LDS store to the lane's next free slot,
+// 4 + 4 slots per lane in a slot-major first tier + one 16-entry extension block) because the version before it was bound by
+// instruction issue; round 6's counters showed the opposite regime and replaced that form (see the template's comment below).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ENUM_POP_BUDGET = 256;
 constexpr uint32_t ENUM_FIX_CHUNK = 512;    // post-pass work-list slots a wave takes per global atomic (unused ones hold FIX_NONE)
@@ -470,11 +467,11 @@ constexpr uint32_t FIX_CLASS_TAG = 0xFFFFFF00u;  // slot 0 of a work-list chunk:
 constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
 #ifndef MTG_ENUM_HOME
 #define MTG_ENUM_HOME 8
-#define MTG_ENUM_NB 17  // (25 blocks of 16 entries: 62 187 sources of the 2^27 bench graph outgrow the level, every one of them because its block is
-#define MTG_ENUM_BE 24  //  full -- 17 blocks of 24 entries in the same LDS: 19 388, the cascade behind 0.20 -> 0.08 ms, the level + 0.04 ms)
+#define MTG_ENUM_NB 25  // (25 blocks of 16 entries: 62 187 sources of the 2^27 bench graph outgrow the level, every one of them because its block is
+#define MTG_ENUM_BE 24  //  full -- 17 blocks of 24 entries: 19 388, half of them because the pool is empty -- 25 of 24: 9 798, cascade 0.20 -> 0.05 ms)
 #endif
 #ifndef MTG_ENUM_TSLOTS
-#define MTG_ENUM_TSLOTS 2  // chunks of sources whose records wait in the wave's table (a power of two)
+#define MTG_ENUM_TSLOTS 4  // chunks of sources whose records wait in the wave's table (a power of two)
 #endif
 #ifndef MTG_ENUM_KRING
 #define MTG_ENUM_KRING 128  // keys of the wave's output ring (a power of two)
@@ -1194,7 +1191,7 @@ static LevelCfg make_cfg() {
                     sssp_kernel<BLOCK, LOGH, QCAP, SCAP, BSRC, true, GLOBAL_WS>, BLOCK, BSRC, LOGH, QCAP, SCAP, GLOBAL_WS};
 }
 
-constexpr int ENUM_WPB = 4, ENUM_HOME = MTG_ENUM_HOME, ENUM_NB = MTG_ENUM_NB;  // 40 KB of LDS per workgroup: 4 workgroups = 16 waves per CU
+constexpr int ENUM_WPB = 4, ENUM_HOME = MTG_ENUM_HOME, ENUM_NB = MTG_ENUM_NB;  // 50 KB of LDS per workgroup: 3 workgroups = 12 waves per CU
 constexpr int ENUM_MAX_HITS = ENUM_HOME + ENUM_BE;  // longest list the level can emit
 static std::string enum_level_name(bool quad, bool prune) {
     char b[160];
@@ -1534,6 +1531,14 @@ int run_levels(Device *d, hipStream_t st, int count_mode, uint64_t src_begin, ui
                      pct(life_us, 0.5) / std::max(1.0, pct(steps, 0.5)));
         std::fprintf(stderr, "[mtg] enum waves: start (us after the first) median %.0f p90 %.0f p99 %.0f max %.0f; life median %.0f p90 %.0f max %.0f us\n",
                      pct(start_us, 0.5), pct(start_us, 0.9), pct(start_us, 0.99), pct(start_us, 1), pct(life_us, 0.5), pct(life_us, 0.9), pct(life_us, 1));
+        {  // by XCD (workgroup b runs on XCD b mod 8; wave w belongs to workgroup w / ENUM_WPB): do some XCDs end later than others?
+            std::vector<double> xe[8], xs[8];
+            for (int w = 0; w < 16384; w++)
+                if (hp[3 * w + 1]) { const int x = (w / ENUM_WPB) % 8; xe[x].push_back((hp[3 * w + 1] - t_min) * 0.01); xs[x].push_back((hp[3 * w + 1] - hp[3 * w]) * 0.01 / std::max<double>(1.0, (double)hp[3 * w + 2])); }
+            char line[512]; int o = 0;
+            for (int x = 0; x < 8; x++) o += std::snprintf(line + o, sizeof line - o, " %d: %.0f / %.0f us, %.2f us per step;", x, pct(xe[x], 0.5), pct(xe[x], 1.0), pct(xs[x], 0.5));
+            std::fprintf(stderr, "[mtg] enum waves by XCD (median / last end):%s\n", line);
+        }
         std::vector<unsigned long long> zero(16384 * 3, 0);
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_enum_prof), zero.data(), zero.size() * 8));
     }
