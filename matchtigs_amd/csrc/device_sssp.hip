@@ -1118,16 +1118,26 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
     for (int k = 0; k < CLS; k++) begin += counters[C_FIX_CLASS0 + k];
     const unsigned long long n = counters[C_FIX_CLASS0 + CLS];
     const uint32_t g = threadIdx.x % G;
-    for (unsigned long long l0 = (unsigned long long)block * LPB; l0 < n; l0 += (unsigned long long)n_blocks * LPB) {
+    // (the list's place comes with its entry: no look-up at the source's index -- those were two of the pass's three scattered reads
+    // per list: 0.30 -> 0.23 ms at 2^27, the compaction 0.045 -> 0.065 ms. Measured and dropped: no compaction at all, a workgroup
+    // per work-list chunk -- most chunks are the half-filled last ones of their wave and class: 0.42 ms)
+    // A pass is a chain of two dependent reads (the place, then the keys there) before its shuffles: the place of the pass after the
+    // next and the keys of the next pass are requested before this pass's keys are sorted.
+    const unsigned long long stride = (unsigned long long)n_blocks * LPB, first = (unsigned long long)block * LPB + threadIdx.x / G;
+    auto place_of = [&](unsigned long long l) -> unsigned long long { return l < n ? dense_val[begin + l] : 0ull; };
+    auto count_of = [&](unsigned long long place) -> uint32_t {
+        const uint32_t c = (uint32_t)place & 0xFFu;
+        return (c < 2 || c > (uint32_t)G || (place >> 8) + c > pool_cap) ? 0u : c;  // (pool too small: the host retries with a larger one)
+    };
+    unsigned long long place = place_of(first), place_next = place_of(first + stride);
+    unsigned long long key = g < count_of(place) ? pool[(place >> 8) + g] : ~0ull;
+    for (unsigned long long l0 = (unsigned long long)block * LPB; l0 < n; l0 += stride) {
         const unsigned long long l = l0 + threadIdx.x / G;
-        // (the list's place comes with its entry: no look-up at the source's index -- those were two of the pass's three scattered reads
-        // per list: 0.30 -> 0.23 ms at 2^27, the compaction 0.045 -> 0.065 ms. Measured and dropped: no compaction at all, a workgroup
-        // per work-list chunk -- most chunks are the half-filled last ones of their wave and class: 0.42 ms)
-        const unsigned long long place = l < n ? dense_val[begin + l] : 0ull;
-        uint32_t c = (uint32_t)place & 0xFFu;
+        const uint32_t c = count_of(place);
         const unsigned long long st = place >> 8;
-        if (c < 2 || c > (uint32_t)G || st + c > pool_cap) c = 0;  // (pool too small: the host retries with a larger one)
-        unsigned long long key = g < c ? pool[st + g] : ~0ull;
+        // (the requests of the passes to come)
+        const unsigned long long place_after = place_of(l + 2 * stride);
+        const unsigned long long key_next = g < count_of(place_next) ? pool[(place_next >> 8) + g] : ~0ull;
 #pragma unroll
         for (int k = 2; k <= G; k <<= 1) {
 #pragma unroll
@@ -1154,6 +1164,7 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
             if (g < c && !dup) pool[st + g - before] = key;
             if (g == 0 && (dm & group)) cand_count[dense[begin + l]] = c - (uint32_t)__popcll(dm & group);
         } else if (g < c) pool[st + g] = key;
+        place = place_next; place_next = place_after; key = key_next;
     }
 }
 // the three length classes in ONE launch (a third of the grid each: their lists are disjoint, and three launches in a row spent more
