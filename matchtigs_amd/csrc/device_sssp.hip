@@ -1122,7 +1122,8 @@ __device__ __forceinline__ void sort_lists_class(unsigned long long *pool, uint6
     // per list: 0.30 -> 0.23 ms at 2^27, the compaction 0.045 -> 0.065 ms. Measured and dropped: no compaction at all, a workgroup
     // per work-list chunk -- most chunks are the half-filled last ones of their wave and class: 0.42 ms)
     // A pass is a chain of two dependent reads (the place, then the keys there) before its shuffles: the place of the pass after the
-    // next and the keys of the next pass are requested before this pass's keys are sorted.
+    // next and the keys of the next pass are requested before this pass's keys are sorted (0.246 -> 0.217 ms at 2^27; three passes
+    // ahead: the same, six: 0.234).
     const unsigned long long stride = (unsigned long long)n_blocks * LPB, first = (unsigned long long)block * LPB + threadIdx.x / G;
     auto place_of = [&](unsigned long long l) -> unsigned long long { return l < n ? dense_val[begin + l] : 0ull; };
     auto count_of = [&](unsigned long long place) -> uint32_t {
